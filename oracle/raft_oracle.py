@@ -1,0 +1,443 @@
+"""TEST INFRASTRUCTURE — CPU oracle for the RAFT-family hot path.
+
+A from-scratch, *functional* restatement (torch CPU fp32 tensors in, tensors out; weights come
+in as a flat ``{name: tensor}`` dict keyed exactly like the reference's ``state_dict``) of what the
+reference computes on the path named by BASELINE.json.  Every function cites the reference
+lines it follows (paths relative to /root/reference).
+
+It is the *checker*, never the product: only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may import it.  ``ptlflow_amd`` never does.
+
+Parity status: **pinned**.  The reference itself ships no test that pins numbers on this path
+(SURVEY.md §4, §8c), so the pin is the reference's own code executed on CPU in the build
+container: ``oracle/make_golden.py`` imports the unmodified reference files through
+``oracle/ref_loader.py``, runs them on seeded inputs and commits small input/output vectors to
+``tests/golden/``; ``tests/test_oracle_golden.py`` checks this file against those vectors, and
+``tests/test_oracle_vs_reference.py`` checks it against the live reference whenever
+/root/reference exists.
+
+The arithmetic the reference delegates to PyTorch (`matmul`, `avg_pool2d`, `grid_sample`,
+`conv2d`) is restated explicitly where its *rounding behaviour* matters for parity — the
+lookup replays grid_sample's fp32 coordinate round trip so that tap indices are bit-exact —
+and delegated to the same torch CPU primitives where only the value tolerance matters (convs).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+Params = Dict[str, Tensor]
+
+
+# --------------------------------------------------------------------------------------
+# a1/a2  all-pairs correlation volume + pyramid           ptlflow/models/raft/corr.py:13-27,56-64
+# --------------------------------------------------------------------------------------
+def all_pairs_correlation(fmap1: Tensor, fmap2: Tensor) -> Tensor:
+    """C[b,i,j] = sum_d f1[b,d,i] f2[b,d,j] / sqrt(D)   (raft/corr.py:56-64).
+
+    Returns the volume already reshaped the way CorrBlock.__init__ stores it
+    (raft/corr.py:21-22): ``[B*N, 1, h, w]`` with N = h*w source pixels.
+    """
+    B, D, h, w = fmap1.shape
+    a = fmap1.reshape(B, D, h * w).transpose(1, 2)  # [B, N, D]
+    b = fmap2.reshape(B, D, h * w)  # [B, D, N]
+    vol = torch.bmm(a, b)
+    vol = vol / torch.sqrt(torch.tensor(D))  # same scalar expression as corr.py:64
+    return vol.reshape(B * h * w, 1, h, w)
+
+
+def pool2x2(vol: Tensor) -> Tensor:
+    """avg_pool2d(kernel 2, stride 2, floor) over the *target* dims (raft/corr.py:26).
+
+    Written out so the summation order is explicit: ((a00 + a01) + a10) + a11, then * 0.25 —
+    the order torch's CPU kernel uses (row-major window walk, one division by 4).
+    """
+    H, W = vol.shape[-2:]
+    Ho, Wo = H // 2, W // 2
+    v = vol[..., : 2 * Ho, : 2 * Wo]
+    a00 = v[..., 0::2, 0::2]
+    a01 = v[..., 0::2, 1::2]
+    a10 = v[..., 1::2, 0::2]
+    a11 = v[..., 1::2, 1::2]
+    return (((a00 + a01) + a10) + a11) * 0.25
+
+
+def correlation_pyramid(fmap1: Tensor, fmap2: Tensor, num_levels: int = 4) -> List[Tensor]:
+    """CorrBlock.__init__ (raft/corr.py:13-27): level 0 + (L-1) successive 2x2 average pools."""
+    pyr = [all_pairs_correlation(fmap1, fmap2)]
+    for _ in range(num_levels - 1):
+        pyr.append(pool2x2(pyr[-1]))
+    return pyr
+
+
+def sea_correlation_pyramid(fmap1: Tensor, fmap2: Tensor, num_levels: int = 4) -> List[Tensor]:
+    """SEA-RAFT variant (sea_raft/corr.py:71-84,109-117): one GEMM per level against fmap2
+    bilinearly halved (align_corners=False), each divided by sqrt(D)."""
+    B, D, h, w = fmap1.shape
+    pyr = []
+    f2 = fmap2
+    for lvl in range(num_levels):
+        if lvl > 0:
+            f2 = F.interpolate(f2, scale_factor=0.5, mode="bilinear", align_corners=False)
+        h2, w2 = f2.shape[-2:]
+        a = fmap1.reshape(B, D, h * w).transpose(1, 2)
+        b = f2.reshape(B, D, h2 * w2)
+        vol = torch.bmm(a, b) / torch.sqrt(torch.tensor(D).float())
+        pyr.append(vol.reshape(B * h * w, 1, h2, w2))
+    return pyr
+
+
+# --------------------------------------------------------------------------------------
+# a3/a4  radius-r bilinear lookup            raft/corr.py:29-54 + raft/utils.py:67-75
+# --------------------------------------------------------------------------------------
+def _roundtrip(p: Tensor, size: int) -> Tensor:
+    """Pixel coord -> normalised -> pixel, in the exact fp32 op order of the reference:
+
+    raft/utils.py:71-72   g  = 2 * p / (S - 1) - 1          (three separate torch ops)
+    torch grid_sample     ix = (g + 1) * ((S - 1) / 2)       (align_corners=True un-normalise)
+
+    Each op below is its own torch kernel, so every intermediate is rounded to fp32 and nothing
+    is fused.  S == 1 divides by zero exactly like the reference does (SURVEY finding 4).
+    """
+    g = 2 * p
+    g = g / (size - 1)
+    g = g - 1
+    ix = g + 1
+    ix = ix * (float(size - 1) / 2)
+    return ix
+
+
+def lookup_taps(coords: Tensor, level: int, radius: int, size_wh: Tuple[int, int]):
+    """Per-axis tap data for one pyramid level.
+
+    Returns (ix, iy) un-normalised sample positions, each ``[B*N, 2r+1]``.  x depends only on
+    the *first* window index i and y only on the second index j, because the reference adds
+    ``meshgrid(dy, dx)`` to ``(x, y)`` (raft/corr.py:36-47): sample (i, j) sits at
+    ``(x/2^l + (i - r), y/2^l + (j - r))`` and lands in output channel ``i*(2r+1) + j``.
+    """
+    B, _, h, w = coords.shape
+    W_l, H_l = size_wh
+    n = 2 * radius + 1
+    off = torch.linspace(-radius, radius, n, dtype=coords.dtype)  # corr.py:36-41
+    cx = coords[:, 0].reshape(B * h * w, 1) / 2**level  # corr.py:45
+    cy = coords[:, 1].reshape(B * h * w, 1) / 2**level
+    xs = cx + off[None, :]
+    ys = cy + off[None, :]
+    return _roundtrip(xs, W_l), _roundtrip(ys, H_l)
+
+
+def lookup_tap_indices(coords: Tensor, level: int, radius: int, size_wh: Tuple[int, int]):
+    """floor() of the sample positions — the indices that must be bit-exact on the GPU."""
+    ix, iy = lookup_taps(coords, level, radius, size_wh)
+    return torch.floor(ix), torch.floor(iy)
+
+
+def _gather_zero(vol2d: Tensor, yi: Tensor, xi: Tensor) -> Tensor:
+    """vol2d [M, H, W]; yi [M, n] (per j), xi [M, n] (per i) float indices (may be out of
+    range / non-finite) -> values [M, n(i), n(j)] with zero padding per tap."""
+    M, H, W = vol2d.shape
+    ok_x = (xi >= 0) & (xi <= W - 1)
+    ok_y = (yi >= 0) & (yi <= H - 1)
+    xc = torch.nan_to_num(xi, nan=0.0, posinf=0.0, neginf=0.0).clamp(0, W - 1).long()
+    yc = torch.nan_to_num(yi, nan=0.0, posinf=0.0, neginf=0.0).clamp(0, H - 1).long()
+    flat = yc[:, None, :] * W + xc[:, :, None]  # [M, i, j]
+    vals = torch.gather(vol2d.reshape(M, H * W), 1, flat.reshape(M, -1)).reshape(flat.shape)
+    ok = ok_x[:, :, None] & ok_y[:, None, :]
+    return torch.where(ok, vals, torch.zeros((), dtype=vals.dtype))
+
+
+def _fma(a: Tensor, b: Tensor, c: Tensor) -> Tensor:
+    """fp32 fused multiply-add emulated through fp64 (24x24-bit product is exact there)."""
+    return (a.double() * b.double() + c.double()).float()
+
+
+def lookup(pyramid: Sequence[Tensor], coords: Tensor, radius: int) -> Tensor:
+    """CorrBlock.__call__ (raft/corr.py:29-54): ``[B, L*(2r+1)^2, h, w]``.
+
+    Bilinear weights and accumulation order follow torch's CPU grid_sample:
+    w = ix - floor(ix), e = 1 - w, n = iy - floor(iy), s = 1 - n,
+    out = nw*(s*e) + ne*(s*w) + sw*(n*e) + se*(n*w), out-of-range taps contribute value 0
+    (but still multiply their weight, so NaN/inf coordinates give NaN as in the reference).
+    torch's vectorised kernel is compiled with FMA contraction; the chain that reproduces
+    it bit-for-bit (measured: 0 mismatching values out of 2.3 M against the live reference) is
+        t = nw*w_nw ; t = fma(ne, w_ne, t) ; t = fma(sw, w_sw, t) ; t = fma(se, w_se, t)
+    which is what `_fma` emulates (product exact in fp64, one rounding back to fp32) and what
+    the HIP kernel computes with `fmaf`.
+    """
+    B, _, h, w = coords.shape
+    n = 2 * radius + 1
+    outs = []
+    for lvl, vol in enumerate(pyramid):
+        H_l, W_l = vol.shape[-2:]
+        ix, iy = lookup_taps(coords, lvl, radius, (W_l, H_l))
+        x0 = torch.floor(ix)
+        y0 = torch.floor(iy)
+        wx = ix - x0
+        ex = 1 - wx
+        ny = iy - y0
+        sy = 1 - ny
+        v2 = vol.reshape(-1, H_l, W_l)
+        nw = _gather_zero(v2, y0, x0)
+        ne = _gather_zero(v2, y0, x0 + 1)
+        sw = _gather_zero(v2, y0 + 1, x0)
+        se = _gather_zero(v2, y0 + 1, x0 + 1)
+        w_nw = sy[:, None, :] * ex[:, :, None]
+        w_ne = sy[:, None, :] * wx[:, :, None]
+        w_sw = ny[:, None, :] * ex[:, :, None]
+        w_se = ny[:, None, :] * wx[:, :, None]
+        out = _fma(se, w_se, _fma(sw, w_sw, _fma(ne, w_ne, nw * w_nw)))  # [B*N, i, j]
+        outs.append(out.reshape(B, h, w, n * n))
+    out = torch.cat(outs, dim=-1)
+    return out.permute(0, 3, 1, 2).contiguous()
+
+
+def coords_grid(B: int, h: int, w: int) -> Tensor:
+    """raft/utils.py:84-91: channel 0 = x, channel 1 = y."""
+    ys, xs = torch.meshgrid(
+        torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij"
+    )
+    return torch.stack([xs, ys], dim=0)[None].repeat(B, 1, 1, 1)
+
+
+# --------------------------------------------------------------------------------------
+# a6-a12  update block                                     ptlflow/models/raft/update.py
+# --------------------------------------------------------------------------------------
+def _conv(P: Params, name: str, x: Tensor, pad) -> Tensor:
+    return F.conv2d(x, P[name + ".weight"], P[name + ".bias"], padding=pad)
+
+
+def motion_encoder(P: Params, flow: Tensor, corr: Tensor, pre: str = "encoder") -> Tensor:
+    """BasicMotionEncoder.forward (raft/update.py:104-112)."""
+    cor = F.relu(_conv(P, f"{pre}.convc1", corr, 0))
+    cor = F.relu(_conv(P, f"{pre}.convc2", cor, 1))
+    flo = F.relu(_conv(P, f"{pre}.convf1", flow, 3))
+    flo = F.relu(_conv(P, f"{pre}.convf2", flo, 1))
+    out = F.relu(_conv(P, f"{pre}.conv", torch.cat([cor, flo], dim=1), 1))
+    return torch.cat([out, flow], dim=1)
+
+
+def small_motion_encoder(P: Params, flow: Tensor, corr: Tensor, pre: str = "encoder") -> Tensor:
+    """SmallMotionEncoder.forward (raft/update.py:85-91)."""
+    cor = F.relu(_conv(P, f"{pre}.convc1", corr, 0))
+    flo = F.relu(_conv(P, f"{pre}.convf1", flow, 3))
+    flo = F.relu(_conv(P, f"{pre}.convf2", flo, 1))
+    out = F.relu(_conv(P, f"{pre}.conv", torch.cat([cor, flo], dim=1), 1))
+    return torch.cat([out, flow], dim=1)
+
+
+def _gru_pass(P: Params, h: Tensor, x: Tensor, z: str, r: str, q: str, pad) -> Tensor:
+    hx = torch.cat([h, x], dim=1)
+    zt = torch.sigmoid(_conv(P, z, hx, pad))
+    rt = torch.sigmoid(_conv(P, r, hx, pad))
+    qt = torch.tanh(_conv(P, q, torch.cat([rt * h, x], dim=1), pad))
+    return (1 - zt) * h + zt * qt
+
+
+def sepconv_gru(P: Params, h: Tensor, x: Tensor, pre: str = "gru") -> Tensor:
+    """SepConvGRU.forward (raft/update.py:58-73): 1x5 pass then 5x1 pass."""
+    h = _gru_pass(P, h, x, f"{pre}.convz1", f"{pre}.convr1", f"{pre}.convq1", (0, 2))
+    h = _gru_pass(P, h, x, f"{pre}.convz2", f"{pre}.convr2", f"{pre}.convq2", (2, 0))
+    return h
+
+
+def conv_gru(P: Params, h: Tensor, x: Tensor, pre: str = "gru") -> Tensor:
+    """ConvGRU.forward (raft/update.py:24-32): single 3x3 pass."""
+    return _gru_pass(P, h, x, f"{pre}.convz", f"{pre}.convr", f"{pre}.convq", 1)
+
+
+def flow_head(P: Params, net: Tensor, pre: str = "flow_head") -> Tensor:
+    """FlowHead.forward (raft/update.py:13-14)."""
+    return _conv(P, f"{pre}.conv2", F.relu(_conv(P, f"{pre}.conv1", net, 1)), 1)
+
+
+def mask_head(P: Params, net: Tensor, pre: str = "mask") -> Tensor:
+    """0.25 * mask(net) (raft/update.py:138-142,152)."""
+    return 0.25 * _conv(P, f"{pre}.2", F.relu(_conv(P, f"{pre}.0", net, 1)), 0)
+
+
+def basic_update_block(P: Params, net, inp, corr, flow):
+    """BasicUpdateBlock.forward (raft/update.py:144-153) -> (net, mask, delta_flow)."""
+    mf = motion_encoder(P, flow, corr)
+    net = sepconv_gru(P, net, torch.cat([inp, mf], dim=1))
+    return net, mask_head(P, net), flow_head(P, net)
+
+
+def small_update_block(P: Params, net, inp, corr, flow):
+    """SmallUpdateBlock.forward (raft/update.py:122-128) -> (net, None, delta_flow)."""
+    mf = small_motion_encoder(P, flow, corr)
+    net = conv_gru(P, net, torch.cat([inp, mf], dim=1))
+    return net, None, flow_head(P, net)
+
+
+def sub(P: Params, prefix: str) -> Params:
+    """View of a state_dict under ``prefix.`` with the prefix stripped."""
+    k = prefix + "."
+    return {n[len(k):]: t for n, t in P.items() if n.startswith(k)}
+
+
+# --------------------------------------------------------------------------------------
+# encoders (adjacent to the path, inside the timed forward)  raft/extractor.py:6-267
+# --------------------------------------------------------------------------------------
+def _norm(P: Params, name: str, x: Tensor, kind: str) -> Tensor:
+    if kind == "instance":  # nn.InstanceNorm2d defaults: no affine, no running stats
+        return F.instance_norm(x, eps=1e-5)
+    if kind == "batch":  # eval mode: running statistics
+        return F.batch_norm(
+            x, P[name + ".running_mean"], P[name + ".running_var"],
+            P[name + ".weight"], P[name + ".bias"], training=False, eps=1e-5,
+        )
+    if kind == "none":
+        return x
+    raise ValueError(kind)
+
+
+def _conv_s(P: Params, name: str, x: Tensor, stride: int, pad: int) -> Tensor:
+    return F.conv2d(x, P[name + ".weight"], P[name + ".bias"], stride=stride, padding=pad)
+
+
+def _residual_block(P: Params, pre: str, x: Tensor, kind: str, stride: int) -> Tensor:
+    """ResidualBlock.forward (raft/extractor.py:51-59)."""
+    y = F.relu(_norm(P, f"{pre}.norm1", _conv_s(P, f"{pre}.conv1", x, stride, 1), kind))
+    y = F.relu(_norm(P, f"{pre}.norm2", _conv_s(P, f"{pre}.conv2", y, 1, 1), kind))
+    if stride != 1:
+        # downsample = Sequential(conv1x1 stride, norm3); norm3 is registered twice
+        # (as .norm3 and as .downsample.1) — same tensors.
+        x = _norm(P, f"{pre}.downsample.1", _conv_s(P, f"{pre}.downsample.0", x, stride, 0), kind)
+    return F.relu(x + y)
+
+
+def _bottleneck_block(P: Params, pre: str, x: Tensor, kind: str, stride: int) -> Tensor:
+    """BottleneckBlock.forward (raft/extractor.py:110-119)."""
+    y = F.relu(_norm(P, f"{pre}.norm1", _conv_s(P, f"{pre}.conv1", x, 1, 0), kind))
+    y = F.relu(_norm(P, f"{pre}.norm2", _conv_s(P, f"{pre}.conv2", y, stride, 1), kind))
+    y = F.relu(_norm(P, f"{pre}.norm3", _conv_s(P, f"{pre}.conv3", y, 1, 0), kind))
+    if stride != 1:
+        x = _norm(P, f"{pre}.downsample.1", _conv_s(P, f"{pre}.downsample.0", x, stride, 0), kind)
+    return F.relu(x + y)
+
+
+def encoder(P: Params, x: Tensor, kind: str, small: bool = False) -> Tensor:
+    """BasicEncoder.forward / SmallEncoder.forward (raft/extractor.py:172-197, 241-267), eval."""
+    block = _bottleneck_block if small else _residual_block
+    x = F.relu(_norm(P, "norm1", _conv_s(P, "conv1", x, 2, 3), kind))
+    for li, stride in ((1, 1), (2, 2), (3, 2)):
+        x = block(P, f"layer{li}.0", x, kind, stride)
+        x = block(P, f"layer{li}.1", x, kind, 1)
+    return _conv_s(P, "conv2", x, 1, 0)
+
+
+# --------------------------------------------------------------------------------------
+# whole forward                                             ptlflow/models/raft/raft.py:112-194
+# --------------------------------------------------------------------------------------
+def pad_amounts(ht: int, wd: int, stride: int = 8) -> Tuple[int, int, int, int]:
+    """Two-sided replicate pad to a multiple of `stride` (utils/external/raft.py:57-72)."""
+    pad_ht = (((ht // stride) + 1) * stride - ht) % stride
+    pad_wd = (((wd // stride) + 1) * stride - wd) % stride
+    return (pad_wd // 2, pad_wd - pad_wd // 2, pad_ht // 2, pad_ht - pad_ht // 2)
+
+
+def preprocess(images: Tensor) -> Tuple[Tensor, Tuple[int, int, int, int]]:
+    """raft.py:127-135 -> base_model.py:207-247: (+(-0.5)) * 2, BGR->RGB, replicate pad."""
+    x = images + (-0.5)
+    x = x * 2.0
+    x = torch.flip(x, [-3])
+    pads = pad_amounts(x.shape[-2], x.shape[-1])
+    shp = x.shape
+    x = F.pad(x.reshape(-1, *shp[-3:]), pads, mode="replicate")
+    return x.reshape(*shp[:-2], *x.shape[-2:]).contiguous(), pads
+
+
+def unpad(x: Tensor, pads) -> Tensor:
+    ht, wd = x.shape[-2:]
+    return x[..., pads[2]: ht - pads[3], pads[0]: wd - pads[1]]
+
+
+def convex_upsample(flow: Tensor, mask: Tensor) -> Tensor:
+    """RAFT.upsample_flow (raft.py:112-123)."""
+    N, _, H, W = flow.shape
+    m = torch.softmax(mask.view(N, 1, 9, 8, 8, H, W), dim=2)
+    up = F.unfold(8 * flow, [3, 3], padding=1).view(N, 2, 9, 1, 1, H, W)
+    up = torch.sum(m * up, dim=2).permute(0, 1, 4, 2, 5, 3)
+    return up.reshape(N, 2, 8 * H, 8 * W)
+
+
+def upflow8(flow: Tensor) -> Tensor:
+    """raft/utils.py:94-96."""
+    size = (8 * flow.shape[2], 8 * flow.shape[3])
+    return 8 * F.interpolate(flow, size=size, mode="bilinear", align_corners=True)
+
+
+@torch.no_grad()
+def raft_forward(P: Params, images: Tensor, iters: int = 32, small: bool = False,
+                 corr_levels: int = 4, corr_radius: Optional[int] = None,
+                 return_trace: bool = False):
+    """RAFT.forward / RAFTSmall.forward in eval mode (raft.py:125-194).
+
+    `images`: [B, 2, 3, H, W] in [0, 1], BGR (what the scripts feed the model).
+    Returns {"flows": [B,1,2,H,W], "flow_small": [B,2,h,w]}.
+    """
+    if corr_radius is None:
+        corr_radius = 3 if small else 4
+    hdim, cdim = (96, 64) if small else (128, 128)
+    x, pads = preprocess(images)
+    image1, image2 = x[:, 0], x[:, 1]
+    B = image1.shape[0]
+
+    fm = encoder(sub(P, "fnet"), torch.cat([image1, image2], 0), "instance", small)
+    fmap1, fmap2 = fm[:B], fm[B:]
+    pyramid = correlation_pyramid(fmap1, fmap2, corr_levels)
+
+    cnet = encoder(sub(P, "cnet"), image1, "none" if small else "batch", small)
+    net, inp = torch.split(cnet, [hdim, cdim], dim=1)
+    net = torch.tanh(net)
+    inp = torch.relu(inp)
+
+    h, w = image1.shape[-2] // 8, image1.shape[-1] // 8
+    coords0 = coords_grid(B, h, w)
+    coords1 = coords_grid(B, h, w)
+    U = sub(P, "update_block")
+    step = small_update_block if small else basic_update_block
+    trace = []
+    flow_up = None
+    for _ in range(iters):
+        corr = lookup(pyramid, coords1, corr_radius)
+        flow = coords1 - coords0
+        net, up_mask, delta = step(U, net, inp, corr, flow)
+        coords1 = coords1 + delta
+        if up_mask is None:
+            flow_up = upflow8(coords1 - coords0)
+        else:
+            flow_up = convex_upsample(coords1 - coords0, up_mask)
+        flow_up = unpad(flow_up, pads)
+        if return_trace:
+            trace.append((coords1 - coords0).clone())
+    out = {"flows": flow_up[:, None], "flow_small": coords1 - coords0}
+    if return_trace:
+        out["trace"] = trace
+    return out
+
+
+def epe(a: Tensor, b: Tensor) -> Tuple[float, float]:
+    """End-point error: L2 norm over the 2 flow channels (utils/flow_metrics.py:199-206).
+    Returns (mean, max) over all pixels."""
+    d = torch.linalg.vector_norm((a - b).float(), dim=-3)
+    return float(d.mean()), float(d.max())
+
+
+# --------------------------------------------------------------------------------------
+# synthetic inputs
+# --------------------------------------------------------------------------------------
+def smooth_pair(B: int, H: int, W: int, seed: int = 1234, shift=(5, -4)) -> Tensor:
+    """A smooth random texture and a copy shifted by `shift` px: [B,2,3,H,W] in [0,1]."""
+    g = torch.Generator().manual_seed(seed)
+    m = 8
+    base = torch.rand(B, 3, H // 8 + 4 + m, W // 8 + 4 + m, generator=g)
+    big = F.interpolate(base, scale_factor=8, mode="bicubic", align_corners=False).clamp(0, 1)
+    oy, ox = 4 * 8, 4 * 8
+    im1 = big[..., oy: oy + H, ox: ox + W]
+    im2 = big[..., oy - shift[1]: oy - shift[1] + H, ox - shift[0]: ox - shift[0] + W]
+    return torch.stack([im1, im2], dim=1).contiguous()

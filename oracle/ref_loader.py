@@ -1,0 +1,128 @@
+"""TEST INFRASTRUCTURE — loads the *real* reference (hmorimitsu/ptlflow at /root/reference)
+in this container so the oracle restatement can be pinned against it.
+
+Only `oracle/make_golden.py` and `tests/test_oracle_vs_reference.py` use this module; nothing
+in `ptlflow_amd/`, `bench.py` or the `-m gpu` tests may import it (the GPU box has no
+/root/reference).
+
+`import ptlflow` does not work here (lightning, jsonargparse, loguru, torchmetrics, cv2,
+torchvision, timm are absent and there is no network) -- SURVEY.md §8(c).  The hot-path
+files themselves only need torch + scipy + einops, so:
+
+  1. stub `lightning.pytorch`, `loguru`, `torchmetrics` with a few lines each;
+  2. register *namespace* modules for `ptlflow`, `ptlflow.models`, `ptlflow.models.<family>`,
+     `ptlflow.utils`... whose `__path__` points into /root/reference, so the heavy package
+     `__init__.py` files are never executed while every leaf module (raft/corr.py,
+     raft/update.py, raft/raft.py, utils/correlation.py ...) is the reference's own file,
+     imported unmodified from where it lies.
+
+Nothing is copied: the reference code runs from /root/reference.
+"""
+from __future__ import annotations
+
+import importlib
+import os
+import sys
+import types
+
+REFERENCE_ROOT = os.environ.get("PTLFLOW_REFERENCE_ROOT", "/root/reference")
+
+
+def reference_available() -> bool:
+    return os.path.isdir(os.path.join(REFERENCE_ROOT, "ptlflow", "models", "raft"))
+
+
+def _install_stubs() -> None:
+    import torch.nn as nn
+
+    if "lightning" not in sys.modules:
+        lightning = types.ModuleType("lightning")
+        pl = types.ModuleType("lightning.pytorch")
+
+        class LightningModule(nn.Module):
+            def save_hyperparameters(self, *a, **k):
+                pass
+
+            def log(self, *a, **k):
+                pass
+
+            def log_dict(self, *a, **k):
+                pass
+
+        pl.LightningModule = LightningModule
+        lightning.pytorch = pl
+        sys.modules["lightning"] = lightning
+        sys.modules["lightning.pytorch"] = pl
+
+    if "loguru" not in sys.modules:
+        loguru = types.ModuleType("loguru")
+
+        class _Logger:
+            def __getattr__(self, name):
+                return lambda *a, **k: None
+
+        loguru.logger = _Logger()
+        sys.modules["loguru"] = loguru
+
+    if "torchmetrics" not in sys.modules:
+        tm = types.ModuleType("torchmetrics")
+
+        class Metric(nn.Module):
+            def __init__(self, *a, **k):
+                super().__init__()
+
+            def add_state(self, name, default, dist_reduce_fx=None):
+                self.register_buffer(name, default)
+
+        tm.Metric = Metric
+        sys.modules["torchmetrics"] = tm
+
+
+def _namespace(name: str, path: str) -> None:
+    if name in sys.modules:
+        return
+    mod = types.ModuleType(name)
+    mod.__path__ = [path]
+    mod.__package__ = name
+    sys.modules[name] = mod
+    if "." in name:
+        parent, child = name.rsplit(".", 1)
+        setattr(sys.modules[parent], child, mod)
+
+
+_LOADED = False
+
+
+def load() -> None:
+    """Make `ptlflow.models.<family>.*` importable from /root/reference (idempotent)."""
+    global _LOADED
+    if _LOADED:
+        return
+    if not reference_available():
+        raise RuntimeError(f"reference not found under {REFERENCE_ROOT}")
+    _install_stubs()
+    root = os.path.join(REFERENCE_ROOT, "ptlflow")
+    _namespace("ptlflow", root)
+    _namespace("ptlflow.models", os.path.join(root, "models"))
+    _namespace("ptlflow.utils", os.path.join(root, "utils"))
+    _namespace("ptlflow.utils.external", os.path.join(root, "utils", "external"))
+    _namespace("ptlflow.models.base_model", os.path.join(root, "models", "base_model"))
+    for fam in ("raft", "gma", "sea_raft", "ccmr", "ms_raft_plus"):
+        _namespace(f"ptlflow.models.{fam}", os.path.join(root, "models", fam))
+    _LOADED = True
+
+
+def ref_module(dotted: str):
+    """Import a reference module, e.g. ref_module('ptlflow.models.raft.corr')."""
+    load()
+    return importlib.import_module(dotted)
+
+
+def build_raft(small: bool = False, seed: int = 1234, **kwargs):
+    """Instantiate the reference RAFT / RAFTSmall with seeded default init, eval mode."""
+    import torch
+
+    m = ref_module("ptlflow.models.raft.raft")
+    torch.manual_seed(seed)
+    model = (m.RAFTSmall if small else m.RAFT)(**kwargs)
+    return model.eval()
