@@ -1,0 +1,172 @@
+/*
+ * pfk.h — C ABI of libpfk.so: hand-written gfx950 (MI355X / CDNA4) kernels for the RAFT-family
+ * optical-flow hot path of hmorimitsu/ptlflow.
+ *
+ * Every entry point is `extern "C"`, takes raw *device* pointers + explicit sizes + a HIP stream,
+ * allocates nothing, never synchronises, never throws; it returns 0 on success or a negative
+ * pfk_status code (pfk_status_string() names it).  No torch types cross this boundary: the torch
+ * extension (ptlflow_amd/csrc/pfk_torch.cpp), the ctypes tests and any other host language bind
+ * exactly these symbols.
+ *
+ * Activation layout is *pixel-major* ("NHWC"): a feature map is a row-major matrix
+ * [B*H*W pixels][ld floats] whose row p = (b*H + y)*W + x holds that pixel's channels
+ * contiguously; `ld >= channels` lets several producers write channel slices of one buffer
+ * (that is how the reference's torch.cat calls disappear).  All pointers must be 16-byte aligned
+ * and every `ld` / channel count / channel offset a multiple of 4 floats.
+ *
+ * Reference interface each entry replaces (paths under hmorimitsu/ptlflow):
+ *   pfk_corr_volume_f32   ptlflow/models/raft/corr.py:56-64   CorrBlock.corr (matmul / sqrt(D));
+ *                         sea_raft/corr.py:109-117 (same op, per level)
+ *   pfk_corr_pool2x2_f32  ptlflow/models/raft/corr.py:25-27   F.avg_pool2d(corr, 2, stride=2)
+ *   pfk_corr_lookup_f32   ptlflow/models/raft/corr.py:29-54   CorrBlock.__call__ and
+ *                         ptlflow/models/raft/utils.py:67-75  bilinear_sampler -> F.grid_sample
+ *   pfk_conv2d_f32        ptlflow/models/raft/update.py:6-153 every nn.Conv2d of the update block
+ *                         (+ the fused sigmoid/tanh/GRU-blend/relu epilogues of :58-73, :24-32,
+ *                         :104-112, :144-153); torch.cat at :60,63,67,70,109,112,146 is replaced by
+ *                         channel-slice addressing
+ *   pfk_conv_cin2_f32     ptlflow/models/raft/update.py:100,107 (convf1: 7x7 conv on the 2-ch flow)
+ *   pfk_flow_delta_f32    ptlflow/models/raft/update.py:10,14 (FlowHead.conv2) fused with
+ *                         ptlflow/models/raft/raft.py:174,178 (flow = coords1-coords0; coords1 += d)
+ *   pfk_convex_upsample_f32  ptlflow/models/raft/raft.py:112-123 RAFT.upsample_flow
+ * The native plug-in precedent in the reference is alt_cuda_corr
+ * (ptlflow/utils/external/alt_cuda_corr/correlation.cpp:23-54: pybind forward/backward on raw
+ * contiguous CUDA tensors); this header is the same kind of boundary, minus torch.
+ */
+#ifndef PFK_H
+#define PFK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* pfk_stream_t; /* a hipStream_t */
+
+enum pfk_status {
+  PFK_OK = 0,
+  PFK_ERR_BAD_ARG = -1,      /* null pointer, non-positive size, unsupported combination */
+  PFK_ERR_ALIGNMENT = -2,    /* pointer not 16-byte aligned or ld/channels not a multiple of 4 */
+  PFK_ERR_UNSUPPORTED = -3,  /* shape outside what the kernels were built for */
+  PFK_ERR_LAUNCH = -4        /* hipLaunchKernel reported an error */
+};
+
+#define PFK_MAX_LEVELS 8
+#define PFK_ABI_VERSION 1
+
+int pfk_abi_version(void);
+const char* pfk_status_string(int status);
+/* tuning/debug knob: force the implicit-GEMM tile configuration (-1 = heuristic). Not thread-safe. */
+void pfk_debug_set_tile(int cfg);
+
+/* ---- K1: all-pairs correlation --------------------------------------------------------------
+ * out[b][i][j] = scale * sum_d f1[b][i][d] * f2[b][j][d]        (fp32 MFMA, exact fp32 products)
+ * f1 [B][N1][ld1], f2 [B][N2][ld2] pixel-major, D channels used; out [B][N1][N2] row-major,
+ * i.e. for source pixel i a full [h2][w2] map — the reference's [B*N,1,h2,w2] volume. */
+int pfk_corr_volume_f32(const float* f1, int ld1, const float* f2, int ld2, float* out,
+                        int B, int N1, int N2, int D, float scale, pfk_stream_t stream);
+
+/* ---- K2: 2x2/stride-2 average pool over the target dims (floor) ------------------------------
+ * in [M][H][W] -> out [M][H/2][W/2], value ((a00+a01)+a10)+a11) * 0.25 (torch's CPU order). */
+int pfk_corr_pool2x2_f32(const float* in, float* out, int64_t M, int H, int W,
+                         pfk_stream_t stream);
+
+/* ---- K3: radius-r bilinear lookup over all pyramid levels in one launch ----------------------
+ * levels[l] is the level-l volume [B*N][lvl_h[l]][lvl_w[l]]; coords is [B][2][h][w] (x then y,
+ * pixel units, fp32, NCHW as the reference passes it).  Output: out[p*out_ld + l*n*n + i*n + j]
+ * with n = 2r+1, sample (i, j) taken at (x/2^l + i - r, y/2^l + j - r) — the reference's
+ * x-offset-major window — through grid_sample's exact fp32 normalise/un-normalise round trip,
+ * zero padding per tap, FMA accumulation order of torch's CPU kernel (bit-exact values for the
+ * same pyramid).  NaN / inf coordinates and 1-pixel levels give NaN exactly like the reference. */
+typedef struct {
+  const float* levels[PFK_MAX_LEVELS];
+  int lvl_h[PFK_MAX_LEVELS];
+  int lvl_w[PFK_MAX_LEVELS];
+  int num_levels;
+  int radius;      /* 1..4 */
+  int B, h, w;     /* source grid: N = h*w pixels per batch element */
+  const float* coords;
+  float* out;
+  int out_ld;      /* >= num_levels*(2r+1)^2, multiple of 4 */
+} pfk_lookup_desc;
+int pfk_corr_lookup_f32(const pfk_lookup_desc* d, pfk_stream_t stream);
+
+/* ---- K4-K6: stride-1 "same" convolution as an implicit GEMM on fp32 MFMA ---------------------
+ * out[p][co] = epilogue( bias[co] + sum_{s, ky, kx, c} src[s][p + (ky-kh/2)*W + (kx-kw/2)][c]
+ *                                                    * weight[co][k(s,ky,kx,c)] )
+ * Input channels may come from up to 3 pixel-major sources (the reference's torch.cat operands).
+ * Packed weight: row-major [cout][ktot]; k enumerates, for each source s in order, each tap
+ * (ky major, kx minor), the source's channels padded up to a multiple of 32 (pad weights = 0):
+ * ktot = sum_s kh*kw*round_up(channels_s, 32).  pfk_conv_ktot() returns it. */
+enum pfk_epilogue {
+  PFK_EPI_LINEAR = 0,  /* v = (acc+bias) ; relu? ; v *= scale ; out[p*out_ld + out_coff + co] = v */
+  PFK_EPI_GRU_ZR = 1,  /* cout = 2*Ch: co<Ch: z=sigmoid -> aux_z[p*Ch+co];
+                          co>=Ch: r=sigmoid -> aux_rh[p*Ch + co-Ch] = r * h[p*h_ld + co-Ch] */
+  PFK_EPI_GRU_Q = 2    /* cout = Ch: q=tanh; h[p*h_ld+co] = (1-z)*h + z*q, z = aux_z[p*Ch+co] */
+};
+
+typedef struct {
+  const float* ptr;
+  int ld;        /* row stride in floats */
+  int channels;  /* channels read from each row (multiple of 4) */
+} pfk_conv_src;
+
+typedef struct {
+  pfk_conv_src src[3];
+  int num_src;
+  int B, H, W;
+  int kh, kw;            /* odd; padding kh/2, kw/2; stride 1 */
+  const float* weight;   /* packed [cout][ktot] */
+  const float* bias;     /* [cout] or NULL */
+  int cout;
+  int epilogue;          /* enum pfk_epilogue */
+  int relu;              /* LINEAR only */
+  float scale;           /* LINEAR only (1.0f for none) */
+  float* out;            /* LINEAR only */
+  int out_ld, out_coff;
+  float* h;              /* GRU_ZR (read) / GRU_Q (read+write): hidden state slice */
+  int h_ld;
+  float* aux_z;          /* [M][Ch] */
+  float* aux_rh;         /* [M][Ch] */
+} pfk_conv_desc;
+
+int pfk_conv_ktot(const pfk_conv_desc* d);
+int pfk_conv2d_f32(const pfk_conv_desc* d, pfk_stream_t stream);
+
+/* ---- small direct kernels ------------------------------------------------------------------- */
+/* k x k conv on a 2-channel map (the flow), relu optional: out[p*out_ld + out_coff + co].
+ * in [M][in_ld] (channels 0,1 used); weight packed [k*k][2][cout]; bias [cout]. */
+int pfk_conv_cin2_f32(const float* in, int in_ld, const float* weight, const float* bias,
+                      float* out, int out_ld, int out_coff, int B, int H, int W, int k, int cout,
+                      int relu, pfk_stream_t stream);
+
+/* FlowHead.conv2 (3x3, cin -> 2) fused with the coordinate update of the RAFT loop:
+ *   delta = conv(in) + bias ; coords1 += delta ; flow = coords1 - coords0
+ * in [M][in_ld]; weight packed [9][2][cin]; coords0/coords1 [B][2][h][w] (NCHW, updated in place);
+ * delta_out [B][2][h][w] (may be NULL); flow_out written as 2 channels at
+ * flow_out[p*flow_ld + 0..1] (may be NULL). */
+int pfk_flow_delta_f32(const float* in, int in_ld, int cin, const float* weight,
+                       const float* bias, const float* coords0, float* coords1, float* delta_out,
+                       float* flow_out, int flow_ld, int B, int H, int W, pfk_stream_t stream);
+
+/* flow = coords1 - coords0 written pixel-major (2 channels) — loop prologue / drop-in mode. */
+int pfk_flow_from_coords_f32(const float* coords0, const float* coords1, float* flow_out,
+                             int flow_ld, int B, int H, int W, pfk_stream_t stream);
+
+/* RAFT.upsample_flow: softmax over the 9 mask taps, convex combination of the 3x3 neighbourhood
+ * of 8*flow, pixel-shuffle to 8x resolution.
+ * flow [B][2][h][w] NCHW; mask pixel-major [M][mask_ld] with channel c = k*64 + sy*8 + sx
+ * (already multiplied by 0.25); out [B][2][8h][8w] NCHW. */
+int pfk_convex_upsample_f32(const float* flow, const float* mask, int mask_ld, float* out,
+                            int B, int H, int W, pfk_stream_t stream);
+
+/* NCHW [B][C][H][W] -> pixel-major [B*H*W][ld] (+ channel offset) and back. */
+int pfk_nchw_to_pm_f32(const float* in, float* out, int out_ld, int out_coff, int B, int C,
+                       int H, int W, pfk_stream_t stream);
+int pfk_pm_to_nchw_f32(const float* in, int in_ld, int in_coff, float* out, int B, int C, int H,
+                       int W, pfk_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PFK_H */

@@ -1,0 +1,135 @@
+"""TEST INFRASTRUCTURE — generates tests/golden/*.pt by running the *reference's own code*
+(/root/reference, imported unmodified through oracle/ref_loader.py) on seeded synthetic inputs.
+
+    python -m oracle.make_golden            # needs /root/reference; run in the build container
+
+The reference has no test that pins numbers on this path (test_forward only checks
+"does not raise", test_accuracy is skipped and needs network checkpoints), so these vectors ARE the
+pin: tests/test_oracle_golden.py holds oracle/raft_oracle.py to them, and the GPU tests hold the HIP
+kernels to the oracle (and to these vectors directly).  Weights are not stored: they are regenerated
+from `ptlflow_amd.synth` (seeded, construction-order independent); only inputs/outputs are saved.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import raft_oracle as O  # noqa: E402
+from oracle import ref_loader  # noqa: E402
+from ptlflow_amd.synth import synth_state_dict, synth_update_block_params  # noqa: E402
+from ptlflow_amd.update import basic_spec, small_spec  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def coords_cases(B, h, w, seed):
+    g = torch.Generator().manual_seed(seed)
+    c0 = O.coords_grid(B, h, w)
+    cases = {
+        "integer": c0,
+        "fractional": c0 + torch.rand(B, 2, h, w, generator=g) * 16 - 8,
+        "out_of_bounds": c0 + torch.randn(B, 2, h, w, generator=g) * 40,
+    }
+    bad = c0.clone()
+    bad[:, 0, 0, 0] = float("nan")
+    bad[:, 1, 0, 1] = float("inf")
+    bad[:, 0, 1, 0] = -float("inf")
+    bad[:, 0, 1, 1] = 3.0e9
+    cases["nonfinite"] = bad
+    return cases
+
+
+def golden_corr():
+    """CorrBlock of raft (avg-pool pyramid) and sea_raft (per-level GEMM) + lookups."""
+    raft_corr = ref_loader.ref_module("ptlflow.models.raft.corr")
+    sea_corr = ref_loader.ref_module("ptlflow.models.sea_raft.corr")
+    out = {}
+    for tag, (h, w, D, L, r) in {"raft_10x16": (10, 16, 32, 4, 4), "small_8x16_degenerate": (8, 16, 32, 4, 3),
+                                 "ccmr_9x13_L2": (9, 13, 32, 2, 4)}.items():
+        g = torch.Generator().manual_seed(len(tag) * 17)
+        f1 = torch.randn(1, D, h, w, generator=g)
+        f2 = torch.randn(1, D, h, w, generator=g)
+        cb = raft_corr.CorrBlock(f1, f2, num_levels=L, radius=r)
+        item = {"fmap1": f1, "fmap2": f2, "levels": L, "radius": r,
+                "pyramid": [p.clone() for p in cb.corr_pyramid], "lookups": {}}
+        for name, c in coords_cases(1, h, w, 5).items():
+            item["lookups"][name] = {"coords": c, "out": cb(c).clone()}
+        out[tag] = item
+    # SEA-RAFT pyramid (sea_raft/corr.py:71-117)
+    g = torch.Generator().manual_seed(99)
+    f1 = torch.randn(1, 32, 16, 24, generator=g)
+    f2 = torch.randn(1, 32, 16, 24, generator=g)
+    cb = sea_corr.CorrBlock(f1, f2, num_levels=4, radius=4)
+    c = O.coords_grid(1, 16, 24) + torch.rand(1, 2, 16, 24, generator=g) * 6 - 3
+    out["sea_16x24"] = {"fmap1": f1, "fmap2": f2, "levels": 4, "radius": 4,
+                        "pyramid": [p.clone() for p in cb.corr_pyramid],
+                        "lookups": {"fractional": {"coords": c, "out": cb(c).clone()}}}
+    torch.save(out, os.path.join(OUT, "corr_lookup.pt"))
+
+
+def golden_update():
+    upd = ref_loader.ref_module("ptlflow.models.raft.update")
+    gma_upd = ref_loader.ref_module("ptlflow.models.gma.update")
+    out = {}
+    for tag, spec, cls, kw in (("basic", basic_spec(), upd.BasicUpdateBlock, dict(corr_levels=4, corr_radius=4, hidden_dim=128)),
+                               ("small", small_spec(), upd.SmallUpdateBlock, dict(corr_levels=4, corr_radius=3, hidden_dim=96))):
+        P = synth_update_block_params(spec, seed=21)
+        m = cls(**kw).eval()
+        m.load_state_dict(P, strict=True)
+        g = torch.Generator().manual_seed(31)
+        B, H, W = 1, 8, 12
+        net = torch.tanh(torch.randn(B, spec.hidden, H, W, generator=g))
+        inp = torch.relu(torch.randn(B, spec.context, H, W, generator=g))
+        corr = torch.randn(B, spec.corr_channels, H, W, generator=g)
+        flow = torch.randn(B, 2, H, W, generator=g) * 3
+        with torch.no_grad():
+            n, mk, d = m(net, inp, corr, flow)
+        out[tag] = {"seed": 21, "net": net, "inp": inp, "corr": corr, "flow": flow,
+                    "net_out": n.clone(), "mask_out": None if mk is None else mk.clone(), "delta_out": d.clone()}
+    # SepConvGRU with the GMA / CCMR input width (C_in = 128 + 384 = 512; gma/update.py:135-137)
+    gru = gma_upd.SepConvGRU(hidden_dim=128, input_dim=384).eval()
+    shapes = {k: tuple(v.shape) for k, v in gru.state_dict().items()}
+    Pg = synth_state_dict(shapes, seed=22)
+    gru.load_state_dict(Pg, strict=True)
+    g = torch.Generator().manual_seed(32)
+    h = torch.tanh(torch.randn(1, 128, 8, 12, generator=g))
+    x = torch.randn(1, 384, 8, 12, generator=g)
+    with torch.no_grad():
+        ho = gru(h, x)
+    out["sepconvgru_512"] = {"seed": 22, "shapes": shapes, "h": h, "x": x, "h_out": ho.clone()}
+    torch.save(out, os.path.join(OUT, "update_block.pt"))
+
+
+def golden_forward():
+    out = {}
+    for tag, small, H, W, iters in (("raft_96x128_it6", False, 96, 128, 6), ("raft_small_128x128_it6", True, 128, 128, 6)):
+        ref = ref_loader.build_raft(small=small, iters=iters)
+        shapes = {k: tuple(v.shape) for k, v in ref.state_dict().items() if not k.startswith("train_metrics")}
+        P = synth_state_dict(shapes, seed=41)
+        missing = ref.load_state_dict(P, strict=False)
+        assert not missing.unexpected_keys and all(k.startswith("train_metrics") for k in missing.missing_keys)
+        x = O.smooth_pair(1, H, W, seed=43)
+        with torch.no_grad():
+            o = ref({"images": x.clone()})
+        out[tag] = {"seed": 41, "shapes": shapes, "small": small, "iters": iters, "images": x,
+                    "flows": o["flows"].clone(), "flow_small": o["flow_small"].clone()}
+    torch.save(out, os.path.join(OUT, "raft_forward.pt"))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(4)
+    golden_corr()
+    golden_update()
+    golden_forward()
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

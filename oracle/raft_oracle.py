@@ -152,6 +152,8 @@ def _gather_zero(vol2d: Tensor, yi: Tensor, xi: Tensor) -> Tensor:
 
 def _fma(a: Tensor, b: Tensor, c: Tensor) -> Tensor:
     """fp32 fused multiply-add emulated through fp64 (24x24-bit product is exact there)."""
+    if a.dtype == torch.float64:  # fp64 sensitivity runs: plain arithmetic
+        return a * b + c
     return (a.double() * b.double() + c.double()).float()
 
 
@@ -195,11 +197,9 @@ def lookup(pyramid: Sequence[Tensor], coords: Tensor, radius: int) -> Tensor:
     return out.permute(0, 3, 1, 2).contiguous()
 
 
-def coords_grid(B: int, h: int, w: int) -> Tensor:
+def coords_grid(B: int, h: int, w: int, dtype=torch.float32) -> Tensor:
     """raft/utils.py:84-91: channel 0 = x, channel 1 = y."""
-    ys, xs = torch.meshgrid(
-        torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij"
-    )
+    ys, xs = torch.meshgrid(torch.arange(h, dtype=dtype), torch.arange(w, dtype=dtype), indexing="ij")
     return torch.stack([xs, ys], dim=0)[None].repeat(B, 1, 1, 1)
 
 
@@ -397,8 +397,8 @@ def raft_forward(P: Params, images: Tensor, iters: int = 32, small: bool = False
     inp = torch.relu(inp)
 
     h, w = image1.shape[-2] // 8, image1.shape[-1] // 8
-    coords0 = coords_grid(B, h, w)
-    coords1 = coords_grid(B, h, w)
+    coords0 = coords_grid(B, h, w, x.dtype)
+    coords1 = coords_grid(B, h, w, x.dtype)
     U = sub(P, "update_block")
     step = small_update_block if small else basic_update_block
     trace = []

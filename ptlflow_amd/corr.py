@@ -1,0 +1,120 @@
+"""Seam B1 — drop-in for ``get_corr_block`` / ``CorrBlock`` (ptlflow/models/raft/corr.py:12-64,104-118;
+identical copies in gma/corr.py, ccmr/corr.py, ms_raft_plus/corr.py; sea_raft/corr.py:71-117 differs
+only in how the pyramid is built).
+
+Same call contract as the reference: built once per forward from ``fmap1, fmap2 [B,D,h,w]``, then
+called ``iters`` times with ``coords [B,2,h,w]`` (x, y in pixels) and returns
+``[B, L*(2r+1)^2, h, w]`` with channel ``l*(2r+1)^2 + (dx+r)*(2r+1) + (dy+r)``.
+
+MI355X layout: the volume is built by one fp32-MFMA GEMM launch (K1) straight into
+``[B*N, h, w]`` maps, pooled by K2, and every lookup is ONE launch over all levels (K3) that
+writes a pixel-major ``[B*N, C]`` buffer; the tensor handed back is a channels-last *view* of that
+buffer (shape and values as the reference, strides NHWC) so the update block's first 1x1
+convolution reads it without any transpose.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import load_native
+
+
+def _ops():
+    load_native()
+    return torch.ops.pfk
+
+
+def to_pixel_major(x: torch.Tensor) -> torch.Tensor:
+    """NCHW (any strides) -> contiguous ``[B, H*W, C]``; free when ``x`` is already channels-last."""
+    B, C, H, W = x.shape
+    if x.dtype != torch.float32:
+        x = x.float()
+    nhwc = x.permute(0, 2, 3, 1)
+    if nhwc.is_contiguous():
+        return nhwc.reshape(B, H * W, C)
+    x = x.contiguous()
+    out = torch.empty(B * H * W, C, device=x.device, dtype=torch.float32)
+    _ops().nchw_to_pm(x, out)
+    return out.view(B, H * W, C)
+
+
+class CorrBlock:
+    """All-pairs correlation pyramid + radius-r lookup on the GPU (inference path; ``coords`` is
+    detached by every caller — raft.py:171 — so no coordinate gradient exists)."""
+
+    def __init__(self, fmap1: torch.Tensor, fmap2: torch.Tensor, num_levels: int = 4, radius: int = 4,
+                 pyramid: str = "avgpool"):
+        if not fmap1.is_cuda:
+            raise RuntimeError("ptlflow_amd.CorrBlock needs GPU tensors (no CPU fallback)")
+        if not 1 <= radius <= 4:
+            raise RuntimeError("radius must be in 1..4")
+        ops = _ops()
+        self.num_levels = num_levels
+        self.radius = radius
+        self.out_dtype = fmap1.dtype
+        B, D, h, w = fmap1.shape
+        self.B, self.h, self.w = B, h, w
+        N = h * w
+        f1 = to_pixel_major(fmap1)
+        scale = 1.0 / math.sqrt(D)
+        self.corr_pyramid: List[torch.Tensor] = []
+        if pyramid == "avgpool":  # raft/corr.py:19-27
+            f2 = to_pixel_major(fmap2)
+            vol = torch.empty(B, N, N, device=f1.device, dtype=torch.float32)
+            ops.corr_volume(f1, f2, scale, vol)
+            lvl = vol.view(B * N, h, w)
+            self.corr_pyramid.append(lvl)
+            for _ in range(num_levels - 1):
+                hl, wl = lvl.shape[1] // 2, lvl.shape[2] // 2
+                nxt = torch.empty(B * N, hl, wl, device=f1.device, dtype=torch.float32)
+                ops.corr_pool2x2(lvl, nxt)
+                self.corr_pyramid.append(nxt)
+                lvl = nxt
+        elif pyramid == "bilinear_f2":  # sea_raft/corr.py:77-84: one GEMM per level
+            f2n = fmap2.float()
+            for l in range(num_levels):
+                if l > 0:
+                    f2n = F.interpolate(f2n, scale_factor=0.5, mode="bilinear", align_corners=False)
+                h2, w2 = f2n.shape[-2:]
+                f2 = to_pixel_major(f2n)
+                vol = torch.empty(B, N, h2 * w2, device=f1.device, dtype=torch.float32)
+                ops.corr_volume(f1, f2, scale, vol)
+                self.corr_pyramid.append(vol.view(B * N, h2, w2))
+        else:
+            raise ValueError(f"unknown pyramid mode {pyramid!r}")
+        n = 2 * radius + 1
+        self.channels = num_levels * n * n
+        self._out: Optional[torch.Tensor] = None
+
+    def lookup_pm(self, coords: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Lookup into a pixel-major ``[B*h*w, C]`` buffer (allocated once and reused unless given)."""
+        if out is None:
+            if self._out is None:
+                self._out = torch.empty(self.B * self.h * self.w, self.channels, device=coords.device,
+                                        dtype=torch.float32)
+            out = self._out
+        c = coords
+        if c.dtype != torch.float32 or not c.is_contiguous():
+            c = c.float().contiguous()
+        _ops().corr_lookup(self.corr_pyramid, c, self.radius, out)
+        return out
+
+    def __call__(self, coords: torch.Tensor) -> torch.Tensor:
+        out = self.lookup_pm(coords)
+        res = out.view(self.B, self.h, self.w, self.channels).permute(0, 3, 1, 2)
+        if self.out_dtype != torch.float32:
+            res = res.to(self.out_dtype)
+        return res
+
+
+def get_corr_block(fmap1: torch.Tensor, fmap2: torch.Tensor, num_levels: int = 4, radius: int = 4,
+                   alternate_corr: bool = False, pyramid: str = "avgpool"):
+    """Same signature as ptlflow/models/raft/corr.py:104-118.  ``alternate_corr=True`` (the on-demand
+    ``alt_cuda_corr`` variant) is a later row of SURVEY.md §8(f); it is refused, not emulated."""
+    if alternate_corr:
+        raise NotImplementedError("alternate_corr (on-demand correlation) is not built yet; use alternate_corr=False")
+    return CorrBlock(fmap1, fmap2, num_levels=num_levels, radius=radius, pyramid=pyramid)

@@ -1,0 +1,183 @@
+// K2 (pyramid pooling) and K3 (radius-r bilinear pyramid lookup) for gfx950.
+//
+// This file is compiled with -ffp-contract=off: the coordinate arithmetic must round after
+// every operation exactly like the reference's chain of separate torch ops
+// (ptlflow/models/raft/utils.py:71-72 then grid_sample's un-normalise), otherwise floor() of the
+// sample position — the tap index — differs from the reference for ~7 % of integer coordinates
+// (SURVEY.md finding 3).  The only fused operations are the three explicit fmaf() of the
+// bilinear accumulation, which reproduce torch's CPU grid_sample bit for bit.
+#include "pfk_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// K3 lookup.  One workgroup per source pixel, one 64-lane wave per pyramid level.
+//
+// All (2r+1)^2 samples of a level share (up to fp32 rounding of the round trip) one fractional
+// offset, so they touch a (2r+2)^2 patch of that pixel's [h_l][w_l] correlation map.  The wave
+// stages a 12x12 patch (one extra ring absorbs the +-1 index wobble of the round trip, so the
+// staged window always contains every tap the reference would read) into LDS with row-contiguous
+// loads — 12 consecutive floats per row, 3 loads per lane — zero-filling everything outside
+// the map (that *is* grid_sample's zero padding), then each lane produces samples k = lane,
+// lane+64 from LDS with its own per-tap floor()/weights.  Algorithmic traffic: (2r+2)^2 reads +
+// (2r+1)^2 writes per pixel per level (20.4 MB / iteration at 55x128, L=4, r=4).
+// ------------------------------------------------------------------------------------------
+constexpr int PATCH = 12;
+constexpr int PATCH_LD = 13;
+
+struct LookupArgs {
+  const float* lv[PFK_MAX_LEVELS];
+  int lh[PFK_MAX_LEVELS];
+  int lw[PFK_MAX_LEVELS];
+  int L, r, B, h, w;
+  const float* coords;
+  float* out;
+  int out_ld;
+};
+
+// pixel -> normalised -> pixel, every step rounded (see file header).
+__device__ __forceinline__ float roundtrip(float p, float size_m1, float half_span) {
+  float g = 2.0f * p;
+  g = g / size_m1;       // correctly rounded IEEE division (hipcc default for fp32)
+  g = g - 1.0f;
+  float ix = g + 1.0f;
+  return ix * half_span;
+}
+
+__device__ __forceinline__ int safe_base(float v) {
+  // integer-valued float -> int; anything non-finite or absurd maps far outside every map so the
+  // patch is staged as zeros (and the weights carry the NaN, as in the reference).
+  return (fabsf(v) < 1.0e9f) ? (int)v : -(1 << 30);
+}
+
+__global__ __launch_bounds__(256) void lookup_kernel(const LookupArgs a) {
+  __shared__ float s_patch[4][PATCH * PATCH_LD];
+  __shared__ float s_x0[4][12], s_wx[4][12], s_y0[4][12], s_wy[4][12];
+
+  const int lane = threadIdx.x & 63;
+  const int wid = threadIdx.x >> 6;
+  const long long p = blockIdx.x;
+  const int N = a.h * a.w;
+  const int b = (int)(p / N);
+  const int pix = (int)(p % N);
+  const float cx0 = a.coords[((long long)b * 2 + 0) * N + pix];
+  const float cy0 = a.coords[((long long)b * 2 + 1) * N + pix];
+  const int r = a.r;
+  const int n = 2 * r + 1;
+  const int nn = n * n;
+
+  const int rounds = (a.L + 3) >> 2;
+  for (int it = 0; it < rounds; ++it) {
+    const int l = it * 4 + wid;
+    const bool active = l < a.L;
+    float xb = 0.f, yb = 0.f;
+    if (active) {
+      const int Hl = a.lh[l], Wl = a.lw[l];
+      const float inv = 1.0f / (float)(1 << l);   // coords / 2**l is exact (corr.py:45)
+      const float cx = cx0 * inv, cy = cy0 * inv;
+      xb = floorf(cx) - (float)(r + 1);
+      yb = floorf(cy) - (float)(r + 1);
+      if (lane < n) {
+        const float off = (float)(lane - r);
+        const float ix = roundtrip(cx + off, (float)(Wl - 1), (float)(Wl - 1) * 0.5f);
+        const float iy = roundtrip(cy + off, (float)(Hl - 1), (float)(Hl - 1) * 0.5f);
+        const float x0 = floorf(ix), y0 = floorf(iy);
+        s_x0[wid][lane] = x0;
+        s_wx[wid][lane] = ix - x0;
+        s_y0[wid][lane] = y0;
+        s_wy[wid][lane] = iy - y0;
+      }
+      const int xbi = safe_base(xb), ybi = safe_base(yb);
+      const float* vol = a.lv[l] + p * (long long)Hl * Wl;
+#pragma unroll
+      for (int e = lane; e < PATCH * PATCH; e += 64) {
+        const int yy = e / PATCH, xx = e - yy * PATCH;
+        const int gy = ybi + yy, gx = xbi + xx;
+        float v = 0.f;
+        if ((unsigned)gy < (unsigned)Hl && (unsigned)gx < (unsigned)Wl)
+          v = vol[(long long)gy * Wl + gx];
+        s_patch[wid][yy * PATCH_LD + xx] = v;
+      }
+    }
+    __syncthreads();
+    if (active) {
+      float* o = a.out + p * a.out_ld + l * nn;
+      for (int k = lane; k < nn; k += 64) {
+        const int i = k / n, j = k - i * n;
+        const float x0 = s_x0[wid][i], wx = s_wx[wid][i];
+        const float y0 = s_y0[wid][j], wy = s_wy[wid][j];
+        const float dxf = x0 - xb, dyf = y0 - yb;
+        const int rx = (dxf >= 0.f && dxf <= (float)(PATCH - 2)) ? (int)dxf : 0;
+        const int ry = (dyf >= 0.f && dyf <= (float)(PATCH - 2)) ? (int)dyf : 0;
+        const float* q = &s_patch[wid][ry * PATCH_LD + rx];
+        const float nw = q[0], ne = q[1], sw = q[PATCH_LD], se = q[PATCH_LD + 1];
+        const float ex = 1.0f - wx, sy = 1.0f - wy;
+        const float w_nw = sy * ex, w_ne = sy * wx, w_sw = wy * ex, w_se = wy * wx;
+        float t = nw * w_nw;
+        t = fmaf(ne, w_ne, t);
+        t = fmaf(sw, w_sw, t);
+        t = fmaf(se, w_se, t);
+        o[k] = t;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K2 pooling: one thread per output element, HBM-bound (reads 4 B x 4, writes 4 B).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pool2x2_kernel(const float* __restrict__ in,
+                                                      float* __restrict__ out, long long total,
+                                                      int H, int W, int Ho, int Wo) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+    const int xo = (int)(idx % Wo);
+    const long long t = idx / Wo;
+    const int yo = (int)(t % Ho);
+    const long long m = t / Ho;
+    const float* src = in + (m * H + 2 * yo) * (long long)W + 2 * xo;
+    const float a00 = src[0], a01 = src[1], a10 = src[W], a11 = src[W + 1];
+    out[idx] = (((a00 + a01) + a10) + a11) * 0.25f;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int pfk_corr_lookup_f32(const pfk_lookup_desc* d, pfk_stream_t stream) {
+  if (!d || !d->coords || !d->out) return PFK_ERR_BAD_ARG;
+  if (d->num_levels < 1 || d->num_levels > PFK_MAX_LEVELS) return PFK_ERR_BAD_ARG;
+  if (d->radius < 1 || d->radius > 4) return PFK_ERR_UNSUPPORTED;
+  if (d->B <= 0 || d->h <= 0 || d->w <= 0) return PFK_ERR_BAD_ARG;
+  const int n = 2 * d->radius + 1;
+  if (d->out_ld < d->num_levels * n * n) return PFK_ERR_BAD_ARG;
+  LookupArgs a{};
+  for (int l = 0; l < d->num_levels; ++l) {
+    if (!d->levels[l] || d->lvl_h[l] <= 0 || d->lvl_w[l] <= 0) return PFK_ERR_BAD_ARG;
+    a.lv[l] = d->levels[l]; a.lh[l] = d->lvl_h[l]; a.lw[l] = d->lvl_w[l];
+  }
+  a.L = d->num_levels; a.r = d->radius; a.B = d->B; a.h = d->h; a.w = d->w;
+  a.coords = d->coords; a.out = d->out; a.out_ld = d->out_ld;
+  const long long blocks = (long long)d->B * d->h * d->w;
+  if (blocks > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(lookup_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), a);
+  return pfk_launch_status();
+}
+
+int pfk_corr_pool2x2_f32(const float* in, float* out, int64_t M, int H, int W,
+                         pfk_stream_t stream) {
+  if (!in || !out || M <= 0 || H <= 0 || W <= 0) return PFK_ERR_BAD_ARG;
+  const int Ho = H / 2, Wo = W / 2;
+  const long long total = (long long)M * Ho * Wo;
+  if (total == 0) return PFK_OK;  // a 1-pixel level pools to nothing
+  long long blocks = (total + 255) / 256;
+  if (blocks > 256LL * 32) blocks = 256LL * 32;  // grid-stride beyond 32 blocks per CU
+  hipLaunchKernelGGL(pool2x2_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), in, out, total, H, W, Ho, Wo);
+  return pfk_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,286 @@
+// Small direct (VALU) kernels around the MFMA convolutions: the 2-channel 7x7 flow convolution,
+// the 2-output flow head fused with the coordinate update, convex upsampling, layout changes.
+// None of them is GEMM-shaped enough to pay for a matrix-core tile; they are bandwidth/latency
+// bound and written for coalesced 64-lane access.
+#include "pfk_common.h"
+
+namespace {
+
+// out[p][co] = relu?( bias[co] + sum_{tap} in[p+off][0]*w[tap][0][co] + in[p+off][1]*w[tap][1][co] )
+// raft/update.py:100,107 (convf1).  Thread per (pixel, co); the flow taps are wave-broadcast
+// loads, the weights are read coalesced along co.
+__global__ __launch_bounds__(256) void conv_cin2_kernel(const float* __restrict__ in, int in_ld,
+                                                        const float* __restrict__ wgt,
+                                                        const float* __restrict__ bias,
+                                                        float* __restrict__ out, int out_ld,
+                                                        int out_coff, long long M, int H, int W,
+                                                        int k, int cout, int relu) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= M * cout) return;
+  const long long p = idx / cout;
+  const int co = (int)(idx - p * cout);
+  const int x = (int)(p % W);
+  const int y = (int)((p / W) % H);
+  const int half = k >> 1;
+  float acc = bias ? bias[co] : 0.f;
+  for (int ky = 0; ky < k; ++ky) {
+    const int yy = y + ky - half;
+    if ((unsigned)yy >= (unsigned)H) continue;
+    for (int kx = 0; kx < k; ++kx) {
+      const int xx = x + kx - half;
+      if ((unsigned)xx >= (unsigned)W) continue;
+      const float* src = in + (p + (long long)(ky - half) * W + (kx - half)) * in_ld;
+      const float* w = wgt + (long long)(ky * k + kx) * 2 * cout;
+      acc = fmaf(src[0], w[co], acc);
+      acc = fmaf(src[1], w[cout + co], acc);
+    }
+  }
+  if (relu) acc = (acc < 0.f) ? 0.f : acc;  // NaN-propagating like torch.relu
+  out[p * out_ld + out_coff + co] = acc;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// FlowHead.conv2 (3x3, cin -> 2; raft/update.py:10,14) + RAFT loop bookkeeping (raft.py:174,178).
+// One wave per pixel: lanes split the input channels (float4 each, coalesced 1 KiB rows), two
+// butterfly reductions, lane 0 applies coords1 += delta and flow = coords1 - coords0.
+__global__ __launch_bounds__(256) void flow_delta_kernel(
+    const float* __restrict__ in, int in_ld, int cin, const float* __restrict__ wgt,
+    const float* __restrict__ bias, const float* __restrict__ coords0, float* coords1,
+    float* delta_out, float* flow_out, int flow_ld, long long M, int H, int W) {
+  const int lane = threadIdx.x & 63;
+  const long long p = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= M) return;
+  const int x = (int)(p % W);
+  const int y = (int)((p / W) % H);
+  float s0 = 0.f, s1 = 0.f;
+  for (int ky = 0; ky < 3; ++ky) {
+    const int yy = y + ky - 1;
+    if ((unsigned)yy >= (unsigned)H) continue;
+    for (int kx = 0; kx < 3; ++kx) {
+      const int xx = x + kx - 1;
+      if ((unsigned)xx >= (unsigned)W) continue;
+      const float* src = in + (p + (long long)(ky - 1) * W + (kx - 1)) * in_ld;
+      const float* w0 = wgt + (long long)((ky * 3 + kx) * 2) * cin;
+      const float* w1 = w0 + cin;
+      for (int c = lane * 4; c < cin; c += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + c);
+        const f32x4 a = *reinterpret_cast<const f32x4*>(w0 + c);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(w1 + c);
+        s0 = fmaf(v.x, a.x, fmaf(v.y, a.y, fmaf(v.z, a.z, fmaf(v.w, a.w, s0))));
+        s1 = fmaf(v.x, b.x, fmaf(v.y, b.y, fmaf(v.z, b.z, fmaf(v.w, b.w, s1))));
+      }
+    }
+  }
+  s0 = wave_sum(s0);
+  s1 = wave_sum(s1);
+  if (lane == 0) {
+    const long long hw = (long long)H * W;
+    const long long b = p / hw, pix = p - b * hw;
+    const long long ix = (b * 2 + 0) * hw + pix, iy = (b * 2 + 1) * hw + pix;
+    const float dx = s0 + (bias ? bias[0] : 0.f);
+    const float dy = s1 + (bias ? bias[1] : 0.f);
+    const float c1x = __fadd_rn(coords1[ix], dx);
+    const float c1y = __fadd_rn(coords1[iy], dy);
+    coords1[ix] = c1x;
+    coords1[iy] = c1y;
+    if (delta_out) { delta_out[ix] = dx; delta_out[iy] = dy; }
+    if (flow_out) {
+      flow_out[p * flow_ld + 0] = __fsub_rn(c1x, coords0[ix]);
+      flow_out[p * flow_ld + 1] = __fsub_rn(c1y, coords0[iy]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void flow_from_coords_kernel(const float* __restrict__ c0,
+                                                               const float* __restrict__ c1,
+                                                               float* __restrict__ flow_out,
+                                                               int flow_ld, long long M,
+                                                               long long hw) {
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= M) return;
+  const long long b = p / hw, pix = p - b * hw;
+  const long long ix = (b * 2 + 0) * hw + pix, iy = (b * 2 + 1) * hw + pix;
+  flow_out[p * flow_ld + 0] = c1[ix] - c0[ix];
+  flow_out[p * flow_ld + 1] = c1[iy] - c0[iy];
+}
+
+// RAFT.upsample_flow (raft.py:112-123).  One wave per coarse pixel, lane = sy*8 + sx: the nine
+// mask reads are 256-byte coalesced rows, the 3x3 flow neighbourhood is broadcast.
+__global__ __launch_bounds__(256) void convex_upsample_kernel(const float* __restrict__ flow,
+                                                              const float* __restrict__ mask,
+                                                              int mask_ld, float* __restrict__ out,
+                                                              long long M, int H, int W) {
+  const int lane = threadIdx.x & 63;
+  const long long p = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= M) return;
+  const long long hw = (long long)H * W;
+  const long long b = p / hw;
+  const int pix = (int)(p - b * hw);
+  const int y = pix / W, x = pix - y * W;
+  const float* mrow = mask + p * mask_ld + lane;
+  float m[9];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { m[k] = mrow[k * 64]; mx = fmaxf(mx, m[k]); }
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { m[k] = expf(m[k] - mx); sum += m[k]; }
+  const float inv = 1.0f / sum;
+  float ox = 0.f, oy = 0.f;
+  const float* fx = flow + (b * 2 + 0) * hw;
+  const float* fy = flow + (b * 2 + 1) * hw;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
+    float vx = 0.f, vy = 0.f;
+    if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
+      vx = 8.0f * fx[yy * W + xx];
+      vy = 8.0f * fy[yy * W + xx];
+    }
+    const float wk = m[k] * inv;
+    ox += wk * vx;
+    oy += wk * vy;
+  }
+  const int sy = lane >> 3, sx = lane & 7;
+  const long long HW8 = hw * 64;
+  const long long o = (long long)(8 * y + sy) * (8 * W) + 8 * x + sx;
+  out[(b * 2 + 0) * HW8 + o] = ox;
+  out[(b * 2 + 1) * HW8 + o] = oy;
+}
+
+// 32x32 LDS tile transposes between NCHW ([C][HW] per image) and pixel-major ([HW][ld]).
+__global__ __launch_bounds__(256) void nchw_to_pm_kernel(const float* __restrict__ in,
+                                                         float* __restrict__ out, int out_ld,
+                                                         int out_coff, int C, int HW) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const float* src = in + (long long)b * C * HW;
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, p = p0 + tx;
+    tile[i][tx] = (c < C && p < HW) ? src[(long long)c * HW + p] : 0.f;
+  }
+  __syncthreads();
+  float* dst = out + (long long)b * HW * out_ld + out_coff;
+  for (int i = ty; i < 32; i += 8) {
+    const int p = p0 + i, c = c0 + tx;
+    if (p < HW && c < C) dst[(long long)p * out_ld + c] = tile[tx][i];
+  }
+}
+
+__global__ __launch_bounds__(256) void pm_to_nchw_kernel(const float* __restrict__ in, int in_ld,
+                                                         int in_coff, float* __restrict__ out,
+                                                         int C, int HW) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const float* src = in + (long long)b * HW * in_ld + in_coff;
+  for (int i = ty; i < 32; i += 8) {
+    const int p = p0 + i, c = c0 + tx;
+    tile[i][tx] = (p < HW && c < C) ? src[(long long)p * in_ld + c] : 0.f;
+  }
+  __syncthreads();
+  float* dst = out + (long long)b * C * HW;
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, p = p0 + tx;
+    if (c < C && p < HW) dst[(long long)c * HW + p] = tile[tx][i];
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int pfk_abi_version(void) { return PFK_ABI_VERSION; }
+
+const char* pfk_status_string(int status) {
+  switch (status) {
+    case PFK_OK: return "ok";
+    case PFK_ERR_BAD_ARG: return "bad argument";
+    case PFK_ERR_ALIGNMENT: return "pointer/stride alignment";
+    case PFK_ERR_UNSUPPORTED: return "unsupported shape";
+    case PFK_ERR_LAUNCH: return "kernel launch failed";
+    default: return "unknown status";
+  }
+}
+
+int pfk_conv_cin2_f32(const float* in, int in_ld, const float* weight, const float* bias,
+                      float* out, int out_ld, int out_coff, int B, int H, int W, int k, int cout,
+                      int relu, pfk_stream_t stream) {
+  if (!in || !weight || !out || B <= 0 || H <= 0 || W <= 0 || cout <= 0) return PFK_ERR_BAD_ARG;
+  if (k <= 0 || !(k & 1) || in_ld < 2 || out_ld < out_coff + cout) return PFK_ERR_BAD_ARG;
+  const long long M = (long long)B * H * W;
+  const long long blocks = (M * cout + 255) / 256;
+  if (blocks > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(conv_cin2_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), in, in_ld, weight, bias, out, out_ld,
+                     out_coff, M, H, W, k, cout, relu);
+  return pfk_launch_status();
+}
+
+int pfk_flow_delta_f32(const float* in, int in_ld, int cin, const float* weight,
+                       const float* bias, const float* coords0, float* coords1, float* delta_out,
+                       float* flow_out, int flow_ld, int B, int H, int W, pfk_stream_t stream) {
+  if (!in || !weight || !coords0 || !coords1 || B <= 0 || H <= 0 || W <= 0) return PFK_ERR_BAD_ARG;
+  if (cin <= 0 || in_ld < cin || (flow_out && flow_ld < 2)) return PFK_ERR_BAD_ARG;
+  if (!pfk_aligned16(in) || !pfk_aligned16(weight) || (in_ld & 3) || (cin & 3))
+    return PFK_ERR_ALIGNMENT;
+  const long long M = (long long)B * H * W;
+  const long long blocks = (M + 3) / 4;
+  if (blocks > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(flow_delta_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), in, in_ld, cin, weight, bias, coords0,
+                     coords1, delta_out, flow_out, flow_ld, M, H, W);
+  return pfk_launch_status();
+}
+
+int pfk_flow_from_coords_f32(const float* coords0, const float* coords1, float* flow_out,
+                             int flow_ld, int B, int H, int W, pfk_stream_t stream) {
+  if (!coords0 || !coords1 || !flow_out || flow_ld < 2 || B <= 0 || H <= 0 || W <= 0)
+    return PFK_ERR_BAD_ARG;
+  const long long M = (long long)B * H * W;
+  hipLaunchKernelGGL(flow_from_coords_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), coords0, coords1, flow_out, flow_ld, M,
+                     (long long)H * W);
+  return pfk_launch_status();
+}
+
+int pfk_convex_upsample_f32(const float* flow, const float* mask, int mask_ld, float* out, int B,
+                            int H, int W, pfk_stream_t stream) {
+  if (!flow || !mask || !out || mask_ld < 576 || B <= 0 || H <= 0 || W <= 0) return PFK_ERR_BAD_ARG;
+  const long long M = (long long)B * H * W;
+  hipLaunchKernelGGL(convex_upsample_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), flow, mask, mask_ld, out, M, H, W);
+  return pfk_launch_status();
+}
+
+int pfk_nchw_to_pm_f32(const float* in, float* out, int out_ld, int out_coff, int B, int C, int H,
+                       int W, pfk_stream_t stream) {
+  if (!in || !out || B <= 0 || C <= 0 || H <= 0 || W <= 0 || out_ld < out_coff + C)
+    return PFK_ERR_BAD_ARG;
+  const int HW = H * W;
+  dim3 grid((HW + 31) / 32, (C + 31) / 32, B);
+  hipLaunchKernelGGL(nchw_to_pm_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), in,
+                     out, out_ld, out_coff, C, HW);
+  return pfk_launch_status();
+}
+
+int pfk_pm_to_nchw_f32(const float* in, int in_ld, int in_coff, float* out, int B, int C, int H,
+                       int W, pfk_stream_t stream) {
+  if (!in || !out || B <= 0 || C <= 0 || H <= 0 || W <= 0 || in_ld < in_coff + C)
+    return PFK_ERR_BAD_ARG;
+  const int HW = H * W;
+  dim3 grid((HW + 31) / 32, (C + 31) / 32, B);
+  hipLaunchKernelGGL(pm_to_nchw_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), in,
+                     in_ld, in_coff, out, C, HW);
+  return pfk_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,208 @@
+// torch.ops.pfk.* — the thin PyTorch-ROCm face of libpfk.so.
+//
+// The only translation unit that sees torch headers.  Each op checks device/dtype/layout,
+// unwraps tensors to raw pointers + strides, picks up torch's *current* HIP stream and forwards
+// to the C ABI of include/pfk.h; a non-zero status becomes a RuntimeError (the convention of
+// the reference's own extension, ptlflow/utils/external/alt_cuda_corr/correlation.cpp:19-21).
+// No kernel code, no allocation on the hot path (callers pass output/workspace tensors).
+//
+// Pixel-major activations are passed as 2-D tensors [M, C] whose row stride is the buffer's
+// `ld` — a channel slice of a wider buffer (buf[:, 128:384]) is just a view.
+#include <ATen/ATen.h>
+#include <c10/hip/HIPStream.h>
+#include <torch/library.h>
+
+#include <vector>
+
+#include "pfk.h"
+
+namespace {
+
+using at::Tensor;
+
+void check_ok(int status, const char* what) {
+  TORCH_CHECK(status == PFK_OK, "pfk::", what, " failed: ", pfk_status_string(status), " (", status, ")");
+}
+
+pfk_stream_t cur_stream() { return static_cast<pfk_stream_t>(c10::hip::getCurrentHIPStream().stream()); }
+
+void check_dev_f32(const Tensor& t, const char* name) {
+  TORCH_CHECK(t.is_cuda(), name, " must be a GPU tensor");
+  TORCH_CHECK(t.scalar_type() == at::kFloat, name, " must be float32");
+}
+
+// 2-D row-strided view [M, C] with unit channel stride.
+void check_pm(const Tensor& t, const char* name) {
+  check_dev_f32(t, name);
+  TORCH_CHECK(t.dim() == 2 && (t.size(1) == 1 || t.stride(1) == 1), name,
+              " must be a [pixels, channels] view with contiguous channels");
+}
+
+float* fptr(const Tensor& t) { return t.data_ptr<float>(); }
+
+// out[b,i,j] = scale * <f1[b,i,:], f2[b,j,:]>
+void corr_volume(const Tensor& f1, const Tensor& f2, double scale, Tensor out) {
+  check_dev_f32(f1, "f1"); check_dev_f32(f2, "f2"); check_dev_f32(out, "out");
+  TORCH_CHECK(f1.dim() == 3 && f2.dim() == 3 && out.dim() == 3, "corr_volume: [B,N,D] inputs, [B,N1,N2] out");
+  TORCH_CHECK(f1.is_contiguous() && f2.is_contiguous() && out.is_contiguous(), "corr_volume: contiguous tensors");
+  const int B = f1.size(0), N1 = f1.size(1), D = f1.size(2), N2 = f2.size(1);
+  TORCH_CHECK(f2.size(0) == B && f2.size(2) == D && out.size(0) == B && out.size(1) == N1 && out.size(2) == N2,
+              "corr_volume: shape mismatch");
+  check_ok(pfk_corr_volume_f32(fptr(f1), D, fptr(f2), D, fptr(out), B, N1, N2, D, (float)scale, cur_stream()),
+           "corr_volume");
+}
+
+void corr_pool2x2(const Tensor& in, Tensor out) {
+  check_dev_f32(in, "in"); check_dev_f32(out, "out");
+  TORCH_CHECK(in.dim() == 3 && in.is_contiguous() && out.is_contiguous(), "corr_pool2x2: [M,H,W] contiguous");
+  const int64_t M = in.size(0); const int H = in.size(1), W = in.size(2);
+  TORCH_CHECK(out.numel() == M * (H / 2) * (W / 2), "corr_pool2x2: out has wrong size");
+  if (out.numel() == 0) return;
+  check_ok(pfk_corr_pool2x2_f32(fptr(in), fptr(out), M, H, W, cur_stream()), "corr_pool2x2");
+}
+
+void corr_lookup(at::TensorList levels, const Tensor& coords, int64_t radius, Tensor out) {
+  check_dev_f32(coords, "coords"); check_pm(out, "out");
+  TORCH_CHECK(coords.dim() == 4 && coords.size(1) == 2 && coords.is_contiguous(), "corr_lookup: coords [B,2,h,w] contiguous");
+  TORCH_CHECK(levels.size() >= 1 && levels.size() <= PFK_MAX_LEVELS, "corr_lookup: 1..8 levels");
+  pfk_lookup_desc d{};
+  d.B = coords.size(0); d.h = coords.size(2); d.w = coords.size(3);
+  const int64_t M = (int64_t)d.B * d.h * d.w;
+  for (size_t l = 0; l < levels.size(); ++l) {
+    const Tensor& v = levels[l];
+    check_dev_f32(v, "level");
+    TORCH_CHECK(v.dim() == 3 && v.is_contiguous() && v.size(0) == M, "corr_lookup: level must be [B*N,h_l,w_l] contiguous");
+    d.levels[l] = fptr(v); d.lvl_h[l] = v.size(1); d.lvl_w[l] = v.size(2);
+  }
+  d.num_levels = levels.size(); d.radius = radius;
+  d.coords = fptr(coords); d.out = fptr(out); d.out_ld = out.stride(0);
+  TORCH_CHECK(out.size(0) == M, "corr_lookup: out rows");
+  const int n = 2 * radius + 1;
+  TORCH_CHECK(out.size(1) >= d.num_levels * n * n, "corr_lookup: out channels");
+  check_ok(pfk_corr_lookup_f32(&d, cur_stream()), "corr_lookup");
+}
+
+void conv2d(at::TensorList srcs, int64_t B, int64_t H, int64_t W, int64_t kh, int64_t kw,
+            const Tensor& weight, const c10::optional<Tensor>& bias, int64_t cout, int64_t epilogue,
+            bool relu, double scale, const c10::optional<Tensor>& out, const c10::optional<Tensor>& h,
+            const c10::optional<Tensor>& aux_z, const c10::optional<Tensor>& aux_rh) {
+  TORCH_CHECK(srcs.size() >= 1 && srcs.size() <= 3, "conv2d: 1..3 sources");
+  pfk_conv_desc d{};
+  const int64_t M = B * H * W;
+  for (size_t i = 0; i < srcs.size(); ++i) {
+    check_pm(srcs[i], "src");
+    TORCH_CHECK(srcs[i].size(0) == M, "conv2d: src rows != B*H*W");
+    d.src[i].ptr = fptr(srcs[i]); d.src[i].ld = srcs[i].stride(0); d.src[i].channels = srcs[i].size(1);
+  }
+  d.num_src = srcs.size();
+  d.B = B; d.H = H; d.W = W; d.kh = kh; d.kw = kw; d.cout = cout;
+  d.epilogue = epilogue; d.relu = relu; d.scale = (float)scale;
+  check_dev_f32(weight, "weight");
+  TORCH_CHECK(weight.is_contiguous() && weight.dim() == 2 && weight.size(0) == cout, "conv2d: packed weight [cout, ktot]");
+  TORCH_CHECK(weight.size(1) == pfk_conv_ktot(&d), "conv2d: packed weight has ktot ", weight.size(1), ", expected ", pfk_conv_ktot(&d));
+  d.weight = fptr(weight);
+  if (bias.has_value()) { check_dev_f32(*bias, "bias"); TORCH_CHECK(bias->numel() == cout && bias->is_contiguous()); d.bias = fptr(*bias); }
+  if (out.has_value()) {
+    check_pm(*out, "out");
+    TORCH_CHECK(out->size(0) == M && out->size(1) == cout, "conv2d: out must be a [M, cout] view");
+    d.out = fptr(*out); d.out_ld = out->stride(0); d.out_coff = 0;
+  }
+  if (h.has_value()) { check_pm(*h, "h"); TORCH_CHECK(h->size(0) == M); d.h = fptr(*h); d.h_ld = h->stride(0); }
+  if (aux_z.has_value()) { check_dev_f32(*aux_z, "aux_z"); TORCH_CHECK(aux_z->is_contiguous()); d.aux_z = fptr(*aux_z); }
+  if (aux_rh.has_value()) { check_dev_f32(*aux_rh, "aux_rh"); TORCH_CHECK(aux_rh->is_contiguous()); d.aux_rh = fptr(*aux_rh); }
+  check_ok(pfk_conv2d_f32(&d, cur_stream()), "conv2d");
+}
+
+void conv_cin2(const Tensor& in, const Tensor& weight, const c10::optional<Tensor>& bias, Tensor out,
+               int64_t B, int64_t H, int64_t W, int64_t k, bool relu) {
+  check_pm(in, "in"); check_pm(out, "out"); check_dev_f32(weight, "weight");
+  const int cout = out.size(1);
+  TORCH_CHECK(weight.is_contiguous() && weight.numel() == k * k * 2 * cout, "conv_cin2: weight [k*k,2,cout]");
+  TORCH_CHECK(in.size(0) == B * H * W && out.size(0) == B * H * W && in.size(1) >= 2);
+  const float* bp = nullptr;
+  if (bias.has_value()) { check_dev_f32(*bias, "bias"); bp = fptr(*bias); }
+  check_ok(pfk_conv_cin2_f32(fptr(in), in.stride(0), fptr(weight), bp, fptr(out), out.stride(0), 0, B, H, W, k,
+                             cout, relu, cur_stream()), "conv_cin2");
+}
+
+void flow_delta(const Tensor& in, const Tensor& weight, const c10::optional<Tensor>& bias, const Tensor& coords0,
+                Tensor coords1, const c10::optional<Tensor>& delta_out, const c10::optional<Tensor>& flow_out) {
+  check_pm(in, "in"); check_dev_f32(weight, "weight"); check_dev_f32(coords0, "coords0"); check_dev_f32(coords1, "coords1");
+  TORCH_CHECK(coords0.dim() == 4 && coords0.size(1) == 2 && coords0.is_contiguous() && coords1.is_contiguous() &&
+              coords1.sizes() == coords0.sizes(), "flow_delta: coords [B,2,h,w] contiguous");
+  const int B = coords0.size(0), H = coords0.size(2), W = coords0.size(3), cin = in.size(1);
+  TORCH_CHECK(in.size(0) == (int64_t)B * H * W && weight.is_contiguous() && weight.numel() == 9 * 2 * cin);
+  const float* bp = nullptr; float* dp = nullptr; float* fp = nullptr; int fld = 0;
+  if (bias.has_value()) { check_dev_f32(*bias, "bias"); bp = fptr(*bias); }
+  if (delta_out.has_value()) { check_dev_f32(*delta_out, "delta"); TORCH_CHECK(delta_out->is_contiguous() && delta_out->sizes() == coords0.sizes()); dp = fptr(*delta_out); }
+  if (flow_out.has_value()) { check_pm(*flow_out, "flow_out"); TORCH_CHECK(flow_out->size(1) >= 2); fp = fptr(*flow_out); fld = flow_out->stride(0); }
+  check_ok(pfk_flow_delta_f32(fptr(in), in.stride(0), cin, fptr(weight), bp, fptr(coords0), fptr(coords1), dp, fp,
+                              fld, B, H, W, cur_stream()), "flow_delta");
+}
+
+void flow_from_coords(const Tensor& coords0, const Tensor& coords1, Tensor flow_out) {
+  check_dev_f32(coords0, "coords0"); check_dev_f32(coords1, "coords1"); check_pm(flow_out, "flow_out");
+  TORCH_CHECK(coords0.dim() == 4 && coords0.is_contiguous() && coords1.is_contiguous() && coords1.sizes() == coords0.sizes());
+  check_ok(pfk_flow_from_coords_f32(fptr(coords0), fptr(coords1), fptr(flow_out), flow_out.stride(0), coords0.size(0),
+                                    coords0.size(2), coords0.size(3), cur_stream()), "flow_from_coords");
+}
+
+void convex_upsample(const Tensor& flow, const Tensor& mask, Tensor out) {
+  check_dev_f32(flow, "flow"); check_pm(mask, "mask"); check_dev_f32(out, "out");
+  TORCH_CHECK(flow.dim() == 4 && flow.size(1) == 2 && flow.is_contiguous() && out.is_contiguous());
+  const int B = flow.size(0), H = flow.size(2), W = flow.size(3);
+  TORCH_CHECK(mask.size(0) == (int64_t)B * H * W && mask.size(1) == 576 && out.numel() == (int64_t)B * 2 * 64 * H * W);
+  check_ok(pfk_convex_upsample_f32(fptr(flow), fptr(mask), mask.stride(0), fptr(out), B, H, W, cur_stream()),
+           "convex_upsample");
+}
+
+void nchw_to_pm(const Tensor& in, Tensor out) {
+  check_dev_f32(in, "in"); check_pm(out, "out");
+  TORCH_CHECK(in.dim() == 4 && in.is_contiguous());
+  const int B = in.size(0), C = in.size(1), H = in.size(2), W = in.size(3);
+  TORCH_CHECK(out.size(0) == (int64_t)B * H * W && out.size(1) == C);
+  check_ok(pfk_nchw_to_pm_f32(fptr(in), fptr(out), out.stride(0), 0, B, C, H, W, cur_stream()), "nchw_to_pm");
+}
+
+void pm_to_nchw(const Tensor& in, Tensor out) {
+  check_pm(in, "in"); check_dev_f32(out, "out");
+  TORCH_CHECK(out.dim() == 4 && out.is_contiguous());
+  const int B = out.size(0), C = out.size(1), H = out.size(2), W = out.size(3);
+  TORCH_CHECK(in.size(0) == (int64_t)B * H * W && in.size(1) == C);
+  check_ok(pfk_pm_to_nchw_f32(fptr(in), in.stride(0), 0, fptr(out), B, C, H, W, cur_stream()), "pm_to_nchw");
+}
+
+int64_t abi_version() { return pfk_abi_version(); }
+void debug_set_tile(int64_t cfg) { pfk_debug_set_tile((int)cfg); }
+
+}  // namespace
+
+TORCH_LIBRARY(pfk, m) {
+  m.def("abi_version() -> int", &abi_version);
+  m.def("debug_set_tile(int cfg) -> ()", &debug_set_tile);
+  m.def("corr_volume(Tensor f1, Tensor f2, float scale, Tensor(a!) out) -> ()");
+  m.def("corr_pool2x2(Tensor inp, Tensor(a!) out) -> ()");
+  m.def("corr_lookup(Tensor[] levels, Tensor coords, int radius, Tensor(a!) out) -> ()");
+  m.def("conv2d(Tensor[] srcs, int B, int H, int W, int kh, int kw, Tensor weight, Tensor? bias, int cout, "
+        "int epilogue, bool relu, float scale, Tensor(a!)? out, Tensor(b!)? h, Tensor(c!)? aux_z, Tensor(d!)? aux_rh) -> ()");
+  m.def("conv_cin2(Tensor inp, Tensor weight, Tensor? bias, Tensor(a!) out, int B, int H, int W, int k, bool relu) -> ()");
+  m.def("flow_delta(Tensor inp, Tensor weight, Tensor? bias, Tensor coords0, Tensor(a!) coords1, Tensor(b!)? delta_out, "
+        "Tensor(c!)? flow_out) -> ()");
+  m.def("flow_from_coords(Tensor coords0, Tensor coords1, Tensor(a!) flow_out) -> ()");
+  m.def("convex_upsample(Tensor flow, Tensor mask, Tensor(a!) out) -> ()");
+  m.def("nchw_to_pm(Tensor inp, Tensor(a!) out) -> ()");
+  m.def("pm_to_nchw(Tensor inp, Tensor(a!) out) -> ()");
+}
+
+TORCH_LIBRARY_IMPL(pfk, CUDA, m) {
+  m.impl("corr_volume", &corr_volume);
+  m.impl("corr_pool2x2", &corr_pool2x2);
+  m.impl("corr_lookup", &corr_lookup);
+  m.impl("conv2d", &conv2d);
+  m.impl("conv_cin2", &conv_cin2);
+  m.impl("flow_delta", &flow_delta);
+  m.impl("flow_from_coords", &flow_from_coords);
+  m.impl("convex_upsample", &convex_upsample);
+  m.impl("nchw_to_pm", &nchw_to_pm);
+  m.impl("pm_to_nchw", &pm_to_nchw);
+}

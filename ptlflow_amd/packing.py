@@ -1,0 +1,49 @@
+"""Weight re-layout for the implicit-GEMM kernels (one-off host glue, pure tensor reshapes).
+
+A PyTorch conv weight ``[cout, cin, kh, kw]`` becomes the K-contiguous matrix ``[cout, ktot]`` that
+``pfk_conv2d_f32`` reads as its B operand (include/pfk.h): for every input *segment* (a channel
+range of the reference's ``torch.cat`` operand that lives in its own pixel-major buffer slice), for
+every tap (ky major, kx minor), the segment's channels zero-padded to a multiple of 32.
+"""
+from __future__ import annotations
+
+from typing import Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+
+def round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def pack_conv_weight(weight: torch.Tensor, segments: Sequence[Tuple[int, int, int]]) -> torch.Tensor:
+    """``segments`` = [(first_channel, n_channels, n_channels_in_buffer)], in source order.
+
+    ``n_channels_in_buffer`` >= ``n_channels`` is how many channels the kernel is told the source
+    has (a multiple of 4; extra ones are zero padding in the buffer and get zero weights here)."""
+    cout, cin, kh, kw = weight.shape
+    parts = []
+    for first, n, n_buf in segments:
+        assert first + n <= cin and n_buf >= n and n_buf % 4 == 0
+        w = weight[:, first:first + n].permute(0, 2, 3, 1)  # [cout, kh, kw, n]
+        w = F.pad(w, (0, round_up(n_buf, 32) - n))
+        parts.append(w.reshape(cout, -1))
+    return torch.cat(parts, dim=1).contiguous()
+
+
+def pack_cin2_weight(weight: torch.Tensor) -> torch.Tensor:
+    """[cout, 2, k, k] -> [k*k, 2, cout] for pfk_conv_cin2_f32."""
+    cout, cin, kh, kw = weight.shape
+    assert cin == 2 and kh == kw
+    return weight.permute(2, 3, 1, 0).reshape(kh * kw, 2, cout).contiguous()
+
+
+def pack_flow_head_weight(weight: torch.Tensor, cin_buf: int = 0) -> torch.Tensor:
+    """[2, cin, 3, 3] -> [9, 2, cin_buf] for pfk_flow_delta_f32."""
+    cout, cin, kh, kw = weight.shape
+    assert cout == 2 and kh == 3 and kw == 3
+    w = weight.permute(2, 3, 0, 1).reshape(9, 2, cin)
+    if cin_buf > cin:
+        w = F.pad(w, (0, cin_buf - cin))
+    return w.contiguous()

@@ -1,0 +1,229 @@
+"""Host-side mirror of the reference's RAFT / RAFTSmall callers (ptlflow/models/raft/raft.py:48-234)
+for machines where ptlflow itself is not installed (the GPU bench box, CI).
+
+Same constructor arguments that matter on the path, same ``forward(inputs) -> outputs`` dict contract
+(``inputs["images"]: [B,2,3,H,W]`` BGR in [0,1]; ``outputs["flows"]: [B,1,2,H,W]``, ``"flow_small"`` in
+eval), and the same ``state_dict`` key names / shapes as the reference classes, so
+``raft-things-802bbcfd.ckpt``-style checkpoints load unchanged (checked against the live reference in
+tests/test_oracle_vs_reference.py).
+
+What runs where:
+* encoders (fnet / cnet, raft/extractor.py) — torch ops on the GPU (MIOpen); SURVEY.md §8(f3) "next";
+* correlation volume, pyramid, per-iteration lookup, the whole update block, coordinate update and
+  convex upsampling — libpfk kernels through torch.ops.pfk, state kept pixel-major across all
+  iterations (no NCHW round trips inside the loop).
+
+On a machine that *has* ptlflow, use `ptlflow_amd.patch.accelerate(model)` on the real model instead.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import load_native
+from .corr import CorrBlock
+from .update import UpdateEngine, UpdateSpec, basic_spec, small_spec
+from .synth import synth_state_dict, update_block_shapes
+
+
+# ----------------------------------------------------------------------------- encoders
+def _make_norm(kind: str, ch: int) -> nn.Module:
+    if kind == "instance":
+        return nn.InstanceNorm2d(ch)
+    if kind == "batch":
+        return nn.BatchNorm2d(ch)
+    if kind == "none":
+        return nn.Sequential()
+    raise ValueError(kind)
+
+
+class _Block(nn.Module):
+    """Residual (3x3,3x3) or bottleneck (1x1,3x3,1x1) unit with the reference's attribute names
+    (raft/extractor.py:6-119) so parameters land on identical state_dict keys."""
+
+    def __init__(self, cin: int, cout: int, kind: str, stride: int, bottleneck: bool):
+        super().__init__()
+        self.bottleneck = bottleneck
+        if bottleneck:
+            mid = cout // 4
+            self.conv1 = nn.Conv2d(cin, mid, 1)
+            self.conv2 = nn.Conv2d(mid, mid, 3, padding=1, stride=stride)
+            self.conv3 = nn.Conv2d(mid, cout, 1)
+            self.norm1, self.norm2, self.norm3 = (_make_norm(kind, c) for c in (mid, mid, cout))
+            extra = "norm4"
+        else:
+            self.conv1 = nn.Conv2d(cin, cout, 3, padding=1, stride=stride)
+            self.conv2 = nn.Conv2d(cout, cout, 3, padding=1)
+            self.norm1, self.norm2 = _make_norm(kind, cout), _make_norm(kind, cout)
+            extra = "norm3"
+        self.downsample = None
+        if stride != 1:
+            setattr(self, extra, _make_norm(kind, cout))
+            self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride=stride), getattr(self, extra))
+
+    def forward(self, x):
+        y = F.relu(self.norm1(self.conv1(x)))
+        y = F.relu(self.norm2(self.conv2(y)))
+        if self.bottleneck:
+            y = F.relu(self.norm3(self.conv3(y)))
+        if self.downsample is not None:
+            x = self.downsample(x)
+        return F.relu(x + y)
+
+
+class Encoder(nn.Module):
+    """BasicEncoder / SmallEncoder (raft/extractor.py:122-267), stride 8."""
+
+    def __init__(self, output_dim: int, norm_fn: str, small: bool):
+        super().__init__()
+        dims = (32, 32, 64, 96) if small else (64, 64, 96, 128)
+        self.norm1 = _make_norm(norm_fn, dims[0])
+        self.conv1 = nn.Conv2d(3, dims[0], 7, stride=2, padding=3)
+        cin = dims[0]
+        for i, (d, stride) in enumerate(zip(dims[1:], (1, 2, 2)), start=1):
+            setattr(self, f"layer{i}", nn.Sequential(_Block(cin, d, norm_fn, stride, small), _Block(d, d, norm_fn, 1, small)))
+            cin = d
+        self.conv2 = nn.Conv2d(cin, output_dim, 1)
+
+    def forward(self, x):
+        x = F.relu(self.norm1(self.conv1(x)))
+        x = self.layer3(self.layer2(self.layer1(x)))
+        return self.conv2(x)
+
+
+# ----------------------------------------------------------------------------- parameter holder
+def _param_tree(shapes: Dict[str, tuple]) -> nn.Module:
+    """Nested modules holding nn.Parameters at the dotted names of `shapes`
+    (`encoder.convc1.weight`, `mask.0.bias`, ...) — a weights-only stand-in for the reference's
+    BasicUpdateBlock whose forward is the kernel chain in `UpdateEngine`."""
+    root = nn.Module()
+    for name, shape in shapes.items():
+        mod = root
+        parts = name.split(".")
+        for p in parts[:-1]:
+            if not hasattr(mod, p):
+                mod.add_module(p, nn.Module())
+            mod = getattr(mod, p)
+        mod.register_parameter(parts[-1], nn.Parameter(torch.zeros(shape)))
+    return root
+
+
+# ----------------------------------------------------------------------------- model
+class RAFT(nn.Module):
+    def __init__(self, corr_levels: int = 4, corr_radius: Optional[int] = None, iters: int = 32, small: bool = False,
+                 upsample_every_iter: bool = True):
+        super().__init__()
+        self.small = small
+        self.corr_levels = corr_levels
+        self.corr_radius = corr_radius if corr_radius is not None else (3 if small else 4)
+        self.iters = iters
+        # The reference computes mask head + convex upsampling on every iteration even in eval, where only
+        # the last one is observable (raft.py:180-187).  True = do the same work; False = skip the dead work.
+        self.upsample_every_iter = upsample_every_iter
+        if small:
+            self.hidden_dim, self.context_dim = 96, 64
+            self.fnet = Encoder(128, "instance", True)
+            self.cnet = Encoder(self.hidden_dim + self.context_dim, "none", True)
+            self.spec: UpdateSpec = small_spec(corr_levels, self.corr_radius)
+        else:
+            self.hidden_dim, self.context_dim = 128, 128
+            self.fnet = Encoder(256, "instance", False)
+            self.cnet = Encoder(self.hidden_dim + self.context_dim, "batch", False)
+            self.spec = basic_spec(corr_levels, self.corr_radius)
+        self.update_block = _param_tree(update_block_shapes(self.spec))
+        self._engine: Optional[UpdateEngine] = None
+        self._versions = None
+
+    # -- weights ---------------------------------------------------------------------------------
+    def load_synthetic(self, seed: int = 1234) -> "RAFT":
+        shapes = {k: tuple(v.shape) for k, v in self.state_dict().items()}
+        self.load_state_dict(synth_state_dict(shapes, seed), strict=True)
+        return self
+
+    def engine(self, device) -> UpdateEngine:
+        params = dict(self.update_block.named_parameters())
+        v = tuple((p.data_ptr(), p._version) for p in params.values())
+        if self._engine is None or self._engine.device != device:
+            self._engine = UpdateEngine(params, self.spec, device)
+        elif v != self._versions:
+            self._engine.pack(params)
+        self._versions = v
+        return self._engine
+
+    # -- pre/post-processing (raft.py:127-135 -> base_model.py:207-247; utils/external/raft.py:57-84)
+    @staticmethod
+    def _pads(ht: int, wd: int, stride: int = 8):
+        ph = (((ht // stride) + 1) * stride - ht) % stride
+        pw = (((wd // stride) + 1) * stride - wd) % stride
+        return (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2)
+
+    def preprocess(self, images: torch.Tensor):
+        x = (images + (-0.5)) * 2.0
+        x = torch.flip(x, [-3])
+        pads = self._pads(x.shape[-2], x.shape[-1])
+        shp = x.shape
+        x = F.pad(x.reshape(-1, *shp[-3:]), pads, mode="replicate")
+        return x.reshape(*shp[:-2], *x.shape[-2:]).contiguous(), pads
+
+    @staticmethod
+    def unpad(x: torch.Tensor, pads):
+        ht, wd = x.shape[-2:]
+        return x[..., pads[2]: ht - pads[3], pads[0]: wd - pads[1]]
+
+    # -- forward -----------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, inputs: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        if self.training:
+            raise RuntimeError("ptlflow_amd.RAFT is the inference mirror; training goes through ptlflow + patch.accelerate")
+        load_native()
+        ops = torch.ops.pfk
+        images = inputs["images"]
+        if not images.is_cuda:
+            raise RuntimeError("ptlflow_amd.RAFT needs GPU inputs (no CPU fallback)")
+        x, pads = self.preprocess(images.float())
+        image1, image2 = x[:, 0], x[:, 1]
+        B = image1.shape[0]
+
+        fm = self.fnet(torch.cat([image1, image2], 0))
+        corr_fn = CorrBlock(fm[:B], fm[B:], num_levels=self.corr_levels, radius=self.corr_radius)
+        cnet = self.cnet(image1)
+        net, inp = torch.split(cnet, [self.hidden_dim, self.context_dim], dim=1)
+        net, inp = torch.tanh(net), torch.relu(inp)
+
+        h, w = image1.shape[-2] // 8, image1.shape[-1] // 8
+        ys, xs = torch.meshgrid(torch.arange(h, device=x.device, dtype=torch.float32),
+                                torch.arange(w, device=x.device, dtype=torch.float32), indexing="ij")
+        coords0 = torch.stack([xs, ys], 0)[None].repeat(B, 1, 1, 1).contiguous()
+        coords1 = coords0.clone()
+        prev = inputs.get("prev_preds")
+        if prev is not None and prev.get("flow_small") is not None:
+            raise NotImplementedError("warm start (forward_interpolate, scipy on host) is outside the accelerated path")
+
+        eng = self.engine(x.device)
+        eng.bind(B, h, w)
+        eng.load_state(net, inp)
+        ops.flow_from_coords(coords0, coords1, eng.flow_view)
+        has_mask = self.spec.has_mask
+        flow_up = torch.empty(B, 2, 8 * h, 8 * w, device=x.device, dtype=torch.float32) if has_mask else None
+        for it in range(self.iters):
+            last = it == self.iters - 1
+            corr_pm = corr_fn.lookup_pm(coords1)
+            do_up = last or self.upsample_every_iter
+            eng.step(corr_pm, coords0, coords1, want_mask=do_up)
+            if do_up:
+                flow = coords1 - coords0
+                if has_mask:
+                    ops.convex_upsample(flow, eng.mask, flow_up)
+                else:  # raft_small: upflow8 (raft/utils.py:94-96)
+                    flow_up = 8 * F.interpolate(flow, size=(8 * h, 8 * w), mode="bilinear", align_corners=True)
+        out_up = self.unpad(flow_up, pads)
+        return {"flows": out_up[:, None], "flow_small": coords1 - coords0}
+
+
+class RAFTSmall(RAFT):
+    def __init__(self, **kw):
+        kw.setdefault("small", True)
+        super().__init__(**kw)

@@ -1,0 +1,294 @@
+"""Seam B3 — the iterative update block (ptlflow/models/raft/update.py:6-153) on gfx950 kernels.
+
+`UpdateEngine` owns the packed weights and the pixel-major work buffers and runs one iteration as a
+fixed chain of launches on torch's current stream:
+
+    lookup (K3, by the caller)                                   -> corr   [M, Cc]
+    convc1 1x1 (+relu)            MFMA implicit GEMM             -> cor1   [M, c1]
+    convc2 3x3 (+relu)            MFMA                           -> corflo [M, :c2]
+    convf1 7x7 on flow (+relu)    direct                         -> flo1   [M, f1]
+    convf2 3x3 (+relu)            MFMA                           -> corflo [M, c2:]
+    conv   3x3 (+relu)            MFMA                           -> hx     [M, Ch+Ci : Ch+Ci+co]
+    GRU pass(es): z|r conv (+sigmoid, r*h)  MFMA, one GEMM for both gates -> z, rh
+                  q conv (+tanh, blend)      MFMA                 -> hx[:, :Ch] (in place)
+    flow-head conv1 | mask conv1 3x3 (+relu)  MFMA, one GEMM      -> fm     [M, 2*fh]
+    flow-head conv2 3x3 -> delta; coords1 += delta; flow = coords1 - coords0   direct, fused
+    mask conv2 1x1, *0.25         MFMA                           -> mask   [M, 576]
+
+``hx`` is the reference's ``torch.cat([net, inp, motion_features])`` laid out once:
+``[ h (Ch) | inp (Ci) | encoder out (co) | flow (2) | zero pad ]`` — every producer writes its channel
+slice in place, so none of the six ``torch.cat`` calls of update.py exists here.
+
+`PfkUpdateBlock` wraps a reference ``BasicUpdateBlock`` / ``SmallUpdateBlock`` module *in place of its
+forward*: the original sub-modules (and therefore ``state_dict`` keys, checkpoints, optimizers) stay,
+weights are re-packed whenever a parameter's ``_version`` changes.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import load_native
+from .packing import pack_cin2_weight, pack_conv_weight, pack_flow_head_weight, round_up
+
+EPI_LINEAR, EPI_GRU_ZR, EPI_GRU_Q = 0, 1, 2
+
+
+@dataclass(frozen=True)
+class UpdateSpec:
+    hidden: int          # Ch
+    context: int         # Ci
+    corr_channels: int   # L*(2r+1)^2
+    c1: int              # convc1 out
+    c2: int              # convc2 out (0: SmallMotionEncoder has no convc2)
+    f1: int              # convf1 out
+    f2: int              # convf2 out
+    enc_out: int         # encoder.conv out (126 / 80)
+    gru_passes: Tuple[Tuple[int, int, str], ...]  # (kh, kw, key suffix)
+    fh_hidden: int
+    has_mask: bool
+
+    @property
+    def x_channels(self) -> int:          # inp | encoder out | flow
+        return self.context + self.enc_out + 2
+
+    @property
+    def hx_channels(self) -> int:         # padded to a multiple of 4
+        return round_up(self.hidden + self.x_channels, 4)
+
+
+def basic_spec(corr_levels: int = 4, corr_radius: int = 4) -> UpdateSpec:
+    """BasicUpdateBlock (raft/update.py:131-142)."""
+    return UpdateSpec(128, 128, corr_levels * (2 * corr_radius + 1) ** 2, 256, 192, 128, 64, 126,
+                      ((1, 5, "1"), (5, 1, "2")), 256, True)
+
+
+def small_spec(corr_levels: int = 4, corr_radius: int = 3) -> UpdateSpec:
+    """SmallUpdateBlock (raft/update.py:115-120)."""
+    return UpdateSpec(96, 64, corr_levels * (2 * corr_radius + 1) ** 2, 96, 0, 64, 32, 80,
+                      ((3, 3, ""),), 128, False)
+
+
+class UpdateEngine:
+    def __init__(self, params: Dict[str, torch.Tensor], spec: UpdateSpec, device: torch.device):
+        load_native()
+        self.ops = torch.ops.pfk
+        self.spec = spec
+        self.device = device
+        self._shape: Optional[Tuple[int, int, int]] = None
+        self.pack(params)
+
+    # ------------------------------------------------------------------ weights
+    def pack(self, P: Dict[str, torch.Tensor]) -> None:
+        s, dev = self.spec, self.device
+
+        def g(name):
+            return P[name].detach().to(device=dev, dtype=torch.float32)
+
+        def seg1(c):
+            return [(0, c, round_up(c, 4))]
+
+        w: Dict[str, torch.Tensor] = {}
+        w["c1.w"] = pack_conv_weight(g("encoder.convc1.weight"), seg1(s.corr_channels))
+        w["c1.b"] = g("encoder.convc1.bias").contiguous()
+        if s.c2:
+            w["c2.w"] = pack_conv_weight(g("encoder.convc2.weight"), seg1(s.c1))
+            w["c2.b"] = g("encoder.convc2.bias").contiguous()
+        w["f1.w"] = pack_cin2_weight(g("encoder.convf1.weight"))
+        w["f1.b"] = g("encoder.convf1.bias").contiguous()
+        w["f2.w"] = pack_conv_weight(g("encoder.convf2.weight"), seg1(s.f1))
+        w["f2.b"] = g("encoder.convf2.bias").contiguous()
+        cf = (s.c2 if s.c2 else s.c1) + s.f2
+        w["cv.w"] = pack_conv_weight(g("encoder.conv.weight"), seg1(cf))
+        w["cv.b"] = g("encoder.conv.bias").contiguous()
+        Ch = s.hidden
+        hxc = s.hx_channels
+        real = Ch + s.x_channels
+        for kh, kw, sfx in s.gru_passes:
+            wz, wr, wq = (g(f"gru.conv{k}{sfx}.weight") for k in "zrq")
+            bz, br, bq = (g(f"gru.conv{k}{sfx}.bias") for k in "zrq")
+            # z|r: one source = the whole hx row (h | x), padded channels get zero weights
+            w[f"zr{sfx}.w"] = pack_conv_weight(torch.cat([wz, wr], 0), [(0, real, hxc)])
+            w[f"zr{sfx}.b"] = torch.cat([bz, br]).contiguous()
+            # q: sources r*h (own buffer) and x (hx slice)
+            w[f"q{sfx}.w"] = pack_conv_weight(wq, [(0, Ch, Ch), (Ch, real - Ch, hxc - Ch)])
+            w[f"q{sfx}.b"] = bq.contiguous()
+        if s.has_mask:
+            w["fm.w"] = pack_conv_weight(torch.cat([g("flow_head.conv1.weight"), g("mask.0.weight")], 0), seg1(Ch))
+            w["fm.b"] = torch.cat([g("flow_head.conv1.bias"), g("mask.0.bias")]).contiguous()
+            w["mk.w"] = pack_conv_weight(g("mask.2.weight"), seg1(s.fh_hidden))
+            w["mk.b"] = g("mask.2.bias").contiguous()
+        else:
+            w["fm.w"] = pack_conv_weight(g("flow_head.conv1.weight"), seg1(Ch))
+            w["fm.b"] = g("flow_head.conv1.bias").contiguous()
+        w["fh2.w"] = pack_flow_head_weight(g("flow_head.conv2.weight"))
+        w["fh2.b"] = g("flow_head.conv2.bias").contiguous()
+        self.w = w
+
+    # ------------------------------------------------------------------ buffers
+    def bind(self, B: int, H: int, W: int) -> None:
+        if self._shape == (B, H, W):
+            return
+        s, dev = self.spec, self.device
+        M = B * H * W
+        z = lambda c: torch.zeros(M, c, device=dev, dtype=torch.float32)  # noqa: E731
+        self.hx = z(s.hx_channels)
+        self.cor1 = z(s.c1) if s.c2 else None   # SmallMotionEncoder: convc1 writes corflo[:, :c1] directly
+        self.corflo = z((s.c2 if s.c2 else s.c1) + s.f2)
+        self.flo1 = z(s.f1)
+        self.zbuf = z(s.hidden)
+        self.rh = z(s.hidden)
+        self.fm = z(s.fh_hidden * (2 if s.has_mask else 1))
+        self.mask = z(576) if s.has_mask else None
+        self._scratch_c0 = torch.zeros(B, 2, H, W, device=dev, dtype=torch.float32)
+        self._scratch_c1 = torch.zeros(B, 2, H, W, device=dev, dtype=torch.float32)
+        self._delta = torch.zeros(B, 2, H, W, device=dev, dtype=torch.float32)
+        self._shape = (B, H, W)
+
+    # views into hx
+    @property
+    def h_view(self):
+        return self.hx[:, : self.spec.hidden]
+
+    @property
+    def inp_view(self):
+        s = self.spec
+        return self.hx[:, s.hidden: s.hidden + s.context]
+
+    @property
+    def x_view(self):
+        return self.hx[:, self.spec.hidden:]
+
+    @property
+    def flow_view(self):
+        s = self.spec
+        o = s.hidden + s.context + s.enc_out
+        return self.hx[:, o: o + 2]
+
+    def load_state(self, net: torch.Tensor, inp: torch.Tensor) -> None:
+        """NCHW ``net`` / ``inp`` -> their hx slices (once per forward)."""
+        self.ops.nchw_to_pm(net.float().contiguous(), self.h_view)
+        self.ops.nchw_to_pm(inp.float().contiguous(), self.inp_view)
+
+    # ------------------------------------------------------------------ one iteration
+    def _conv(self, srcs: List[torch.Tensor], kh, kw, key, cout, relu=True, scale=1.0, out=None,
+              epi=EPI_LINEAR, h=None, z=None, rh=None):
+        B, H, W = self._shape
+        self.ops.conv2d(srcs, B, H, W, kh, kw, self.w[key + ".w"], self.w[key + ".b"], cout, epi, relu, scale,
+                        out, h, z, rh)
+
+    def motion_and_gru(self, corr_pm: torch.Tensor) -> None:
+        """update.py:104-112 (encoder) + :58-73 / :24-32 (GRU); `flow` must already be in hx."""
+        s = self.spec
+        B, H, W = self._shape
+        if s.c2:
+            self._conv([corr_pm], 1, 1, "c1", s.c1, out=self.cor1)
+            self._conv([self.cor1], 3, 3, "c2", s.c2, out=self.corflo[:, : s.c2])
+            cor_c = s.c2
+        else:
+            self._conv([corr_pm], 1, 1, "c1", s.c1, out=self.corflo[:, : s.c1])
+            cor_c = s.c1
+        self.ops.conv_cin2(self.flow_view, self.w["f1.w"], self.w["f1.b"], self.flo1, B, H, W, 7, True)
+        self._conv([self.flo1], 3, 3, "f2", s.f2, out=self.corflo[:, cor_c: cor_c + s.f2])
+        o = s.hidden + s.context
+        self._conv([self.corflo], 3, 3, "cv", s.enc_out, out=self.hx[:, o: o + s.enc_out])
+        Ch = s.hidden
+        for kh, kw, sfx in s.gru_passes:
+            self._conv([self.hx], kh, kw, "zr" + sfx, 2 * Ch, epi=EPI_GRU_ZR, h=self.h_view, z=self.zbuf, rh=self.rh)
+            self._conv([self.rh, self.x_view], kh, kw, "q" + sfx, Ch, epi=EPI_GRU_Q, h=self.h_view, z=self.zbuf)
+
+    def heads(self, coords0: torch.Tensor, coords1: torch.Tensor, delta_out: Optional[torch.Tensor],
+              want_mask: bool = True, write_flow: bool = True) -> None:
+        """update.py:13-14 + :152 and the coordinate bookkeeping of raft.py:174,178."""
+        s = self.spec
+        nf = s.fh_hidden * (2 if s.has_mask else 1)
+        self._conv([self.h_view], 3, 3, "fm", nf, out=self.fm)
+        self.ops.flow_delta(self.fm[:, : s.fh_hidden], self.w["fh2.w"], self.w["fh2.b"], coords0, coords1, delta_out,
+                            self.flow_view if write_flow else None)
+        if s.has_mask and want_mask:
+            self._conv([self.fm[:, s.fh_hidden:]], 1, 1, "mk", 576, relu=False, scale=0.25, out=self.mask)
+
+    def step(self, corr_pm: torch.Tensor, coords0: torch.Tensor, coords1: torch.Tensor, want_mask: bool = True) -> None:
+        """One full RAFT iteration body after the lookup; updates hx (net, flow) and coords1 in place."""
+        self.motion_and_gru(corr_pm)
+        self.heads(coords0, coords1, None, want_mask=want_mask)
+
+    # ------------------------------------------------------------------ NCHW views of the state
+    def nchw_view(self, pm: torch.Tensor) -> torch.Tensor:
+        B, H, W = self._shape
+        return pm.view(B, H, W, pm.shape[1]) if pm.is_contiguous() else pm.unflatten(0, (B, H, W))
+
+    def net_nchw(self) -> torch.Tensor:
+        B, H, W = self._shape
+        return self.h_view.unflatten(0, (B, H, W)).permute(0, 3, 1, 2)
+
+    def mask_nchw(self) -> torch.Tensor:
+        B, H, W = self._shape
+        return self.mask.view(B, H, W, 576).permute(0, 3, 1, 2)
+
+
+class PfkUpdateBlock(torch.nn.Module):
+    """Drop-in for ``model.update_block`` (seam B3): same ``forward(net, inp, corr, flow)`` ->
+    ``(net, mask, delta_flow)`` contract as raft/update.py:144-153 / :122-128, same parameters.
+
+    The tensors handed back are views of the engine's buffers (net: channels-last strides); they are
+    overwritten by the next call, which is how the reference loop uses them (raft.py:169-187)."""
+
+    def __init__(self, ref_block: torch.nn.Module, spec: UpdateSpec):
+        super().__init__()
+        # keep the reference sub-modules so state_dict keys/checkpoints/optimizers are unchanged
+        for name, child in ref_block.named_children():
+            self.add_module(name, child)
+        self.spec = spec
+        self._engine: Optional[UpdateEngine] = None
+        self._versions = None
+        self._inp_key = None
+
+    def _param_versions(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def _get_engine(self, device) -> UpdateEngine:
+        v = self._param_versions()
+        if self._engine is None or self._engine.device != device:
+            self._engine = UpdateEngine(dict(self.named_parameters()), self.spec, device)
+            self._versions = v
+        elif v != self._versions:
+            self._engine.pack(dict(self.named_parameters()))
+            self._versions = v
+        return self._engine
+
+    @torch.no_grad()
+    def forward(self, net, inp, corr, flow):
+        if not net.is_cuda:
+            raise RuntimeError("PfkUpdateBlock needs GPU tensors (no CPU fallback)")
+        eng = self._get_engine(net.device)
+        B, _, H, W = net.shape
+        eng.bind(B, H, W)
+        ops = eng.ops
+        # state in: skip copies when the tensor already *is* our buffer (second iteration onwards)
+        if net.data_ptr() != eng.hx.data_ptr():
+            ops.nchw_to_pm(net.float().contiguous(), eng.h_view)
+        key = (inp.data_ptr(), inp._version, tuple(inp.shape))
+        if key != self._inp_key:
+            ops.nchw_to_pm(inp.float().contiguous(), eng.inp_view)
+            self._inp_key = key
+        # corr: a channels-last view of a [M, C] buffer (what ptlflow_amd.CorrBlock returns) is used as is
+        cpm = corr.permute(0, 2, 3, 1)
+        if corr.dtype == torch.float32 and cpm.is_contiguous():
+            corr_pm = cpm.reshape(B * H * W, corr.shape[1])
+        else:
+            corr_pm = torch.empty(B * H * W, corr.shape[1], device=net.device, dtype=torch.float32)
+            ops.nchw_to_pm(corr.float().contiguous(), corr_pm)
+        ops.nchw_to_pm(flow.float().contiguous(), eng.flow_view)
+        eng.motion_and_gru(corr_pm)
+        eng._scratch_c1.zero_()
+        eng.heads(eng._scratch_c0, eng._scratch_c1, eng._delta, want_mask=True, write_flow=False)
+        mask = eng.mask_nchw() if eng.spec.has_mask else None
+        out_net = eng.net_nchw()
+        delta = eng._delta
+        if net.dtype != torch.float32:
+            out_net, delta = out_net.to(net.dtype), delta.to(net.dtype)
+            mask = mask.to(net.dtype) if mask is not None else None
+        return out_net, mask, delta

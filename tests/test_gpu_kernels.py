@@ -1,0 +1,287 @@
+"""Parity of every libpfk kernel (through torch.ops.pfk -> C ABI) against the CPU oracle.
+
+Tolerances (fp32):
+  * lookup: BIT-EXACT for the same pyramid (tap indices and values) — north-star requirement;
+  * pooling: bit-exact for the same input (same summation order);
+  * GEMM-shaped kernels: |err| <= 2e-5 * (1 + |ref|) — fp32 MFMA accumulates a k-ordered fmaf chain,
+    MKL/oneDNN use a different summation order; values are O(1..10).
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import raft_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+EPI_LINEAR, EPI_GRU_ZR, EPI_GRU_Q = 0, 1, 2
+
+
+def close(a, b, rtol=2e-5, atol=2e-5):
+    a, b = a.float().cpu(), b.float().cpu()
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    assert bool((err <= tol).all()), f"max err {err.max().item():.3e} (ref max {b.abs().max().item():.3e})"
+
+
+def pm(x):  # NCHW cpu -> [M, C] gpu
+    B, C, H, W = x.shape
+    return x.permute(0, 2, 3, 1).reshape(B * H * W, C).contiguous().cuda()
+
+
+def unpm(x, B, H, W):
+    return x.view(B, H, W, -1).permute(0, 3, 1, 2).cpu()
+
+
+@pytest.mark.parametrize("B,h,w,D", [(1, 16, 24, 64), (2, 9, 13, 128), (1, 55, 128, 256)])
+def test_corr_volume(gpu, B, h, w, D):
+    torch.manual_seed(0)
+    f1, f2 = torch.randn(B, D, h, w), torch.randn(B, D, h, w)
+    ref = O.all_pairs_correlation(f1, f2)
+    N = h * w
+    out = torch.empty(B, N, N, device=gpu)
+    torch.ops.pfk.corr_volume(pm(f1).view(B, N, D), pm(f2).view(B, N, D), 1.0 / math.sqrt(D), out)
+    close(out.view(B * N, 1, h, w), ref, rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("M,H,W", [(7, 55, 128), (64, 27, 64), (5, 13, 32), (3, 6, 16), (4, 3, 5), (2, 1, 2)])
+def test_pool_bit_exact(gpu, M, H, W):
+    torch.manual_seed(1)
+    x = torch.randn(M, 1, H, W)
+    ref = O.pool2x2(x)
+    out = torch.empty(M, H // 2, W // 2, device=gpu)
+    torch.ops.pfk.corr_pool2x2(x.view(M, H, W).cuda(), out)
+    assert torch.equal(out.cpu(), ref.view(M, H // 2, W // 2))
+
+
+def _coords_cases(B, h, w):
+    g = torch.Generator().manual_seed(7)
+    c0 = O.coords_grid(B, h, w)
+    yield "integer", c0
+    yield "fractional", c0 + torch.rand(B, 2, h, w, generator=g) * 16 - 8
+    yield "half", c0 + 0.5
+    yield "out_of_bounds", c0 + torch.randn(B, 2, h, w, generator=g) * 80
+    edge = c0.clone()
+    edge[:, 0] = torch.where(edge[:, 0] < w / 2, -0.25, w - 0.75)
+    edge[:, 1] = torch.where(edge[:, 1] < h / 2, -1.0, float(h - 1))
+    yield "edges", edge
+    bad = c0.clone()
+    bad[:, 0, 0, 0] = float("nan")
+    bad[:, 1, 0, 1] = float("inf")
+    bad[:, 0, 1, 0] = -float("inf")
+    bad[:, 0, 1, 1] = 3.0e9
+    bad[:, 1, 1, 2] = -2.5e7
+    yield "nonfinite", bad
+
+
+@pytest.mark.parametrize("B,h,w,L,r", [(1, 16, 24, 4, 4), (2, 23, 39, 4, 3), (1, 55, 128, 4, 4), (1, 8, 16, 4, 4), (1, 13, 17, 2, 4)])
+def test_lookup_bit_exact(gpu, B, h, w, L, r):
+    torch.manual_seed(2)
+    D = 32
+    f1, f2 = torch.randn(B, D, h, w), torch.randn(B, D, h, w)
+    pyr = O.correlation_pyramid(f1, f2, L)
+    lv = [p.view(B * h * w, p.shape[-2], p.shape[-1]).contiguous().cuda() for p in pyr]
+    n = 2 * r + 1
+    for name, c in _coords_cases(B, h, w):
+        ref = O.lookup(pyr, c, r)
+        out = torch.full((B * h * w, L * n * n), -7.0, device=gpu)
+        torch.ops.pfk.corr_lookup(lv, c.cuda(), r, out)
+        got = unpm(out, B, h, w)
+        same = (got == ref) | (torch.isnan(got) & torch.isnan(ref))
+        assert bool(same.all()), f"{name}: {(~same).sum().item()} of {same.numel()} differ, max {(got - ref).abs().nan_to_num().max().item():.3e}"
+
+
+def _packed(weight, segs):
+    from ptlflow_amd.packing import pack_conv_weight
+    return pack_conv_weight(weight, segs).cuda()
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,kh,kw,relu", [
+    (1, 12, 20, 64, 96, 3, 3, True),
+    (2, 9, 7, 324, 256, 1, 1, True),
+    (1, 17, 33, 128, 126, 3, 3, True),
+    (1, 10, 12, 256, 576, 1, 1, False),
+    (1, 11, 19, 36, 40, 5, 1, False),
+    (1, 55, 128, 128, 64, 3, 3, True),
+])
+def test_conv_linear(gpu, B, H, W, cin, cout, kh, kw, relu):
+    torch.manual_seed(3)
+    x = torch.randn(B, cin, H, W)
+    wt = torch.randn(cout, cin, kh, kw) / math.sqrt(cin * kh * kw)
+    bias = torch.randn(cout)
+    ref = F.conv2d(x, wt, bias, padding=(kh // 2, kw // 2))
+    if relu:
+        ref = F.relu(ref)
+    ref = ref * 0.25
+    M = B * H * W
+    buf = torch.full((M, cout + 12), 5.0, device=gpu)
+    out = buf[:, 4:4 + cout]
+    torch.ops.pfk.conv2d([pm(x)], B, H, W, kh, kw, _packed(wt, [(0, cin, cin)]), bias.cuda(), cout, EPI_LINEAR, relu, 0.25,
+                         out, None, None, None)
+    close(unpm(out, B, H, W), ref)
+    assert bool((buf[:, :4] == 5.0).all()) and bool((buf[:, 4 + cout:] == 5.0).all()), "wrote outside its channel slice"
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+def test_conv_all_tile_configs(gpu, tile):
+    torch.manual_seed(4)
+    B, H, W, cin, cout = 1, 21, 37, 96, 160
+    x = torch.randn(B, cin, H, W)
+    wt = torch.randn(cout, cin, 3, 3) / math.sqrt(cin * 9)
+    bias = torch.randn(cout)
+    ref = F.conv2d(x, wt, bias, padding=1)
+    out = torch.zeros(B * H * W, cout, device=gpu)
+    torch.ops.pfk.debug_set_tile(tile)
+    try:
+        torch.ops.pfk.conv2d([pm(x)], B, H, W, 3, 3, _packed(wt, [(0, cin, cin)]), bias.cuda(), cout, EPI_LINEAR, False, 1.0,
+                             out, None, None, None)
+    finally:
+        torch.ops.pfk.debug_set_tile(-1)
+    close(unpm(out, B, H, W), ref)
+
+
+def test_conv_multi_source(gpu):
+    """torch.cat([a, b, c]) -> conv  ==  three channel-slice sources (one of them a strided slice)."""
+    torch.manual_seed(5)
+    B, H, W = 1, 14, 18
+    ca, cb, cc, cout = 96, 148, 32, 128
+    a, b, c = torch.randn(B, ca, H, W), torch.randn(B, cb, H, W), torch.randn(B, cc, H, W)
+    b[:, 146:] = 0  # two zero pad channels, as in raft_small's hx
+    wt = torch.randn(cout, ca + 146 + cc, 3, 3) / 40
+    bias = torch.randn(cout)
+    ref = F.conv2d(torch.cat([a, b[:, :146], c], 1), wt, bias, padding=1)
+    wide = torch.zeros(B * H * W, 300, device=gpu)
+    wide[:, 100:248] = pm(b)
+    packed = _packed(wt, [(0, ca, ca), (ca, 146, 148), (ca + 146, cc, cc)])
+    out = torch.zeros(B * H * W, cout, device=gpu)
+    torch.ops.pfk.conv2d([pm(a), wide[:, 100:248], pm(c)], B, H, W, 3, 3, packed, bias.cuda(), cout, EPI_LINEAR, False, 1.0,
+                         out, None, None, None)
+    close(unpm(out, B, H, W), ref)
+
+
+def _gru_params(Ch, Cx, passes):
+    P = {}
+    for kh, kw, sfx in passes:
+        for k in "zrq":
+            P[f"gru.conv{k}{sfx}.weight"] = torch.randn(Ch, Ch + Cx, kh, kw) / math.sqrt((Ch + Cx) * kh * kw)
+            P[f"gru.conv{k}{sfx}.bias"] = torch.randn(Ch) * 0.1
+    return P
+
+
+@pytest.mark.parametrize("B,H,W,Ch,Cx,passes", [
+    (1, 12, 16, 128, 256, ((1, 5, "1"), (5, 1, "2"))),   # SepConvGRU (raft)
+    (1, 9, 21, 128, 384, ((1, 5, "1"), (5, 1, "2"))),    # SepConvGRU (gma/ccmr C_in=512)
+    (2, 10, 14, 96, 148, ((3, 3, ""),)),                 # ConvGRU (raft_small, x padded 146->148)
+])
+def test_gru(gpu, B, H, W, Ch, Cx, passes):
+    torch.manual_seed(6)
+    P = _gru_params(Ch, Cx, passes)
+    h = torch.tanh(torch.randn(B, Ch, H, W))
+    x = torch.randn(B, Cx, H, W)
+    ref = O.sepconv_gru(P, h, x) if len(passes) == 2 else O.conv_gru(P, h, x)
+    from ptlflow_amd.packing import pack_conv_weight
+    M = B * H * W
+    hx = torch.cat([pm(h), pm(x)], 1).contiguous()
+    z = torch.zeros(M, Ch, device=gpu)
+    rh = torch.zeros(M, Ch, device=gpu)
+    for kh, kw, sfx in passes:
+        wzr = pack_conv_weight(torch.cat([P[f"gru.convz{sfx}.weight"], P[f"gru.convr{sfx}.weight"]], 0), [(0, Ch + Cx, Ch + Cx)]).cuda()
+        bzr = torch.cat([P[f"gru.convz{sfx}.bias"], P[f"gru.convr{sfx}.bias"]]).cuda()
+        wq = pack_conv_weight(P[f"gru.convq{sfx}.weight"], [(0, Ch, Ch), (Ch, Cx, Cx)]).cuda()
+        bq = P[f"gru.convq{sfx}.bias"].cuda()
+        torch.ops.pfk.conv2d([hx], B, H, W, kh, kw, wzr, bzr, 2 * Ch, EPI_GRU_ZR, False, 1.0, None, hx[:, :Ch], z, rh)
+        torch.ops.pfk.conv2d([rh, hx[:, Ch:]], B, H, W, kh, kw, wq, bq, Ch, EPI_GRU_Q, False, 1.0, None, hx[:, :Ch], z, None)
+    close(unpm(hx[:, :Ch], B, H, W), ref, rtol=2e-5, atol=3e-5)
+
+
+def test_conv_cin2(gpu):
+    torch.manual_seed(8)
+    B, H, W, cout = 2, 13, 17, 128
+    flow = torch.randn(B, 2, H, W) * 3
+    wt = torch.randn(cout, 2, 7, 7) / 10
+    bias = torch.randn(cout)
+    ref = F.relu(F.conv2d(flow, wt, bias, padding=3))
+    from ptlflow_amd.packing import pack_cin2_weight
+    buf = torch.zeros(B * H * W, 384, device=gpu)
+    buf[:, 382:384] = pm(flow)
+    out = torch.zeros(B * H * W, cout, device=gpu)
+    torch.ops.pfk.conv_cin2(buf[:, 382:384], pack_cin2_weight(wt).cuda(), bias.cuda(), out, B, H, W, 7, True)
+    close(unpm(out, B, H, W), ref)
+
+
+def test_flow_delta(gpu):
+    torch.manual_seed(9)
+    B, H, W, cin = 2, 11, 15, 256
+    x = torch.randn(B, cin, H, W)
+    wt = torch.randn(2, cin, 3, 3) / 48
+    bias = torch.randn(2)
+    delta_ref = F.conv2d(x, wt, bias, padding=1)
+    c0 = O.coords_grid(B, H, W)
+    c1 = c0 + torch.randn(B, 2, H, W)
+    from ptlflow_amd.packing import pack_flow_head_weight
+    fm = torch.zeros(B * H * W, 512, device=gpu)
+    fm[:, :cin] = pm(x)
+    c1g = c1.clone().cuda()
+    delta = torch.zeros(B, 2, H, W, device=gpu)
+    hx = torch.zeros(B * H * W, 384, device=gpu)
+    torch.ops.pfk.flow_delta(fm[:, :cin], pack_flow_head_weight(wt).cuda(), bias.cuda(), c0.cuda(), c1g, delta, hx[:, 382:384])
+    close(delta, delta_ref)
+    d = delta.cpu()
+    assert torch.equal(c1g.cpu(), c1 + d)                       # coords1 += delta, one rounding
+    assert torch.equal(unpm(hx[:, 382:384], B, H, W), (c1 + d) - c0)   # flow = coords1 - coords0
+    f2 = torch.zeros(B * H * W, 4, device=gpu)
+    torch.ops.pfk.flow_from_coords(c0.cuda(), c1.cuda(), f2[:, 1:3])
+    assert torch.equal(unpm(f2[:, 1:3], B, H, W), c1 - c0)
+
+
+def test_convex_upsample(gpu):
+    torch.manual_seed(10)
+    B, H, W = 2, 9, 13
+    flow = torch.randn(B, 2, H, W) * 4
+    mask = torch.randn(B, 576, H, W)
+    ref = O.convex_upsample(flow, mask)
+    out = torch.zeros(B, 2, 8 * H, 8 * W, device=gpu)
+    torch.ops.pfk.convex_upsample(flow.cuda(), pm(mask), out)
+    close(out, ref, rtol=1e-5, atol=1e-5)
+
+
+def test_layout_roundtrip(gpu):
+    torch.manual_seed(11)
+    x = torch.randn(2, 126, 7, 45)
+    buf = torch.zeros(2 * 7 * 45, 384, device=gpu)
+    torch.ops.pfk.nchw_to_pm(x.cuda(), buf[:, 256:382])
+    assert torch.equal(buf[:, 256:382].cpu(), pm(x).cpu())
+    back = torch.zeros(2, 126, 7, 45, device=gpu)
+    torch.ops.pfk.pm_to_nchw(buf[:, 256:382], back)
+    assert torch.equal(back.cpu(), x)
+
+
+@pytest.mark.parametrize("small", [False, True])
+def test_update_engine_step(gpu, small):
+    """One whole BasicUpdateBlock / SmallUpdateBlock step vs the oracle (update.py:144-153 / :122-128)."""
+    from ptlflow_amd.synth import synth_update_block_params
+    from ptlflow_amd.update import UpdateEngine, basic_spec, small_spec
+    torch.manual_seed(12)
+    spec = small_spec() if small else basic_spec()
+    P = synth_update_block_params(spec, seed=5)
+    B, H, W = 1, 14, 22
+    net = torch.tanh(torch.randn(B, spec.hidden, H, W))
+    inp = torch.relu(torch.randn(B, spec.context, H, W))
+    corr = torch.randn(B, spec.corr_channels, H, W)
+    c0 = O.coords_grid(B, H, W)
+    c1 = c0 + torch.randn(B, 2, H, W) * 2
+    flow = c1 - c0
+    step = O.small_update_block if small else O.basic_update_block
+    net_ref, mask_ref, delta_ref = step(P, net, inp, corr, flow)
+    eng = UpdateEngine(P, spec, gpu)
+    eng.bind(B, H, W)
+    eng.load_state(net.cuda(), inp.cuda())
+    c0g, c1g = c0.cuda(), c1.clone().cuda()
+    torch.ops.pfk.flow_from_coords(c0g, c1g, eng.flow_view)
+    eng.step(pm(corr), c0g, c1g)
+    close(eng.net_nchw(), net_ref, rtol=5e-5, atol=5e-5)
+    close(c1g, c1 + delta_ref, rtol=5e-5, atol=5e-5)
+    if not small:
+        close(eng.mask_nchw(), mask_ref, rtol=5e-5, atol=5e-5)

@@ -1,0 +1,71 @@
+"""End-to-end parity: ptlflow_amd.RAFT on the MI355X vs the CPU oracle on identical seeded weights/inputs.
+
+Gate (BASELINE.json north_star): end-point error of `flows` <= 1e-3 px (mean) in fp32; we also bound the
+max.  The oracle itself differs from an fp64 run of the same model by ~1e-5 mean / 5e-5 max after 32
+iterations, so the gate is meaningful."""
+import pytest
+import torch
+
+from oracle import raft_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_pair(small, H, W, iters, B=1, seed=1234, upsample_every_iter=True, smooth=True):
+    from ptlflow_amd.raft import RAFT
+    from ptlflow_amd.synth import rand_pair
+    model = RAFT(small=small, iters=iters, upsample_every_iter=upsample_every_iter).load_synthetic(seed).eval()
+    P = {k: v.clone() for k, v in model.state_dict().items()}
+    x = O.smooth_pair(B, H, W, seed) if smooth else rand_pair(B, H, W, seed)
+    ref = O.raft_forward(P, x, iters=iters, small=small)
+    model = model.cuda()
+    out = model({"images": x.cuda()})
+    torch.cuda.synchronize()
+    return out, ref
+
+
+@pytest.mark.parametrize("small,H,W,iters", [(False, 128, 192, 4), (False, 184, 320, 12), (True, 128, 256, 12)])
+def test_raft_small_shapes(gpu, small, H, W, iters):
+    out, ref = _run_pair(small, H, W, iters)
+    assert out["flows"].shape == ref["flows"].shape
+    mean, mx = O.epe(out["flows"][:, 0].cpu(), ref["flows"][:, 0])
+    mean_s, mx_s = O.epe(out["flow_small"].cpu(), ref["flow_small"])
+    assert mean <= 1e-3 and mx <= 1e-2, f"EPE mean {mean:.2e} max {mx:.2e}"
+    assert mean_s <= 1e-3 and mx_s <= 1e-2, f"flow_small EPE mean {mean_s:.2e} max {mx_s:.2e}"
+
+
+def test_raft_headline_config(gpu):
+    """BASELINE.json configs[1]: raft, 436x1024 (Sintel), 32 iterations, fp32."""
+    out, ref = _run_pair(False, 436, 1024, 32)
+    assert tuple(out["flows"].shape) == (1, 1, 2, 436, 1024)
+    mean, mx = O.epe(out["flows"][:, 0].cpu(), ref["flows"][:, 0])
+    print(f"headline EPE mean {mean:.3e} max {mx:.3e}")
+    assert mean <= 1e-3 and mx <= 1e-2, f"EPE mean {mean:.2e} max {mx:.2e}"
+
+
+def test_skip_dead_upsample_is_output_identical(gpu):
+    """Skipping mask head + upsampling on non-final eval iterations (dead work in raft.py:180-187) must not
+    change a single output bit."""
+    a, _ = _run_pair(False, 128, 192, 5, upsample_every_iter=True)
+    b, _ = _run_pair(False, 128, 192, 5, upsample_every_iter=False)
+    assert torch.equal(a["flows"], b["flows"]) and torch.equal(a["flow_small"], b["flow_small"])
+
+
+def test_degenerate_64x128_nan_pattern(gpu):
+    """BASELINE.json configs[0]: raft_small at 64x128 is all-NaN in the reference (1-pixel pyramid level,
+    SURVEY finding 4); the accelerated path must reproduce the NaN pattern, not hide it."""
+    out, ref = _run_pair(True, 64, 128, 3, smooth=False)
+    assert torch.equal(torch.isnan(out["flows"].cpu()), torch.isnan(ref["flows"]))
+    assert bool(torch.isnan(ref["flows"]).all())
+
+
+def test_batch_independence(gpu):
+    """Frame pairs are independent units: a batch of 2 equals two batches of 1 (the encoders go
+    through MIOpen, whose algorithm choice may depend on the batch size, hence a tolerance, not bit-equality)."""
+    from ptlflow_amd.raft import RAFT
+    m = RAFT(iters=3).load_synthetic(7).eval().cuda()
+    x = O.smooth_pair(2, 128, 160, 3).cuda()
+    both = m({"images": x})["flows"]
+    one = torch.cat([m({"images": x[i:i + 1]})["flows"] for i in range(2)], 0)
+    mean, mx = O.epe(both[:, 0].cpu(), one[:, 0].cpu())
+    assert mean <= 1e-4 and mx <= 1e-3, f"EPE mean {mean:.2e} max {mx:.2e}"
