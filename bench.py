@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py — frame-pairs/s of the RAFT hot path on MI355X (BASELINE.json metric).
+
+    python bench.py                              # 1 GPU, raft 436x1024, 32 iterations, fp32
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A *step* is one forward of `ptlflow_amd.RAFT` (encoders on MIOpen, correlation volume + pyramid +
+32 x {lookup, update block, coordinate update, convex upsample} on libpfk kernels) over one batch of
+synthetic 436x1024 frame pairs already resident in HBM.  One process per GPU, frame pairs are
+independent so ranks share nothing (no data-path collective; RCCL is used only for the barrier and the
+max-over-ranks of the elapsed time): weak scaling, `value` = all pairs of all ranks / max time.
+
+Besides the driver's contract fields the JSON line carries
+  roofline      dominant kernel (largest summed time among the MFMA conv launches), HIP events around every
+                launch of it during one separate instrumented forward; bound = fp32 MFMA peak 157.3 TFLOP/s
+  cpu_baseline  the CPU oracle (`oracle/raft_oracle.raft_forward`, a port of the reference forward on torch
+                CPU) timed on this host's cores on the same input: a reported baseline, not a target
+  epe_vs_cpu    end-point error of the GPU `flows` vs that CPU forward on the same input (gate: mean <= 1e-3)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1, help="frame pairs per GPU per step")
+    ap.add_argument("--height", type=int, default=436)
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--iters", type=int, default=32)
+    ap.add_argument("--model", default="raft", choices=["raft", "raft_small"])
+    ap.add_argument("--skip-dead-upsample", action="store_true",
+                    help="skip mask head + upsampling on non-final iterations (output-identical dead work)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-forwards", type=int, default=3)
+    return ap.parse_args()
+
+
+def instrumented_forward(model, inputs):
+    """One extra forward with HIP events around every MFMA conv launch -> per-kernel-key stats."""
+    eng = model.engine(inputs["images"].device)
+    eng.profile = {}
+    try:
+        model(inputs)
+        torch.cuda.synchronize()
+        stats = {}
+        for key, evs in eng.profile.items():
+            ms = [a.elapsed_time(b) for a, b in evs]
+            stats[key] = {"launches": len(ms), "avg_us": 1e3 * sum(ms) / len(ms), "total_ms": sum(ms),
+                          "gflop_per_launch": eng.flops[key] / 1e9}
+    finally:
+        eng.profile = None
+    return stats
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # noqa: F811
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+
+    import ptlflow_amd
+    from ptlflow_amd.raft import RAFT
+    from ptlflow_amd.synth import smooth_pair
+
+    ptlflow_amd.load_native()
+    small = args.model == "raft_small"
+    model = RAFT(small=small, iters=args.iters, upsample_every_iter=not args.skip_dead_upsample)
+    model.load_synthetic(1234).eval()
+    cpu_state = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.to(dev)
+    images_cpu = smooth_pair(args.batch, args.height, args.width, seed=1234 + rank)
+    inputs = {"images": images_cpu.to(dev)}
+
+    for _ in range(args.warmup):
+        out = model(inputs)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = model(inputs)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    pairs = args.batch * args.steps * world
+    result = {
+        "metric": "frame-pairs/sec, RAFT 32-iter 436x1024" if (not small and args.iters == 32 and (args.height, args.width) == (436, 1024))
+                  else f"frame-pairs/sec, {args.model} {args.iters}-iter {args.height}x{args.width}",
+        "value": pairs / elapsed,
+        "unit": "frame-pairs/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"{args.model} random-init (seeded), {args.height}x{args.width} frame pairs, {args.iters} iterations, "
+                               f"fp32, batch {args.batch}/GPU, eval forward incl. encoders, "
+                               + ("dead mask/upsample work skipped on non-final iterations" if args.skip_dead_upsample
+                                  else "mask head + convex upsample on every iteration as the reference"),
+                   "global_batch": args.batch * world, "parallelism": f"dp{world} (independent replicas, no collectives)"},
+    }
+
+    if rank == 0:
+        if not args.no_roofline:
+            stats = instrumented_forward(model, inputs)
+            dom = max(stats, key=lambda k: stats[k]["total_ms"])
+            s = stats[dom]
+            achieved = s["gflop_per_launch"] / (s["avg_us"] * 1e-6) / 1e3  # TFLOP/s
+            result["roofline"] = {"kernel": f"conv_gemm_kernel[{dom}]", "bound": "mfma", "achieved": achieved,
+                                  "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
+                                  "traffic": None, "avg_us": s["avg_us"], "launches_per_forward": s["launches"],
+                                  "gflop_per_launch": s["gflop_per_launch"],
+                                  "method": "HIP events around each launch, separate instrumented forward"}
+            result["kernels"] = {k: {"avg_us": round(v["avg_us"], 2), "n": v["launches"],
+                                     "tflops": round(v["gflop_per_launch"] / (v["avg_us"] * 1e-6) / 1e3, 1)}
+                                 for k, v in sorted(stats.items(), key=lambda kv: -kv[1]["total_ms"])}
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import raft_oracle as O  # checker + reported baseline only
+            torch.set_num_threads(os.cpu_count() or 1)
+            times = []
+            ref = None
+            for i in range(args.cpu_forwards + 1):
+                c0 = time.perf_counter()
+                ref = O.raft_forward(cpu_state, images_cpu, iters=args.iters, small=small)
+                if i:
+                    times.append(time.perf_counter() - c0)
+            times.sort()
+            med = times[len(times) // 2]
+            result["cpu_baseline"] = {"value": args.batch / med, "unit": "frame-pairs/s", "cores": torch.get_num_threads(),
+                                      "kind": "port",
+                                      "sample": f"{args.cpu_forwards} full forwards (1 warm-up) of the same workload, median; torch {torch.__version__} CPU"}
+            mean, mx = O.epe(out["flows"][:, 0].float().cpu(), ref["flows"][:, 0])
+            result["epe_vs_cpu"] = {"mean": mean, "max": mx, "gate": 1e-3}
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

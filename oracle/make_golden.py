@@ -107,7 +107,7 @@ def golden_update():
 
 def golden_forward():
     out = {}
-    for tag, small, H, W, iters in (("raft_96x128_it6", False, 96, 128, 6), ("raft_small_128x128_it6", True, 128, 128, 6)):
+    for tag, small, H, W, iters in (("raft_128x160_it6", False, 128, 160, 6), ("raft_small_128x128_it6", True, 128, 128, 6)):
         ref = ref_loader.build_raft(small=small, iters=iters)
         shapes = {k: tuple(v.shape) for k, v in ref.state_dict().items() if not k.startswith("train_metrics")}
         P = synth_state_dict(shapes, seed=41)

@@ -88,3 +88,18 @@ def rand_pair(B: int, H: int, W: int, seed: int = 1234) -> torch.Tensor:
     (model_benchmark.py:445-453)."""
     g = torch.Generator().manual_seed(seed)
     return torch.rand(B, 2, 3, H, W, generator=g)
+
+
+def smooth_pair(B: int, H: int, W: int, seed: int = 1234, shift=(5, -4)) -> torch.Tensor:
+    """A smooth random texture and a copy shifted by `shift` px: [B,2,3,H,W] in [0,1] — flow-like input
+    for EPE checks (distribution ii).  Same construction as oracle.raft_oracle.smooth_pair."""
+    import torch.nn.functional as F
+
+    g = torch.Generator().manual_seed(seed)
+    m = 8
+    base = torch.rand(B, 3, H // 8 + 4 + m, W // 8 + 4 + m, generator=g)
+    big = F.interpolate(base, scale_factor=8, mode="bicubic", align_corners=False).clamp(0, 1)
+    oy, ox = 4 * 8, 4 * 8
+    im1 = big[..., oy: oy + H, ox: ox + W]
+    im2 = big[..., oy - shift[1]: oy - shift[1] + H, ox - shift[0]: ox - shift[0] + W]
+    return torch.stack([im1, im2], dim=1).contiguous()

@@ -78,6 +78,9 @@ class UpdateEngine:
         self.spec = spec
         self.device = device
         self._shape: Optional[Tuple[int, int, int]] = None
+        # optional per-launch instrumentation: key -> [(start_event, end_event)], and key -> algorithmic FLOPs
+        self.profile: Optional[Dict[str, list]] = None
+        self.flops: Dict[str, float] = {}
         self.pack(params)
 
     # ------------------------------------------------------------------ weights
@@ -91,6 +94,12 @@ class UpdateEngine:
             return [(0, c, round_up(c, 4))]
 
         w: Dict[str, torch.Tensor] = {}
+        real = s.hidden + s.x_channels
+        self._real_cin = {"c1": s.corr_channels, "c2": s.c1, "f2": s.f1, "cv": (s.c2 if s.c2 else s.c1) + s.f2,
+                          "fm": s.hidden, "mk": s.fh_hidden}
+        for _, _, sfx in s.gru_passes:
+            self._real_cin["zr" + sfx] = real
+            self._real_cin["q" + sfx] = real
         w["c1.w"] = pack_conv_weight(g("encoder.convc1.weight"), seg1(s.corr_channels))
         w["c1.b"] = g("encoder.convc1.bias").contiguous()
         if s.c2:
@@ -176,8 +185,17 @@ class UpdateEngine:
     def _conv(self, srcs: List[torch.Tensor], kh, kw, key, cout, relu=True, scale=1.0, out=None,
               epi=EPI_LINEAR, h=None, z=None, rh=None):
         B, H, W = self._shape
+        prof = self.profile
+        if prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         self.ops.conv2d(srcs, B, H, W, kh, kw, self.w[key + ".w"], self.w[key + ".b"], cout, epi, relu, scale,
                         out, h, z, rh)
+        if prof is not None:
+            e1.record()
+            prof.setdefault(key, []).append((e0, e1))
+            # algorithmic work: 2 * pixels * cout * taps * real input channels (padding is not work)
+            self.flops[key] = 2.0 * B * H * W * cout * kh * kw * self._real_cin[key]
 
     def motion_and_gru(self, corr_pm: torch.Tensor) -> None:
         """update.py:104-112 (encoder) + :58-73 / :24-32 (GRU); `flow` must already be in hx."""

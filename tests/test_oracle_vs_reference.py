@@ -1,0 +1,61 @@
+"""Oracle and RAFT mirror vs the LIVE reference (only where /root/reference exists: the build container)."""
+import pytest
+import torch
+
+from oracle import raft_oracle as O
+from oracle import ref_loader
+
+pytestmark = [pytest.mark.reference,
+              pytest.mark.skipif(not ref_loader.reference_available(), reason="needs /root/reference")]
+
+
+def _sd(model):
+    return {k: v.detach() for k, v in model.state_dict().items() if not k.startswith("train_metrics")}
+
+
+@pytest.mark.parametrize("small", [False, True])
+def test_forward_bit_identical(small):
+    ref = ref_loader.build_raft(small=small, iters=5)
+    x = O.smooth_pair(1, 128, 192, seed=3)
+    with torch.no_grad():
+        r = ref({"images": x.clone()})
+    o = O.raft_forward(_sd(ref), x, iters=5, small=small)
+    mean, mx = O.epe(o["flows"][:, 0], r["flows"][:, 0])
+    assert mean <= 1e-6 and mx <= 1e-5
+
+
+@pytest.mark.parametrize("fam", ["raft", "gma", "ccmr", "ms_raft_plus"])
+def test_corrblock_copies_agree(fam):
+    """Every family's private CorrBlock copy computes the same thing (SURVEY finding 1) = our oracle."""
+    mod = ref_loader.ref_module(f"ptlflow.models.{fam}.corr")
+    g = torch.Generator().manual_seed(4)
+    f1, f2 = torch.randn(1, 32, 16, 24, generator=g), torch.randn(1, 32, 16, 24, generator=g)
+    cb = mod.CorrBlock(f1, f2, num_levels=4, radius=4)
+    c = O.coords_grid(1, 16, 24) + torch.rand(1, 2, 16, 24, generator=g) * 12 - 6
+    ref = cb(c)
+    out = O.lookup(cb.corr_pyramid, c, 4)
+    assert not bool(torch.isnan(ref).any()) and torch.equal(ref, out)
+
+
+def test_lookup_nonfinite_matches_reference():
+    mod = ref_loader.ref_module("ptlflow.models.raft.corr")
+    g = torch.Generator().manual_seed(5)
+    f1, f2 = torch.randn(1, 16, 8, 16, generator=g), torch.randn(1, 16, 8, 16, generator=g)
+    cb = mod.CorrBlock(f1, f2, num_levels=4, radius=4)
+    c = O.coords_grid(1, 8, 16)
+    c[0, 0, 0, 0] = float("nan"); c[0, 1, 0, 1] = float("inf"); c[0, 0, 1, 0] = -float("inf"); c[0, 0, 1, 1] = 3e9
+    ref, out = cb(c), O.lookup(cb.corr_pyramid, c, 4)
+    assert bool(((ref == out) | (torch.isnan(ref) & torch.isnan(out))).all())
+
+
+@pytest.mark.parametrize("small", [False, True])
+def test_mirror_state_dict_is_checkpoint_compatible(small):
+    from ptlflow_amd.raft import RAFT
+    ref = ref_loader.build_raft(small=small)
+    m = RAFT(small=small)
+    sd = _sd(ref)
+    assert set(m.state_dict()) == set(sd)
+    m.load_state_dict(sd, strict=True)
+    x = torch.randn(1, 3, 64, 96)
+    with torch.no_grad():
+        assert torch.equal(m.eval().fnet(x), ref.fnet(x)) and torch.equal(m.cnet(x), ref.cnet(x))
