@@ -31,6 +31,26 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+def host_cores() -> int:
+    """Cores this process may really use: scheduler affinity, capped by the cgroup CPU quota.  os.cpu_count()
+    reports the whole host inside a container; oversubscribing OpenMP beyond the quota makes torch CPU ops
+    orders of magnitude slower."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except Exception:
+            pass
+    return max(1, min(n, 64))
+
+
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 HBM_PEAK_GBS = 8000.0
 
@@ -50,6 +70,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-forwards", type=int, default=3)
+    ap.add_argument("--cpu-budget-s", type=float, default=30.0, help="stop timing CPU forwards after this many seconds")
     return ap.parse_args()
 
 
@@ -156,19 +177,26 @@ def main():
                                  for k, v in sorted(stats.items(), key=lambda kv: -kv[1]["total_ms"])}
         if world == 1 and not args.no_cpu_baseline:
             from oracle import raft_oracle as O  # checker + reported baseline only
-            torch.set_num_threads(os.cpu_count() or 1)
+            cores = host_cores()
+            torch.set_num_threads(cores)
             times = []
             ref = None
+            t_start = time.perf_counter()
             for i in range(args.cpu_forwards + 1):
                 c0 = time.perf_counter()
                 ref = O.raft_forward(cpu_state, images_cpu, iters=args.iters, small=small)
-                if i:
-                    times.append(time.perf_counter() - c0)
+                dt = time.perf_counter() - c0
+                # the first forward is a warm-up unless the budget leaves room for nothing else
+                if i or dt > args.cpu_budget_s / 2:
+                    times.append(dt)
+                if time.perf_counter() - t_start > args.cpu_budget_s:
+                    break
             times.sort()
             med = times[len(times) // 2]
-            result["cpu_baseline"] = {"value": args.batch / med, "unit": "frame-pairs/s", "cores": torch.get_num_threads(),
+            result["cpu_baseline"] = {"value": args.batch / med, "unit": "frame-pairs/s", "cores": cores,
                                       "kind": "port",
-                                      "sample": f"{args.cpu_forwards} full forwards (1 warm-up) of the same workload, median; torch {torch.__version__} CPU"}
+                                      "sample": f"{len(times)} full forward(s) of the same workload (batch {args.batch}), median; "
+                                                f"torch {torch.__version__} CPU, {cores} threads"}
             mean, mx = O.epe(out["flows"][:, 0].float().cpu(), ref["flows"][:, 0])
             result["epe_vs_cpu"] = {"mean": mean, "max": mx, "gate": 1e-3}
         print(json.dumps(result), flush=True)

@@ -259,6 +259,7 @@ class PfkUpdateBlock(torch.nn.Module):
         # keep the reference sub-modules so state_dict keys/checkpoints/optimizers are unchanged
         for name, child in ref_block.named_children():
             self.add_module(name, child)
+        self._ref = [ref_block]  # in a list: not registered twice in the module tree
         self.spec = spec
         self._engine: Optional[UpdateEngine] = None
         self._versions = None
@@ -277,8 +278,14 @@ class PfkUpdateBlock(torch.nn.Module):
             self._versions = v
         return self._engine
 
-    @torch.no_grad()
     def forward(self, net, inp, corr, flow):
+        if torch.is_grad_enabled() and (net.requires_grad or any(p.requires_grad for p in self.parameters())):
+            # training graph: the reference module keeps doing its own job (backward kernels are SURVEY §8 f4)
+            return self._ref[0](net, inp, corr, flow)
+        with torch.no_grad():
+            return self._forward_kernels(net, inp, corr, flow)
+
+    def _forward_kernels(self, net, inp, corr, flow):
         if not net.is_cuda:
             raise RuntimeError("PfkUpdateBlock needs GPU tensors (no CPU fallback)")
         eng = self._get_engine(net.device)

@@ -1,0 +1,77 @@
+"""Seams B1 + B3 used the way the reference's loop uses them (raft.py:144-187): NCHW tensors in, NCHW out,
+`get_corr_block(...)` once, then `corr_fn(coords1)` / `update_block(net, inp, corr, flow)` per iteration."""
+import pytest
+import torch
+
+from oracle import raft_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("small", [False, True])
+def test_reference_style_loop(gpu, small):
+    from ptlflow_amd.corr import get_corr_block
+    from ptlflow_amd.raft import _param_tree
+    from ptlflow_amd.synth import synth_state_dict, update_block_shapes
+    from ptlflow_amd.update import PfkUpdateBlock, basic_spec, small_spec
+
+    spec = small_spec() if small else basic_spec()
+    r = 3 if small else 4
+    holder = _param_tree(update_block_shapes(spec))            # stands in for the reference's BasicUpdateBlock
+    P = synth_state_dict({k: tuple(v.shape) for k, v in holder.state_dict().items()}, seed=9)
+    holder.load_state_dict(P)
+    ub = PfkUpdateBlock(holder, spec).cuda().eval()
+    assert set(ub.state_dict()) == set(P)                       # checkpoint keys unchanged by the wrapper
+
+    g = torch.Generator().manual_seed(3)
+    B, D, h, w = 2, 64, 18, 26
+    f1, f2 = torch.randn(B, D, h, w, generator=g), torch.randn(B, D, h, w, generator=g)
+    net = torch.tanh(torch.randn(B, spec.hidden, h, w, generator=g))
+    inp = torch.relu(torch.randn(B, spec.context, h, w, generator=g))
+
+    # oracle loop
+    pyr = O.correlation_pyramid(f1, f2, 4)
+    c0 = O.coords_grid(B, h, w)
+    c1 = c0.clone()
+    n_ref = net
+    step = O.small_update_block if small else O.basic_update_block
+    for _ in range(4):
+        corr = O.lookup(pyr, c1, r)
+        n_ref, m_ref, d = step(P, n_ref, inp, corr, c1 - c0)
+        c1 = c1 + d
+
+    # reference-style loop on the GPU through the two seams
+    with torch.no_grad():
+        corr_fn = get_corr_block(fmap1=f1.cuda(), fmap2=f2.cuda(), radius=r, num_levels=4, alternate_corr=False)
+        g0 = c0.cuda()
+        g1 = g0.clone()
+        n, i = net.cuda(), inp.cuda()
+        for _ in range(4):
+            g1 = g1.detach()
+            corr = corr_fn(g1)
+            assert tuple(corr.shape) == (B, spec.corr_channels, h, w)
+            flow = g1 - g0
+            n, up_mask, delta = ub(n, i, corr, flow)
+            g1 = g1 + delta
+    err = (g1.cpu() - c1).abs().max().item()
+    assert err < 2e-4, f"coords differ by {err:.2e}"
+    assert (n.cpu() - n_ref).abs().max().item() < 2e-4
+    if small:
+        assert up_mask is None
+    else:
+        assert tuple(up_mask.shape) == (B, 576, h, w)
+        assert (up_mask.cpu() - m_ref).abs().max().item() < 2e-4
+
+
+def test_sea_raft_pyramid_mode(gpu):
+    """sea_raft/corr.py:71-84: per-level GEMM against bilinear-halved fmap2."""
+    from ptlflow_amd.corr import CorrBlock
+    g = torch.Generator().manual_seed(4)
+    f1, f2 = torch.randn(1, 64, 16, 24, generator=g), torch.randn(1, 64, 16, 24, generator=g)
+    pyr = O.sea_correlation_pyramid(f1, f2, 4)
+    cb = CorrBlock(f1.cuda(), f2.cuda(), 4, 4, pyramid="bilinear_f2")
+    for a, b in zip(cb.corr_pyramid, pyr):
+        assert (a.cpu().reshape(b.shape) - b).abs().max().item() < 2e-5
+    c = O.coords_grid(1, 16, 24) + torch.rand(1, 2, 16, 24, generator=g) * 6 - 3
+    ref = O.lookup(pyr, c, 4)
+    assert (cb(c.cuda()).cpu() - ref).abs().max().item() < 5e-5
