@@ -23,6 +23,8 @@
 // slices of pixel-major buffers (no torch.cat).
 #include "pfk_common.h"
 
+#include <utility>
+
 namespace {
 
 constexpr int BK = 32;       // channels per K-step
@@ -52,176 +54,220 @@ struct GemmArgs {
 
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-template <int BM, int BN, int WM, int WN, int EPI>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs a) {
-  constexpr int WAVES_N = BN / WN;
-  static_assert((BM / WM) * WAVES_N == 4, "4 waves per block");
-  constexpr int MT = WM / 32, NT = WN / 32;
-  constexpr int A_PT = BM / 32;  // staging rows per thread (256 threads cover 32 rows x 8 float4)
-  constexpr int B_PT = BN / 32;
+// -------------------------------------------------------------------------------------------------
+// Staging: 256 threads move one K-step (BM + BN rows x 32 floats) global -> VGPR -> LDS.
+// Thread t owns float4 column (t & 7) of rows (t >> 3) + 32*i.  The K iterator walks
+// source -> tap (ky, kx) -> 32-channel chunk.
+//
+// All loads are raw *buffer* loads with 32-bit byte offsets: a lane whose tap falls outside the
+// image (the convolution's zero padding), whose row is past M / cout, or whose channel chunk is
+// past the source's channel count gets an out-of-range offset and the hardware returns zeros —
+// no branches, no 64-bit address arithmetic in the K loop.  The buffer descriptors are built from
+// kernel arguments only (provably wave-uniform, so hipcc emits no waterfall loops).
+// -------------------------------------------------------------------------------------------------
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB = 0x80000000u;  // >= num_records of every descriptor below
 
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* sA = smem;                          // [2][BM][LDS_LD]
-  float* sB = smem + 2 * BM * LDS_LD;        // [2][BN][LDS_LD]
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, 0x7fffffff, 0x00020000);
+}
 
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wid = tid >> 6;
-  const int wm0 = (wid / WAVES_N) * WM;
-  const int wn0 = (wid % WAVES_N) * WN;
-
-  const int bid = pfk_xcd_remap(blockIdx.x, gridDim.x);
-  const int tile_n = bid % a.tiles_n;
-  const int tile_m = bid / a.tiles_n;
-  const long long m0 = (long long)tile_m * BM;
-  const int n0 = tile_n * BN;
-  const long long batch = blockIdx.y;
-
-  const float* src0 = a.src0 + batch * a.a_bs;
-  const float* wgt = a.weight + batch * a.b_bs;
-
-  // ---- per-thread staging coordinates -------------------------------------------------------
-  const int c4 = (tid & 7) * 4;  // float offset inside the 32-float K chunk
-  const int r0 = tid >> 3;       // 0..31
-  long long prow[A_PT];
-  int py[A_PT], px[A_PT];
-  bool pok[A_PT];
-#pragma unroll
-  for (int i = 0; i < A_PT; ++i) {
-    const long long p = m0 + r0 + 32 * i;
-    pok[i] = p < a.M;
-    prow[i] = p;
-    px[i] = (int)(p % a.W);
-    py[i] = (int)((p / a.W) % a.H);
-  }
-  const float* wrow[B_PT];
-  bool wok[B_PT];
-#pragma unroll
-  for (int i = 0; i < B_PT; ++i) {
-    const int n = n0 + r0 + 32 * i;
-    wok[i] = n < a.b_rows;
-    wrow[i] = wgt + (long long)(wok[i] ? n : 0) * a.ktot + c4;
-  }
-
-  // ---- K-step iterator: source -> tap (ky, kx) -> 32-channel chunk ----------------------------
+template <int BM, int BN>
+struct Stager {
+  static constexpr int A_PT = BM / 32;
+  static constexpr int B_PT = BN / 32;
+  // uniform
+  int H, W, kh, kw, ph, pw, nsrc;
+  int ld0, ld1, ld2, ch0, ch1, ch2;
+  __amdgpu_buffer_rsrc_t rs0, rs1, rs2, rsw, rs;
+  int cld, cch;
   int seg = 0, ky = 0, kx = 0, c0 = 0, kofs = 0;
-  const int ph = a.kh >> 1, pw = a.kw >> 1;
-  int total_steps = 0;
-  {
-    const int taps = a.kh * a.kw;
-    total_steps += taps * ((a.ch0 + BK - 1) / BK);
-    if (a.nsrc > 1) total_steps += taps * ((a.ch1 + BK - 1) / BK);
-    if (a.nsrc > 2) total_steps += taps * ((a.ch2 + BK - 1) / BK);
-  }
-
+  // per thread
+  int c4, r0;
+  int prow[A_PT], py[A_PT], px[A_PT];
+  bool pok[A_PT];
+  unsigned abase[A_PT];
+  unsigned wvoff[B_PT];
   f32x4 ra[A_PT], rb[B_PT];
 
-  auto load_step = [&]() {
-    const float* sp = seg == 0 ? src0 : (seg == 1 ? a.src1 : a.src2);
-    const int sld = seg == 0 ? a.ld0 : (seg == 1 ? a.ld1 : a.ld2);
-    const int sch = seg == 0 ? a.ch0 : (seg == 1 ? a.ch1 : a.ch2);
-    const int dy = ky - ph, dx = kx - pw;
-    const bool cok = (c0 + c4) < sch;
+  __device__ __forceinline__ Stager(const GemmArgs& a, long long m0, int n0, int t, long long batch) {
+    H = a.H; W = a.W; kh = a.kh; kw = a.kw; ph = a.kh >> 1; pw = a.kw >> 1; nsrc = a.nsrc;
+    ld0 = a.ld0; ld1 = a.ld1; ld2 = a.ld2; ch0 = a.ch0; ch1 = a.ch1; ch2 = a.ch2;
+    rs0 = make_rsrc(a.src0 + batch * a.a_bs);
+    rs1 = make_rsrc(a.src1);
+    rs2 = make_rsrc(a.src2);
+    rsw = make_rsrc(a.weight + batch * a.b_bs);
+    c4 = (t & 7) * 4;
+    r0 = t >> 3;
 #pragma unroll
     for (int i = 0; i < A_PT; ++i) {
-      const bool ok = pok[i] && cok && (unsigned)(py[i] + dy) < (unsigned)a.H &&
-                      (unsigned)(px[i] + dx) < (unsigned)a.W;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ok) {
-        const float* g = sp + (prow[i] + (long long)dy * a.W + dx) * sld + c0 + c4;
-        v = *reinterpret_cast<const f32x4*>(g);
-      }
-      ra[i] = v;
+      const long long p = m0 + r0 + 32 * i;
+      pok[i] = p < a.M;
+      prow[i] = (int)p;
+      px[i] = (int)(p % a.W);
+      py[i] = (int)((p / a.W) % a.H);
     }
 #pragma unroll
     for (int i = 0; i < B_PT; ++i) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (wok[i]) v = *reinterpret_cast<const f32x4*>(wrow[i] + kofs);
-      rb[i] = v;
+      const int n = n0 + r0 + 32 * i;
+      wvoff[i] = n < a.b_rows ? (unsigned)(n * a.ktot + c4) * 4u : OOB;
     }
-  };
-  auto advance = [&]() {
-    const int sch = seg == 0 ? a.ch0 : (seg == 1 ? a.ch1 : a.ch2);
+    set_segment(0);
+  }
+
+  __device__ __forceinline__ void set_segment(int s) {
+    if (s == 0) { rs = rs0; cld = ld0; cch = ch0; }
+    else if (s == 1) { rs = rs1; cld = ld1; cch = ch1; }
+    else { rs = rs2; cld = ld2; cch = ch2; }
+#pragma unroll
+    for (int i = 0; i < A_PT; ++i) abase[i] = (unsigned)(prow[i] * cld + c4) * 4u;
+  }
+
+  __device__ __forceinline__ int total_steps() const {
+    const int taps = kh * kw;
+    int s = taps * ((ch0 + BK - 1) / BK);
+    if (nsrc > 1) s += taps * ((ch1 + BK - 1) / BK);
+    if (nsrc > 2) s += taps * ((ch2 + BK - 1) / BK);
+    return s;
+  }
+
+  // `live` = false turns every lane out-of-range (loads return zeros, touch nothing): lets the caller keep
+  // the K loop body branch-free so the scheduler can interleave these loads with the MFMAs.
+  __device__ __forceinline__ void load(bool live = true) {
+    const int dy = ky - ph, dx = kx - pw;
+    const int toff = ((dy * W + dx) * cld + c0) * 4;   // byte offset of this tap/chunk, may be negative
+    const bool cok = live && (c0 + c4) < cch;
+#pragma unroll
+    for (int i = 0; i < A_PT; ++i) {
+      const bool ok = pok[i] && cok && (unsigned)(py[i] + dy) < (unsigned)H && (unsigned)(px[i] + dx) < (unsigned)W;
+      const unsigned off = ok ? abase[i] + (unsigned)toff : OOB;
+      ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+    }
+    const int koff = kofs * 4;
+#pragma unroll
+    for (int i = 0; i < B_PT; ++i)
+      rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, live ? wvoff[i] : OOB, koff, 0));
+  }
+
+  // ---- the same work in small pieces, for hand-placed interleaving with MFMAs (variant 3) -------------
+  int p_toff, p_koff, p_dy, p_dx;
+  bool p_cok, p_live;
+  __device__ __forceinline__ void load_setup(bool live) {
+    p_dy = ky - ph; p_dx = kx - pw;
+    p_toff = ((p_dy * W + p_dx) * cld + c0) * 4;
+    p_cok = live && (c0 + c4) < cch;
+    p_live = live;
+    p_koff = kofs * 4;
+  }
+  template <int i>
+  __device__ __forceinline__ void load_a() {
+    const bool ok = pok[i] && p_cok && (unsigned)(py[i] + p_dy) < (unsigned)H && (unsigned)(px[i] + p_dx) < (unsigned)W;
+    const unsigned off = ok ? abase[i] + (unsigned)p_toff : OOB;
+    ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+  }
+  template <int i>
+  __device__ __forceinline__ void load_b() {
+    rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, p_live ? wvoff[i] : OOB, p_koff, 0));
+  }
+  // piece q in [0, A_PT + B_PT): one ds_write_b128 of the staged registers into `stage`
+  template <int q>
+  __device__ __forceinline__ void store_piece(float* stage) const {
+    if constexpr (q < A_PT) *reinterpret_cast<f32x4*>(stage + (r0 + 32 * q) * LDS_LD + c4) = ra[q];
+    else *reinterpret_cast<f32x4*>(stage + BM * LDS_LD + (r0 + 32 * (q - A_PT)) * LDS_LD + c4) = rb[q - A_PT];
+  }
+
+  __device__ __forceinline__ void advance() {
     kofs += BK;
     c0 += BK;
-    if (c0 >= sch) {
+    if (c0 >= cch) {
       c0 = 0;
-      if (++kx == a.kw) {
+      if (++kx == kw) {
         kx = 0;
-        if (++ky == a.kh) { ky = 0; ++seg; }
+        if (++ky == kh) {
+          ky = 0;
+          ++seg;
+          if (seg < nsrc) set_segment(seg);
+        }
       }
     }
-  };
-  auto store_lds = [&](int buf) {
-    float* dA = sA + buf * BM * LDS_LD;
-    float* dB = sB + buf * BN * LDS_LD;
+  }
+
+  __device__ __forceinline__ void store(float* dA, float* dB) const {
 #pragma unroll
     for (int i = 0; i < A_PT; ++i)
       *reinterpret_cast<f32x4*>(dA + (r0 + 32 * i) * LDS_LD + c4) = ra[i];
 #pragma unroll
     for (int i = 0; i < B_PT; ++i)
       *reinterpret_cast<f32x4*>(dB + (r0 + 32 * i) * LDS_LD + c4) = rb[i];
-  };
+  }
+};
 
-  f32x16 acc[MT][NT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+// One K-step (32 channels) of MFMAs for a wave tile of MT x NT 32x32 blocks, operands from LDS.
+// Split in two so the caller can issue the next K-step's address arithmetic + buffer loads right
+// after the first fragment reads (they then run in the shadow of the LDS latency / first MFMAs).
+// NB: no lambdas here — capturing the Stager by reference forces it into scratch memory and turns
+// its wave-uniform state into VGPRs (waterfall loops around every buffer load).
+template <int MT, int NT>
+struct Frags {
+  f32x4 fa[MT], fb[NT];
+};
 
-  load_step();
-  advance();
-  store_lds(0);
-  __syncthreads();
-
-  const int frow = lane & 31;
-  const int fk = (lane >> 5) * 4;
-
-  for (int step = 0; step < total_steps; ++step) {
-    const int buf = step & 1;
-    const bool more = (step + 1) < total_steps;
-    if (more) { load_step(); advance(); }
-
-    const float* cA = sA + buf * BM * LDS_LD + (wm0 + frow) * LDS_LD + fk;
-    const float* cB = sB + buf * BN * LDS_LD + (wn0 + frow) * LDS_LD + fk;
+template <int MT, int NT>
+__device__ __forceinline__ void frag_read(Frags<MT, NT>& f, const float* cA, const float* cB, int kk) {
 #pragma unroll
-    for (int kk = 0; kk < BK / 8; ++kk) {
-      f32x4 fa[MT], fb[NT];
+  for (int mt = 0; mt < MT; ++mt) f.fa[mt] = *reinterpret_cast<const f32x4*>(cA + mt * 32 * LDS_LD + kk * 8);
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-        fa[mt] = *reinterpret_cast<const f32x4*>(cA + mt * 32 * LDS_LD + kk * 8);
+  for (int nt = 0; nt < NT; ++nt) f.fb[nt] = *reinterpret_cast<const f32x4*>(cB + nt * 32 * LDS_LD + kk * 8);
+}
+
+template <int MT, int NT>
+__device__ __forceinline__ void mma_one(f32x16 (&acc)[MT][NT], const Frags<MT, NT>& f) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
-        fb[nt] = *reinterpret_cast<const f32x4*>(cB + nt * 32 * LDS_LD + kk * 8);
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mt][s], fb[nt][s], acc[mt][nt], 0, 0, 0);
-    }
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.fa[mt][s], f.fb[nt][s], acc[mt][nt], 0, 0, 0);
+}
 
-    if (more) store_lds(buf ^ 1);
-    __syncthreads();
-  }
+// Remaining three sub-steps after the caller read sub-step 0: reads for kk+1 are pinned in front of the
+// MFMAs of kk so the LDS latency hides under the matrix pipe.
+template <int MT, int NT>
+__device__ __forceinline__ void mma_rest(f32x16 (&acc)[MT][NT], Frags<MT, NT>& f, const float* cA, const float* cB) {
+  Frags<MT, NT> g;
+  frag_read<MT, NT>(g, cA, cB, 1);
+  __builtin_amdgcn_sched_barrier(0);
+  mma_one<MT, NT>(acc, f);
+  __builtin_amdgcn_sched_barrier(0);
+  frag_read<MT, NT>(f, cA, cB, 2);
+  __builtin_amdgcn_sched_barrier(0);
+  mma_one<MT, NT>(acc, g);
+  __builtin_amdgcn_sched_barrier(0);
+  frag_read<MT, NT>(g, cA, cB, 3);
+  __builtin_amdgcn_sched_barrier(0);
+  mma_one<MT, NT>(acc, f);
+  __builtin_amdgcn_sched_barrier(0);
+  mma_one<MT, NT>(acc, g);
+}
 
-  // ---- epilogue -------------------------------------------------------------------------------
+// Epilogue for accumulator registers [R0, R1) of every 32x32 block of the wave tile.
+template <int MT, int NT, int EPI, int R0, int R1>
+__device__ __forceinline__ void epilogue(const GemmArgs& a, const f32x16 (&acc)[MT][NT], long long m_base,
+                                         int n_base, int lane, long long batch) {
   const int col_l = lane & 31;
   const int row_l = (lane >> 5) * 4;
   float* outp = a.out + batch * a.o_bs;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    const int n = n0 + wn0 + nt * 32 + col_l;
+    const int n = n_base + nt * 32 + col_l;
     const bool nok = n < a.b_rows;
     const float bias = (a.bias != nullptr && nok) ? a.bias[n] : 0.f;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const long long p = m0 + wm0 + mt * 32 + (r & 3) + 8 * (r >> 2) + row_l;
+      for (int r = R0; r < R1; ++r) {
+        const long long p = m_base + mt * 32 + (r & 3) + 8 * (r >> 2) + row_l;
         if (!nok || p >= a.M) continue;
         float v = acc[mt][nt][r] + bias;
         if constexpr (EPI == PFK_EPI_LINEAR) {
@@ -252,44 +298,329 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs a) {
   }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int MT, int NT>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[MT][NT]) {
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+}
+
+// -------------------------------------------------------------------------------------------------
+// Variant 1: 4 waves, one K pipeline, LDS double buffer (next step's loads in flight during the MFMAs).
+// Good when the grid has several blocks per CU to overlap with.
+// -------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, int EPI>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs a) {
+  constexpr int WAVES_N = BN / WN;
+  static_assert((BM / WM) * WAVES_N == 4, "4 waves per block");
+  constexpr int MT = WM / 32, NT = WN / 32;
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sA = smem;                          // [2][BM][LDS_LD]
+  float* sB = smem + 2 * BM * LDS_LD;        // [2][BN][LDS_LD]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = tid >> 6;
+  const int wm0 = (wid / WAVES_N) * WM;
+  const int wn0 = (wid % WAVES_N) * WN;
+
+  const int bid = pfk_xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_n = bid % a.tiles_n;
+  const int tile_m = bid / a.tiles_n;
+  const long long m0 = (long long)tile_m * BM;
+  const int n0 = tile_n * BN;
+  const long long batch = blockIdx.y;
+
+  Stager<BM, BN> st(a, m0, n0, tid, batch);
+  const int total_steps = st.total_steps();
+
+  f32x16 acc[MT][NT];
+  zero_acc<MT, NT>(acc);
+
+  st.load();
+  st.advance();
+  st.store(sA, sB);
+  __syncthreads();
+
+  const int frow = lane & 31;
+  const int fk = (lane >> 5) * 4;
+
+  for (int step = 0; step < total_steps; ++step) {
+    const int buf = step & 1;
+    const bool more = (step + 1) < total_steps;
+    const float* cA = sA + buf * BM * LDS_LD + (wm0 + frow) * LDS_LD + fk;
+    const float* cB = sB + buf * BN * LDS_LD + (wn0 + frow) * LDS_LD + fk;
+    Frags<MT, NT> fr;
+    frag_read<MT, NT>(fr, cA, cB, 0);
+    st.load(more);                      // branch-free; all lanes out of range on the last step
+    __builtin_amdgcn_sched_barrier(0);  // keep the prefetch in front of the MFMAs (hipcc otherwise sinks it to its use)
+    mma_rest<MT, NT>(acc, fr, cA, cB);
+    __builtin_amdgcn_sched_barrier(0);
+    st.store(sA + (buf ^ 1) * BM * LDS_LD, sB + (buf ^ 1) * BN * LDS_LD);   // last step: zeros into a dead buffer
+    if (more) st.advance();
+    __syncthreads();
+  }
+  epilogue<MT, NT, EPI, 0, 16>(a, acc, m0 + wm0, n0 + wn0, lane, batch);
+}
+
+// -------------------------------------------------------------------------------------------------
+// Variant 3 (the tuned path): three LDS stages per wave group, global prefetch distance 2, register
+// double-buffered MFMA fragments, one s_barrier per K-step.
+//
+//   step j:  regs(j+2) -> LDS stage (j+2)%3      [loads issued a full step earlier: no vmcnt stall]
+//            issue buffer loads for step j+3 -> regs
+//            MFMAs on stage j%3; the fragments of sub-step kk+1 are read while sub-step kk is on the
+//            matrix pipe, and the first fragments of step j+1 are read (from stage (j+1)%3, stored
+//            during step j-1, a barrier ago) before the barrier — so after the barrier the wave goes
+//            straight to MFMAs: no LDS or global latency is exposed at the step boundary.
+//
+// GROUPS = 2 adds in-block split-K: two 4-wave groups (K-steps g, g+2, ...) with private LDS stages
+// share the barriers; each SIMD then hosts two waves whose address arithmetic / LDS traffic overlaps
+// the other's MFMAs — the regime of the RAFT update block at batch 1, where M = 7040 pixels gives
+// fewer 32x32 output tiles than the chip has SIMDs.  The groups swap accumulator halves through LDS at
+// the end (deterministic 2-term sum) and each finishes the epilogue for 8 of the 16 registers.
+// -------------------------------------------------------------------------------------------------
+template <int MT, int NT>
+__device__ __forceinline__ void mma_frags(f32x16 (&acc)[MT][NT], const Frags<MT, NT>& f) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.fa[mt][s], f.fb[nt][s], acc[mt][nt], 0, 0, 0);
+}
+
+// Hand-placed instruction stream for one K-step of variant 3.  A wave issues in order, so anything that does
+// not sit BETWEEN two MFMAs in program order runs while the matrix pipe idles; each fp32 32x32x2 MFMA covers
+// 64 issue cycles, enough for one small "filler" (a ds_write, a buffer load with its address arithmetic, a
+// pair of fragment reads).  sched_barrier(0) after every item pins the order:
+//   MFMA, [fragment reads of the next sub-step, right after the first MFMA of this one], filler, MFMA, ...
+// Fillers in order: LDS stores of step j+2 (loaded a full step ago), scalar setup, the buffer loads of
+// step j+3.  All indices are template constants so every register array stays in registers.
+template <int BM, int BN, int MT, int NT, int ABL, int Q>
+__device__ __forceinline__ void v3_slot(f32x16 (&acc)[MT][NT], Frags<MT, NT>& f0, Frags<MT, NT>& f1, Stager<BM, BN>& st,
+                                        const float* cA, const float* cB, const float* nA, const float* nB,
+                                        float* s_fill, bool live) {
+  constexpr int N0 = 4 * MT * NT;
+  constexpr int kk = Q / N0, i = Q % N0;
+  constexpr int sidx = i / (MT * NT), mt = (i / NT) % MT, nt = i % NT;
+  constexpr int A_PT = Stager<BM, BN>::A_PT, B_PT = Stager<BM, BN>::B_PT, NW = A_PT + B_PT;
+  static_assert(2 * NW + 1 <= 4 * N0, "not enough MFMA slots for the fillers");
+  // ABL (timing ablations, results are garbage): 1 no buffer loads, 2 + no LDS stores, 3 + no fragment reads, 4 no MFMAs
+  if constexpr (ABL != 4) {
+    if constexpr (kk & 1) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(f1.fa[mt][sidx], f1.fb[nt][sidx], acc[mt][nt], 0, 0, 0);
+    else                  acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(f0.fa[mt][sidx], f0.fb[nt][sidx], acc[mt][nt], 0, 0, 0);
+  } else {
+    if constexpr (kk & 1) asm volatile("" :: "v"(f1.fa[mt][sidx]), "v"(f1.fb[nt][sidx]));
+    else                  asm volatile("" :: "v"(f0.fa[mt][sidx]), "v"(f0.fb[nt][sidx]));
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (i == 0 && (ABL < 3 || ABL == 4)) {  // (ABL 3,5,6: MFMA-only skeletons)   // next sub-step's fragments, >= 3 MFMAs (192 cycles) ahead of their first use
+    if constexpr (kk == 0) frag_read<MT, NT>(f1, cA, cB, 1);
+    else if constexpr (kk == 1) frag_read<MT, NT>(f0, cA, cB, 2);
+    else if constexpr (kk == 2) frag_read<MT, NT>(f1, cA, cB, 3);
+    else frag_read<MT, NT>(f0, nA, nB, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if constexpr (Q < NW) { if constexpr (ABL < 2 || ABL == 4) st.template store_piece<Q>(s_fill); }
+  else if constexpr (Q == NW) st.load_setup(live);
+  else if constexpr (Q <= NW + A_PT) { if constexpr (ABL < 1 || ABL == 4) st.template load_a<Q - NW - 1>(); }
+  else if constexpr (Q <= NW + A_PT + B_PT) { if constexpr (ABL < 1 || ABL == 4) st.template load_b<Q - NW - A_PT - 1>(); }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int BM, int BN, int MT, int NT, int ABL, int... Qs>
+__device__ __forceinline__ void v3_step(f32x16 (&acc)[MT][NT], Frags<MT, NT>& f0, Frags<MT, NT>& f1, Stager<BM, BN>& st,
+                                        const float* cA, const float* cB, const float* nA, const float* nB,
+                                        float* s_fill, bool live, std::integer_sequence<int, Qs...>) {
+  (v3_slot<BM, BN, MT, NT, ABL, Qs>(acc, f0, f1, st, cA, cB, nA, nB, s_fill, live), ...);
+}
+
+template <int BM, int BN, int WM, int WN, int EPI, int GROUPS, int ABL = 0>
+__global__ __launch_bounds__(256 * GROUPS) void conv_gemm_v3_kernel(const GemmArgs a) {
+  constexpr int WAVES_N = BN / WN;
+  static_assert((BM / WM) * WAVES_N == 4, "4 waves per group");
+  static_assert(BK == 32, "fragment schedule below is written for 4 sub-steps");
+  constexpr int MT = WM / 32, NT = WN / 32;
+  constexpr int STAGE = (BM + BN) * LDS_LD;      // floats per stage: A rows then B rows
+  constexpr int GROUP_LDS = 3 * STAGE;
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int grp = GROUPS == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);  // wave-uniform
+  const int gtid = threadIdx.x & 255;
+  float* base = smem + grp * GROUP_LDS;
+
+  const int lane = gtid & 63;
+  const int wid = gtid >> 6;
+  const int wm0 = (wid / WAVES_N) * WM;
+  const int wn0 = (wid % WAVES_N) * WN;
+
+  const int bid = pfk_xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_n = bid % a.tiles_n;
+  const int tile_m = bid / a.tiles_n;
+  const long long m0 = (long long)tile_m * BM;
+  const int n0 = tile_n * BN;
+  const long long batch = blockIdx.y;
+
+  Stager<BM, BN> st(a, m0, n0, gtid, batch);
+  const int S = st.total_steps();
+  const int my_steps = (S - grp + GROUPS - 1) / GROUPS;
+  const int max_steps = (S + GROUPS - 1) / GROUPS;   // same trip count for every wave (barriers)
+  if (GROUPS > 1 && grp) st.advance();
+
+  f32x16 acc[MT][NT];
+  zero_acc<MT, NT>(acc);
+
+  float* s_cur = base;               // stage holding step j
+  float* s_nxt = base + STAGE;       // step j+1
+  float* s_fill = base + 2 * STAGE;  // receives step j+2
+
+  // prologue: steps 0 and 1 into LDS, step 2 into registers (dead steps load zeros)
+  st.load(0 < my_steps);
+#pragma unroll
+  for (int g = 0; g < GROUPS; ++g) st.advance();
+  st.store(s_cur, s_cur + BM * LDS_LD);
+  st.load(1 < my_steps);
+#pragma unroll
+  for (int g = 0; g < GROUPS; ++g) st.advance();
+  st.store(s_nxt, s_nxt + BM * LDS_LD);
+  st.load(2 < my_steps);
+#pragma unroll
+  for (int g = 0; g < GROUPS; ++g) st.advance();
+  __syncthreads();
+
+  const int foff_a = (wm0 + (lane & 31)) * LDS_LD + (lane >> 5) * 4;
+  const int foff_b = BM * LDS_LD + (wn0 + (lane & 31)) * LDS_LD + (lane >> 5) * 4;
+  Frags<MT, NT> f0, f1;
+  frag_read<MT, NT>(f0, s_cur + foff_a, s_cur + foff_b, 0);
+
+  for (int j = 0; j < max_steps; ++j) {
+    v3_step<BM, BN, MT, NT, ABL>(acc, f0, f1, st, s_cur + foff_a, s_cur + foff_b, s_nxt + foff_a, s_nxt + foff_b, s_fill,
+                            j + 3 < my_steps, std::make_integer_sequence<int, 16 * MT * NT>{});
+    if constexpr (ABL != 6) {
+#pragma unroll
+      for (int g = 0; g < GROUPS; ++g) st.advance();
+    }
+    float* t = s_cur; s_cur = s_nxt; s_nxt = s_fill; s_fill = t;
+    if constexpr (ABL != 5) __syncthreads();
+  }
+
+  if constexpr (GROUPS == 1) {
+    epilogue<MT, NT, EPI, 0, 16>(a, acc, m0 + wm0, n0 + wn0, lane, batch);
+  } else {
+    // exchange accumulator halves: group g finishes registers [8g, 8g+8).
+    // red[group][wave][tile][reg8][lane]: lane-contiguous, conflict-free.  (All stage reads are
+    // behind the loop's final barrier, so the staging LDS can be reused.)
+    float* red = smem;
+    constexpr int PER_WAVE = MT * NT * 8 * 64;
+    {
+      float* mine = red + ((grp * 4 + wid) * PER_WAVE) + lane;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            const float v = grp ? acc[mt][nt][r] : acc[mt][nt][8 + r];   // the half the partner finishes
+            mine[((mt * NT + nt) * 8 + r) * 64] = v;
+          }
+    }
+    __syncthreads();
+    {
+      const float* theirs = red + (((1 - grp) * 4 + wid) * PER_WAVE) + lane;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            const float v = theirs[((mt * NT + nt) * 8 + r) * 64];
+            if (grp) acc[mt][nt][8 + r] += v; else acc[mt][nt][r] += v;
+          }
+    }
+    if (grp) epilogue<MT, NT, EPI, 8, 16>(a, acc, m0 + wm0, n0 + wn0, lane, batch);
+    else     epilogue<MT, NT, EPI, 0, 8>(a, acc, m0 + wm0, n0 + wn0, lane, batch);
+  }
+}
+
+// VARIANT: 0 = 4-wave double-buffered pipeline (v1), 1 = v3 one group, 2 = v3 two groups (in-block split-K)
+template <int BM, int BN, int WM, int WN, int EPI, int VARIANT>
+int launch_one(const GemmArgs& g, dim3 grid, hipStream_t st) {
+  if constexpr (VARIANT == 0) {
+    constexpr size_t smem = 2 * (BM + BN) * LDS_LD * sizeof(float);
+    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, EPI>), grid, dim3(256), smem, st, g);
+  } else {
+    constexpr int G = VARIANT % 10, ABL = VARIANT / 10;
+    constexpr size_t smem = (size_t)G * 3 * (BM + BN) * LDS_LD * sizeof(float);
+    static_assert(smem <= 160 * 1024, "LDS budget");
+    static bool attr_set = false;
+    auto kern = conv_gemm_v3_kernel<BM, BN, WM, WN, EPI, G, ABL>;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256 * G), smem, st, g);
+  }
+  return pfk_launch_status();
+}
+
+template <int BM, int BN, int WM, int WN, int VARIANT>
 int launch_cfg(const GemmArgs& a, int epi, int batches, hipStream_t st) {
   GemmArgs g = a;
   const long long tiles_m = (a.M + BM - 1) / BM;
   g.tiles_n = (a.b_rows + BN - 1) / BN;
   const long long nblk = tiles_m * g.tiles_n;
   if (nblk <= 0 || nblk > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
-  const size_t smem = 2 * (BM + BN) * LDS_LD * sizeof(float);
-  dim3 grid((unsigned)nblk, (unsigned)batches), block(256);
+  dim3 grid((unsigned)nblk, (unsigned)batches);
   switch (epi) {
-    case PFK_EPI_LINEAR:
-      hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PFK_EPI_LINEAR>), grid, block, smem, st, g);
-      break;
-    case PFK_EPI_GRU_ZR:
-      hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PFK_EPI_GRU_ZR>), grid, block, smem, st, g);
-      break;
-    case PFK_EPI_GRU_Q:
-      hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PFK_EPI_GRU_Q>), grid, block, smem, st, g);
-      break;
-    default:
-      return PFK_ERR_BAD_ARG;
+    case PFK_EPI_LINEAR: return launch_one<BM, BN, WM, WN, PFK_EPI_LINEAR, VARIANT>(g, grid, st);
+    case PFK_EPI_GRU_ZR: return launch_one<BM, BN, WM, WN, PFK_EPI_GRU_ZR, VARIANT>(g, grid, st);
+    case PFK_EPI_GRU_Q:  return launch_one<BM, BN, WM, WN, PFK_EPI_GRU_Q, VARIANT>(g, grid, st);
+    default: return PFK_ERR_BAD_ARG;
   }
-  return pfk_launch_status();
 }
 
 int g_force_tile = -1;  // debug/tuning knob, see pfk_debug_set_tile
 
+// Configurations: 0-3 = v1 (64x64, 64x128, 128x128, 128x64); 4-7 = v3 one group, same tiles;
+// 8 = v3 two groups 64x64 (in-block split-K).
 int launch(const GemmArgs& a, int epi, int batches, hipStream_t st) {
   int cfg;
-  if (g_force_tile >= 0) cfg = g_force_tile;
-  else if (a.b_rows >= 2048 && a.M >= 2048) cfg = 2;  // big square-ish GEMM (correlation volume)
-  else if (a.b_rows > 64) cfg = 1;
-  else cfg = 0;
+  if (g_force_tile >= 0) {
+    cfg = g_force_tile;
+  } else if (a.b_rows >= 2048 && a.M >= 2048) {
+    cfg = 6;                                             // big square-ish GEMM (correlation volume)
+  } else {
+    const long long tiles64 = (a.M + 63) / 64;
+    const long long blocks64 = tiles64 * ((a.b_rows + 63) / 64);
+    // measured on MI355X (scripts/conv_bench.py): with < 4 blocks of 64x64 per CU the 3-stage hand-interleaved
+    // pipeline on 64x64 tiles wins; with plenty of blocks the lighter 2-stage pipeline on 64x128 tiles (two
+    // resident blocks per CU) does.
+    if (blocks64 < 4 * 256) cfg = 4;
+    else cfg = a.b_rows > 64 ? 1 : 0;
+  }
   switch (cfg) {
-    case 0: return launch_cfg<64, 64, 32, 32>(a, epi, batches, st);
-    case 1: return launch_cfg<64, 128, 32, 64>(a, epi, batches, st);
-    case 2: return launch_cfg<128, 128, 64, 64>(a, epi, batches, st);
-    case 3: return launch_cfg<128, 64, 64, 32>(a, epi, batches, st);
+    case 0: return launch_cfg<64, 64, 32, 32, 0>(a, epi, batches, st);
+    case 1: return launch_cfg<64, 128, 32, 64, 0>(a, epi, batches, st);
+    case 2: return launch_cfg<128, 128, 64, 64, 0>(a, epi, batches, st);
+    case 3: return launch_cfg<128, 64, 64, 32, 0>(a, epi, batches, st);
+    case 4: return launch_cfg<64, 64, 32, 32, 1>(a, epi, batches, st);
+    case 5: return launch_cfg<64, 128, 32, 64, 1>(a, epi, batches, st);
+    case 6: return launch_cfg<128, 128, 64, 64, 1>(a, epi, batches, st);
+    case 7: return launch_cfg<128, 64, 64, 32, 1>(a, epi, batches, st);
+    case 8: return launch_cfg<64, 64, 32, 32, 2>(a, epi, batches, st);
+    // timing ablations of cfg 4 (results are garbage; used by scripts/conv_bench.py only)
+    case 21: return epi == PFK_EPI_LINEAR ? launch_cfg<64, 64, 32, 32, 11>(a, epi, batches, st) : PFK_ERR_BAD_ARG;
+    case 22: return epi == PFK_EPI_LINEAR ? launch_cfg<64, 64, 32, 32, 21>(a, epi, batches, st) : PFK_ERR_BAD_ARG;
+    case 23: return epi == PFK_EPI_LINEAR ? launch_cfg<64, 64, 32, 32, 31>(a, epi, batches, st) : PFK_ERR_BAD_ARG;
+    case 24: return epi == PFK_EPI_LINEAR ? launch_cfg<64, 64, 32, 32, 41>(a, epi, batches, st) : PFK_ERR_BAD_ARG;
+    case 25: return epi == PFK_EPI_LINEAR ? launch_cfg<64, 64, 32, 32, 51>(a, epi, batches, st) : PFK_ERR_BAD_ARG;
+    case 26: return epi == PFK_EPI_LINEAR ? launch_cfg<64, 64, 32, 32, 61>(a, epi, batches, st) : PFK_ERR_BAD_ARG;
     default: return PFK_ERR_BAD_ARG;
   }
 }
@@ -329,6 +660,9 @@ int pfk_conv2d_f32(const pfk_conv_desc* d, pfk_stream_t stream) {
   a.ktot = pfk_conv_ktot(d);
   a.relu = d->relu; a.scale = d->scale;
   a.M = (long long)d->B * d->H * d->W;
+  for (int i = 0; i < d->num_src; ++i)   // kernels address sources with 32-bit byte offsets
+    if (a.M * s[i].ld * 4 >= 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
+  if ((long long)d->cout * a.ktot * 4 >= 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
   switch (d->epilogue) {
     case PFK_EPI_LINEAR:
       if (!d->out || d->out_ld < d->out_coff + d->cout) return PFK_ERR_BAD_ARG;
@@ -357,6 +691,7 @@ int pfk_corr_volume_f32(const float* f1, int ld1, const float* f2, int ld2, floa
   if (!pfk_aligned16(f1) || !pfk_aligned16(f2) || (ld1 & 3) || (ld2 & 3) || (D & 3))
     return PFK_ERR_ALIGNMENT;
   if (ld2 != round_up32(D)) return PFK_ERR_UNSUPPORTED;  // f2 rows are read as packed weight rows
+  if ((long long)N1 * ld1 * 4 >= 0x7fffffffLL || (long long)N2 * ld2 * 4 >= 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
   GemmArgs a{};
   a.src0 = f1; a.ld0 = ld1; a.ch0 = D; a.nsrc = 1;
   a.H = 1; a.W = N1; a.kh = 1; a.kw = 1;

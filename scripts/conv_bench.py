@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Micro-benchmark + correctness of pfk::conv2d on the update-block shapes (GPU box).
+    python scripts/conv_bench.py [--batch 1] [--cfgs -1,1,5] [--reps 30]
+Reference = torch conv2d on the same GPU (MIOpen fp32), only to catch wrong results quickly; the parity gate
+proper is tests/ against the CPU oracle."""
+import argparse
+import math
+import os
+import sys
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ptlflow_amd  # noqa: E402
+from ptlflow_amd.packing import pack_conv_weight  # noqa: E402
+
+ptlflow_amd.load_native()
+ops = torch.ops.pfk
+
+# name, cin segments, cout, kh, kw, epilogue
+SHAPES = [
+    ("c1", [324], 256, 1, 1, 0), ("c2", [256], 192, 3, 3, 0), ("f2", [128], 64, 3, 3, 0), ("cv", [256], 126, 3, 3, 0),
+    ("zr1", [384], 256, 1, 5, 1), ("q1", [128, 256], 128, 1, 5, 2), ("zr2", [384], 256, 5, 1, 1), ("q2", [128, 256], 128, 5, 1, 2),
+    ("fm", [128], 512, 3, 3, 0), ("mk", [256], 576, 1, 1, 0),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--cfgs", default="-1")
+    ap.add_argument("--reps", type=int, default=30)
+    ap.add_argument("--H", type=int, default=55)
+    ap.add_argument("--W", type=int, default=128)
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    cfgs = [int(c) for c in args.cfgs.split(",")]
+    B, H, W = args.batch, args.H, args.W
+    M = B * H * W
+    dev = torch.device("cuda")
+    torch.manual_seed(0)
+    tot = {c: 0.0 for c in cfgs}
+    for name, segs, cout, kh, kw, epi in SHAPES:
+        if args.only and name not in args.only.split(","):
+            continue
+        cin = sum(segs)
+        xs = [torch.randn(M, c, device=dev) for c in segs]
+        wt = torch.randn(cout, cin, kh, kw, device=dev) / math.sqrt(cin * kh * kw)
+        bias = torch.randn(cout, device=dev) * 0.1
+        offs, o = [], 0
+        for c in segs:
+            offs.append((o, c, c)); o += c
+        packed = pack_conv_weight(wt, offs)
+        x_nchw = torch.cat(xs, 1).view(B, H, W, cin).permute(0, 3, 1, 2).contiguous()
+        ref = F.conv2d(x_nchw, wt, bias, padding=(kh // 2, kw // 2)).permute(0, 2, 3, 1).reshape(M, cout)
+        Ch = cout // 2 if epi == 1 else cout
+        hbuf0 = torch.tanh(torch.randn(M, Ch, device=dev))
+        zbuf0 = torch.rand(M, Ch, device=dev)
+        flops = 2.0 * M * cout * kh * kw * cin
+        line = f"{name:4s} cout={cout:3d} K={kh*kw*cin:5d} {flops/1e9:5.2f} GF |"
+        for cfg in cfgs:
+            ops.debug_set_tile(cfg)
+            out = torch.zeros(M, cout, device=dev)
+            hbuf, zbuf, rh = hbuf0.clone(), zbuf0.clone(), torch.zeros(M, Ch, device=dev)
+
+            def run():
+                if epi == 0:
+                    ops.conv2d(xs, B, H, W, kh, kw, packed, bias, cout, 0, False, 1.0, out, None, None, None)
+                elif epi == 1:
+                    ops.conv2d(xs, B, H, W, kh, kw, packed, bias, cout, 1, False, 1.0, None, hbuf, zbuf, rh)
+                else:
+                    ops.conv2d(xs, B, H, W, kh, kw, packed, bias, cout, 2, False, 1.0, None, hbuf, zbuf, None)
+            run()
+            torch.cuda.synchronize()
+            if epi == 0:
+                err = (out - ref).abs().max().item()
+            elif epi == 1:
+                g = torch.sigmoid(ref)
+                err = max((zbuf - g[:, :Ch]).abs().max().item(), (rh - g[:, Ch:] * hbuf0).abs().max().item())
+            else:
+                q = torch.tanh(ref)
+                err = (hbuf - ((1 - zbuf0) * hbuf0 + zbuf0 * q)).abs().max().item()
+            for _ in range(3):
+                run()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.reps):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            us = 1e3 * e0.elapsed_time(e1) / args.reps
+            tot[cfg] += us
+            line += f" cfg{cfg:2d}: {us:7.1f} us {flops/us/1e6:6.1f} TF err {err:.1e} |"
+        print(line, flush=True)
+    ops.debug_set_tile(-1)
+    print("sum us per iteration:", {c: round(v, 1) for c, v in tot.items()})
+
+
+if __name__ == "__main__":
+    main()
