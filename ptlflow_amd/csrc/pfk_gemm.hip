@@ -86,7 +86,8 @@ struct Stager {
   int c4, r0;
   int prow[A_PT], py[A_PT], px[A_PT];
   bool pok[A_PT];
-  unsigned abase[A_PT];
+  unsigned abase[A_PT];   // byte offset of (row, channel c4) in the current source
+  unsigned aoff[A_PT];    // abase + current tap's offset, or OOB when the tap falls outside the image for this row
   unsigned wvoff[B_PT];
   f32x4 ra[A_PT], rb[B_PT];
 
@@ -113,6 +114,7 @@ struct Stager {
       wvoff[i] = n < a.b_rows ? (unsigned)(n * a.ktot + c4) * 4u : OOB;
     }
     set_segment(0);
+    set_tap();
   }
 
   __device__ __forceinline__ void set_segment(int s) {
@@ -123,6 +125,17 @@ struct Stager {
     for (int i = 0; i < A_PT; ++i) abase[i] = (unsigned)(prow[i] * cld + c4) * 4u;
   }
 
+  // Per-tap work (once every cch/32 K-steps): zero-padding predicate and tap offset folded into one VGPR per row.
+  __device__ __forceinline__ void set_tap() {
+    const int dy = ky - ph, dx = kx - pw;
+    const unsigned toff = (unsigned)((dy * W + dx) * cld * 4);
+#pragma unroll
+    for (int i = 0; i < A_PT; ++i) {
+      const bool ok = pok[i] && (unsigned)(py[i] + dy) < (unsigned)H && (unsigned)(px[i] + dx) < (unsigned)W;
+      aoff[i] = ok ? abase[i] + toff : OOB;
+    }
+  }
+
   __device__ __forceinline__ int total_steps() const {
     const int taps = kh * kw;
     int s = taps * ((ch0 + BK - 1) / BK);
@@ -131,43 +144,36 @@ struct Stager {
     return s;
   }
 
-  // `live` = false turns every lane out-of-range (loads return zeros, touch nothing): lets the caller keep
-  // the K loop body branch-free so the scheduler can interleave these loads with the MFMAs.
+  // Per-step work: the channel chunk goes into the scalar offset of the buffer instruction; the only vector work
+  // is the partial-chunk / dead-step predicate (1 compare + 1 select per row).  `live` = false turns every A lane
+  // out-of-range (zeros) and parks the B loads on K-step 0 (valid memory, multiplied by zeros), which keeps the
+  // K loop body branch-free.
   __device__ __forceinline__ void load(bool live = true) {
-    const int dy = ky - ph, dx = kx - pw;
-    const int toff = ((dy * W + dx) * cld + c0) * 4;   // byte offset of this tap/chunk, may be negative
-    const bool cok = live && (c0 + c4) < cch;
+    load_setup(live);
 #pragma unroll
-    for (int i = 0; i < A_PT; ++i) {
-      const bool ok = pok[i] && cok && (unsigned)(py[i] + dy) < (unsigned)H && (unsigned)(px[i] + dx) < (unsigned)W;
-      const unsigned off = ok ? abase[i] + (unsigned)toff : OOB;
-      ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
-    }
-    const int koff = kofs * 4;
+    for (int i = 0; i < A_PT; ++i)
+      ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, p_cok ? aoff[i] : OOB, p_coff, 0));
 #pragma unroll
     for (int i = 0; i < B_PT; ++i)
-      rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, live ? wvoff[i] : OOB, koff, 0));
+      rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, wvoff[i], p_koff, 0));
   }
 
   // ---- the same work in small pieces, for hand-placed interleaving with MFMAs (variant 3) -------------
-  int p_toff, p_koff, p_dy, p_dx;
-  bool p_cok, p_live;
+  int p_coff, p_koff;
+  bool p_cok;
   __device__ __forceinline__ void load_setup(bool live) {
-    p_dy = ky - ph; p_dx = kx - pw;
-    p_toff = ((p_dy * W + p_dx) * cld + c0) * 4;
-    p_cok = live && (c0 + c4) < cch;
-    p_live = live;
-    p_koff = kofs * 4;
+    const int lim = live ? cch - c0 : 0;
+    p_cok = c4 < lim;
+    p_coff = c0 * 4;
+    p_koff = live ? kofs * 4 : 0;
   }
   template <int i>
   __device__ __forceinline__ void load_a() {
-    const bool ok = pok[i] && p_cok && (unsigned)(py[i] + p_dy) < (unsigned)H && (unsigned)(px[i] + p_dx) < (unsigned)W;
-    const unsigned off = ok ? abase[i] + (unsigned)p_toff : OOB;
-    ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+    ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, p_cok ? aoff[i] : OOB, p_coff, 0));
   }
   template <int i>
   __device__ __forceinline__ void load_b() {
-    rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, p_live ? wvoff[i] : OOB, p_koff, 0));
+    rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, wvoff[i], p_koff, 0));
   }
   // piece q in [0, A_PT + B_PT): one ds_write_b128 of the staged registers into `stage`
   template <int q>
@@ -189,6 +195,7 @@ struct Stager {
           if (seg < nsrc) set_segment(seg);
         }
       }
+      set_tap();
     }
   }
 
@@ -410,7 +417,7 @@ __device__ __forceinline__ void v3_slot(f32x16 (&acc)[MT][NT], Frags<MT, NT>& f0
   constexpr int kk = Q / N0, i = Q % N0;
   constexpr int sidx = i / (MT * NT), mt = (i / NT) % MT, nt = i % NT;
   constexpr int A_PT = Stager<BM, BN>::A_PT, B_PT = Stager<BM, BN>::B_PT, NW = A_PT + B_PT;
-  static_assert(2 * NW + 1 <= 4 * N0, "not enough MFMA slots for the fillers");
+  static_assert(N0 + NW <= 4 * N0, "not enough MFMA slots for the fillers");
   // ABL (timing ablations, results are garbage): 1 no buffer loads, 2 + no LDS stores, 3 + no fragment reads, 4 no MFMAs
   if constexpr (ABL != 4) {
     if constexpr (kk & 1) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(f1.fa[mt][sidx], f1.fb[nt][sidx], acc[mt][nt], 0, 0, 0);
@@ -427,10 +434,19 @@ __device__ __forceinline__ void v3_slot(f32x16 (&acc)[MT][NT], Frags<MT, NT>& f0
     else frag_read<MT, NT>(f0, nA, nB, 0);
     __builtin_amdgcn_sched_barrier(0);
   }
-  if constexpr (Q < NW) { if constexpr (ABL < 2 || ABL == 4) st.template store_piece<Q>(s_fill); }
-  else if constexpr (Q == NW) st.load_setup(live);
-  else if constexpr (Q <= NW + A_PT) { if constexpr (ABL < 1 || ABL == 4) st.template load_a<Q - NW - 1>(); }
-  else if constexpr (Q <= NW + A_PT + B_PT) { if constexpr (ABL < 1 || ABL == 4) st.template load_b<Q - NW - A_PT - 1>(); }
+  // Filler q (from the second sub-step on): store staged register q into the free stage and immediately reload
+  // that register with its share of step j+3 — every load then has one full K-step (~1000+ cycles) to land
+  // before its ds_write in the next step, wherever in the step it sits.
+  constexpr int S0 = N0;                       // first filler slot
+  if constexpr (Q == S0 - 1) st.load_setup(live);
+  else if constexpr (Q >= S0 && Q < S0 + NW) {
+    constexpr int q = Q - S0;
+    if constexpr (ABL < 2 || ABL == 4) st.template store_piece<q>(s_fill);
+    if constexpr (ABL < 1 || ABL == 4) {
+      if constexpr (q < A_PT) st.template load_a<q>();
+      else st.template load_b<q - A_PT>();
+    }
+  }
   __builtin_amdgcn_sched_barrier(0);
 }
 
