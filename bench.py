@@ -113,11 +113,16 @@ def main():
     from ptlflow_amd.synth import smooth_pair
 
     ptlflow_amd.load_native()
+    if os.environ.get("PFK_CUDNN_BENCHMARK") == "1":      # experiment knob: MIOpen find mode for the encoders
+        torch.backends.cudnn.benchmark = True
     small = args.model == "raft_small"
     model = RAFT(small=small, iters=args.iters, upsample_every_iter=not args.skip_dead_upsample)
     model.load_synthetic(1234).eval()
     cpu_state = {k: v.clone() for k, v in model.state_dict().items()}
     model = model.to(dev)
+    if os.environ.get("PFK_CHANNELS_LAST") == "1":        # experiment knob: NHWC encoders
+        model.fnet = model.fnet.to(memory_format=torch.channels_last)
+        model.cnet = model.cnet.to(memory_format=torch.channels_last)
     images_cpu = smooth_pair(args.batch, args.height, args.width, seed=1234 + rank)
     inputs = {"images": images_cpu.to(dev)}
 

@@ -159,6 +159,9 @@ int pfk_flow_from_coords_f32(const float* coords0, const float* coords1, float* 
  * (already multiplied by 0.25); out [B][2][8h][8w] NCHW. */
 int pfk_convex_upsample_f32(const float* flow, const float* mask, int mask_ld, float* out,
                             int B, int H, int W, pfk_stream_t stream);
+/* same, with the flow read pixel-major (flow_pm[p*flow_ld + 0..1], e.g. the update engine's hx slice) */
+int pfk_convex_upsample_pm_f32(const float* flow_pm, int flow_ld, const float* mask, int mask_ld,
+                               float* out, int B, int H, int W, pfk_stream_t stream);
 
 /* NCHW [B][C][H][W] -> pixel-major [B*H*W][ld] (+ channel offset) and back. */
 int pfk_nchw_to_pm_f32(const float* in, float* out, int out_ld, int out_coff, int B, int C,

@@ -39,6 +39,75 @@ __global__ __launch_bounds__(256) void conv_cin2_kernel(const float* __restrict_
   out[p * out_ld + out_coff + co] = acc;
 }
 
+// Tiled version for the common odd k <= 7: one block = 16 consecutive pixels of one image row x up to 128
+// output channels (thread = one channel x 8 pixels).  The (k x (16+k-1)) two-channel flow patch is staged once
+// in LDS with the zero padding applied there; per ky a thread pulls its 8+k-1 patch columns into registers
+// (LDS broadcast reads) and reuses them across kx, so the inner loop is pure FMA.  Same FMA order as the
+// simple kernel (tap-major, x then y channel; padded taps add exactly 0), so results are bit-identical to it.
+template <int K>
+__global__ __launch_bounds__(256) void conv_cin2_tiled_kernel(const float* __restrict__ in, int in_ld,
+                                                              const float* __restrict__ wgt,
+                                                              const float* __restrict__ bias,
+                                                              float* __restrict__ out, int out_ld,
+                                                              int out_coff, int H, int W, int tiles_per_row,
+                                                              int cout, int relu) {
+  constexpr int TP = 16, R = K / 2, PW = TP + 2 * R, NP = 8;
+  __shared__ float sf[2][K][PW];
+  const int tile = blockIdx.x;
+  const int row = tile / tiles_per_row;           // b*H + y
+  const int x0 = (tile - row * tiles_per_row) * TP;
+  const int y = row % H;
+  const long long rowbase = (long long)(row - y) * W;   // b*H*W
+  for (int e = threadIdx.x; e < K * PW; e += 256) {
+    const int ky = e / PW, xx = e - ky * PW;
+    const int gy = y + ky - R, gx = x0 + xx - R;
+    float fx = 0.f, fy = 0.f;
+    if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
+      const float* src = in + (rowbase + (long long)gy * W + gx) * in_ld;
+      fx = src[0];
+      fy = src[1];
+    }
+    sf[0][ky][xx] = fx;
+    sf[1][ky][xx] = fy;
+  }
+  __syncthreads();
+  const int g = threadIdx.x >> 7;
+  const int xs = x0 + g * NP;
+  for (int c = threadIdx.x & 127; c < cout; c += 128) {
+    float acc[NP];
+    const float b0 = bias ? bias[c] : 0.f;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) acc[p] = b0;
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) {
+      float fx[NP + K - 1], fy[NP + K - 1];
+#pragma unroll
+      for (int j = 0; j < NP + K - 1; ++j) {
+        fx[j] = sf[0][ky][g * NP + j];
+        fy[j] = sf[1][ky][g * NP + j];
+      }
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) {
+        const float* w = wgt + (long long)(ky * K + kx) * 2 * cout;
+        const float w0 = w[c], w1 = w[cout + c];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          acc[p] = fmaf(fx[p + kx], w0, acc[p]);
+          acc[p] = fmaf(fy[p + kx], w1, acc[p]);
+        }
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      if (xs + p < W) {
+        float v = acc[p];
+        if (relu) v = (v < 0.f) ? 0.f : v;
+        out[(rowbase + (long long)y * W + xs + p) * out_ld + out_coff + c] = v;
+      }
+    }
+  }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -111,7 +180,7 @@ __global__ __launch_bounds__(256) void flow_from_coords_kernel(const float* __re
 
 // RAFT.upsample_flow (raft.py:112-123).  One wave per coarse pixel, lane = sy*8 + sx: the nine
 // mask reads are 256-byte coalesced rows, the 3x3 flow neighbourhood is broadcast.
-__global__ __launch_bounds__(256) void convex_upsample_kernel(const float* __restrict__ flow,
+__global__ __launch_bounds__(256) void convex_upsample_kernel(const float* __restrict__ flow, int flow_ld,
                                                               const float* __restrict__ mask,
                                                               int mask_ld, float* __restrict__ out,
                                                               long long M, int H, int W) {
@@ -139,8 +208,14 @@ __global__ __launch_bounds__(256) void convex_upsample_kernel(const float* __res
     const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
     float vx = 0.f, vy = 0.f;
     if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
-      vx = 8.0f * fx[yy * W + xx];
-      vy = 8.0f * fy[yy * W + xx];
+      if (flow_ld > 0) {   // pixel-major: flow[p][0..1] (the update engine's hx slice)
+        const float* f = flow + (b * hw + (long long)yy * W + xx) * flow_ld;
+        vx = 8.0f * f[0];
+        vy = 8.0f * f[1];
+      } else {             // NCHW
+        vx = 8.0f * fx[yy * W + xx];
+        vy = 8.0f * fy[yy * W + xx];
+      }
     }
     const float wk = m[k] * inv;
     ox += wk * vx;
@@ -217,10 +292,20 @@ int pfk_conv_cin2_f32(const float* in, int in_ld, const float* weight, const flo
   if (!in || !weight || !out || B <= 0 || H <= 0 || W <= 0 || cout <= 0) return PFK_ERR_BAD_ARG;
   if (k <= 0 || !(k & 1) || in_ld < 2 || out_ld < out_coff + cout) return PFK_ERR_BAD_ARG;
   const long long M = (long long)B * H * W;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (k == 3 || k == 5 || k == 7) {
+    const int tpr = (W + 15) / 16;
+    const long long tiles = (long long)B * H * tpr;
+    if (tiles > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
+    dim3 grid((unsigned)tiles), block(256);
+    if (k == 7) hipLaunchKernelGGL(conv_cin2_tiled_kernel<7>, grid, block, 0, st, in, in_ld, weight, bias, out, out_ld, out_coff, H, W, tpr, cout, relu);
+    else if (k == 5) hipLaunchKernelGGL(conv_cin2_tiled_kernel<5>, grid, block, 0, st, in, in_ld, weight, bias, out, out_ld, out_coff, H, W, tpr, cout, relu);
+    else hipLaunchKernelGGL(conv_cin2_tiled_kernel<3>, grid, block, 0, st, in, in_ld, weight, bias, out, out_ld, out_coff, H, W, tpr, cout, relu);
+    return pfk_launch_status();
+  }
   const long long blocks = (M * cout + 255) / 256;
   if (blocks > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(conv_cin2_kernel, dim3((unsigned)blocks), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), in, in_ld, weight, bias, out, out_ld,
+  hipLaunchKernelGGL(conv_cin2_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, in_ld, weight, bias, out, out_ld,
                      out_coff, M, H, W, k, cout, relu);
   return pfk_launch_status();
 }
@@ -257,7 +342,16 @@ int pfk_convex_upsample_f32(const float* flow, const float* mask, int mask_ld, f
   if (!flow || !mask || !out || mask_ld < 576 || B <= 0 || H <= 0 || W <= 0) return PFK_ERR_BAD_ARG;
   const long long M = (long long)B * H * W;
   hipLaunchKernelGGL(convex_upsample_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), flow, mask, mask_ld, out, M, H, W);
+                     static_cast<hipStream_t>(stream), flow, 0, mask, mask_ld, out, M, H, W);
+  return pfk_launch_status();
+}
+
+int pfk_convex_upsample_pm_f32(const float* flow_pm, int flow_ld, const float* mask, int mask_ld, float* out,
+                               int B, int H, int W, pfk_stream_t stream) {
+  if (!flow_pm || !mask || !out || flow_ld < 2 || mask_ld < 576 || B <= 0 || H <= 0 || W <= 0) return PFK_ERR_BAD_ARG;
+  const long long M = (long long)B * H * W;
+  hipLaunchKernelGGL(convex_upsample_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), flow_pm, flow_ld, mask, mask_ld, out, M, H, W);
   return pfk_launch_status();
 }
 

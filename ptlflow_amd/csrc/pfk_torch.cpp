@@ -156,6 +156,15 @@ void convex_upsample(const Tensor& flow, const Tensor& mask, Tensor out) {
            "convex_upsample");
 }
 
+void convex_upsample_pm(const Tensor& flow_pm, const Tensor& mask, Tensor out) {
+  check_pm(flow_pm, "flow_pm"); check_pm(mask, "mask"); check_dev_f32(out, "out");
+  TORCH_CHECK(out.dim() == 4 && out.size(1) == 2 && out.is_contiguous() && out.size(2) % 8 == 0 && out.size(3) % 8 == 0);
+  const int B = out.size(0), H = out.size(2) / 8, W = out.size(3) / 8;
+  TORCH_CHECK(mask.size(0) == (int64_t)B * H * W && mask.size(1) == 576 && flow_pm.size(0) == mask.size(0) && flow_pm.size(1) >= 2);
+  check_ok(pfk_convex_upsample_pm_f32(fptr(flow_pm), flow_pm.stride(0), fptr(mask), mask.stride(0), fptr(out), B, H, W,
+                                      cur_stream()), "convex_upsample_pm");
+}
+
 void nchw_to_pm(const Tensor& in, Tensor out) {
   check_dev_f32(in, "in"); check_pm(out, "out");
   TORCH_CHECK(in.dim() == 4 && in.is_contiguous());
@@ -190,6 +199,7 @@ TORCH_LIBRARY(pfk, m) {
         "Tensor(c!)? flow_out) -> ()");
   m.def("flow_from_coords(Tensor coords0, Tensor coords1, Tensor(a!) flow_out) -> ()");
   m.def("convex_upsample(Tensor flow, Tensor mask, Tensor(a!) out) -> ()");
+  m.def("convex_upsample_pm(Tensor flow_pm, Tensor mask, Tensor(a!) out) -> ()");
   m.def("nchw_to_pm(Tensor inp, Tensor(a!) out) -> ()");
   m.def("pm_to_nchw(Tensor inp, Tensor(a!) out) -> ()");
 }
@@ -203,6 +213,7 @@ TORCH_LIBRARY_IMPL(pfk, CUDA, m) {
   m.impl("flow_delta", &flow_delta);
   m.impl("flow_from_coords", &flow_from_coords);
   m.impl("convex_upsample", &convex_upsample);
+  m.impl("convex_upsample_pm", &convex_upsample_pm);
   m.impl("nchw_to_pm", &nchw_to_pm);
   m.impl("pm_to_nchw", &pm_to_nchw);
 }

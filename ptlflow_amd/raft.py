@@ -214,11 +214,10 @@ class RAFT(nn.Module):
             do_up = last or self.upsample_every_iter
             eng.step(corr_pm, coords0, coords1, want_mask=do_up)
             if do_up:
-                flow = coords1 - coords0
-                if has_mask:
-                    ops.convex_upsample(flow, eng.mask, flow_up)
-                else:  # raft_small: upflow8 (raft/utils.py:94-96)
-                    flow_up = 8 * F.interpolate(flow, size=(8 * h, 8 * w), mode="bilinear", align_corners=True)
+                if has_mask:   # flow = coords1 - coords0 is already in the engine's hx slice (written by flow_delta)
+                    ops.convex_upsample_pm(eng.flow_view, eng.mask, flow_up)
+                else:          # raft_small: upflow8 (raft/utils.py:94-96)
+                    flow_up = 8 * F.interpolate(coords1 - coords0, size=(8 * h, 8 * w), mode="bilinear", align_corners=True)
         out_up = self.unpad(flow_up, pads)
         return {"flows": out_up[:, None], "flow_small": coords1 - coords0}
 

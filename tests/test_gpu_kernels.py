@@ -196,18 +196,19 @@ def test_gru(gpu, B, H, W, Ch, Cx, passes):
     close(unpm(hx[:, :Ch], B, H, W), ref, rtol=2e-5, atol=3e-5)
 
 
-def test_conv_cin2(gpu):
+@pytest.mark.parametrize("k,cout,W", [(7, 128, 17), (7, 64, 128), (3, 160, 33), (9, 32, 20)])
+def test_conv_cin2(gpu, k, cout, W):
     torch.manual_seed(8)
-    B, H, W, cout = 2, 13, 17, 128
+    B, H = 2, 13
     flow = torch.randn(B, 2, H, W) * 3
-    wt = torch.randn(cout, 2, 7, 7) / 10
+    wt = torch.randn(cout, 2, k, k) / 10
     bias = torch.randn(cout)
-    ref = F.relu(F.conv2d(flow, wt, bias, padding=3))
+    ref = F.relu(F.conv2d(flow, wt, bias, padding=k // 2))
     from ptlflow_amd.packing import pack_cin2_weight
     buf = torch.zeros(B * H * W, 384, device=gpu)
     buf[:, 382:384] = pm(flow)
     out = torch.zeros(B * H * W, cout, device=gpu)
-    torch.ops.pfk.conv_cin2(buf[:, 382:384], pack_cin2_weight(wt).cuda(), bias.cuda(), out, B, H, W, 7, True)
+    torch.ops.pfk.conv_cin2(buf[:, 382:384], pack_cin2_weight(wt).cuda(), bias.cuda(), out, B, H, W, k, True)
     close(unpm(out, B, H, W), ref)
 
 
@@ -245,6 +246,11 @@ def test_convex_upsample(gpu):
     out = torch.zeros(B, 2, 8 * H, 8 * W, device=gpu)
     torch.ops.pfk.convex_upsample(flow.cuda(), pm(mask), out)
     close(out, ref, rtol=1e-5, atol=1e-5)
+    out2 = torch.zeros_like(out)
+    hx = torch.zeros(B * H * W, 384, device=gpu)
+    hx[:, 382:384] = pm(flow)
+    torch.ops.pfk.convex_upsample_pm(hx[:, 382:384], pm(mask), out2)
+    assert torch.equal(out, out2)
 
 
 def test_layout_roundtrip(gpu):
