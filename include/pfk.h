@@ -128,8 +128,12 @@ typedef struct {
   int h_ld;
   float* aux_z;          /* [M][Ch] */
   float* aux_rh;         /* [M][Ch] */
+  void* workspace;       /* optional: >= pfk_conv_workspace_bytes() of device memory, 16-byte aligned, private to
+                            the stream; enables the stream-K schedule for small grids (deterministic).  NULL: tile grid */
+  long long workspace_bytes;
 } pfk_conv_desc;
 
+long long pfk_conv_workspace_bytes(void);
 int pfk_conv_ktot(const pfk_conv_desc* d);
 int pfk_conv2d_f32(const pfk_conv_desc* d, pfk_stream_t stream);
 

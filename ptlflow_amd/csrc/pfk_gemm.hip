@@ -50,6 +50,10 @@ struct GemmArgs {
   long long M;
   long long a_bs, b_bs, o_bs;  // per-blockIdx.y strides (batched correlation), floats
   int tiles_n;
+  float* sk_ws;            // stream-K: one 64x64 fp32 partial per block
+  unsigned* sk_flags;      // stream-K: one ready flag per block (zeroed before every launch)
+  int sk_steps;            // K-steps per tile (host-computed)
+  long long sk_tiles;      // output tiles
 };
 
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -134,6 +138,20 @@ struct Stager {
       const bool ok = pok[i] && (unsigned)(py[i] + dy) < (unsigned)H && (unsigned)(px[i] + dx) < (unsigned)W;
       aoff[i] = ok ? abase[i] + toff : OOB;
     }
+  }
+
+  // Position the iterator at K-step `step` (stream-K segments start mid-tile).
+  __device__ __forceinline__ void seek(int step) {
+    const int taps = kh * kw;
+    int r = step, sg = 0, cps = (ch0 + BK - 1) / BK;
+    if (nsrc > 1 && r >= taps * cps) {
+      r -= taps * cps; sg = 1; cps = (ch1 + BK - 1) / BK;
+      if (nsrc > 2 && r >= taps * cps) { r -= taps * cps; sg = 2; cps = (ch2 + BK - 1) / BK; }
+    }
+    const int tap = r / cps;
+    seg = sg; ky = tap / kw; kx = tap - ky * kw; c0 = (r - tap * cps) * BK; kofs = step * BK;
+    set_segment(sg);
+    set_tap();
   }
 
   __device__ __forceinline__ int total_steps() const {
@@ -564,6 +582,131 @@ __global__ __launch_bounds__(256 * GROUPS) void conv_gemm_v3_kernel(const GemmAr
   }
 }
 
+// -------------------------------------------------------------------------------------------------
+// Variant 4: stream-K on 64x64 tiles.  The update block at batch 1 has M = 7040 pixels: 220..880 tiles of
+// 64x64 for 256 CUs, so a tile-per-block grid leaves the busiest CU with up to 1.6x the average work.
+// Here the (tile, K-step) space is cut into gridDim.x equal contiguous ranges (two resident blocks per CU);
+// a block walks its range from the top tile down, running the variant-3 pipeline on each tile segment:
+//   * a segment that does not contain the tile's LAST K-step (only possible for the block's top segment) is
+//     a contribution: the 64x64 partial goes to the block's workspace slot, released with a flag;
+//   * the segment containing the last K-step owns the tile: it adds the partials of the lower-numbered
+//     blocks that hold the rest of the tile (fixed order => deterministic sum) and runs the epilogue.
+// Owners wait only on LOWER block ids, which produced their contribution as the FIRST thing they did, so the
+// wait is short and cannot deadlock whatever the residency.  Cross-workgroup visibility follows the
+// agent-scope release/acquire recipe of cdna_hip_programming.md (Guideline 16); flags are zeroed by a
+// hipMemsetAsync in front of every launch; the spin is bounded.
+// -------------------------------------------------------------------------------------------------
+constexpr int SK_MAX_BLOCKS = 512;
+constexpr size_t SK_WS_BYTES = (size_t)SK_MAX_BLOCKS * (64 * 64 * 4 + 64);   // partials + flags (flags after the partials)
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void conv_gemm_sk_kernel(const GemmArgs a) {
+  constexpr int BM = 64, BN = 64, MT = 1, NT = 1;
+  constexpr int STAGE = (BM + BN) * LDS_LD;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = tid >> 6;
+  const int wm0 = (wid >> 1) * 32, wn0 = (wid & 1) * 32;
+  const int foff_a = (wm0 + (lane & 31)) * LDS_LD + (lane >> 5) * 4;
+  const int foff_b = BM * LDS_LD + (wn0 + (lane & 31)) * LDS_LD + (lane >> 5) * 4;
+
+  const long long G = gridDim.x;
+  const long long lb = pfk_xcd_remap(blockIdx.x, gridDim.x);
+  const int S = a.sk_steps;
+  const long long U = a.sk_tiles * S;
+  const long long u0 = lb * U / G, u1 = (lb + 1) * U / G;
+
+  long long hi = u1;
+  while (hi > u0) {
+    const long long tile = (hi - 1) / S;
+    const long long tbeg = tile * S;
+    const long long lo = u0 > tbeg ? u0 : tbeg;
+    const int s0 = (int)(lo - tbeg), s1 = (int)(hi - tbeg), nsteps = s1 - s0;
+    const int tile_n = (int)(tile % a.tiles_n);
+    const long long m0 = (tile / a.tiles_n) * BM;
+    const int n0 = tile_n * BN;
+
+    Stager<BM, BN> st(a, m0, n0, tid, 0);
+    if (s0) st.seek(s0);
+    f32x16 acc[MT][NT];
+    zero_acc<MT, NT>(acc);
+
+    float* s_cur = smem;
+    float* s_nxt = smem + STAGE;
+    float* s_fill = smem + 2 * STAGE;
+    st.load(0 < nsteps); st.advance(); st.store(s_cur, s_cur + BM * LDS_LD);
+    st.load(1 < nsteps); st.advance(); st.store(s_nxt, s_nxt + BM * LDS_LD);
+    st.load(2 < nsteps); st.advance();
+    __syncthreads();
+    Frags<MT, NT> f0, f1;
+    frag_read<MT, NT>(f0, s_cur + foff_a, s_cur + foff_b, 0);
+    for (int j = 0; j < nsteps; ++j) {
+      v3_step<BM, BN, MT, NT, 0>(acc, f0, f1, st, s_cur + foff_a, s_cur + foff_b, s_nxt + foff_a, s_nxt + foff_b, s_fill,
+                                 j + 3 < nsteps, std::make_integer_sequence<int, 16 * MT * NT>{});
+      st.advance();
+      float* t = s_cur; s_cur = s_nxt; s_nxt = s_fill; s_fill = t;
+      __syncthreads();
+    }
+
+    if (s1 < S) {
+      // contribution: partial -> workspace slot of this block, then publish
+      float* mine = a.sk_ws + (lb * 4 + wid) * (16 * 64) + lane;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mine[r * 64] = acc[0][0][r];
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(a.sk_flags + lb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    } else {
+      if (s0 > 0) {
+        // owner of a split tile: add the partials of blocks lb-1, lb-2, ... that cover [tbeg, lo)
+        for (long long k = lb - 1; k >= 0; --k) {
+          if (tid == 0) {
+            unsigned spins = 0;
+            while (__hip_atomic_load(a.sk_flags + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+              __builtin_amdgcn_s_sleep(4);
+              if (++spins > (1u << 24)) break;   // bounded: a lost contribution shows up as a wrong result, not a hang
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          }
+          __syncthreads();
+          const float* theirs = a.sk_ws + (k * 4 + wid) * (16 * 64) + lane;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[0][0][r] += theirs[r * 64];
+          if (k * U / G <= tbeg) break;   // block k's range starts at or before the tile: it was the last contributor
+        }
+      }
+      epilogue<MT, NT, EPI, 0, 16>(a, acc, m0 + wm0, n0 + wn0, lane, 0);
+    }
+    hi = lo;
+    __syncthreads();   // LDS stages are reused by the next segment
+  }
+}
+
+int launch_sk(const GemmArgs& a, int epi, hipStream_t st) {
+  GemmArgs g = a;
+  g.tiles_n = (a.b_rows + 63) / 64;
+  g.sk_tiles = ((a.M + 63) / 64) * g.tiles_n;
+  const long long U = g.sk_tiles * g.sk_steps;
+  long long G = SK_MAX_BLOCKS;             // two resident 256-thread blocks per CU (55 KB LDS each)
+  if (U / G < 6) G = U / 6 > 0 ? U / 6 : 1; // keep segments long enough to amortise the pipeline prologue
+  if (hipMemsetAsync(g.sk_flags, 0, (size_t)G * sizeof(unsigned), st) != hipSuccess) return PFK_ERR_LAUNCH;
+  constexpr size_t smem = 3 * 128 * LDS_LD * sizeof(float);
+  dim3 grid((unsigned)G), block(256);
+  switch (epi) {
+    case PFK_EPI_LINEAR: hipLaunchKernelGGL(conv_gemm_sk_kernel<PFK_EPI_LINEAR>, grid, block, smem, st, g); break;
+    case PFK_EPI_GRU_ZR: hipLaunchKernelGGL(conv_gemm_sk_kernel<PFK_EPI_GRU_ZR>, grid, block, smem, st, g); break;
+    case PFK_EPI_GRU_Q:  hipLaunchKernelGGL(conv_gemm_sk_kernel<PFK_EPI_GRU_Q>, grid, block, smem, st, g); break;
+    default: return PFK_ERR_BAD_ARG;
+  }
+  return pfk_launch_status();
+}
+
 // VARIANT: 0 = 4-wave double-buffered pipeline (v1), 1 = v3 one group, 2 = v3 two groups (in-block split-K)
 template <int BM, int BN, int WM, int WN, int EPI, int VARIANT>
 int launch_one(const GemmArgs& g, dim3 grid, hipStream_t st) {
@@ -604,7 +747,7 @@ int launch_cfg(const GemmArgs& a, int epi, int batches, hipStream_t st) {
 int g_force_tile = -1;  // debug/tuning knob, see pfk_debug_set_tile
 
 // Configurations: 0-3 = v1 (64x64, 64x128, 128x128, 128x64); 4-7 = v3 one group, same tiles;
-// 8 = v3 two groups 64x64 (in-block split-K).
+// 8 = v3 two groups 64x64 (in-block split-K); 9 = stream-K on 64x64 tiles (needs a workspace).
 int launch(const GemmArgs& a, int epi, int batches, hipStream_t st) {
   int cfg;
   if (g_force_tile >= 0) {
@@ -617,8 +760,14 @@ int launch(const GemmArgs& a, int epi, int batches, hipStream_t st) {
     // measured on MI355X (scripts/conv_bench.py): with < 4 blocks of 64x64 per CU the 3-stage hand-interleaved
     // pipeline on 64x64 tiles wins; with plenty of blocks the lighter 2-stage pipeline on 64x128 tiles (two
     // resident blocks per CU) does.
-    if (blocks64 < 4 * 256) cfg = 4;
-    else cfg = a.b_rows > 64 ? 1 : 0;
+    if (blocks64 < 4 * 256) {
+      // stream-K (needs the caller's workspace) only where the tile grid quantises badly on 256 CUs and K is long
+      // enough to amortise segment prologues + fix-up: measured on MI355X it wins for convc2 (330 tiles: 80 -> 65 us)
+      // and loses for 220-tile or short-K launches.
+      const double fill = (double)blocks64 / (256.0 * (double)((blocks64 + 255) / 256));
+      const bool sk = a.sk_ws != nullptr && batches == 1 && blocks64 > 256 && fill < 0.75 && a.sk_steps >= 24;
+      cfg = sk ? 9 : 4;
+    } else cfg = a.b_rows > 64 ? 1 : 0;
   }
   switch (cfg) {
     case 0: return launch_cfg<64, 64, 32, 32, 0>(a, epi, batches, st);
@@ -630,6 +779,7 @@ int launch(const GemmArgs& a, int epi, int batches, hipStream_t st) {
     case 6: return launch_cfg<128, 128, 64, 64, 1>(a, epi, batches, st);
     case 7: return launch_cfg<128, 64, 64, 32, 1>(a, epi, batches, st);
     case 8: return launch_cfg<64, 64, 32, 32, 2>(a, epi, batches, st);
+    case 9: return (a.sk_ws != nullptr && batches == 1) ? launch_sk(a, epi, st) : PFK_ERR_BAD_ARG;
     // timing ablations of cfg 4 (results are garbage; used by scripts/conv_bench.py only)
     case 21: return epi == PFK_EPI_LINEAR ? launch_cfg<64, 64, 32, 32, 11>(a, epi, batches, st) : PFK_ERR_BAD_ARG;
     case 22: return epi == PFK_EPI_LINEAR ? launch_cfg<64, 64, 32, 32, 21>(a, epi, batches, st) : PFK_ERR_BAD_ARG;
@@ -648,6 +798,8 @@ inline int round_up32(int c) { return (c + 31) & ~31; }
 extern "C" {
 
 void pfk_debug_set_tile(int cfg) { g_force_tile = cfg; }
+
+long long pfk_conv_workspace_bytes(void) { return (long long)SK_WS_BYTES; }
 
 int pfk_conv_ktot(const pfk_conv_desc* d) {
   if (!d || d->num_src < 1 || d->num_src > 3) return PFK_ERR_BAD_ARG;
@@ -676,6 +828,12 @@ int pfk_conv2d_f32(const pfk_conv_desc* d, pfk_stream_t stream) {
   a.ktot = pfk_conv_ktot(d);
   a.relu = d->relu; a.scale = d->scale;
   a.M = (long long)d->B * d->H * d->W;
+  a.sk_steps = 0;
+  for (int i = 0; i < d->num_src; ++i) a.sk_steps += d->kh * d->kw * (round_up32(s[i].channels) / 32);
+  if (d->workspace && d->workspace_bytes >= (long long)SK_WS_BYTES && pfk_aligned16(d->workspace)) {
+    a.sk_ws = static_cast<float*>(d->workspace);
+    a.sk_flags = reinterpret_cast<unsigned*>(static_cast<char*>(d->workspace) + (size_t)SK_MAX_BLOCKS * 64 * 64 * 4);
+  }
   for (int i = 0; i < d->num_src; ++i)   // kernels address sources with 32-bit byte offsets
     if (a.M * s[i].ld * 4 >= 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
   if ((long long)d->cout * a.ktot * 4 >= 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;

@@ -85,7 +85,8 @@ void corr_lookup(at::TensorList levels, const Tensor& coords, int64_t radius, Te
 void conv2d(at::TensorList srcs, int64_t B, int64_t H, int64_t W, int64_t kh, int64_t kw,
             const Tensor& weight, const c10::optional<Tensor>& bias, int64_t cout, int64_t epilogue,
             bool relu, double scale, const c10::optional<Tensor>& out, const c10::optional<Tensor>& h,
-            const c10::optional<Tensor>& aux_z, const c10::optional<Tensor>& aux_rh) {
+            const c10::optional<Tensor>& aux_z, const c10::optional<Tensor>& aux_rh,
+            const c10::optional<Tensor>& workspace) {
   TORCH_CHECK(srcs.size() >= 1 && srcs.size() <= 3, "conv2d: 1..3 sources");
   pfk_conv_desc d{};
   const int64_t M = B * H * W;
@@ -110,6 +111,10 @@ void conv2d(at::TensorList srcs, int64_t B, int64_t H, int64_t W, int64_t kh, in
   if (h.has_value()) { check_pm(*h, "h"); TORCH_CHECK(h->size(0) == M); d.h = fptr(*h); d.h_ld = h->stride(0); }
   if (aux_z.has_value()) { check_dev_f32(*aux_z, "aux_z"); TORCH_CHECK(aux_z->is_contiguous()); d.aux_z = fptr(*aux_z); }
   if (aux_rh.has_value()) { check_dev_f32(*aux_rh, "aux_rh"); TORCH_CHECK(aux_rh->is_contiguous()); d.aux_rh = fptr(*aux_rh); }
+  if (workspace.has_value()) {
+    TORCH_CHECK(workspace->is_cuda() && workspace->is_contiguous(), "conv2d: workspace must be a contiguous GPU tensor");
+    d.workspace = workspace->data_ptr(); d.workspace_bytes = (long long)workspace->nbytes();
+  }
   check_ok(pfk_conv2d_f32(&d, cur_stream()), "conv2d");
 }
 
@@ -182,6 +187,7 @@ void pm_to_nchw(const Tensor& in, Tensor out) {
 }
 
 int64_t abi_version() { return pfk_abi_version(); }
+int64_t conv_workspace_bytes() { return pfk_conv_workspace_bytes(); }
 void debug_set_tile(int64_t cfg) { pfk_debug_set_tile((int)cfg); }
 
 }  // namespace
@@ -193,7 +199,9 @@ TORCH_LIBRARY(pfk, m) {
   m.def("corr_pool2x2(Tensor inp, Tensor(a!) out) -> ()");
   m.def("corr_lookup(Tensor[] levels, Tensor coords, int radius, Tensor(a!) out) -> ()");
   m.def("conv2d(Tensor[] srcs, int B, int H, int W, int kh, int kw, Tensor weight, Tensor? bias, int cout, "
-        "int epilogue, bool relu, float scale, Tensor(a!)? out, Tensor(b!)? h, Tensor(c!)? aux_z, Tensor(d!)? aux_rh) -> ()");
+        "int epilogue, bool relu, float scale, Tensor(a!)? out, Tensor(b!)? h, Tensor(c!)? aux_z, Tensor(d!)? aux_rh, "
+        "Tensor(e!)? workspace=None) -> ()");
+  m.def("conv_workspace_bytes() -> int", &conv_workspace_bytes);
   m.def("conv_cin2(Tensor inp, Tensor weight, Tensor? bias, Tensor(a!) out, int B, int H, int W, int k, bool relu) -> ()");
   m.def("flow_delta(Tensor inp, Tensor weight, Tensor? bias, Tensor coords0, Tensor(a!) coords1, Tensor(b!)? delta_out, "
         "Tensor(c!)? flow_out) -> ()");

@@ -154,6 +154,8 @@ class UpdateEngine:
         self._scratch_c0 = torch.zeros(B, 2, H, W, device=dev, dtype=torch.float32)
         self._scratch_c1 = torch.zeros(B, 2, H, W, device=dev, dtype=torch.float32)
         self._delta = torch.zeros(B, 2, H, W, device=dev, dtype=torch.float32)
+        # scratch for the stream-K conv schedule (partials + flags); all launches are on one stream, so one is enough
+        self.workspace = torch.zeros(self.ops.conv_workspace_bytes(), device=dev, dtype=torch.uint8)
         self._shape = (B, H, W)
 
     # views into hx
@@ -190,7 +192,7 @@ class UpdateEngine:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         self.ops.conv2d(srcs, B, H, W, kh, kw, self.w[key + ".w"], self.w[key + ".b"], cout, epi, relu, scale,
-                        out, h, z, rh)
+                        out, h, z, rh, self.workspace)
         if prof is not None:
             e1.record()
             prof.setdefault(key, []).append((e0, e1))

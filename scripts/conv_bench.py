@@ -41,6 +41,7 @@ def main():
     dev = torch.device("cuda")
     torch.manual_seed(0)
     tot = {c: 0.0 for c in cfgs}
+    ws = torch.zeros(ops.conv_workspace_bytes(), device=dev, dtype=torch.uint8)
     for name, segs, cout, kh, kw, epi in SHAPES:
         if args.only and name not in args.only.split(","):
             continue
@@ -66,11 +67,11 @@ def main():
 
             def run():
                 if epi == 0:
-                    ops.conv2d(xs, B, H, W, kh, kw, packed, bias, cout, 0, False, 1.0, out, None, None, None)
+                    ops.conv2d(xs, B, H, W, kh, kw, packed, bias, cout, 0, False, 1.0, out, None, None, None, ws)
                 elif epi == 1:
-                    ops.conv2d(xs, B, H, W, kh, kw, packed, bias, cout, 1, False, 1.0, None, hbuf, zbuf, rh)
+                    ops.conv2d(xs, B, H, W, kh, kw, packed, bias, cout, 1, False, 1.0, None, hbuf, zbuf, rh, ws)
                 else:
-                    ops.conv2d(xs, B, H, W, kh, kw, packed, bias, cout, 2, False, 1.0, None, hbuf, zbuf, None)
+                    ops.conv2d(xs, B, H, W, kh, kw, packed, bias, cout, 2, False, 1.0, None, hbuf, zbuf, None, ws)
             run()
             torch.cuda.synchronize()
             if epi == 0:

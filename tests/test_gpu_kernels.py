@@ -142,6 +142,38 @@ def test_conv_all_tile_configs(gpu, tile):
     close(unpm(out, B, H, W), ref)
 
 
+@pytest.mark.parametrize("B,H,W,segs,cout,kh,kw", [
+    (1, 12, 20, [64], 96, 3, 3),          # 8 tiles x 18 steps over 24 blocks: every tile split across 3 blocks
+    (1, 55, 128, [128, 256], 128, 1, 5),  # the q conv of the headline config (220 tiles, 60 steps, 512 blocks)
+    (2, 9, 7, [324], 256, 1, 1),          # short K (11 steps), partial channel chunk
+    (1, 23, 31, [96, 148, 32], 160, 3, 3),
+    (1, 5, 6, [32], 40, 1, 1),            # one K-step, one tile
+])
+def test_conv_stream_k(gpu, B, H, W, segs, cout, kh, kw):
+    """Stream-K schedule (workspace given) vs the tile-grid schedule vs the CPU reference; and run-to-run determinism."""
+    torch.manual_seed(13)
+    cin = sum(segs)
+    xs = [torch.randn(B, c, H, W) for c in segs]
+    wt = torch.randn(cout, cin, kh, kw) / math.sqrt(cin * kh * kw)
+    bias = torch.randn(cout)
+    ref = F.conv2d(torch.cat(xs, 1), wt, bias, padding=(kh // 2, kw // 2))
+    offs, o = [], 0
+    for c in segs:
+        offs.append((o, c, c)); o += c
+    packed = _packed(wt, offs)
+    srcs = [pm(x) for x in xs]
+    M = B * H * W
+    ws = torch.zeros(torch.ops.pfk.conv_workspace_bytes(), device=gpu, dtype=torch.uint8)
+    outs = []
+    for w in (ws, ws, None):
+        out = torch.zeros(M, cout, device=gpu)
+        torch.ops.pfk.conv2d(srcs, B, H, W, kh, kw, packed, bias.cuda(), cout, EPI_LINEAR, False, 1.0, out, None, None, None, w)
+        outs.append(out)
+    close(unpm(outs[0], B, H, W), ref)
+    close(unpm(outs[2], B, H, W), ref)
+    assert torch.equal(outs[0], outs[1]), "stream-K result is not deterministic"
+
+
 def test_conv_multi_source(gpu):
     """torch.cat([a, b, c]) -> conv  ==  three channel-slice sources (one of them a strided slice)."""
     torch.manual_seed(5)
