@@ -28,6 +28,7 @@
  *   pfk_flow_delta_f32    ptlflow/models/raft/update.py:10,14 (FlowHead.conv2) fused with
  *                         ptlflow/models/raft/raft.py:174,178 (flow = coords1-coords0; coords1 += d)
  *   pfk_convex_upsample_f32  ptlflow/models/raft/raft.py:112-123 RAFT.upsample_flow
+ *   pfk_altcorr_forward_f32  ptlflow/utils/external/alt_cuda_corr/correlation_kernel.cu:258-285 (alt_cuda_corr.forward)
  * The native plug-in precedent in the reference is alt_cuda_corr
  * (ptlflow/utils/external/alt_cuda_corr/correlation.cpp:23-54: pybind forward/backward on raw
  * contiguous CUDA tensors); this header is the same kind of boundary, minus torch.
@@ -166,6 +167,15 @@ int pfk_convex_upsample_f32(const float* flow, const float* mask, int mask_ld, f
 /* same, with the flow read pixel-major (flow_pm[p*flow_ld + 0..1], e.g. the update engine's hx slice) */
 int pfk_convex_upsample_pm_f32(const float* flow_pm, int flow_ld, const float* mask, int mask_ld,
                                float* out, int B, int H, int W, pfk_stream_t stream);
+
+/* ---- on-demand correlation behind the reference's alt_cuda_corr ABI --------------------------------
+ * replaces corr_cuda_forward (ptlflow/utils/external/alt_cuda_corr/correlation_kernel.cu:258-285; pybind
+ * `alt_cuda_corr.forward`, correlation.cpp:23-37, called from AlternateCorrBlock, raft/corr.py:76-101):
+ * fmap1 [B][H1][W1][C], fmap2 [B][H2][W2][C] (NHWC fp32 contiguous), coords [B][H1][W1][2] (x, y) ->
+ * out [B][(2r+1)^2][H1][W1], cell = oy + (2r+1)*ox, UNSCALED (the caller divides by sqrt(C)). */
+int pfk_altcorr_forward_f32(const float* fmap1, const float* fmap2, const float* coords, float* out,
+                            int B, int H1, int W1, int H2, int W2, int C, int radius,
+                            pfk_stream_t stream);
 
 /* NCHW [B][C][H][W] -> pixel-major [B*H*W][ld] (+ channel offset) and back. */
 int pfk_nchw_to_pm_f32(const float* in, float* out, int out_ld, int out_coff, int B, int C,

@@ -197,6 +197,57 @@ def lookup(pyramid: Sequence[Tensor], coords: Tensor, radius: int) -> Tensor:
     return out.permute(0, 3, 1, 2).contiguous()
 
 
+def alt_corr_forward(fmap1: Tensor, fmap2: Tensor, coords: Tensor, radius: int) -> Tensor:
+    """What `alt_cuda_corr.forward` computes (ptlflow/utils/external/alt_cuda_corr/correlation_kernel.cu:18-119),
+    restated on CPU: fmap1 [B,H1,W1,C], fmap2 [B,H2,W2,C], coords [B,N,H1,W1,2] -> [B,N,(2r+1)^2,H1,W1].
+
+    s[iy][ix] = <f1[p], f2[floor(y)-r+iy, floor(x)-r+ix]> for iy, ix in [0, 2r+1] (zero outside fmap2, :78-83);
+    the kernel scatters s to up to four cells with weights dy*dx / dy*(1-dx) / (1-dy)*dx / (1-dy)*(1-dx)
+    (:92-114), which amounts to  out[oy + rd*ox] = bilinear(s; oy + dy, ox + dx).  Unscaled."""
+    B, H1, W1, C = fmap1.shape
+    H2, W2 = fmap2.shape[1:3]
+    N = coords.shape[1]
+    r, rd = radius, 2 * radius + 1
+    n = rd + 1
+    out = torch.zeros(B, N, rd * rd, H1, W1, dtype=fmap1.dtype)
+    f2 = fmap2.reshape(B, H2 * W2, C)
+    for nn in range(N):
+        x, y = coords[:, nn, :, :, 0], coords[:, nn, :, :, 1]
+        fx, fy = torch.floor(x), torch.floor(y)
+        dx, dy = (x - fx)[..., None, None], (y - fy)[..., None, None]
+        off = torch.arange(n, dtype=fmap1.dtype)
+        yy = (fy - r)[..., None] + off                      # [B,H1,W1,n]  (iy)
+        xx = (fx - r)[..., None] + off                      # [B,H1,W1,n]  (ix)
+        ok = ((yy >= 0) & (yy <= H2 - 1))[..., :, None] & ((xx >= 0) & (xx <= W2 - 1))[..., None, :]
+        yc = torch.nan_to_num(yy, nan=0.0, posinf=0.0, neginf=0.0).clamp(0, H2 - 1).long()
+        xc = torch.nan_to_num(xx, nan=0.0, posinf=0.0, neginf=0.0).clamp(0, W2 - 1).long()
+        flat = (yc[..., :, None] * W2 + xc[..., None, :]).reshape(B, -1)            # [B, H1*W1*n*n]
+        g = torch.gather(f2, 1, flat[..., None].expand(-1, -1, C)).reshape(B, H1, W1, n, n, C)
+        s = (g * fmap1[:, :, :, None, None, :]).sum(-1)
+        s = torch.where(ok, s, torch.zeros((), dtype=s.dtype))                     # [B,H1,W1,iy,ix]
+        val = (s[..., :rd, :rd] * (1 - dy) * (1 - dx) + s[..., :rd, 1:] * (1 - dy) * dx
+               + s[..., 1:, :rd] * dy * (1 - dx) + s[..., 1:, 1:] * dy * dx)       # [B,H1,W1,oy,ox]
+        out[:, nn] = val.permute(0, 4, 3, 1, 2).reshape(B, rd * rd, H1, W1)         # cell = oy + rd*ox
+    return out
+
+
+def alternate_corr_block(fmap1: Tensor, fmap2: Tensor, coords: Tensor, num_levels: int, radius: int) -> Tensor:
+    """AlternateCorrBlock (raft/corr.py:67-101): per level, avg-pooled fmap2, coords / 2^i, then / sqrt(C).
+    fmap NCHW, coords [B,2,H,W] -> [B, L*(2r+1)^2, H, W]."""
+    B, C, H, W = fmap1.shape
+    f1 = fmap1.permute(0, 2, 3, 1).contiguous()
+    c = coords.permute(0, 2, 3, 1)
+    outs = []
+    f2 = fmap2
+    for i in range(num_levels):
+        if i > 0:
+            f2 = F.avg_pool2d(f2, 2, stride=2)
+        ci = (c / 2**i).reshape(B, 1, H, W, 2).contiguous()
+        outs.append(alt_corr_forward(f1, f2.permute(0, 2, 3, 1).contiguous(), ci, radius).squeeze(1))
+    corr = torch.stack(outs, dim=1).reshape(B, -1, H, W)
+    return corr / torch.sqrt(torch.tensor(C))
+
+
 def coords_grid(B: int, h: int, w: int, dtype=torch.float32) -> Tensor:
     """raft/utils.py:84-91: channel 0 = x, channel 1 = y."""
     ys, xs = torch.meshgrid(torch.arange(h, dtype=dtype), torch.arange(w, dtype=dtype), indexing="ij")

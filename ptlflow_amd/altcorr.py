@@ -1,0 +1,43 @@
+"""Seam B2 — the reference's only native plug-in point on this path: a Python module literally importable as
+``alt_cuda_corr`` with ``forward(fmap1, fmap2, coords, radius) -> [corr]``
+(ptlflow/utils/external/alt_cuda_corr/correlation.cpp:23-54; imported in a bare try/except by every family's
+corr.py, e.g. ptlflow/models/raft/corr.py:5-8, and called from ``AlternateCorrBlock.__call__``, :76-101).
+
+``install()`` registers this module under that name in ``sys.modules`` (do it before ``import ptlflow``), after
+which ccmr / ccmr_p / ms_raft_p — which default to ``alternate_corr=True`` — pick the gfx950 kernel up with zero
+patching.  The repo root also carries a one-line ``alt_cuda_corr.py`` so that having the repo on ``sys.path``
+is enough.
+
+``forward`` keeps the reference's contract exactly: fp32 contiguous GPU tensors, ``fmap1 [B,H1,W1,C]``,
+``fmap2 [B,H2,W2,C]``, ``coords [B,N,H1,W1,2]`` (x, y), returns ``[corr]`` with ``corr [B,N,(2r+1)^2,H1,W1]``,
+cell index ``iy + (2r+1)*ix`` (x-major), unscaled.  ``backward`` (training with alternate_corr — which the reference
+itself never wires into autograd) is not built yet and raises.
+"""
+from __future__ import annotations
+
+import sys
+from typing import List
+
+import torch
+
+from . import load_native
+
+
+def forward(fmap1: torch.Tensor, fmap2: torch.Tensor, coords: torch.Tensor, radius: int) -> List[torch.Tensor]:
+    load_native()
+    for name, t in (("fmap1", fmap1), ("fmap2", fmap2), ("coords", coords)):
+        if not t.is_cuda:                       # CHECK_CUDA, correlation.cpp:19
+            raise RuntimeError(f"{name} must be a CUDA tensor")
+        if not t.is_contiguous():               # CHECK_CONTIGUOUS, correlation.cpp:20
+            raise RuntimeError(f"{name} must be contiguous")
+    return [torch.ops.pfk.altcorr_forward(fmap1, fmap2, coords, int(radius))]
+
+
+def backward(fmap1, fmap2, coords, corr_grad, radius):
+    raise NotImplementedError("alt_cuda_corr.backward is not built yet (SURVEY.md §8 f1/f4); the reference never calls it "
+                              "through autograd either (AlternateCorrBlock calls forward directly)")
+
+
+def install() -> None:
+    """Make ``import alt_cuda_corr`` resolve to this module."""
+    sys.modules.setdefault("alt_cuda_corr", sys.modules[__name__])

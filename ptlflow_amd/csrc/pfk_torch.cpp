@@ -170,6 +170,26 @@ void convex_upsample_pm(const Tensor& flow_pm, const Tensor& mask, Tensor out) {
                                       cur_stream()), "convex_upsample_pm");
 }
 
+// alt_cuda_corr.forward semantics (correlation.cpp:23-37): returns [B, N, (2r+1)^2, H1, W1], unscaled
+Tensor altcorr_forward(const Tensor& fmap1, const Tensor& fmap2, const Tensor& coords, int64_t radius) {
+  check_dev_f32(fmap1, "fmap1"); check_dev_f32(fmap2, "fmap2"); check_dev_f32(coords, "coords");
+  TORCH_CHECK(fmap1.dim() == 4 && fmap2.dim() == 4 && coords.dim() == 5 && coords.size(4) == 2, "altcorr_forward: fmap [B,H,W,C], coords [B,N,H1,W1,2]");
+  TORCH_CHECK(fmap1.is_contiguous() && fmap2.is_contiguous() && coords.is_contiguous(), "altcorr_forward: contiguous inputs");  // CHECK_CONTIGUOUS in the reference
+  const int B = fmap1.size(0), H1 = fmap1.size(1), W1 = fmap1.size(2), C = fmap1.size(3);
+  const int H2 = fmap2.size(1), W2 = fmap2.size(2), N = coords.size(1);
+  TORCH_CHECK(fmap2.size(0) == B && fmap2.size(3) == C && coords.size(0) == B && coords.size(2) == H1 && coords.size(3) == W1);
+  const int rd = 2 * radius + 1;
+  Tensor out = at::empty({B, N, rd * rd, H1, W1}, fmap1.options());
+  for (int n = 0; n < N; ++n) {
+    Tensor cn = coords.select(1, n).contiguous();
+    Tensor on = N == 1 ? out.view({B, rd * rd, H1, W1}) : at::empty({B, rd * rd, H1, W1}, fmap1.options());
+    check_ok(pfk_altcorr_forward_f32(fptr(fmap1), fptr(fmap2), fptr(cn), fptr(on), B, H1, W1, H2, W2, C, radius, cur_stream()),
+             "altcorr_forward");
+    if (N != 1) out.select(1, n).copy_(on);
+  }
+  return out;
+}
+
 void nchw_to_pm(const Tensor& in, Tensor out) {
   check_dev_f32(in, "in"); check_pm(out, "out");
   TORCH_CHECK(in.dim() == 4 && in.is_contiguous());
@@ -208,6 +228,7 @@ TORCH_LIBRARY(pfk, m) {
   m.def("flow_from_coords(Tensor coords0, Tensor coords1, Tensor(a!) flow_out) -> ()");
   m.def("convex_upsample(Tensor flow, Tensor mask, Tensor(a!) out) -> ()");
   m.def("convex_upsample_pm(Tensor flow_pm, Tensor mask, Tensor(a!) out) -> ()");
+  m.def("altcorr_forward(Tensor fmap1, Tensor fmap2, Tensor coords, int radius) -> Tensor");
   m.def("nchw_to_pm(Tensor inp, Tensor(a!) out) -> ()");
   m.def("pm_to_nchw(Tensor inp, Tensor(a!) out) -> ()");
 }
@@ -222,6 +243,7 @@ TORCH_LIBRARY_IMPL(pfk, CUDA, m) {
   m.impl("flow_from_coords", &flow_from_coords);
   m.impl("convex_upsample", &convex_upsample);
   m.impl("convex_upsample_pm", &convex_upsample_pm);
+  m.impl("altcorr_forward", &altcorr_forward);
   m.impl("nchw_to_pm", &nchw_to_pm);
   m.impl("pm_to_nchw", &pm_to_nchw);
 }

@@ -75,3 +75,30 @@ def test_sea_raft_pyramid_mode(gpu):
     c = O.coords_grid(1, 16, 24) + torch.rand(1, 2, 16, 24, generator=g) * 6 - 3
     ref = O.lookup(pyr, c, 4)
     assert (cb(c.cuda()).cpu() - ref).abs().max().item() < 5e-5
+
+
+@pytest.mark.parametrize("B,H1,W1,H2,W2,C,r", [(1, 16, 24, 16, 24, 256, 4), (2, 11, 13, 5, 6, 128, 3), (1, 9, 10, 9, 10, 36, 4)])
+def test_alt_cuda_corr_abi(gpu, B, H1, W1, H2, W2, C, r):
+    """Seam B2: the module importable as `alt_cuda_corr` (correlation.cpp:23-37 contract) vs the oracle."""
+    import importlib
+    import ptlflow_amd.altcorr as altcorr
+    altcorr.install()
+    mod = importlib.import_module("alt_cuda_corr")
+    g = torch.Generator().manual_seed(8)
+    f1 = torch.randn(B, H1, W1, C, generator=g)
+    f2 = torch.randn(B, H2, W2, C, generator=g)
+    base = torch.stack(torch.meshgrid(torch.arange(H1, dtype=torch.float32), torch.arange(W1, dtype=torch.float32),
+                                      indexing="ij")[::-1], -1)[None, None].repeat(B, 1, 1, 1, 1)
+    coords = base * (W2 / W1) + torch.randn(B, 1, H1, W1, 2, generator=g) * 3     # includes out-of-map windows
+    coords[0, 0, 0, 0, 0] = float("nan")
+    coords[0, 0, 0, 1, 1] = 1e12
+    ref = O.alt_corr_forward(f1, f2, coords, r)
+    (out,) = mod.forward(f1.cuda(), f2.cuda(), coords.cuda(), r)
+    assert tuple(out.shape) == (B, 1, (2 * r + 1) ** 2, H1, W1)
+    got = out.cpu()
+    both_nan = torch.isnan(got) & torch.isnan(ref)
+    err = torch.where(both_nan, torch.zeros_like(ref), (got - ref).abs())
+    assert bool((torch.isnan(got) == torch.isnan(ref)).all())
+    assert err.max().item() < 2e-4 * max(1.0, ref.nan_to_num().abs().max().item())
+    with pytest.raises(RuntimeError):
+        mod.forward(f1.cuda().permute(0, 2, 1, 3), f2.cuda(), coords.cuda(), r)   # CHECK_CONTIGUOUS

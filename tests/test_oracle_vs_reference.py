@@ -91,3 +91,21 @@ def test_patch_accelerate_keeps_checkpoint_keys_and_restores():
     assert mod.get_corr_block is orig_fn and not isinstance(ref.update_block, PfkUpdateBlock)
     with torch.no_grad():
         assert torch.equal(ref({"images": x.clone()})["flows"], before)
+
+
+def test_alt_corr_oracle_matches_reference_iterative_block():
+    """The reference's pure-torch stand-in for alt_cuda_corr (ptlflow/utils/correlation.py:539-615, selected by
+    raft/corr.py:111-113 when the extension is missing) and its materialised CorrBlock both agree with the oracle's
+    restatement of the CUDA kernel's arithmetic (away from the image border, where grid_sample's round trip and the
+    kernel's raw floor() see the same taps)."""
+    corr_mod = ref_loader.ref_module("ptlflow.models.raft.corr")
+    g = torch.Generator().manual_seed(6)
+    B, C, H, W = 1, 32, 16, 24
+    f1, f2 = torch.randn(B, C, H, W, generator=g), torch.randn(B, C, H, W, generator=g)
+    c = O.coords_grid(B, H, W) + torch.rand(B, 2, H, W, generator=g) * 6 - 3 + 0.013
+    ours = O.alternate_corr_block(f1, f2, c, num_levels=3, radius=3)
+    it = corr_mod.IterativeCorrBlock(fmap1=f1, fmap2=f2, radius=3, num_levels=3)(c)
+    assert ours.shape == it.shape
+    assert (ours - it).abs().max().item() < 1e-4
+    full = corr_mod.CorrBlock(f1, f2, num_levels=3, radius=3)(c)
+    assert (ours - full).abs().max().item() < 1e-4
