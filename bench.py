@@ -186,9 +186,16 @@ def main():
             dom = max(stats, key=lambda k: stats[k]["total_ms"])
             s = stats[dom]
             achieved = s["gflop_per_launch"] / (s["avg_us"] * 1e-6) / 1e3  # TFLOP/s
+            traffic = None
+            try:   # PMC counters cannot be read from inside this process: take the committed rocprofv3 figures if they cover this launch
+                rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["entries"].get(f"{dom.rstrip('12')}@b{args.batch}")
+                if rec and (args.height, args.width, small) == (436, 1024, False):
+                    traffic = {"bytes": (rec["fetch_kb"] + rec["write_kb"]) * 1024, "source": "profiles/pmc_traffic.json (rocprofv3 FETCH_SIZE+WRITE_SIZE, earlier run of this command)"}
+            except Exception:
+                pass
             result["roofline"] = {"kernel": f"conv_gemm_kernel[{dom}]", "bound": "mfma", "achieved": achieved,
                                   "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-                                  "traffic": None, "avg_us": s["avg_us"], "launches_per_forward": s["launches"],
+                                  "traffic": traffic, "avg_us": s["avg_us"], "launches_per_forward": s["launches"],
                                   "gflop_per_launch": s["gflop_per_launch"],
                                   "method": "HIP events around each launch, separate instrumented forward"}
             result["kernels"] = {k: {"avg_us": round(v["avg_us"], 2), "n": v["launches"],
