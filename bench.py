@@ -65,7 +65,7 @@ def parse():
     ap.add_argument("--height", type=int, default=436)
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--iters", type=int, default=32)
-    ap.add_argument("--model", default="raft", choices=["raft", "raft_small"])
+    ap.add_argument("--model", default="raft", choices=["raft", "raft_small", "gma"])
     ap.add_argument("--skip-dead-upsample", action="store_true",
                     help="skip mask head + upsampling on non-final iterations (output-identical dead work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -111,14 +111,17 @@ def main():
         dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
 
     import ptlflow_amd
-    from ptlflow_amd.raft import RAFT
+    from ptlflow_amd.raft import GMA, RAFT
     from ptlflow_amd.synth import smooth_pair
 
     ptlflow_amd.load_native()
     if os.environ.get("PFK_CUDNN_BENCHMARK") == "1":      # experiment knob: MIOpen find mode for the encoders
         torch.backends.cudnn.benchmark = True
     small = args.model == "raft_small"
-    model = RAFT(small=small, iters=args.iters, upsample_every_iter=not args.skip_dead_upsample)
+    if args.model == "gma":
+        model = GMA(iters=args.iters, upsample_every_iter=not args.skip_dead_upsample)
+    else:
+        model = RAFT(small=small, iters=args.iters, upsample_every_iter=not args.skip_dead_upsample)
     model.load_synthetic(1234).eval()
     cpu_state = {k: v.clone() for k, v in model.state_dict().items()}
     model = model.to(dev)
@@ -210,7 +213,10 @@ def main():
             t_start = time.perf_counter()
             for i in range(args.cpu_forwards + 1):
                 c0 = time.perf_counter()
-                ref = O.raft_forward(cpu_state, images_cpu[:1], iters=args.iters, small=small)
+                if args.model == "gma":
+                    ref = O.gma_forward(cpu_state, images_cpu[:1], iters=args.iters)
+                else:
+                    ref = O.raft_forward(cpu_state, images_cpu[:1], iters=args.iters, small=small)
                 dt = time.perf_counter() - c0
                 # the first forward is a warm-up unless the budget leaves room for nothing else
                 if i or dt > args.cpu_budget_s / 2:

@@ -100,7 +100,8 @@ int pfk_corr_lookup_f32(const pfk_lookup_desc* d, pfk_stream_t stream);
  * (ky major, kx minor), the source's channels padded up to a multiple of 32 (pad weights = 0):
  * ktot = sum_s kh*kw*round_up(channels_s, 32).  pfk_conv_ktot() returns it. */
 enum pfk_epilogue {
-  PFK_EPI_LINEAR = 0,  /* v = (acc+bias) ; relu? ; v *= scale ; out[p*out_ld + out_coff + co] = v */
+  PFK_EPI_LINEAR = 0,  /* v = (acc+bias) ; relu? ; v *= scale ; [v = residual[p*residual_ld+co] + v] ;
+                          out[p*out_ld + out_coff + co] = v */
   PFK_EPI_GRU_ZR = 1,  /* cout = 2*Ch: co<Ch: z=sigmoid -> aux_z[p*Ch+co];
                           co>=Ch: r=sigmoid -> aux_rh[p*Ch + co-Ch] = r * h[p*h_ld + co-Ch] */
   PFK_EPI_GRU_Q = 2    /* cout = Ch: q=tanh; h[p*h_ld+co] = (1-z)*h + z*q, z = aux_z[p*Ch+co] */
@@ -129,6 +130,8 @@ typedef struct {
   int h_ld;
   float* aux_z;          /* [M][Ch] */
   float* aux_rh;         /* [M][Ch] */
+  const float* residual; /* LINEAR only, optional: added after relu/scale (GMA's `fmap + gamma*out`, gma_utils.py:111) */
+  int residual_ld;
   void* workspace;       /* optional: >= pfk_conv_workspace_bytes() of device memory, 16-byte aligned, private to
                             the stream; enables the stream-K schedule for small grids (deterministic).  NULL: tile grid */
   long long workspace_bytes;
@@ -182,6 +185,10 @@ int pfk_nchw_to_pm_f32(const float* in, float* out, int out_ld, int out_coff, in
                        int H, int W, pfk_stream_t stream);
 int pfk_pm_to_nchw_f32(const float* in, int in_ld, int in_coff, float* out, int B, int C, int H,
                        int W, pfk_stream_t stream);
+/* pixel-major [B*N][in_ld] -> channel-major out[b][c][n] with row stride out_ld >= N (a K-contiguous "weight"
+ * operand for pfk_conv2d_f32, e.g. GMA's value matrix V^T, gma_utils.py:103-105) */
+int pfk_pm_to_cm_f32(const float* in, int in_ld, float* out, int out_ld, int B, int C, int N,
+                     pfk_stream_t stream);
 
 #ifdef __cplusplus
 }

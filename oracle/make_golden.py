@@ -121,12 +121,41 @@ def golden_forward():
     torch.save(out, os.path.join(OUT, "raft_forward.pt"))
 
 
+def golden_gma():
+    """GMA (gma/gma.py) whole forward + one GMAUpdateBlock step with a real attention map."""
+    g = ref_loader.ref_module("ptlflow.models.gma.gma")
+    ref = g.GMA(iters=4).eval()
+    shapes = {k: tuple(v.shape) for k, v in ref.state_dict().items()
+              if not k.startswith("train_metrics") and v.is_floating_point()}
+    P = synth_state_dict(shapes, seed=51)
+    missing = ref.load_state_dict(P, strict=False)
+    assert not missing.unexpected_keys
+    x = O.smooth_pair(1, 128, 160, seed=53)
+    with torch.no_grad():
+        o = ref({"images": x.clone()})
+    out = {"forward": {"seed": 51, "shapes": shapes, "iters": 4, "images": x, "flows": o["flows"].clone(),
+                       "flow_small": o["flow_small"].clone()}}
+    gen = torch.Generator().manual_seed(54)
+    B, H, W = 1, 8, 12
+    net = torch.tanh(torch.randn(B, 128, H, W, generator=gen))
+    inp = torch.relu(torch.randn(B, 128, H, W, generator=gen))
+    corr = torch.randn(B, 324, H, W, generator=gen)
+    flow = torch.randn(B, 2, H, W, generator=gen) * 3
+    with torch.no_grad():
+        attn = ref.att(inp)
+        n, mk, d = ref.update_block(net, inp, corr, flow, attn)
+    out["update"] = {"net": net, "inp": inp, "corr": corr, "flow": flow, "attention": attn.clone(),
+                     "net_out": n.clone(), "mask_out": mk.clone(), "delta_out": d.clone()}
+    torch.save(out, os.path.join(OUT, "gma.pt"))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(4)
     golden_corr()
     golden_update()
     golden_forward()
+    golden_gma()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
 

@@ -324,6 +324,39 @@ def small_update_block(P: Params, net, inp, corr, flow):
     return net, None, flow_head(P, net)
 
 
+# --------------------------------------------------------------------------------------
+# a13  GMA: attention (once per forward) + aggregate (every iteration)    ptlflow/models/gma/gma_utils.py
+# --------------------------------------------------------------------------------------
+def gma_attention(P: Params, fmap: Tensor, heads: int = 1, pre: str = "att") -> Tensor:
+    """Attention.forward, content-only mode (gma_utils.py:55-78; the `gma` defaults position_only=False,
+    position_and_content=False, gma.py:66-67): softmax(scale * q k^T) -> [B, heads, N, N]."""
+    B, C, h, w = fmap.shape
+    qk = F.conv2d(fmap, P[f"{pre}.to_qk.weight"])
+    q, k = qk.chunk(2, dim=1)
+    dh = q.shape[1] // heads
+    q = q.reshape(B, heads, dh, h * w).transpose(2, 3) * (dh ** -0.5)    # dim_head == context dim in gma.py:95
+    k = k.reshape(B, heads, dh, h * w)
+    return torch.softmax(torch.matmul(q, k), dim=-1)
+
+
+def gma_aggregate(P: Params, attn: Tensor, fmap: Tensor, pre: str = "aggregator") -> Tensor:
+    """Aggregate.forward (gma_utils.py:100-113) with dim == inner_dim (no projection): fmap + gamma * (attn @ v)."""
+    B, C, h, w = fmap.shape
+    heads = attn.shape[1]
+    v = F.conv2d(fmap, P[f"{pre}.to_v.weight"]).reshape(B, heads, C // heads, h * w).transpose(2, 3)
+    out = torch.matmul(attn, v)                                           # [B, heads, N, d]
+    out = out.transpose(2, 3).reshape(B, C, h, w)
+    return fmap + P[f"{pre}.gamma"] * out
+
+
+def gma_update_block(P: Params, net, inp, corr, flow, attn):
+    """GMAUpdateBlock.forward (gma/update.py:148-160)."""
+    mf = motion_encoder(P, flow, corr)
+    mfg = gma_aggregate(P, attn, mf)
+    net = sepconv_gru(P, net, torch.cat([inp, mf, mfg], dim=1))
+    return net, mask_head(P, net), flow_head(P, net)
+
+
 def sub(P: Params, prefix: str) -> Params:
     """View of a state_dict under ``prefix.`` with the prefix stripped."""
     k = prefix + "."
@@ -470,6 +503,31 @@ def raft_forward(P: Params, images: Tensor, iters: int = 32, small: bool = False
     if return_trace:
         out["trace"] = trace
     return out
+
+
+@torch.no_grad()
+def gma_forward(P: Params, images: Tensor, iters: int = 32, corr_levels: int = 4, corr_radius: int = 4):
+    """GMA.forward in eval mode (gma/gma.py:141-214): RAFT's loop with one attention map per forward."""
+    x, pads = preprocess(images)
+    image1, image2 = x[:, 0], x[:, 1]
+    B = image1.shape[0]
+    fm = encoder(sub(P, "fnet"), torch.cat([image1, image2], 0), "instance", False)
+    pyramid = correlation_pyramid(fm[:B], fm[B:], corr_levels)
+    cnet = encoder(sub(P, "cnet"), image1, "batch", False)
+    net, inp = torch.split(cnet, [128, 128], dim=1)
+    net, inp = torch.tanh(net), torch.relu(inp)
+    attn = gma_attention(P, inp, heads=1)
+    h, w = image1.shape[-2] // 8, image1.shape[-1] // 8
+    coords0 = coords_grid(B, h, w, x.dtype)
+    coords1 = coords_grid(B, h, w, x.dtype)
+    U = sub(P, "update_block")
+    flow_up = None
+    for _ in range(iters):
+        corr = lookup(pyramid, coords1, corr_radius)
+        net, up_mask, delta = gma_update_block(U, net, inp, corr, coords1 - coords0, attn)
+        coords1 = coords1 + delta
+        flow_up = unpad(convex_upsample(coords1 - coords0, up_mask), pads)
+    return {"flows": flow_up[:, None], "flow_small": coords1 - coords0}
 
 
 def epe(a: Tensor, b: Tensor) -> Tuple[float, float]:

@@ -44,6 +44,7 @@ struct GemmArgs {
   int relu;
   float scale;
   float* out; int out_ld; int out_coff;
+  const float* residual; int residual_ld;   // LINEAR: out = residual[p][n] + v (after relu/scale)
   float* h; int h_ld;
   float* aux_z; float* aux_rh;
   int ch_hidden;       // Ch for the GRU epilogues
@@ -298,6 +299,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& a, const f32x16 (&acc)[
         if constexpr (EPI == PFK_EPI_LINEAR) {
           if (a.relu) v = (v < 0.f) ? 0.f : v;  // NaN-propagating like torch.relu (fmaxf would drop NaN)
           v *= a.scale;
+          if (a.residual != nullptr) v = a.residual[p * a.residual_ld + n] + v;
           outp[p * a.out_ld + a.out_coff + n] = v;
         } else if constexpr (EPI == PFK_EPI_GRU_ZR) {
           const int ch = a.ch_hidden;
@@ -841,6 +843,10 @@ int pfk_conv2d_f32(const pfk_conv_desc* d, pfk_stream_t stream) {
     case PFK_EPI_LINEAR:
       if (!d->out || d->out_ld < d->out_coff + d->cout) return PFK_ERR_BAD_ARG;
       a.out = d->out; a.out_ld = d->out_ld; a.out_coff = d->out_coff;
+      if (d->residual) {
+        if (d->residual_ld < d->cout) return PFK_ERR_BAD_ARG;
+        a.residual = d->residual; a.residual_ld = d->residual_ld;
+      }
       break;
     case PFK_EPI_GRU_ZR:
       if (!d->h || !d->aux_z || !d->aux_rh || (d->cout & 63)) return PFK_ERR_BAD_ARG;

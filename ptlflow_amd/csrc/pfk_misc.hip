@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void nchw_to_pm_kernel(const float* __restrict
 
 __global__ __launch_bounds__(256) void pm_to_nchw_kernel(const float* __restrict__ in, int in_ld,
                                                          int in_coff, float* __restrict__ out,
-                                                         int C, int HW) {
+                                                         int C, int HW, int out_ld) {
   __shared__ float tile[32][33];
   const int b = blockIdx.z;
   const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
@@ -262,10 +262,10 @@ __global__ __launch_bounds__(256) void pm_to_nchw_kernel(const float* __restrict
     tile[i][tx] = (p < HW && c < C) ? src[(long long)p * in_ld + c] : 0.f;
   }
   __syncthreads();
-  float* dst = out + (long long)b * C * HW;
+  float* dst = out + (long long)b * C * out_ld;
   for (int i = ty; i < 32; i += 8) {
     const int c = c0 + i, p = p0 + tx;
-    if (c < C && p < HW) dst[(long long)c * HW + p] = tile[tx][i];
+    if (c < C && p < HW) dst[(long long)c * out_ld + p] = tile[tx][i];
   }
 }
 
@@ -373,7 +373,16 @@ int pfk_pm_to_nchw_f32(const float* in, int in_ld, int in_coff, float* out, int 
   const int HW = H * W;
   dim3 grid((HW + 31) / 32, (C + 31) / 32, B);
   hipLaunchKernelGGL(pm_to_nchw_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), in,
-                     in_ld, in_coff, out, C, HW);
+                     in_ld, in_coff, out, C, HW, HW);
+  return pfk_launch_status();
+}
+
+int pfk_pm_to_cm_f32(const float* in, int in_ld, float* out, int out_ld, int B, int C, int N,
+                     pfk_stream_t stream) {
+  if (!in || !out || B <= 0 || C <= 0 || N <= 0 || in_ld < C || out_ld < N) return PFK_ERR_BAD_ARG;
+  dim3 grid((N + 31) / 32, (C + 31) / 32, B);
+  hipLaunchKernelGGL(pm_to_nchw_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), in,
+                     in_ld, 0, out, C, N, out_ld);
   return pfk_launch_status();
 }
 

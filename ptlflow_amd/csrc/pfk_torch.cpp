@@ -86,7 +86,7 @@ void conv2d(at::TensorList srcs, int64_t B, int64_t H, int64_t W, int64_t kh, in
             const Tensor& weight, const c10::optional<Tensor>& bias, int64_t cout, int64_t epilogue,
             bool relu, double scale, const c10::optional<Tensor>& out, const c10::optional<Tensor>& h,
             const c10::optional<Tensor>& aux_z, const c10::optional<Tensor>& aux_rh,
-            const c10::optional<Tensor>& workspace) {
+            const c10::optional<Tensor>& workspace, const c10::optional<Tensor>& residual) {
   TORCH_CHECK(srcs.size() >= 1 && srcs.size() <= 3, "conv2d: 1..3 sources");
   pfk_conv_desc d{};
   const int64_t M = B * H * W;
@@ -111,6 +111,11 @@ void conv2d(at::TensorList srcs, int64_t B, int64_t H, int64_t W, int64_t kh, in
   if (h.has_value()) { check_pm(*h, "h"); TORCH_CHECK(h->size(0) == M); d.h = fptr(*h); d.h_ld = h->stride(0); }
   if (aux_z.has_value()) { check_dev_f32(*aux_z, "aux_z"); TORCH_CHECK(aux_z->is_contiguous()); d.aux_z = fptr(*aux_z); }
   if (aux_rh.has_value()) { check_dev_f32(*aux_rh, "aux_rh"); TORCH_CHECK(aux_rh->is_contiguous()); d.aux_rh = fptr(*aux_rh); }
+  if (residual.has_value()) {
+    check_pm(*residual, "residual");
+    TORCH_CHECK(residual->size(0) == M && residual->size(1) == cout, "conv2d: residual must be a [M, cout] view");
+    d.residual = fptr(*residual); d.residual_ld = residual->stride(0);
+  }
   if (workspace.has_value()) {
     TORCH_CHECK(workspace->is_cuda() && workspace->is_contiguous(), "conv2d: workspace must be a contiguous GPU tensor");
     d.workspace = workspace->data_ptr(); d.workspace_bytes = (long long)workspace->nbytes();
@@ -206,6 +211,17 @@ void pm_to_nchw(const Tensor& in, Tensor out) {
   check_ok(pfk_pm_to_nchw_f32(fptr(in), in.stride(0), 0, fptr(out), B, C, H, W, cur_stream()), "pm_to_nchw");
 }
 
+// in [B*N, C] pixel-major view -> out [B, C, Npad] channel-major (row stride = out.stride(1))
+void pm_to_cm(const Tensor& in, Tensor out) {
+  check_pm(in, "in"); check_dev_f32(out, "out");
+  TORCH_CHECK(out.dim() == 3 && out.stride(2) == 1 && out.stride(0) == out.size(1) * out.stride(1), "pm_to_cm: out [B,C,Npad]");
+  const int B = out.size(0), C = out.size(1);
+  TORCH_CHECK(in.size(1) == C && in.size(0) % B == 0);
+  const int N = in.size(0) / B;
+  TORCH_CHECK(out.stride(1) >= N);
+  check_ok(pfk_pm_to_cm_f32(fptr(in), in.stride(0), fptr(out), out.stride(1), B, C, N, cur_stream()), "pm_to_cm");
+}
+
 int64_t abi_version() { return pfk_abi_version(); }
 int64_t conv_workspace_bytes() { return pfk_conv_workspace_bytes(); }
 void debug_set_tile(int64_t cfg) { pfk_debug_set_tile((int)cfg); }
@@ -220,7 +236,7 @@ TORCH_LIBRARY(pfk, m) {
   m.def("corr_lookup(Tensor[] levels, Tensor coords, int radius, Tensor(a!) out) -> ()");
   m.def("conv2d(Tensor[] srcs, int B, int H, int W, int kh, int kw, Tensor weight, Tensor? bias, int cout, "
         "int epilogue, bool relu, float scale, Tensor(a!)? out, Tensor(b!)? h, Tensor(c!)? aux_z, Tensor(d!)? aux_rh, "
-        "Tensor(e!)? workspace=None) -> ()");
+        "Tensor(e!)? workspace=None, Tensor? residual=None) -> ()");
   m.def("conv_workspace_bytes() -> int", &conv_workspace_bytes);
   m.def("conv_cin2(Tensor inp, Tensor weight, Tensor? bias, Tensor(a!) out, int B, int H, int W, int k, bool relu) -> ()");
   m.def("flow_delta(Tensor inp, Tensor weight, Tensor? bias, Tensor coords0, Tensor(a!) coords1, Tensor(b!)? delta_out, "
@@ -231,6 +247,7 @@ TORCH_LIBRARY(pfk, m) {
   m.def("altcorr_forward(Tensor fmap1, Tensor fmap2, Tensor coords, int radius) -> Tensor");
   m.def("nchw_to_pm(Tensor inp, Tensor(a!) out) -> ()");
   m.def("pm_to_nchw(Tensor inp, Tensor(a!) out) -> ()");
+  m.def("pm_to_cm(Tensor inp, Tensor(a!) out) -> ()");
 }
 
 TORCH_LIBRARY_IMPL(pfk, CUDA, m) {
@@ -246,4 +263,5 @@ TORCH_LIBRARY_IMPL(pfk, CUDA, m) {
   m.impl("altcorr_forward", &altcorr_forward);
   m.impl("nchw_to_pm", &nchw_to_pm);
   m.impl("pm_to_nchw", &pm_to_nchw);
+  m.impl("pm_to_cm", &pm_to_cm);
 }

@@ -24,13 +24,14 @@ import torch
 
 from . import load_native
 from .corr import get_corr_block as _pfk_get_corr_block
-from .update import PfkUpdateBlock, UpdateSpec, basic_spec, small_spec
+from .update import PfkUpdateBlock, UpdateSpec, basic_spec, gma_spec, small_spec
 
 _ORIG = "_pfk_original_get_corr_block"
 
 # class name of model.update_block -> spec factory (raft/update.py:115-142)
 _SPECS = {
     "BasicUpdateBlock": lambda m: basic_spec(getattr(m, "corr_levels", 4), getattr(m, "corr_radius", 4)),
+    "GMAUpdateBlock": lambda m: gma_spec(getattr(m, "corr_levels", 4), getattr(m, "corr_radius", 4)),
     "SmallUpdateBlock": lambda m: small_spec(getattr(m, "corr_levels", 4), getattr(m, "corr_radius", 3)),
 }
 # families whose CorrBlock pyramid is not the avg-pool one

@@ -25,7 +25,7 @@ import torch.nn.functional as F
 
 from . import load_native
 from .corr import CorrBlock
-from .update import UpdateEngine, UpdateSpec, basic_spec, small_spec
+from .update import UpdateEngine, UpdateSpec, basic_spec, gma_spec, small_spec
 from .synth import synth_state_dict, update_block_shapes
 
 
@@ -132,15 +132,24 @@ class RAFT(nn.Module):
             self.hidden_dim, self.context_dim = 128, 128
             self.fnet = Encoder(256, "instance", False)
             self.cnet = Encoder(self.hidden_dim + self.context_dim, "batch", False)
-            self.spec = basic_spec(corr_levels, self.corr_radius)
+            self.spec = self._basic_spec(corr_levels, self.corr_radius)
         self.update_block = _param_tree(update_block_shapes(self.spec))
         self._engine: Optional[UpdateEngine] = None
         self._versions = None
 
+    def _basic_spec(self, corr_levels: int, corr_radius: int) -> UpdateSpec:
+        return basic_spec(corr_levels, corr_radius)
+
+    def _after_context(self, eng: UpdateEngine, inp: torch.Tensor) -> None:
+        """Hook between the context network and the loop (GMA computes its attention map here)."""
+
     # -- weights ---------------------------------------------------------------------------------
     def load_synthetic(self, seed: int = 1234) -> "RAFT":
-        shapes = {k: tuple(v.shape) for k, v in self.state_dict().items()}
-        self.load_state_dict(synth_state_dict(shapes, seed), strict=True)
+        own = self.state_dict()
+        shapes = {k: tuple(v.shape) for k, v in own.items() if v.is_floating_point()}
+        new = synth_state_dict(shapes, seed)
+        new.update({k: v for k, v in own.items() if not v.is_floating_point()})   # index buffers / counters stay
+        self.load_state_dict(new, strict=True)
         return self
 
     def engine(self, device) -> UpdateEngine:
@@ -205,6 +214,7 @@ class RAFT(nn.Module):
         eng = self.engine(x.device)
         eng.bind(B, h, w)
         eng.load_state(net, inp)
+        self._after_context(eng, inp)
         ops.flow_from_coords(coords0, coords1, eng.flow_view)
         has_mask = self.spec.has_mask
         flow_up = torch.empty(B, 2, 8 * h, 8 * w, device=x.device, dtype=torch.float32) if has_mask else None
@@ -226,3 +236,51 @@ class RAFTSmall(RAFT):
     def __init__(self, **kw):
         kw.setdefault("small", True)
         super().__init__(**kw)
+
+
+class _RelPosEmb(nn.Module):
+    """Parameter holder for GMA's relative position embedding (gma_utils.py:6-30).  The `gma` model registers it
+    but never uses it in its default content-only attention; it exists here so checkpoints load with strict=True."""
+
+    def __init__(self, max_pos_size: int, dim_head: int):
+        super().__init__()
+        self.rel_height = nn.Embedding(2 * max_pos_size - 1, dim_head)
+        self.rel_width = nn.Embedding(2 * max_pos_size - 1, dim_head)
+        deltas = torch.arange(max_pos_size).view(1, -1) - torch.arange(max_pos_size).view(-1, 1)
+        self.register_buffer("rel_ind", deltas + max_pos_size - 1)
+
+
+class _Attention(nn.Module):
+    """GMA attention, content-only mode (gma_utils.py:33-78): one [B,1,N,N] softmax map per forward (torch ops: it is
+    computed once, outside the iteration loop)."""
+
+    def __init__(self, dim: int = 128, heads: int = 1, dim_head: int = 128, max_pos_size: int = 160):
+        super().__init__()
+        self.heads, self.scale = heads, dim_head ** -0.5
+        self.to_qk = nn.Conv2d(dim, heads * dim_head * 2, 1, bias=False)
+        self.pos_emb = _RelPosEmb(max_pos_size, dim_head)
+
+    def forward(self, fmap: torch.Tensor) -> torch.Tensor:
+        B, _, h, w = fmap.shape
+        q, k = self.to_qk(fmap).chunk(2, dim=1)
+        d = q.shape[1] // self.heads
+        q = q.reshape(B, self.heads, d, h * w).transpose(2, 3) * self.scale
+        k = k.reshape(B, self.heads, d, h * w)
+        return torch.softmax(torch.matmul(q, k), dim=-1)
+
+
+class GMA(RAFT):
+    """Mirror of ptlflow/models/gma/gma.py:51-214 (`gma`, one head, content-only attention): RAFT's loop with the
+    update block of gma/update.py:127-160.  The per-iteration `attn @ v` (12.7 GFLOP, reads the 198 MB map) runs on
+    the same MFMA GEMM kernel as the convolutions, with the residual `fmap + gamma * out` fused in its epilogue."""
+
+    def __init__(self, corr_levels: int = 4, corr_radius: int = 4, iters: int = 32, upsample_every_iter: bool = True):
+        super().__init__(corr_levels=corr_levels, corr_radius=corr_radius, iters=iters, small=False,
+                         upsample_every_iter=upsample_every_iter)
+        self.att = _Attention(dim=self.context_dim, heads=1, dim_head=self.context_dim, max_pos_size=160)
+
+    def _basic_spec(self, corr_levels: int, corr_radius: int) -> UpdateSpec:
+        return gma_spec(corr_levels, corr_radius)
+
+    def _after_context(self, eng: UpdateEngine, inp: torch.Tensor) -> None:
+        eng.set_attention(self.att(inp))

@@ -24,6 +24,8 @@ def synth_tensor(name: str, shape: Sequence[int], gen: torch.Generator, fan_in: 
         return 1.0 + 0.2 * torch.rand(shape, generator=gen)
     if name.endswith("running_mean"):
         return 0.05 * torch.randn(shape, generator=gen)
+    if name.endswith(".gamma"):   # GMA's aggregate gate (init 0 in the reference; non-zero here so the path is exercised)
+        return 0.5 + 0.1 * torch.randn(shape, generator=gen)
     if len(shape) == 4:
         if name.startswith(("fnet.", "cnet.")):
             fan_out = shape[0] * shape[2] * shape[3]
@@ -67,7 +69,10 @@ def update_block_shapes(spec) -> Dict[str, tuple]:
     conv("encoder.convf1", s.f1, 2, 7, 7)
     conv("encoder.convf2", s.f2, s.f1, 3, 3)
     conv("encoder.conv", s.enc_out, (s.c2 if s.c2 else s.c1) + s.f2, 3, 3)
-    cin = s.hidden + s.context + s.enc_out + 2
+    cin = s.hidden + s.x_channels
+    if getattr(s, "aggregate", False):
+        sh["aggregator.to_v.weight"] = (s.motion_channels, s.motion_channels, 1, 1)
+        sh["aggregator.gamma"] = (1,)
     for kh, kw, sfx in s.gru_passes:
         for k in "zrq":
             conv(f"gru.conv{k}{sfx}", s.hidden, cin, kh, kw)

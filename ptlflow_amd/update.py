@@ -49,10 +49,15 @@ class UpdateSpec:
     gru_passes: Tuple[Tuple[int, int, str], ...]  # (kh, kw, key suffix)
     fh_hidden: int
     has_mask: bool
+    aggregate: bool = False   # GMA: + attention-aggregated motion features (gma/update.py:148-152)
 
     @property
-    def x_channels(self) -> int:          # inp | encoder out | flow
-        return self.context + self.enc_out + 2
+    def motion_channels(self) -> int:     # encoder out | flow
+        return self.enc_out + 2
+
+    @property
+    def x_channels(self) -> int:          # inp | encoder out | flow [| aggregated motion features]
+        return self.context + self.motion_channels * (2 if self.aggregate else 1)
 
     @property
     def hx_channels(self) -> int:         # padded to a multiple of 4
@@ -63,6 +68,12 @@ def basic_spec(corr_levels: int = 4, corr_radius: int = 4) -> UpdateSpec:
     """BasicUpdateBlock (raft/update.py:131-142)."""
     return UpdateSpec(128, 128, corr_levels * (2 * corr_radius + 1) ** 2, 256, 192, 128, 64, 126,
                       ((1, 5, "1"), (5, 1, "2")), 256, True)
+
+
+def gma_spec(corr_levels: int = 4, corr_radius: int = 4) -> UpdateSpec:
+    """GMAUpdateBlock (gma/update.py:127-160): BasicUpdateBlock + Aggregate, SepConvGRU input 128+128+128."""
+    return UpdateSpec(128, 128, corr_levels * (2 * corr_radius + 1) ** 2, 256, 192, 128, 64, 126,
+                      ((1, 5, "1"), (5, 1, "2")), 256, True, True)
 
 
 def small_spec(corr_levels: int = 4, corr_radius: int = 3) -> UpdateSpec:
@@ -132,6 +143,11 @@ class UpdateEngine:
         else:
             w["fm.w"] = pack_conv_weight(g("flow_head.conv1.weight"), seg1(Ch))
             w["fm.b"] = g("flow_head.conv1.bias").contiguous()
+        if s.aggregate:
+            w["tv.w"] = pack_conv_weight(g("aggregator.to_v.weight"), seg1(s.motion_channels))
+            w["tv.b"] = None
+            self.gamma = float(P["aggregator.gamma"].detach().float().cpu().item())   # one host read per (re)pack
+            self._real_cin["tv"] = s.motion_channels
         w["fh2.w"] = pack_flow_head_weight(g("flow_head.conv2.weight"))
         w["fh2.b"] = g("flow_head.conv2.bias").contiguous()
         self.w = w
@@ -154,6 +170,11 @@ class UpdateEngine:
         self._scratch_c0 = torch.zeros(B, 2, H, W, device=dev, dtype=torch.float32)
         self._scratch_c1 = torch.zeros(B, 2, H, W, device=dev, dtype=torch.float32)
         self._delta = torch.zeros(B, 2, H, W, device=dev, dtype=torch.float32)
+        if s.aggregate:
+            N = H * W
+            self.vbuf = z(s.motion_channels)
+            self.vT = torch.zeros(B, s.motion_channels, round_up(N, 32), device=dev, dtype=torch.float32)
+            self.attn = None
         # scratch for the stream-K conv schedule (partials + flags); all launches are on one stream, so one is enough
         self.workspace = torch.zeros(self.ops.conv_workspace_bytes(), device=dev, dtype=torch.uint8)
         self._shape = (B, H, W)
@@ -178,6 +199,44 @@ class UpdateEngine:
         o = s.hidden + s.context + s.enc_out
         return self.hx[:, o: o + 2]
 
+    def set_attention(self, attn: torch.Tensor) -> None:
+        """GMA attention map [B, 1, N, N] (gma_utils.py:76-78), kept for the whole forward; rows are the K-contiguous
+        A operand of the per-iteration `attn @ v` GEMM (row stride must be a multiple of 4 floats)."""
+        B, H, W = self._shape
+        N = H * W
+        if attn.dim() != 4 or attn.shape[0] != B or attn.shape[1] != 1 or attn.shape[2] != N or attn.shape[3] != N:
+            raise RuntimeError(f"attention must be [B,1,N,N] with one head, got {tuple(attn.shape)}")
+        a = attn.float().reshape(B, N, N)
+        if N % 4 or not a.is_contiguous():
+            pad = torch.zeros(B, N, round_up(N, 4), device=a.device, dtype=torch.float32)
+            pad[:, :, :N] = a
+            a = pad
+        self.attn = a
+
+    def _aggregate(self) -> None:
+        """Aggregate.forward (gma_utils.py:100-113): v = to_v(mf); mf_global = mf + gamma * (attn @ v)."""
+        s = self.spec
+        B, H, W = self._shape
+        N = H * W
+        o = s.hidden + s.context
+        mc = s.motion_channels
+        mf = self.hx[:, o: o + mc]
+        self._conv([mf], 1, 1, "tv", mc, relu=False, out=self.vbuf)
+        self.ops.pm_to_cm(self.vbuf, self.vT)
+        for b in range(B):
+            rows = slice(b * N, (b + 1) * N)
+            src = self.attn[b]
+            prof = self.profile
+            if prof is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            self.ops.conv2d([src], 1, H, W, 1, 1, self.vT[b], None, mc, EPI_LINEAR, False, self.gamma,
+                            self.hx[rows, o + mc: o + 2 * mc], None, None, None, self.workspace, self.hx[rows, o: o + mc])
+            if prof is not None:
+                e1.record()
+                prof.setdefault("ag", []).append((e0, e1))
+                self.flops["ag"] = 2.0 * N * N * mc
+
     def load_state(self, net: torch.Tensor, inp: torch.Tensor) -> None:
         """NCHW ``net`` / ``inp`` -> their hx slices (once per forward)."""
         self.ops.nchw_to_pm(net.float().contiguous(), self.h_view)
@@ -191,7 +250,7 @@ class UpdateEngine:
         if prof is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        self.ops.conv2d(srcs, B, H, W, kh, kw, self.w[key + ".w"], self.w[key + ".b"], cout, epi, relu, scale,
+        self.ops.conv2d(srcs, B, H, W, kh, kw, self.w[key + ".w"], self.w.get(key + ".b"), cout, epi, relu, scale,
                         out, h, z, rh, self.workspace)
         if prof is not None:
             e1.record()
@@ -214,6 +273,10 @@ class UpdateEngine:
         self._conv([self.flo1], 3, 3, "f2", s.f2, out=self.corflo[:, cor_c: cor_c + s.f2])
         o = s.hidden + s.context
         self._conv([self.corflo], 3, 3, "cv", s.enc_out, out=self.hx[:, o: o + s.enc_out])
+        if s.aggregate:
+            if self.attn is None:
+                raise RuntimeError("GMA update block needs set_attention() before the first iteration")
+            self._aggregate()
         Ch = s.hidden
         for kh, kw, sfx in s.gru_passes:
             self._conv([self.hx], kh, kw, "zr" + sfx, 2 * Ch, epi=EPI_GRU_ZR, h=self.h_view, z=self.zbuf, rh=self.rh)
@@ -280,14 +343,15 @@ class PfkUpdateBlock(torch.nn.Module):
             self._versions = v
         return self._engine
 
-    def forward(self, net, inp, corr, flow):
+    def forward(self, net, inp, corr, flow, attention=None):
+        extra = () if attention is None else (attention,)
         if torch.is_grad_enabled() and (net.requires_grad or any(p.requires_grad for p in self.parameters())):
             # training graph: the reference module keeps doing its own job (backward kernels are SURVEY §8 f4)
-            return self._ref[0](net, inp, corr, flow)
+            return self._ref[0](net, inp, corr, flow, *extra)
         with torch.no_grad():
-            return self._forward_kernels(net, inp, corr, flow)
+            return self._forward_kernels(net, inp, corr, flow, attention)
 
-    def _forward_kernels(self, net, inp, corr, flow):
+    def _forward_kernels(self, net, inp, corr, flow, attention=None):
         if not net.is_cuda:
             raise RuntimeError("PfkUpdateBlock needs GPU tensors (no CPU fallback)")
         eng = self._get_engine(net.device)
@@ -309,6 +373,11 @@ class PfkUpdateBlock(torch.nn.Module):
             corr_pm = torch.empty(B * H * W, corr.shape[1], device=net.device, dtype=torch.float32)
             ops.nchw_to_pm(corr.float().contiguous(), corr_pm)
         ops.nchw_to_pm(flow.float().contiguous(), eng.flow_view)
+        if eng.spec.aggregate:
+            akey = (attention.data_ptr(), attention._version, tuple(attention.shape))
+            if akey != getattr(self, "_attn_key", None) or eng.attn is None:
+                eng.set_attention(attention)
+                self._attn_key = akey
         eng.motion_and_gru(corr_pm)
         eng._scratch_c1.zero_()
         eng.heads(eng._scratch_c0, eng._scratch_c1, eng._delta, want_mask=True, write_flow=False)

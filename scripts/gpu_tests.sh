@@ -1,5 +1,4 @@
 #!/bin/bash
-# Run on the GPU box via: gpurun --timeout 900 -- 'bash scripts/gpu_tests.sh'
-mkdir -p gpurun_out
-python -m pytest tests -m gpu -q 2>&1 | tail -80 > gpurun_out/pytest_gpu.log
-cat gpurun_out/pytest_gpu.log
+O=$GRAFT_REPO_ROOT/gpurun_out; mkdir -p $O
+timeout 600 python -m pytest tests -m gpu -q 2>&1 | tail -25 > $O/pytest_gpu.log
+cat $O/pytest_gpu.log

@@ -102,3 +102,27 @@ def test_alt_cuda_corr_abi(gpu, B, H1, W1, H2, W2, C, r):
     assert err.max().item() < 2e-4 * max(1.0, ref.nan_to_num().abs().max().item())
     with pytest.raises(RuntimeError):
         mod.forward(f1.cuda().permute(0, 2, 1, 3), f2.cuda(), coords.cuda(), r)   # CHECK_CONTIGUOUS
+
+
+def test_gma_update_block_dropin(gpu):
+    """Seam B3 with GMA's five-argument forward(net, inp, corr, flow, attention) (gma/update.py:148)."""
+    from ptlflow_amd.raft import _param_tree
+    from ptlflow_amd.synth import synth_state_dict, update_block_shapes
+    from ptlflow_amd.update import PfkUpdateBlock, gma_spec
+    spec = gma_spec()
+    holder = _param_tree(update_block_shapes(spec))
+    P = synth_state_dict({k: tuple(v.shape) for k, v in holder.state_dict().items()}, seed=19)
+    holder.load_state_dict(P)
+    ub = PfkUpdateBlock(holder, spec).cuda().eval()
+    g = torch.Generator().manual_seed(5)
+    B, h, w = 2, 10, 14
+    net = torch.tanh(torch.randn(B, 128, h, w, generator=g))
+    inp = torch.relu(torch.randn(B, 128, h, w, generator=g))
+    corr = torch.randn(B, 324, h, w, generator=g)
+    flow = torch.randn(B, 2, h, w, generator=g) * 2
+    attn = torch.softmax(torch.randn(B, 1, h * w, h * w, generator=g), dim=-1)
+    n_ref, m_ref, d_ref = O.gma_update_block(P, net, inp, corr, flow, attn)
+    with torch.no_grad():
+        n, m, d = ub(net.cuda(), inp.cuda(), corr.cuda(), flow.cuda(), attn.cuda())
+    for a, b in ((n, n_ref), (m, m_ref), (d, d_ref)):
+        assert (a.cpu() - b).abs().max().item() < 2e-4

@@ -69,3 +69,28 @@ def test_batch_independence(gpu):
     one = torch.cat([m({"images": x[i:i + 1]})["flows"] for i in range(2)], 0)
     mean, mx = O.epe(both[:, 0].cpu(), one[:, 0].cpu())
     assert mean <= 1e-4 and mx <= 1e-3, f"EPE mean {mean:.2e} max {mx:.2e}"
+
+
+def test_gma_forward(gpu):
+    """Second model family on the same kernels: GMA, 6 iterations, vs the CPU oracle."""
+    from ptlflow_amd.raft import GMA
+    model = GMA(iters=6).load_synthetic(77).eval()
+    P = {k: v.clone() for k, v in model.state_dict().items()}
+    assert abs(float(P["update_block.aggregator.gamma"])) > 0.1      # the aggregate branch is really exercised
+    x = O.smooth_pair(2, 184, 248, seed=9)
+    ref = O.gma_forward(P, x, iters=6)
+    out = model.cuda()({"images": x.cuda()})
+    mean, mx = O.epe(out["flows"][:, 0].cpu(), ref["flows"][:, 0])
+    assert mean <= 1e-3 and mx <= 1e-2, f"EPE mean {mean:.2e} max {mx:.2e}"
+
+
+def test_gma_odd_grid(gpu):
+    """h*w not a multiple of 4 / 32: the attention operand and V^T get padded."""
+    from ptlflow_amd.raft import GMA
+    model = GMA(iters=3).load_synthetic(78).eval()
+    P = {k: v.clone() for k, v in model.state_dict().items()}
+    x = O.smooth_pair(1, 136, 168, seed=10)          # 17 x 21 = 357 pixels
+    ref = O.gma_forward(P, x, iters=3)
+    out = model.cuda()({"images": x.cuda()})
+    mean, mx = O.epe(out["flows"][:, 0].cpu(), ref["flows"][:, 0])
+    assert mean <= 1e-3 and mx <= 1e-2, f"EPE mean {mean:.2e} max {mx:.2e}"
