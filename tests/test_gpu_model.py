@@ -94,3 +94,13 @@ def test_gma_odd_grid(gpu):
     out = model.cuda()({"images": x.cuda()})
     mean, mx = O.epe(out["flows"][:, 0].cpu(), ref["flows"][:, 0])
     assert mean <= 1e-3 and mx <= 1e-2, f"EPE mean {mean:.2e} max {mx:.2e}"
+
+
+@pytest.mark.parametrize("H,W,B,iters", [(375, 1242, 2, 4), (368, 496, 2, 4)])
+def test_other_baseline_shapes(gpu, H, W, B, iters):
+    """BASELINE.json configs[3] (KITTI 1242x375 -> 47x156 grid, N = 7332: not a multiple of 32/64) and configs[4]'s
+    FlyingChairs crop (368x496 -> 46x62), a few iterations, batch > 1."""
+    out, ref = _run_pair(False, H, W, iters, B=B)
+    assert out["flows"].shape == ref["flows"].shape == (B, 1, 2, H, W)
+    mean, mx = O.epe(out["flows"][:, 0].cpu(), ref["flows"][:, 0])
+    assert mean <= 1e-3 and mx <= 1e-2, f"EPE mean {mean:.2e} max {mx:.2e}"
