@@ -11,7 +11,7 @@
 namespace {
 
 // ------------------------------------------------------------------------------------------
-// K3 lookup.  One workgroup per source pixel, one 64-lane wave per pyramid level.
+// K3 lookup.  One workgroup per PIX consecutive source pixels, one 64-lane wave per pyramid level.
 //
 // All (2r+1)^2 samples of a level share (up to fp32 rounding of the round trip) one fractional
 // offset, so they touch a (2r+2)^2 patch of that pixel's [h_l][w_l] correlation map.  The wave
@@ -50,74 +50,109 @@ __device__ __forceinline__ int safe_base(float v) {
   return (fabsf(v) < 1.0e9f) ? (int)v : -(1 << 30);
 }
 
+// PIX consecutive source pixels per workgroup: the kernel is a chain of dependent latencies (coords -> patch
+// loads -> LDS -> outputs), so each wave keeps PIX independent patches in flight instead of one — 4x fewer,
+// 4x fatter workgroups, one resident round on the chip at 55x128.
+constexpr int PIX = 4;
+
 __global__ __launch_bounds__(256) void lookup_kernel(const LookupArgs a) {
-  __shared__ float s_patch[4][PATCH * PATCH_LD];
-  __shared__ float s_x0[4][12], s_wx[4][12], s_y0[4][12], s_wy[4][12];
+  __shared__ float s_patch[4][PIX][PATCH * PATCH_LD];
+  __shared__ float s_x0[4][PIX][12], s_wx[4][PIX][12], s_y0[4][PIX][12], s_wy[4][PIX][12];
 
   const int lane = threadIdx.x & 63;
   const int wid = threadIdx.x >> 6;
-  const long long p = blockIdx.x;
+  const long long M = (long long)a.B * a.h * a.w;
+  const long long p0 = (long long)blockIdx.x * PIX;
   const int N = a.h * a.w;
-  const int b = (int)(p / N);
-  const int pix = (int)(p % N);
-  const float cx0 = a.coords[((long long)b * 2 + 0) * N + pix];
-  const float cy0 = a.coords[((long long)b * 2 + 1) * N + pix];
   const int r = a.r;
   const int n = 2 * r + 1;
   const int nn = n * n;
+
+  float cx0[PIX], cy0[PIX];
+#pragma unroll
+  for (int q = 0; q < PIX; ++q) {
+    const long long p = p0 + q;
+    cx0[q] = 0.f; cy0[q] = 0.f;
+    if (p < M) {
+      const int b = (int)(p / N);
+      const int pix = (int)(p % N);
+      cx0[q] = a.coords[((long long)b * 2 + 0) * N + pix];
+      cy0[q] = a.coords[((long long)b * 2 + 1) * N + pix];
+    }
+  }
 
   const int rounds = (a.L + 3) >> 2;
   for (int it = 0; it < rounds; ++it) {
     const int l = it * 4 + wid;
     const bool active = l < a.L;
-    float xb = 0.f, yb = 0.f;
+    float xb[PIX], yb[PIX];
     if (active) {
       const int Hl = a.lh[l], Wl = a.lw[l];
       const float inv = 1.0f / (float)(1 << l);   // coords / 2**l is exact (corr.py:45)
-      const float cx = cx0 * inv, cy = cy0 * inv;
-      xb = floorf(cx) - (float)(r + 1);
-      yb = floorf(cy) - (float)(r + 1);
-      if (lane < n) {
-        const float off = (float)(lane - r);
-        const float ix = roundtrip(cx + off, (float)(Wl - 1), (float)(Wl - 1) * 0.5f);
-        const float iy = roundtrip(cy + off, (float)(Hl - 1), (float)(Hl - 1) * 0.5f);
-        const float x0 = floorf(ix), y0 = floorf(iy);
-        s_x0[wid][lane] = x0;
-        s_wx[wid][lane] = ix - x0;
-        s_y0[wid][lane] = y0;
-        s_wy[wid][lane] = iy - y0;
-      }
-      const int xbi = safe_base(xb), ybi = safe_base(yb);
-      const float* vol = a.lv[l] + p * (long long)Hl * Wl;
+      float v[PIX][3];
 #pragma unroll
-      for (int e = lane; e < PATCH * PATCH; e += 64) {
-        const int yy = e / PATCH, xx = e - yy * PATCH;
-        const int gy = ybi + yy, gx = xbi + xx;
-        float v = 0.f;
-        if ((unsigned)gy < (unsigned)Hl && (unsigned)gx < (unsigned)Wl)
-          v = vol[(long long)gy * Wl + gx];
-        s_patch[wid][yy * PATCH_LD + xx] = v;
+      for (int q = 0; q < PIX; ++q) {
+        const float cx = cx0[q] * inv, cy = cy0[q] * inv;
+        xb[q] = floorf(cx) - (float)(r + 1);
+        yb[q] = floorf(cy) - (float)(r + 1);
+        if (lane < n) {
+          const float off = (float)(lane - r);
+          const float ix = roundtrip(cx + off, (float)(Wl - 1), (float)(Wl - 1) * 0.5f);
+          const float iy = roundtrip(cy + off, (float)(Hl - 1), (float)(Hl - 1) * 0.5f);
+          const float x0 = floorf(ix), y0 = floorf(iy);
+          s_x0[wid][q][lane] = x0;
+          s_wx[wid][q][lane] = ix - x0;
+          s_y0[wid][q][lane] = y0;
+          s_wy[wid][q][lane] = iy - y0;
+        }
+        const int xbi = safe_base(xb[q]), ybi = safe_base(yb[q]);
+        const bool pl = (p0 + q) < M;
+        const float* vol = a.lv[l] + (p0 + q) * (long long)Hl * Wl;
+#pragma unroll
+        for (int e3 = 0; e3 < 3; ++e3) {          // all loads of all PIX patches are issued before any is used
+          const int e = lane + 64 * e3;
+          const int yy = e / PATCH, xx = e - yy * PATCH;
+          const int gy = ybi + yy, gx = xbi + xx;
+          float t = 0.f;
+          if (pl && e < PATCH * PATCH && (unsigned)gy < (unsigned)Hl && (unsigned)gx < (unsigned)Wl)
+            t = vol[(long long)gy * Wl + gx];
+          v[q][e3] = t;
+        }
       }
+#pragma unroll
+      for (int q = 0; q < PIX; ++q)
+#pragma unroll
+        for (int e3 = 0; e3 < 3; ++e3) {
+          const int e = lane + 64 * e3;
+          if (e < PATCH * PATCH) {
+            const int yy = e / PATCH, xx = e - yy * PATCH;
+            s_patch[wid][q][yy * PATCH_LD + xx] = v[q][e3];
+          }
+        }
     }
     __syncthreads();
     if (active) {
-      float* o = a.out + p * a.out_ld + l * nn;
-      for (int k = lane; k < nn; k += 64) {
-        const int i = k / n, j = k - i * n;
-        const float x0 = s_x0[wid][i], wx = s_wx[wid][i];
-        const float y0 = s_y0[wid][j], wy = s_wy[wid][j];
-        const float dxf = x0 - xb, dyf = y0 - yb;
-        const int rx = (dxf >= 0.f && dxf <= (float)(PATCH - 2)) ? (int)dxf : 0;
-        const int ry = (dyf >= 0.f && dyf <= (float)(PATCH - 2)) ? (int)dyf : 0;
-        const float* q = &s_patch[wid][ry * PATCH_LD + rx];
-        const float nw = q[0], ne = q[1], sw = q[PATCH_LD], se = q[PATCH_LD + 1];
-        const float ex = 1.0f - wx, sy = 1.0f - wy;
-        const float w_nw = sy * ex, w_ne = sy * wx, w_sw = wy * ex, w_se = wy * wx;
-        float t = nw * w_nw;
-        t = fmaf(ne, w_ne, t);
-        t = fmaf(sw, w_sw, t);
-        t = fmaf(se, w_se, t);
-        o[k] = t;
+#pragma unroll
+      for (int q = 0; q < PIX; ++q) {
+        if (p0 + q >= M) break;
+        float* o = a.out + (p0 + q) * a.out_ld + l * nn;
+        for (int k = lane; k < nn; k += 64) {
+          const int i = k / n, j = k - i * n;
+          const float x0 = s_x0[wid][q][i], wx = s_wx[wid][q][i];
+          const float y0 = s_y0[wid][q][j], wy = s_wy[wid][q][j];
+          const float dxf = x0 - xb[q], dyf = y0 - yb[q];
+          const int rx = (dxf >= 0.f && dxf <= (float)(PATCH - 2)) ? (int)dxf : 0;
+          const int ry = (dyf >= 0.f && dyf <= (float)(PATCH - 2)) ? (int)dyf : 0;
+          const float* pq = &s_patch[wid][q][ry * PATCH_LD + rx];
+          const float nw = pq[0], ne = pq[1], sw = pq[PATCH_LD], se = pq[PATCH_LD + 1];
+          const float ex = 1.0f - wx, sy = 1.0f - wy;
+          const float w_nw = sy * ex, w_ne = sy * wx, w_sw = wy * ex, w_se = wy * wx;
+          float t = nw * w_nw;
+          t = fmaf(ne, w_ne, t);
+          t = fmaf(sw, w_sw, t);
+          t = fmaf(se, w_se, t);
+          o[k] = t;
+        }
       }
     }
     __syncthreads();
@@ -160,7 +195,7 @@ int pfk_corr_lookup_f32(const pfk_lookup_desc* d, pfk_stream_t stream) {
   }
   a.L = d->num_levels; a.r = d->radius; a.B = d->B; a.h = d->h; a.w = d->w;
   a.coords = d->coords; a.out = d->out; a.out_ld = d->out_ld;
-  const long long blocks = (long long)d->B * d->h * d->w;
+  const long long blocks = ((long long)d->B * d->h * d->w + PIX - 1) / PIX;
   if (blocks > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(lookup_kernel, dim3((unsigned)blocks), dim3(256), 0,
                      static_cast<hipStream_t>(stream), a);
