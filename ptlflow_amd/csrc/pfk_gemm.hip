@@ -759,17 +759,15 @@ int launch(const GemmArgs& a, int epi, int batches, hipStream_t st) {
   } else {
     const long long tiles64 = (a.M + 63) / 64;
     const long long blocks64 = tiles64 * ((a.b_rows + 63) / 64);
-    // measured on MI355X (scripts/conv_bench.py): with < 4 blocks of 64x64 per CU the 3-stage hand-interleaved
-    // pipeline on 64x64 tiles wins; with plenty of blocks the lighter 2-stage pipeline on 64x128 tiles (two
-    // resident blocks per CU) does.
-    if (blocks64 < 4 * 256) {
-      // stream-K (needs the caller's workspace) only where the tile grid quantises badly on 256 CUs and K is long
-      // enough to amortise segment prologues + fix-up: measured on MI355X it wins for convc2 (330 tiles: 80 -> 65 us)
-      // and loses for 220-tile or short-K launches.
-      const double fill = (double)blocks64 / (256.0 * (double)((blocks64 + 255) / 256));
-      const bool sk = a.sk_ws != nullptr && batches == 1 && blocks64 > 256 && fill < 0.75 && a.sk_steps >= 24;
-      cfg = sk ? 9 : 4;
-    } else cfg = a.b_rows > 64 ? 1 : 0;
+    // Measured on MI355X (scripts/conv_bench.py, batch 1 / 4 / 8): 64x64 tiles with the 3-stage hand-interleaved
+    // pipeline (cfg 4) win at every batch size once K is long; for short K (1x1 convs: <= 15 K-steps) the lighter
+    // 2-stage pipeline (cfg 0) has the cheaper prologue.  Stream-K (needs the caller's workspace) only where a small
+    // tile grid quantises badly on 256 CUs and K is long enough to amortise segment prologues + fix-up: it wins for
+    // convc2 at batch 1 (330 tiles: 80 -> 65 us) and loses for 220-tile or short-K launches.
+    const double fill = (double)blocks64 / (256.0 * (double)((blocks64 + 255) / 256));
+    const bool sk = a.sk_ws != nullptr && batches == 1 && blocks64 > 256 && blocks64 < 4 * 256 && fill < 0.75 &&
+                    a.sk_steps >= 24;
+    cfg = sk ? 9 : (a.sk_steps < 16 ? 0 : 4);
   }
   switch (cfg) {
     case 0: return launch_cfg<64, 64, 32, 32, 0>(a, epi, batches, st);
