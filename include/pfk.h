@@ -180,6 +180,13 @@ int pfk_altcorr_forward_f32(const float* fmap1, const float* fmap2, const float*
                             int B, int H1, int W1, int H2, int W2, int C, int radius,
                             pfk_stream_t stream);
 
+/* backward of the above w.r.t. the feature maps: corr_cuda_backward (correlation_kernel.cu:288-324, pybind
+ * `alt_cuda_corr.backward`).  corr_grad [B][(2r+1)^2][H1][W1] -> fmap1_grad [B][H1][W1][C] (overwritten),
+ * fmap2_grad [B][H2][W2][C] (zeroed here, then accumulated with fp32 atomics like the reference). */
+int pfk_altcorr_backward_f32(const float* fmap1, const float* fmap2, const float* coords,
+                             const float* corr_grad, float* fmap1_grad, float* fmap2_grad, int B, int H1,
+                             int W1, int H2, int W2, int C, int radius, pfk_stream_t stream);
+
 /* NCHW [B][C][H][W] -> pixel-major [B*H*W][ld] (+ channel offset) and back. */
 int pfk_nchw_to_pm_f32(const float* in, float* out, int out_ld, int out_coff, int B, int C,
                        int H, int W, pfk_stream_t stream);

@@ -10,8 +10,8 @@ is enough.
 
 ``forward`` keeps the reference's contract exactly: fp32 contiguous GPU tensors, ``fmap1 [B,H1,W1,C]``,
 ``fmap2 [B,H2,W2,C]``, ``coords [B,N,H1,W1,2]`` (x, y), returns ``[corr]`` with ``corr [B,N,(2r+1)^2,H1,W1]``,
-cell index ``iy + (2r+1)*ix`` (x-major), unscaled.  ``backward`` (training with alternate_corr — which the reference
-itself never wires into autograd) is not built yet and raises.
+cell index ``iy + (2r+1)*ix`` (x-major), unscaled.  ``backward`` mirrors correlation.cpp:39-49 (the reference itself never
+wires it into autograd: AlternateCorrBlock calls ``forward`` directly).
 """
 from __future__ import annotations
 
@@ -33,9 +33,17 @@ def forward(fmap1: torch.Tensor, fmap2: torch.Tensor, coords: torch.Tensor, radi
     return [torch.ops.pfk.altcorr_forward(fmap1, fmap2, coords, int(radius))]
 
 
-def backward(fmap1, fmap2, coords, corr_grad, radius):
-    raise NotImplementedError("alt_cuda_corr.backward is not built yet (SURVEY.md §8 f1/f4); the reference never calls it "
-                              "through autograd either (AlternateCorrBlock calls forward directly)")
+def backward(fmap1: torch.Tensor, fmap2: torch.Tensor, coords: torch.Tensor, corr_grad: torch.Tensor,
+             radius: int) -> List[torch.Tensor]:
+    """`alt_cuda_corr.backward` (correlation.cpp:39-49): [fmap1_grad, fmap2_grad, coords_grad]; like the reference,
+    coords_grad is all zeros (correlation_kernel.cu:307) and fmap2_grad is accumulated with fp32 atomics."""
+    load_native()
+    for name, t in (("fmap1", fmap1), ("fmap2", fmap2), ("coords", coords), ("corr_grad", corr_grad)):
+        if not t.is_cuda:
+            raise RuntimeError(f"{name} must be a CUDA tensor")
+        if not t.is_contiguous():
+            raise RuntimeError(f"{name} must be contiguous")
+    return list(torch.ops.pfk.altcorr_backward(fmap1, fmap2, coords, corr_grad, int(radius)))
 
 
 def install() -> None:

@@ -615,7 +615,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_sk_kernel(const GemmArgs a) 
   const int foff_b = BM * LDS_LD + (wn0 + (lane & 31)) * LDS_LD + (lane >> 5) * 4;
 
   const long long G = gridDim.x;
-  const long long lb = pfk_xcd_remap(blockIdx.x, gridDim.x);
+  // NO XCD remap here: a block may only wait on blocks with a LOWER dispatch index (those are running or done whatever
+  // the residency), so the logical order of the unit ranges must be the dispatch order.
+  const long long lb = blockIdx.x;
   const int S = a.sk_steps;
   const long long U = a.sk_tiles * S;
   const long long u0 = lb * U / G, u1 = (lb + 1) * U / G;

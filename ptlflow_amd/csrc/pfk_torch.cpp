@@ -195,6 +195,24 @@ Tensor altcorr_forward(const Tensor& fmap1, const Tensor& fmap2, const Tensor& c
   return out;
 }
 
+// alt_cuda_corr.backward semantics (correlation.cpp:39-49): returns {fmap1_grad, fmap2_grad, coords_grad (zeros)}
+std::vector<Tensor> altcorr_backward(const Tensor& fmap1, const Tensor& fmap2, const Tensor& coords, const Tensor& corr_grad,
+                                     int64_t radius) {
+  check_dev_f32(fmap1, "fmap1"); check_dev_f32(fmap2, "fmap2"); check_dev_f32(coords, "coords"); check_dev_f32(corr_grad, "corr_grad");
+  TORCH_CHECK(fmap1.is_contiguous() && fmap2.is_contiguous() && coords.is_contiguous() && corr_grad.is_contiguous(),
+              "altcorr_backward: contiguous inputs");
+  TORCH_CHECK(fmap1.dim() == 4 && fmap2.dim() == 4 && coords.dim() == 5 && corr_grad.dim() == 5);
+  const int B = fmap1.size(0), H1 = fmap1.size(1), W1 = fmap1.size(2), C = fmap1.size(3);
+  const int H2 = fmap2.size(1), W2 = fmap2.size(2), N = coords.size(1);
+  TORCH_CHECK(N == 1, "altcorr_backward: one coordinate set per call (as AlternateCorrBlock uses it)");
+  const int rd = 2 * radius + 1;
+  TORCH_CHECK(corr_grad.size(0) == B && corr_grad.size(2) == rd * rd && corr_grad.size(3) == H1 && corr_grad.size(4) == W1);
+  Tensor g1 = at::empty_like(fmap1), g2 = at::empty_like(fmap2), gc = at::zeros_like(coords);
+  check_ok(pfk_altcorr_backward_f32(fptr(fmap1), fptr(fmap2), fptr(coords), fptr(corr_grad), fptr(g1), fptr(g2), B, H1, W1, H2,
+                                    W2, C, radius, cur_stream()), "altcorr_backward");
+  return {g1, g2, gc};
+}
+
 void nchw_to_pm(const Tensor& in, Tensor out) {
   check_dev_f32(in, "in"); check_pm(out, "out");
   TORCH_CHECK(in.dim() == 4 && in.is_contiguous());
@@ -245,6 +263,7 @@ TORCH_LIBRARY(pfk, m) {
   m.def("convex_upsample(Tensor flow, Tensor mask, Tensor(a!) out) -> ()");
   m.def("convex_upsample_pm(Tensor flow_pm, Tensor mask, Tensor(a!) out) -> ()");
   m.def("altcorr_forward(Tensor fmap1, Tensor fmap2, Tensor coords, int radius) -> Tensor");
+  m.def("altcorr_backward(Tensor fmap1, Tensor fmap2, Tensor coords, Tensor corr_grad, int radius) -> Tensor[]");
   m.def("nchw_to_pm(Tensor inp, Tensor(a!) out) -> ()");
   m.def("pm_to_nchw(Tensor inp, Tensor(a!) out) -> ()");
   m.def("pm_to_cm(Tensor inp, Tensor(a!) out) -> ()");
@@ -261,6 +280,7 @@ TORCH_LIBRARY_IMPL(pfk, CUDA, m) {
   m.impl("convex_upsample", &convex_upsample);
   m.impl("convex_upsample_pm", &convex_upsample_pm);
   m.impl("altcorr_forward", &altcorr_forward);
+  m.impl("altcorr_backward", &altcorr_backward);
   m.impl("nchw_to_pm", &nchw_to_pm);
   m.impl("pm_to_nchw", &pm_to_nchw);
   m.impl("pm_to_cm", &pm_to_cm);

@@ -126,3 +126,22 @@ def test_gma_update_block_dropin(gpu):
         n, m, d = ub(net.cuda(), inp.cuda(), corr.cuda(), flow.cuda(), attn.cuda())
     for a, b in ((n, n_ref), (m, m_ref), (d, d_ref)):
         assert (a.cpu() - b).abs().max().item() < 2e-4
+
+
+def test_alt_cuda_corr_backward(gpu):
+    """`alt_cuda_corr.backward` (correlation.cpp:39-49) vs autograd through the oracle's restatement of the forward."""
+    import ptlflow_amd.altcorr as altcorr
+    g = torch.Generator().manual_seed(9)
+    B, H1, W1, H2, W2, C, r = 2, 9, 11, 7, 8, 64, 3
+    f1 = torch.randn(B, H1, W1, C, generator=g, requires_grad=True)
+    f2 = torch.randn(B, H2, W2, C, generator=g, requires_grad=True)
+    base = torch.stack(torch.meshgrid(torch.arange(H1, dtype=torch.float32), torch.arange(W1, dtype=torch.float32),
+                                      indexing="ij")[::-1], -1)[None, None].repeat(B, 1, 1, 1, 1)
+    coords = base * 0.7 + torch.randn(B, 1, H1, W1, 2, generator=g) * 2
+    out = O.alt_corr_forward(f1, f2, coords, r)
+    grad = torch.randn(out.shape, generator=g)
+    out.backward(grad)
+    g1, g2, gc = altcorr.backward(f1.detach().cuda(), f2.detach().cuda(), coords.cuda(), grad.cuda(), r)
+    assert (g1.cpu() - f1.grad).abs().max().item() < 1e-4 * max(1.0, f1.grad.abs().max().item())
+    assert (g2.cpu() - f2.grad).abs().max().item() < 1e-4 * max(1.0, f2.grad.abs().max().item())
+    assert tuple(gc.shape) == tuple(coords.shape) and float(gc.abs().max()) == 0.0
