@@ -28,7 +28,9 @@
 namespace {
 
 constexpr int BK = 32;       // channels per K-step
-constexpr int LDS_LD = 36;   // padded LDS row length (floats)
+constexpr int LDS_LD = 36;   // padded LDS row length (floats), 2-stage pipeline (v1)
+constexpr int LDS_LDX = 32;  // un-padded rows + XOR swizzle of the 16-byte chunk index, 3-stage pipelines (v3, stream-K):
+                             // 48 KB per 64x64 block instead of 55 KB => three resident blocks per CU instead of two
 
 struct GemmArgs {
   const float* src0; const float* src1; const float* src2;
@@ -77,7 +79,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, 0x7fffffff, 0x00020000);
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int LD = LDS_LD>
 struct Stager {
   static constexpr int A_PT = BM / 32;
   static constexpr int B_PT = BN / 32;
@@ -89,6 +91,7 @@ struct Stager {
   int seg = 0, ky = 0, kx = 0, c0 = 0, kofs = 0;
   // per thread
   int c4, r0;
+  int scol;   // LDS column of this thread's float4: c4, or its XOR-swizzled chunk when rows are un-padded (LD == 32)
   int prow[A_PT], py[A_PT], px[A_PT];
   bool pok[A_PT];
   unsigned abase[A_PT];   // byte offset of (row, channel c4) in the current source
@@ -105,6 +108,9 @@ struct Stager {
     rsw = make_rsrc(a.weight + batch * a.b_bs);
     c4 = (t & 7) * 4;
     r0 = t >> 3;
+    // LD == 32: chunk' = chunk ^ ((row >> 1) & 7) — a 16-lane ds_read_b128 group (16 rows, one logical chunk) then
+    // covers all 16 sixteen-byte slots of the 256-byte bank row: conflict-free without padding.  (row + 32*i keeps the key.)
+    scol = LD == 32 ? ((((t & 7) ^ ((r0 >> 1) & 7))) << 2) : c4;
 #pragma unroll
     for (int i = 0; i < A_PT; ++i) {
       const long long p = m0 + r0 + 32 * i;
@@ -197,8 +203,8 @@ struct Stager {
   // piece q in [0, A_PT + B_PT): one ds_write_b128 of the staged registers into `stage`
   template <int q>
   __device__ __forceinline__ void store_piece(float* stage) const {
-    if constexpr (q < A_PT) *reinterpret_cast<f32x4*>(stage + (r0 + 32 * q) * LDS_LD + c4) = ra[q];
-    else *reinterpret_cast<f32x4*>(stage + BM * LDS_LD + (r0 + 32 * (q - A_PT)) * LDS_LD + c4) = rb[q - A_PT];
+    if constexpr (q < A_PT) *reinterpret_cast<f32x4*>(stage + (r0 + 32 * q) * LD + scol) = ra[q];
+    else *reinterpret_cast<f32x4*>(stage + BM * LD + (r0 + 32 * (q - A_PT)) * LD + scol) = rb[q - A_PT];
   }
 
   __device__ __forceinline__ void advance() {
@@ -221,10 +227,10 @@ struct Stager {
   __device__ __forceinline__ void store(float* dA, float* dB) const {
 #pragma unroll
     for (int i = 0; i < A_PT; ++i)
-      *reinterpret_cast<f32x4*>(dA + (r0 + 32 * i) * LDS_LD + c4) = ra[i];
+      *reinterpret_cast<f32x4*>(dA + (r0 + 32 * i) * LD + scol) = ra[i];
 #pragma unroll
     for (int i = 0; i < B_PT; ++i)
-      *reinterpret_cast<f32x4*>(dB + (r0 + 32 * i) * LDS_LD + c4) = rb[i];
+      *reinterpret_cast<f32x4*>(dB + (r0 + 32 * i) * LD + scol) = rb[i];
   }
 };
 
@@ -238,12 +244,22 @@ struct Frags {
   f32x4 fa[MT], fb[NT];
 };
 
-template <int MT, int NT>
-__device__ __forceinline__ void frag_read(Frags<MT, NT>& f, const float* cA, const float* cB, int kk) {
+// Fragment read for sub-step kk: lane l wants row (l & 31), logical 16-byte chunk kk*2 + (l >> 5); `ko[kk]` is that
+// chunk's float offset inside the row (swizzled or not), precomputed per lane by frag_offsets().
+template <int MT, int NT, int LD>
+__device__ __forceinline__ void frag_read(Frags<MT, NT>& f, const float* cA, const float* cB, const int (&ko)[4], int kk) {
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) f.fa[mt] = *reinterpret_cast<const f32x4*>(cA + mt * 32 * LDS_LD + kk * 8);
+  for (int mt = 0; mt < MT; ++mt) f.fa[mt] = *reinterpret_cast<const f32x4*>(cA + mt * 32 * LD + ko[kk]);
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) f.fb[nt] = *reinterpret_cast<const f32x4*>(cB + nt * 32 * LDS_LD + kk * 8);
+  for (int nt = 0; nt < NT; ++nt) f.fb[nt] = *reinterpret_cast<const f32x4*>(cB + nt * 32 * LD + ko[kk]);
+}
+
+template <int LD>
+__device__ __forceinline__ void frag_offsets(int (&ko)[4], int lane) {
+  const int hl = lane >> 5;
+  const int key = LD == 32 ? (((lane & 31) >> 1) & 7) : 0;   // (row >> 1) & 7; wave/tile row offsets are multiples of 32
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) ko[kk] = ((kk * 2 + hl) ^ key) << 2;
 }
 
 template <int MT, int NT>
@@ -260,17 +276,18 @@ __device__ __forceinline__ void mma_one(f32x16 (&acc)[MT][NT], const Frags<MT, N
 // Remaining three sub-steps after the caller read sub-step 0: reads for kk+1 are pinned in front of the
 // MFMAs of kk so the LDS latency hides under the matrix pipe.
 template <int MT, int NT>
-__device__ __forceinline__ void mma_rest(f32x16 (&acc)[MT][NT], Frags<MT, NT>& f, const float* cA, const float* cB) {
+__device__ __forceinline__ void mma_rest(f32x16 (&acc)[MT][NT], Frags<MT, NT>& f, const float* cA, const float* cB,
+                                         const int (&ko)[4]) {
   Frags<MT, NT> g;
-  frag_read<MT, NT>(g, cA, cB, 1);
+  frag_read<MT, NT, LDS_LD>(g, cA, cB, ko, 1);
   __builtin_amdgcn_sched_barrier(0);
   mma_one<MT, NT>(acc, f);
   __builtin_amdgcn_sched_barrier(0);
-  frag_read<MT, NT>(f, cA, cB, 2);
+  frag_read<MT, NT, LDS_LD>(f, cA, cB, ko, 2);
   __builtin_amdgcn_sched_barrier(0);
   mma_one<MT, NT>(acc, g);
   __builtin_amdgcn_sched_barrier(0);
-  frag_read<MT, NT>(g, cA, cB, 3);
+  frag_read<MT, NT, LDS_LD>(g, cA, cB, ko, 3);
   __builtin_amdgcn_sched_barrier(0);
   mma_one<MT, NT>(acc, f);
   __builtin_amdgcn_sched_barrier(0);
@@ -374,18 +391,19 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs a) {
   __syncthreads();
 
   const int frow = lane & 31;
-  const int fk = (lane >> 5) * 4;
+  int ko[4];
+  frag_offsets<LDS_LD>(ko, lane);
 
   for (int step = 0; step < total_steps; ++step) {
     const int buf = step & 1;
     const bool more = (step + 1) < total_steps;
-    const float* cA = sA + buf * BM * LDS_LD + (wm0 + frow) * LDS_LD + fk;
-    const float* cB = sB + buf * BN * LDS_LD + (wn0 + frow) * LDS_LD + fk;
+    const float* cA = sA + buf * BM * LDS_LD + (wm0 + frow) * LDS_LD;
+    const float* cB = sB + buf * BN * LDS_LD + (wn0 + frow) * LDS_LD;
     Frags<MT, NT> fr;
-    frag_read<MT, NT>(fr, cA, cB, 0);
+    frag_read<MT, NT, LDS_LD>(fr, cA, cB, ko, 0);
     st.load(more);                      // branch-free; all lanes out of range on the last step
     __builtin_amdgcn_sched_barrier(0);  // keep the prefetch in front of the MFMAs (hipcc otherwise sinks it to its use)
-    mma_rest<MT, NT>(acc, fr, cA, cB);
+    mma_rest<MT, NT>(acc, fr, cA, cB, ko);
     __builtin_amdgcn_sched_barrier(0);
     st.store(sA + (buf ^ 1) * BM * LDS_LD, sB + (buf ^ 1) * BN * LDS_LD);   // last step: zeros into a dead buffer
     if (more) st.advance();
@@ -429,14 +447,14 @@ __device__ __forceinline__ void mma_frags(f32x16 (&acc)[MT][NT], const Frags<MT,
 //   MFMA, [fragment reads of the next sub-step, right after the first MFMA of this one], filler, MFMA, ...
 // Fillers in order: LDS stores of step j+2 (loaded a full step ago), scalar setup, the buffer loads of
 // step j+3.  All indices are template constants so every register array stays in registers.
-template <int BM, int BN, int MT, int NT, int ABL, int Q>
-__device__ __forceinline__ void v3_slot(f32x16 (&acc)[MT][NT], Frags<MT, NT>& f0, Frags<MT, NT>& f1, Stager<BM, BN>& st,
-                                        const float* cA, const float* cB, const float* nA, const float* nB,
-                                        float* s_fill, bool live) {
+template <int BM, int BN, int MT, int NT, int ABL, int LD, int Q>
+__device__ __forceinline__ void v3_slot(f32x16 (&acc)[MT][NT], Frags<MT, NT>& f0, Frags<MT, NT>& f1,
+                                        Stager<BM, BN, LD>& st, const float* cA, const float* cB, const float* nA,
+                                        const float* nB, float* s_fill, bool live, const int (&ko)[4]) {
   constexpr int N0 = 4 * MT * NT;
   constexpr int kk = Q / N0, i = Q % N0;
   constexpr int sidx = i / (MT * NT), mt = (i / NT) % MT, nt = i % NT;
-  constexpr int A_PT = Stager<BM, BN>::A_PT, B_PT = Stager<BM, BN>::B_PT, NW = A_PT + B_PT;
+  constexpr int A_PT = Stager<BM, BN, LD>::A_PT, B_PT = Stager<BM, BN, LD>::B_PT, NW = A_PT + B_PT;
   static_assert(N0 + NW <= 4 * N0, "not enough MFMA slots for the fillers");
   // ABL (timing ablations, results are garbage): 1 no buffer loads, 2 + no LDS stores, 3 + no fragment reads, 4 no MFMAs
   if constexpr (ABL != 4) {
@@ -448,10 +466,10 @@ __device__ __forceinline__ void v3_slot(f32x16 (&acc)[MT][NT], Frags<MT, NT>& f0
   }
   __builtin_amdgcn_sched_barrier(0);
   if constexpr (i == 0 && (ABL < 3 || ABL == 4)) {  // (ABL 3,5,6: MFMA-only skeletons)   // next sub-step's fragments, >= 3 MFMAs (192 cycles) ahead of their first use
-    if constexpr (kk == 0) frag_read<MT, NT>(f1, cA, cB, 1);
-    else if constexpr (kk == 1) frag_read<MT, NT>(f0, cA, cB, 2);
-    else if constexpr (kk == 2) frag_read<MT, NT>(f1, cA, cB, 3);
-    else frag_read<MT, NT>(f0, nA, nB, 0);
+    if constexpr (kk == 0) frag_read<MT, NT, LD>(f1, cA, cB, ko, 1);
+    else if constexpr (kk == 1) frag_read<MT, NT, LD>(f0, cA, cB, ko, 2);
+    else if constexpr (kk == 2) frag_read<MT, NT, LD>(f1, cA, cB, ko, 3);
+    else frag_read<MT, NT, LD>(f0, nA, nB, ko, 0);
     __builtin_amdgcn_sched_barrier(0);
   }
   // Filler q (from the second sub-step on): store staged register q into the free stage and immediately reload
@@ -470,20 +488,21 @@ __device__ __forceinline__ void v3_slot(f32x16 (&acc)[MT][NT], Frags<MT, NT>& f0
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int BM, int BN, int MT, int NT, int ABL, int... Qs>
-__device__ __forceinline__ void v3_step(f32x16 (&acc)[MT][NT], Frags<MT, NT>& f0, Frags<MT, NT>& f1, Stager<BM, BN>& st,
-                                        const float* cA, const float* cB, const float* nA, const float* nB,
-                                        float* s_fill, bool live, std::integer_sequence<int, Qs...>) {
-  (v3_slot<BM, BN, MT, NT, ABL, Qs>(acc, f0, f1, st, cA, cB, nA, nB, s_fill, live), ...);
+template <int BM, int BN, int MT, int NT, int ABL, int LD, int... Qs>
+__device__ __forceinline__ void v3_step(f32x16 (&acc)[MT][NT], Frags<MT, NT>& f0, Frags<MT, NT>& f1,
+                                        Stager<BM, BN, LD>& st, const float* cA, const float* cB, const float* nA,
+                                        const float* nB, float* s_fill, bool live, const int (&ko)[4],
+                                        std::integer_sequence<int, Qs...>) {
+  (v3_slot<BM, BN, MT, NT, ABL, LD, Qs>(acc, f0, f1, st, cA, cB, nA, nB, s_fill, live, ko), ...);
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, int GROUPS, int ABL = 0>
+template <int BM, int BN, int WM, int WN, int EPI, int GROUPS, int ABL = 0, int LD = LDS_LD>
 __global__ __launch_bounds__(256 * GROUPS) void conv_gemm_v3_kernel(const GemmArgs a) {
   constexpr int WAVES_N = BN / WN;
   static_assert((BM / WM) * WAVES_N == 4, "4 waves per group");
   static_assert(BK == 32, "fragment schedule below is written for 4 sub-steps");
   constexpr int MT = WM / 32, NT = WN / 32;
-  constexpr int STAGE = (BM + BN) * LDS_LD;      // floats per stage: A rows then B rows
+  constexpr int STAGE = (BM + BN) * LD;      // floats per stage: A rows then B rows
   constexpr int GROUP_LDS = 3 * STAGE;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -503,7 +522,7 @@ __global__ __launch_bounds__(256 * GROUPS) void conv_gemm_v3_kernel(const GemmAr
   const int n0 = tile_n * BN;
   const long long batch = blockIdx.y;
 
-  Stager<BM, BN> st(a, m0, n0, gtid, batch);
+  Stager<BM, BN, LD> st(a, m0, n0, gtid, batch);
   const int S = st.total_steps();
   const int my_steps = (S - grp + GROUPS - 1) / GROUPS;
   const int max_steps = (S + GROUPS - 1) / GROUPS;   // same trip count for every wave (barriers)
@@ -520,24 +539,26 @@ __global__ __launch_bounds__(256 * GROUPS) void conv_gemm_v3_kernel(const GemmAr
   st.load(0 < my_steps);
 #pragma unroll
   for (int g = 0; g < GROUPS; ++g) st.advance();
-  st.store(s_cur, s_cur + BM * LDS_LD);
+  st.store(s_cur, s_cur + BM * LD);
   st.load(1 < my_steps);
 #pragma unroll
   for (int g = 0; g < GROUPS; ++g) st.advance();
-  st.store(s_nxt, s_nxt + BM * LDS_LD);
+  st.store(s_nxt, s_nxt + BM * LD);
   st.load(2 < my_steps);
 #pragma unroll
   for (int g = 0; g < GROUPS; ++g) st.advance();
   __syncthreads();
 
-  const int foff_a = (wm0 + (lane & 31)) * LDS_LD + (lane >> 5) * 4;
-  const int foff_b = BM * LDS_LD + (wn0 + (lane & 31)) * LDS_LD + (lane >> 5) * 4;
+  const int foff_a = (wm0 + (lane & 31)) * LD;
+  const int foff_b = BM * LD + (wn0 + (lane & 31)) * LD;
+  int ko[4];
+  frag_offsets<LD>(ko, lane);
   Frags<MT, NT> f0, f1;
-  frag_read<MT, NT>(f0, s_cur + foff_a, s_cur + foff_b, 0);
+  frag_read<MT, NT, LD>(f0, s_cur + foff_a, s_cur + foff_b, ko, 0);
 
   for (int j = 0; j < max_steps; ++j) {
-    v3_step<BM, BN, MT, NT, ABL>(acc, f0, f1, st, s_cur + foff_a, s_cur + foff_b, s_nxt + foff_a, s_nxt + foff_b, s_fill,
-                            j + 3 < my_steps, std::make_integer_sequence<int, 16 * MT * NT>{});
+    v3_step<BM, BN, MT, NT, ABL, LD>(acc, f0, f1, st, s_cur + foff_a, s_cur + foff_b, s_nxt + foff_a, s_nxt + foff_b, s_fill,
+                            j + 3 < my_steps, ko, std::make_integer_sequence<int, 16 * MT * NT>{});
     if constexpr (ABL != 6) {
 #pragma unroll
       for (int g = 0; g < GROUPS; ++g) st.advance();
@@ -611,8 +632,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_sk_kernel(const GemmArgs a) 
   const int lane = tid & 63;
   const int wid = tid >> 6;
   const int wm0 = (wid >> 1) * 32, wn0 = (wid & 1) * 32;
-  const int foff_a = (wm0 + (lane & 31)) * LDS_LD + (lane >> 5) * 4;
-  const int foff_b = BM * LDS_LD + (wn0 + (lane & 31)) * LDS_LD + (lane >> 5) * 4;
+  const int foff_a = (wm0 + (lane & 31)) * LDS_LD;
+  const int foff_b = BM * LDS_LD + (wn0 + (lane & 31)) * LDS_LD;
+  int ko[4];
+  frag_offsets<LDS_LD>(ko, lane);
 
   const long long G = gridDim.x;
   // NO XCD remap here: a block may only wait on blocks with a LOWER dispatch index (those are running or done whatever
@@ -632,7 +655,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_sk_kernel(const GemmArgs a) 
     const long long m0 = (tile / a.tiles_n) * BM;
     const int n0 = tile_n * BN;
 
-    Stager<BM, BN> st(a, m0, n0, tid, 0);
+    Stager<BM, BN, LDS_LD> st(a, m0, n0, tid, 0);
     if (s0) st.seek(s0);
     f32x16 acc[MT][NT];
     zero_acc<MT, NT>(acc);
@@ -645,10 +668,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_sk_kernel(const GemmArgs a) 
     st.load(2 < nsteps); st.advance();
     __syncthreads();
     Frags<MT, NT> f0, f1;
-    frag_read<MT, NT>(f0, s_cur + foff_a, s_cur + foff_b, 0);
+    frag_read<MT, NT, LDS_LD>(f0, s_cur + foff_a, s_cur + foff_b, ko, 0);
     for (int j = 0; j < nsteps; ++j) {
-      v3_step<BM, BN, MT, NT, 0>(acc, f0, f1, st, s_cur + foff_a, s_cur + foff_b, s_nxt + foff_a, s_nxt + foff_b, s_fill,
-                                 j + 3 < nsteps, std::make_integer_sequence<int, 16 * MT * NT>{});
+      v3_step<BM, BN, MT, NT, 0, LDS_LD>(acc, f0, f1, st, s_cur + foff_a, s_cur + foff_b, s_nxt + foff_a, s_nxt + foff_b, s_fill,
+                                 j + 3 < nsteps, ko, std::make_integer_sequence<int, 16 * MT * NT>{});
       st.advance();
       float* t = s_cur; s_cur = s_nxt; s_nxt = s_fill; s_fill = t;
       __syncthreads();
@@ -711,18 +734,19 @@ int launch_sk(const GemmArgs& a, int epi, hipStream_t st) {
   return pfk_launch_status();
 }
 
-// VARIANT: 0 = 4-wave double-buffered pipeline (v1), 1 = v3 one group, 2 = v3 two groups (in-block split-K)
+// VARIANT: 0 = 4-wave double-buffered pipeline (v1), 1 = v3 one group, 2 = v3 two groups (in-block split-K);
+// +10*ABL = timing ablation; +100 = un-padded XOR-swizzled LDS rows (48 KB per 64x64 block: three blocks per CU)
 template <int BM, int BN, int WM, int WN, int EPI, int VARIANT>
 int launch_one(const GemmArgs& g, dim3 grid, hipStream_t st) {
   if constexpr (VARIANT == 0) {
     constexpr size_t smem = 2 * (BM + BN) * LDS_LD * sizeof(float);
     hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, EPI>), grid, dim3(256), smem, st, g);
   } else {
-    constexpr int G = VARIANT % 10, ABL = VARIANT / 10;
-    constexpr size_t smem = (size_t)G * 3 * (BM + BN) * LDS_LD * sizeof(float);
+    constexpr int G = VARIANT % 10, ABL = (VARIANT / 10) % 10, LD = VARIANT >= 100 ? LDS_LDX : LDS_LD;
+    constexpr size_t smem = (size_t)G * 3 * (BM + BN) * LD * sizeof(float);
     static_assert(smem <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
-    auto kern = conv_gemm_v3_kernel<BM, BN, WM, WN, EPI, G, ABL>;
+    auto kern = conv_gemm_v3_kernel<BM, BN, WM, WN, EPI, G, ABL, LD>;
     if (!attr_set) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       attr_set = true;
@@ -751,7 +775,7 @@ int launch_cfg(const GemmArgs& a, int epi, int batches, hipStream_t st) {
 int g_force_tile = -1;  // debug/tuning knob, see pfk_debug_set_tile
 
 // Configurations: 0-3 = v1 (64x64, 64x128, 128x128, 128x64); 4-7 = v3 one group, same tiles;
-// 8 = v3 two groups 64x64 (in-block split-K); 9 = stream-K on 64x64 tiles (needs a workspace).
+// 8 = v3 two groups 64x64 (in-block split-K); 9 = stream-K on 64x64 tiles (needs a workspace); 10 = cfg 4 on swizzled LDS.
 int launch(const GemmArgs& a, int epi, int batches, hipStream_t st) {
   int cfg;
   if (g_force_tile >= 0) {
@@ -769,7 +793,9 @@ int launch(const GemmArgs& a, int epi, int batches, hipStream_t st) {
     const double fill = (double)blocks64 / (256.0 * (double)((blocks64 + 255) / 256));
     const bool sk = a.sk_ws != nullptr && batches == 1 && blocks64 > 256 && blocks64 < 4 * 256 && fill < 0.75 &&
                     a.sk_steps >= 24;
-    cfg = sk ? 9 : (a.sk_steps < 16 ? 0 : 4);
+    // >= 3 tiles per CU: the swizzled 48 KB layout (cfg 10) keeps three blocks resident; below that the padded rows'
+    // immediate-offset fragment reads are a few % faster (cfg 4).
+    cfg = sk ? 9 : (a.sk_steps < 16 ? 0 : (blocks64 >= 3 * 256 ? 10 : 4));
   }
   switch (cfg) {
     case 0: return launch_cfg<64, 64, 32, 32, 0>(a, epi, batches, st);
@@ -782,6 +808,7 @@ int launch(const GemmArgs& a, int epi, int batches, hipStream_t st) {
     case 7: return launch_cfg<128, 64, 64, 32, 1>(a, epi, batches, st);
     case 8: return launch_cfg<64, 64, 32, 32, 2>(a, epi, batches, st);
     case 9: return (a.sk_ws != nullptr && batches == 1) ? launch_sk(a, epi, st) : PFK_ERR_BAD_ARG;
+    case 10: return launch_cfg<64, 64, 32, 32, 101>(a, epi, batches, st);
     // timing ablations of cfg 4 (results are garbage; used by scripts/conv_bench.py only)
     case 21: return epi == PFK_EPI_LINEAR ? launch_cfg<64, 64, 32, 32, 11>(a, epi, batches, st) : PFK_ERR_BAD_ARG;
     case 22: return epi == PFK_EPI_LINEAR ? launch_cfg<64, 64, 32, 32, 21>(a, epi, batches, st) : PFK_ERR_BAD_ARG;

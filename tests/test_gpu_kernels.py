@@ -124,7 +124,7 @@ def test_conv_linear(gpu, B, H, W, cin, cout, kh, kw, relu):
     assert bool((buf[:, :4] == 5.0).all()) and bool((buf[:, 4 + cout:] == 5.0).all()), "wrote outside its channel slice"
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 10])
 def test_conv_all_tile_configs(gpu, tile):
     torch.manual_seed(4)
     B, H, W, cin, cout = 1, 21, 37, 96, 160
