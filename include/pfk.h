@@ -141,6 +141,18 @@ long long pfk_conv_workspace_bytes(void);
 int pfk_conv_ktot(const pfk_conv_desc* d);
 int pfk_conv2d_f32(const pfk_conv_desc* d, pfk_stream_t stream);
 
+/* Same convolution on the bf16 matrix cores with split operands (fp32 in HBM, fp32 accumulate, fp32 epilogue).
+ * Every fp32 operand x is replaced by the sum of its first `nsplit` bf16 planes x0 = bf16(x), x1 = bf16(x - x0),
+ * x2 = bf16(x - x0 - x1); a product keeps the terms a_i*b_j with i + j < nsplit:
+ *   nsplit 1: plain bf16 operands (what the reference computes under `--fp16` autocast with bf16,
+ *             model_benchmark.py:311 / base_model.py autocast), nsplit 2: ~2^-17 relative product error,
+ *   nsplit 3: fp32-grade products at 6 bf16 MFMAs per 16 channels.
+ * Activations are split by the kernel while staging; the caller pre-splits the weight:
+ * weight_planes = bf16 [nsplit][cout][ktot], ktot = pfk_conv_ktot_bf16(d) = sum_s kh*kw*round_up(channels_s, 64)
+ * (same k order as pfk_conv2d_f32, channels padded per tap to 64).  d->weight, d->workspace are ignored. */
+int pfk_conv_ktot_bf16(const pfk_conv_desc* d);
+int pfk_conv2d_bf16s(const pfk_conv_desc* d, const void* weight_planes, int nsplit, pfk_stream_t stream);
+
 /* ---- small direct kernels ------------------------------------------------------------------- */
 /* k x k conv on a 2-channel map (the flow), relu optional: out[p*out_ld + out_coff + co].
  * in [M][in_ld] (channels 0,1 used); weight packed [k*k][2][cout]; bias [cout]. */

@@ -31,6 +31,7 @@ LIBTORCH_EXT = PKG / "_pfk_torch.so"
 # (source, extra flags)
 HIP_SOURCES = [
     ("pfk_gemm.hip", []),
+    ("pfk_gemm_bf.hip", []),
     ("pfk_corr.hip", ["-ffp-contract=off"]),  # index-exact coordinate arithmetic
     ("pfk_misc.hip", ["-ffp-contract=off"]),
     ("pfk_altcorr.hip", []),
@@ -53,7 +54,7 @@ def _run(cmd) -> None:
 
 def build_libpfk(force: bool = False) -> Path:
     OBJ.mkdir(exist_ok=True)
-    headers = [INCLUDE / "pfk.h", CSRC / "pfk_common.h"]
+    headers = [INCLUDE / "pfk.h", CSRC / "pfk_common.h", CSRC / "pfk_gemm.h"]
     objs = []
     for src, extra in HIP_SOURCES:
         s = CSRC / src

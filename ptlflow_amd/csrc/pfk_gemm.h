@@ -1,0 +1,107 @@
+// Pieces shared by the implicit-GEMM translation units (pfk_gemm.hip: fp32 MFMA; pfk_gemm_bf.hip: split-bf16 MFMA):
+// the kernel argument block, the buffer-descriptor helper and the fused epilogues.
+#pragma once
+#include "pfk_common.h"
+
+namespace pfkg {
+
+struct GemmArgs {
+  const float* src0; const float* src1; const float* src2;
+  int ld0, ld1, ld2;
+  int ch0, ch1, ch2;
+  int nsrc;
+  int H, W;            // image dims for tap bounds (M = B*H*W rows, batch folded into M)
+  int kh, kw;
+  const float* weight; // [b_rows][ktot]
+  const float* bias;
+  int b_rows;          // valid rows of weight (= cout)
+  int ktot;
+  int relu;
+  float scale;
+  float* out; int out_ld; int out_coff;
+  const float* residual; int residual_ld;   // LINEAR: out = residual[p][n] + v (after relu/scale)
+  float* h; int h_ld;
+  float* aux_z; float* aux_rh;
+  int ch_hidden;       // Ch for the GRU epilogues
+  long long M;
+  long long a_bs, b_bs, o_bs;  // per-blockIdx.y strides (batched correlation), floats
+  int tiles_n;
+  float* sk_ws;            // stream-K: one 64x64 fp32 partial per block
+  unsigned* sk_flags;      // stream-K: one ready flag per block (zeroed before every launch)
+  int sk_steps;            // K-steps per tile (host-computed)
+  long long sk_tiles;      // output tiles
+  const void* wbf;         // split-bf16 path: weight planes [nsplit][cout][ktot] bf16 (ktot padded per tap to 64 channels)
+  long long wbf_plane_bytes;
+};
+
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB = 0x80000000u;  // >= num_records of every descriptor below
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
+}
+
+// Epilogue for accumulator registers [R0, R1) of every 32x32 block of the wave tile.
+template <int MT, int NT, int EPI, int R0, int R1>
+__device__ __forceinline__ void epilogue(const GemmArgs& a, const f32x16 (&acc)[MT][NT], long long m_base,
+                                         int n_base, int lane, long long batch) {
+  const int col_l = lane & 31;
+  const int row_l = (lane >> 5) * 4;
+  float* outp = a.out + batch * a.o_bs;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = n_base + nt * 32 + col_l;
+    const bool nok = n < a.b_rows;
+    const float bias = (a.bias != nullptr && nok) ? a.bias[n] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int r = R0; r < R1; ++r) {
+        const long long p = m_base + mt * 32 + (r & 3) + 8 * (r >> 2) + row_l;
+        if (!nok || p >= a.M) continue;
+        float v = acc[mt][nt][r] + bias;
+        if constexpr (EPI == PFK_EPI_LINEAR) {
+          if (a.relu) v = (v < 0.f) ? 0.f : v;  // NaN-propagating like torch.relu (fmaxf would drop NaN)
+          v *= a.scale;
+          if (a.residual != nullptr) v = a.residual[p * a.residual_ld + n] + v;
+          outp[p * a.out_ld + a.out_coff + n] = v;
+        } else if constexpr (EPI == PFK_EPI_GRU_ZR) {
+          const int ch = a.ch_hidden;
+          const float g = sigmoid_f(v);
+          if (n < ch) {
+            a.aux_z[p * ch + n] = g;
+          } else {
+            const int c = n - ch;
+            a.aux_rh[p * ch + c] = g * a.h[p * a.h_ld + c];
+          }
+        } else {  // PFK_EPI_GRU_Q
+          const int ch = a.ch_hidden;
+          const float q = tanhf(v);
+          const float z = a.aux_z[p * ch + n];
+          const float hv = a.h[p * a.h_ld + n];
+          // (1 - z) * h + z * q, each product rounded (no contraction), as update.py:64,71
+          const float t0 = __fmul_rn(__fsub_rn(1.0f, z), hv);
+          const float t1 = __fmul_rn(z, q);
+          a.h[p * a.h_ld + n] = __fadd_rn(t0, t1);
+        }
+      }
+    }
+  }
+}
+
+template <int MT, int NT>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[MT][NT]) {
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+}
+
+// pfk_gemm_bf.hip: split-bf16 implicit GEMM (nsplit 1..3) on 64x64 tiles
+int launch_bf(const GemmArgs& a, int epi, int nsplit, hipStream_t st);
+
+}  // namespace pfkg

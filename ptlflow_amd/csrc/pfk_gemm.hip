@@ -21,9 +21,11 @@
 // Epilogues fuse what the reference does in separate torch ops (raft/update.py:58-73 etc.):
 // bias, relu, scale, sigmoid gates + r*h, tanh + GRU blend, and write straight into channel
 // slices of pixel-major buffers (no torch.cat).
-#include "pfk_common.h"
+#include "pfk_gemm.h"
 
 #include <utility>
+
+using namespace pfkg;
 
 namespace {
 
@@ -31,35 +33,6 @@ constexpr int BK = 32;       // channels per K-step
 constexpr int LDS_LD = 36;   // padded LDS row length (floats), 2-stage pipeline (v1)
 constexpr int LDS_LDX = 32;  // un-padded rows + XOR swizzle of the 16-byte chunk index, 3-stage pipelines (v3, stream-K):
                              // 48 KB per 64x64 block instead of 55 KB => three resident blocks per CU instead of two
-
-struct GemmArgs {
-  const float* src0; const float* src1; const float* src2;
-  int ld0, ld1, ld2;
-  int ch0, ch1, ch2;
-  int nsrc;
-  int H, W;            // image dims for tap bounds (M = B*H*W rows, batch folded into M)
-  int kh, kw;
-  const float* weight; // [b_rows][ktot]
-  const float* bias;
-  int b_rows;          // valid rows of weight (= cout)
-  int ktot;
-  int relu;
-  float scale;
-  float* out; int out_ld; int out_coff;
-  const float* residual; int residual_ld;   // LINEAR: out = residual[p][n] + v (after relu/scale)
-  float* h; int h_ld;
-  float* aux_z; float* aux_rh;
-  int ch_hidden;       // Ch for the GRU epilogues
-  long long M;
-  long long a_bs, b_bs, o_bs;  // per-blockIdx.y strides (batched correlation), floats
-  int tiles_n;
-  float* sk_ws;            // stream-K: one 64x64 fp32 partial per block
-  unsigned* sk_flags;      // stream-K: one ready flag per block (zeroed before every launch)
-  int sk_steps;            // K-steps per tile (host-computed)
-  long long sk_tiles;      // output tiles
-};
-
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // -------------------------------------------------------------------------------------------------
 // Staging: 256 threads move one K-step (BM + BN rows x 32 floats) global -> VGPR -> LDS.
@@ -72,13 +45,6 @@ __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf
 // no branches, no 64-bit address arithmetic in the K loop.  The buffer descriptors are built from
 // kernel arguments only (provably wave-uniform, so hipcc emits no waterfall loops).
 // -------------------------------------------------------------------------------------------------
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-constexpr unsigned OOB = 0x80000000u;  // >= num_records of every descriptor below
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, 0x7fffffff, 0x00020000);
-}
-
 template <int BM, int BN, int LD = LDS_LD>
 struct Stager {
   static constexpr int A_PT = BM / 32;
@@ -292,64 +258,6 @@ __device__ __forceinline__ void mma_rest(f32x16 (&acc)[MT][NT], Frags<MT, NT>& f
   mma_one<MT, NT>(acc, f);
   __builtin_amdgcn_sched_barrier(0);
   mma_one<MT, NT>(acc, g);
-}
-
-// Epilogue for accumulator registers [R0, R1) of every 32x32 block of the wave tile.
-template <int MT, int NT, int EPI, int R0, int R1>
-__device__ __forceinline__ void epilogue(const GemmArgs& a, const f32x16 (&acc)[MT][NT], long long m_base,
-                                         int n_base, int lane, long long batch) {
-  const int col_l = lane & 31;
-  const int row_l = (lane >> 5) * 4;
-  float* outp = a.out + batch * a.o_bs;
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int n = n_base + nt * 32 + col_l;
-    const bool nok = n < a.b_rows;
-    const float bias = (a.bias != nullptr && nok) ? a.bias[n] : 0.f;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-      for (int r = R0; r < R1; ++r) {
-        const long long p = m_base + mt * 32 + (r & 3) + 8 * (r >> 2) + row_l;
-        if (!nok || p >= a.M) continue;
-        float v = acc[mt][nt][r] + bias;
-        if constexpr (EPI == PFK_EPI_LINEAR) {
-          if (a.relu) v = (v < 0.f) ? 0.f : v;  // NaN-propagating like torch.relu (fmaxf would drop NaN)
-          v *= a.scale;
-          if (a.residual != nullptr) v = a.residual[p * a.residual_ld + n] + v;
-          outp[p * a.out_ld + a.out_coff + n] = v;
-        } else if constexpr (EPI == PFK_EPI_GRU_ZR) {
-          const int ch = a.ch_hidden;
-          const float g = sigmoid_f(v);
-          if (n < ch) {
-            a.aux_z[p * ch + n] = g;
-          } else {
-            const int c = n - ch;
-            a.aux_rh[p * ch + c] = g * a.h[p * a.h_ld + c];
-          }
-        } else {  // PFK_EPI_GRU_Q
-          const int ch = a.ch_hidden;
-          const float q = tanhf(v);
-          const float z = a.aux_z[p * ch + n];
-          const float hv = a.h[p * a.h_ld + n];
-          // (1 - z) * h + z * q, each product rounded (no contraction), as update.py:64,71
-          const float t0 = __fmul_rn(__fsub_rn(1.0f, z), hv);
-          const float t1 = __fmul_rn(z, q);
-          a.h[p * a.h_ld + n] = __fadd_rn(t0, t1);
-        }
-      }
-    }
-  }
-}
-
-template <int MT, int NT>
-__device__ __forceinline__ void zero_acc(f32x16 (&acc)[MT][NT]) {
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -822,50 +730,35 @@ int launch(const GemmArgs& a, int epi, int batches, hipStream_t st) {
 
 inline int round_up32(int c) { return (c + 31) & ~31; }
 
-}  // namespace
-
-extern "C" {
-
-void pfk_debug_set_tile(int cfg) { g_force_tile = cfg; }
-
-long long pfk_conv_workspace_bytes(void) { return (long long)SK_WS_BYTES; }
-
-int pfk_conv_ktot(const pfk_conv_desc* d) {
+int conv_ktot(const pfk_conv_desc* d, int kpad) {
   if (!d || d->num_src < 1 || d->num_src > 3) return PFK_ERR_BAD_ARG;
   int k = 0;
-  for (int s = 0; s < d->num_src; ++s) k += d->kh * d->kw * round_up32(d->src[s].channels);
+  for (int s = 0; s < d->num_src; ++s) k += d->kh * d->kw * ((d->src[s].channels + kpad - 1) / kpad * kpad);
   return k;
 }
 
-int pfk_conv2d_f32(const pfk_conv_desc* d, pfk_stream_t stream) {
-  if (!d || d->num_src < 1 || d->num_src > 3 || !d->weight) return PFK_ERR_BAD_ARG;
+// Validate a conv descriptor and fill everything but the weight operand.  kpad = channels per K-step (32 fp32, 64 bf16).
+int desc_to_args(const pfk_conv_desc* d, GemmArgs& a, int kpad) {
+  if (d->num_src < 1 || d->num_src > 3) return PFK_ERR_BAD_ARG;
   if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->cout <= 0) return PFK_ERR_BAD_ARG;
   if (d->kh <= 0 || d->kw <= 0 || !(d->kh & 1) || !(d->kw & 1)) return PFK_ERR_BAD_ARG;
-  GemmArgs a{};
   const pfk_conv_src* s = d->src;
   for (int i = 0; i < d->num_src; ++i) {
     if (!s[i].ptr || s[i].channels <= 0 || s[i].ld < s[i].channels) return PFK_ERR_BAD_ARG;
     if (!pfk_aligned16(s[i].ptr) || (s[i].ld & 3) || (s[i].channels & 3)) return PFK_ERR_ALIGNMENT;
   }
-  if (!pfk_aligned16(d->weight)) return PFK_ERR_ALIGNMENT;
   a.src0 = s[0].ptr; a.ld0 = s[0].ld; a.ch0 = s[0].channels;
   if (d->num_src > 1) { a.src1 = s[1].ptr; a.ld1 = s[1].ld; a.ch1 = s[1].channels; }
   if (d->num_src > 2) { a.src2 = s[2].ptr; a.ld2 = s[2].ld; a.ch2 = s[2].channels; }
   a.nsrc = d->num_src;
   a.H = d->H; a.W = d->W; a.kh = d->kh; a.kw = d->kw;
-  a.weight = d->weight; a.bias = d->bias; a.b_rows = d->cout;
-  a.ktot = pfk_conv_ktot(d);
+  a.bias = d->bias; a.b_rows = d->cout;
+  a.ktot = conv_ktot(d, kpad);
   a.relu = d->relu; a.scale = d->scale;
   a.M = (long long)d->B * d->H * d->W;
-  a.sk_steps = 0;
-  for (int i = 0; i < d->num_src; ++i) a.sk_steps += d->kh * d->kw * (round_up32(s[i].channels) / 32);
-  if (d->workspace && d->workspace_bytes >= (long long)SK_WS_BYTES && pfk_aligned16(d->workspace)) {
-    a.sk_ws = static_cast<float*>(d->workspace);
-    a.sk_flags = reinterpret_cast<unsigned*>(static_cast<char*>(d->workspace) + (size_t)SK_MAX_BLOCKS * 64 * 64 * 4);
-  }
+  a.sk_steps = a.ktot / kpad;
   for (int i = 0; i < d->num_src; ++i)   // kernels address sources with 32-bit byte offsets
     if (a.M * s[i].ld * 4 >= 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
-  if ((long long)d->cout * a.ktot * 4 >= 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
   switch (d->epilogue) {
     case PFK_EPI_LINEAR:
       if (!d->out || d->out_ld < d->out_coff + d->cout) return PFK_ERR_BAD_ARG;
@@ -888,7 +781,46 @@ int pfk_conv2d_f32(const pfk_conv_desc* d, pfk_stream_t stream) {
     default:
       return PFK_ERR_BAD_ARG;
   }
+  return PFK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void pfk_debug_set_tile(int cfg) { g_force_tile = cfg; }
+
+long long pfk_conv_workspace_bytes(void) { return (long long)SK_WS_BYTES; }
+
+int pfk_conv_ktot(const pfk_conv_desc* d) { return conv_ktot(d, 32); }
+
+int pfk_conv_ktot_bf16(const pfk_conv_desc* d) { return conv_ktot(d, 64); }
+
+int pfk_conv2d_f32(const pfk_conv_desc* d, pfk_stream_t stream) {
+  GemmArgs a{};
+  if (!d || !d->weight) return PFK_ERR_BAD_ARG;
+  if (!pfk_aligned16(d->weight)) return PFK_ERR_ALIGNMENT;
+  const int rc = desc_to_args(d, a, 32);
+  if (rc != PFK_OK) return rc;
+  a.weight = d->weight;
+  if ((long long)d->cout * a.ktot * 4 >= 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
+  if (d->workspace && d->workspace_bytes >= (long long)SK_WS_BYTES && pfk_aligned16(d->workspace)) {
+    a.sk_ws = static_cast<float*>(d->workspace);
+    a.sk_flags = reinterpret_cast<unsigned*>(static_cast<char*>(d->workspace) + (size_t)SK_MAX_BLOCKS * 64 * 64 * 4);
+  }
   return launch(a, d->epilogue, 1, static_cast<hipStream_t>(stream));
+}
+
+int pfk_conv2d_bf16s(const pfk_conv_desc* d, const void* weight_planes, int nsplit, pfk_stream_t stream) {
+  GemmArgs a{};
+  if (!d || !weight_planes || nsplit < 1 || nsplit > 3) return PFK_ERR_BAD_ARG;
+  if (!pfk_aligned16(weight_planes)) return PFK_ERR_ALIGNMENT;
+  const int rc = desc_to_args(d, a, 64);
+  if (rc != PFK_OK) return rc;
+  a.wbf = weight_planes;
+  a.wbf_plane_bytes = (long long)d->cout * a.ktot * 2;
+  if (a.wbf_plane_bytes * nsplit >= 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
+  return launch_bf(a, d->epilogue, nsplit, static_cast<hipStream_t>(stream));
 }
 
 int pfk_corr_volume_f32(const float* f1, int ld1, const float* f2, int ld2, float* out, int B,

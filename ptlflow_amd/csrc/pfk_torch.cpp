@@ -98,10 +98,19 @@ void conv2d(at::TensorList srcs, int64_t B, int64_t H, int64_t W, int64_t kh, in
   d.num_src = srcs.size();
   d.B = B; d.H = H; d.W = W; d.kh = kh; d.kw = kw; d.cout = cout;
   d.epilogue = epilogue; d.relu = relu; d.scale = (float)scale;
-  check_dev_f32(weight, "weight");
-  TORCH_CHECK(weight.is_contiguous() && weight.dim() == 2 && weight.size(0) == cout, "conv2d: packed weight [cout, ktot]");
-  TORCH_CHECK(weight.size(1) == pfk_conv_ktot(&d), "conv2d: packed weight has ktot ", weight.size(1), ", expected ", pfk_conv_ktot(&d));
-  d.weight = fptr(weight);
+  // fp32 packed weight [cout, ktot] -> fp32 MFMA path; bf16 planes [nsplit, cout, ktot64] -> split-bf16 path
+  const bool split = weight.scalar_type() == at::kBFloat16;
+  if (split) {
+    TORCH_CHECK(weight.is_cuda() && weight.is_contiguous() && weight.dim() == 3 && weight.size(1) == cout &&
+                weight.size(0) >= 1 && weight.size(0) <= 3, "conv2d: bf16 weight planes [nsplit, cout, ktot]");
+    TORCH_CHECK(weight.size(2) == pfk_conv_ktot_bf16(&d), "conv2d: bf16 weight planes have ktot ", weight.size(2),
+                ", expected ", pfk_conv_ktot_bf16(&d));
+  } else {
+    check_dev_f32(weight, "weight");
+    TORCH_CHECK(weight.is_contiguous() && weight.dim() == 2 && weight.size(0) == cout, "conv2d: packed weight [cout, ktot]");
+    TORCH_CHECK(weight.size(1) == pfk_conv_ktot(&d), "conv2d: packed weight has ktot ", weight.size(1), ", expected ", pfk_conv_ktot(&d));
+    d.weight = fptr(weight);
+  }
   if (bias.has_value()) { check_dev_f32(*bias, "bias"); TORCH_CHECK(bias->numel() == cout && bias->is_contiguous()); d.bias = fptr(*bias); }
   if (out.has_value()) {
     check_pm(*out, "out");
@@ -120,7 +129,8 @@ void conv2d(at::TensorList srcs, int64_t B, int64_t H, int64_t W, int64_t kh, in
     TORCH_CHECK(workspace->is_cuda() && workspace->is_contiguous(), "conv2d: workspace must be a contiguous GPU tensor");
     d.workspace = workspace->data_ptr(); d.workspace_bytes = (long long)workspace->nbytes();
   }
-  check_ok(pfk_conv2d_f32(&d, cur_stream()), "conv2d");
+  if (split) check_ok(pfk_conv2d_bf16s(&d, weight.data_ptr(), (int)weight.size(0), cur_stream()), "conv2d (split bf16)");
+  else check_ok(pfk_conv2d_f32(&d, cur_stream()), "conv2d");
 }
 
 void conv_cin2(const Tensor& in, const Tensor& weight, const c10::optional<Tensor>& bias, Tensor out,

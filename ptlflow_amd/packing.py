@@ -17,8 +17,9 @@ def round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
 
-def pack_conv_weight(weight: torch.Tensor, segments: Sequence[Tuple[int, int, int]]) -> torch.Tensor:
+def pack_conv_weight(weight: torch.Tensor, segments: Sequence[Tuple[int, int, int]], kpad: int = 32) -> torch.Tensor:
     """``segments`` = [(first_channel, n_channels, n_channels_in_buffer)], in source order.
+    ``kpad`` = channels per K-step of the kernel that will read it (32: fp32 MFMA, 64: split-bf16 MFMA).
 
     ``n_channels_in_buffer`` >= ``n_channels`` is how many channels the kernel is told the source
     has (a multiple of 4; extra ones are zero padding in the buffer and get zero weights here)."""
@@ -27,9 +28,21 @@ def pack_conv_weight(weight: torch.Tensor, segments: Sequence[Tuple[int, int, in
     for first, n, n_buf in segments:
         assert first + n <= cin and n_buf >= n and n_buf % 4 == 0
         w = weight[:, first:first + n].permute(0, 2, 3, 1)  # [cout, kh, kw, n]
-        w = F.pad(w, (0, round_up(n_buf, 32) - n))
+        w = F.pad(w, (0, round_up(n_buf, kpad) - n))
         parts.append(w.reshape(cout, -1))
     return torch.cat(parts, dim=1).contiguous()
+
+
+def split_bf16_planes(packed: torch.Tensor, nsplit: int) -> torch.Tensor:
+    """fp32 ``[cout, ktot]`` -> bf16 ``[nsplit, cout, ktot]`` with plane 0 = bf16(w), plane 1 = bf16(w - plane 0), ...
+    (round to nearest even; every residual is exact in fp32) — the weight operand of ``pfk_conv2d_bf16s``."""
+    assert 1 <= nsplit <= 3 and packed.dtype == torch.float32
+    planes, r = [], packed
+    for _ in range(nsplit):
+        p = r.to(torch.bfloat16)
+        planes.append(p)
+        r = r - p.to(torch.float32)
+    return torch.stack(planes, 0).contiguous()
 
 
 def pack_cin2_weight(weight: torch.Tensor) -> torch.Tensor:

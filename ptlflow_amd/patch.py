@@ -51,8 +51,12 @@ def _make_corr_hook(module_name: str, original):
     return get_corr_block
 
 
-def accelerate(model: torch.nn.Module, corr: bool = True, update_block: bool = True) -> torch.nn.Module:
-    """Patch seams B1/B3 of a ptlflow model instance in place and return it."""
+def accelerate(model: torch.nn.Module, corr: bool = True, update_block: bool = True,
+               conv_precision: str = "fp32") -> torch.nn.Module:
+    """Patch seams B1/B3 of a ptlflow model instance in place and return it.
+
+    ``conv_precision``: "fp32" (default, the parity path) or a split-bf16 mode of the update block's convolutions
+    ("bf16x6", "bf16x3", "bf16"), see ``UpdateEngine``."""
     load_native()
     mod_name = type(model).__module__
     # registered classes (`class raft(RAFT)`) live in the same module as the implementation
@@ -65,7 +69,7 @@ def accelerate(model: torch.nn.Module, corr: bool = True, update_block: bool = T
         factory = _SPECS.get(type(ub).__name__)
         if factory is not None:
             spec: UpdateSpec = factory(model)
-            model.update_block = PfkUpdateBlock(ub, spec)
+            model.update_block = PfkUpdateBlock(ub, spec, conv_precision)
     return model
 
 

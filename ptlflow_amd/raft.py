@@ -114,9 +114,12 @@ def _param_tree(shapes: Dict[str, tuple]) -> nn.Module:
 # ----------------------------------------------------------------------------- model
 class RAFT(nn.Module):
     def __init__(self, corr_levels: int = 4, corr_radius: Optional[int] = None, iters: int = 32, small: bool = False,
-                 upsample_every_iter: bool = True):
+                 upsample_every_iter: bool = True, conv_precision: str = "fp32"):
         super().__init__()
         self.small = small
+        # "fp32" (default: fp32 matrix cores, the parity path) | "bf16x6" | "bf16x3" | "bf16": split-bf16 operands
+        # for the update block's convolutions (include/pfk.h, pfk_conv2d_bf16s)
+        self.conv_precision = conv_precision
         self.corr_levels = corr_levels
         self.corr_radius = corr_radius if corr_radius is not None else (3 if small else 4)
         self.iters = iters
@@ -156,7 +159,7 @@ class RAFT(nn.Module):
         params = dict(self.update_block.named_parameters())
         v = tuple((p.data_ptr(), p._version) for p in params.values())
         if self._engine is None or self._engine.device != device:
-            self._engine = UpdateEngine(params, self.spec, device)
+            self._engine = UpdateEngine(params, self.spec, device, self.conv_precision)
         elif v != self._versions:
             self._engine.pack(params)
         self._versions = v
@@ -274,9 +277,10 @@ class GMA(RAFT):
     update block of gma/update.py:127-160.  The per-iteration `attn @ v` (12.7 GFLOP, reads the 198 MB map) runs on
     the same MFMA GEMM kernel as the convolutions, with the residual `fmap + gamma * out` fused in its epilogue."""
 
-    def __init__(self, corr_levels: int = 4, corr_radius: int = 4, iters: int = 32, upsample_every_iter: bool = True):
+    def __init__(self, corr_levels: int = 4, corr_radius: int = 4, iters: int = 32, upsample_every_iter: bool = True,
+                 conv_precision: str = "fp32"):
         super().__init__(corr_levels=corr_levels, corr_radius=corr_radius, iters=iters, small=False,
-                         upsample_every_iter=upsample_every_iter)
+                         upsample_every_iter=upsample_every_iter, conv_precision=conv_precision)
         self.att = _Attention(dim=self.context_dim, heads=1, dim_head=self.context_dim, max_pos_size=160)
 
     def _basic_spec(self, corr_levels: int, corr_radius: int) -> UpdateSpec:

@@ -31,7 +31,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from . import load_native
-from .packing import pack_cin2_weight, pack_conv_weight, pack_flow_head_weight, round_up
+from .packing import pack_cin2_weight, pack_conv_weight, pack_flow_head_weight, round_up, split_bf16_planes
 
 EPI_LINEAR, EPI_GRU_ZR, EPI_GRU_Q = 0, 1, 2
 
@@ -82,9 +82,18 @@ def small_spec(corr_levels: int = 4, corr_radius: int = 3) -> UpdateSpec:
                       ((3, 3, ""),), 128, False)
 
 
+# conv_precision -> number of bf16 planes per operand (0 = the fp32 matrix-core path, the default and the parity path)
+CONV_PRECISIONS = {"fp32": 0, "bf16": 1, "bf16x3": 2, "bf16x6": 3}
+
+
 class UpdateEngine:
-    def __init__(self, params: Dict[str, torch.Tensor], spec: UpdateSpec, device: torch.device):
+    def __init__(self, params: Dict[str, torch.Tensor], spec: UpdateSpec, device: torch.device,
+                 conv_precision: str = "fp32"):
         load_native()
+        if conv_precision not in CONV_PRECISIONS:
+            raise ValueError(f"conv_precision must be one of {sorted(CONV_PRECISIONS)}, got {conv_precision!r}")
+        self.conv_precision = conv_precision
+        self.nsplit = CONV_PRECISIONS[conv_precision]
         self.ops = torch.ops.pfk
         self.spec = spec
         self.device = device
@@ -104,6 +113,12 @@ class UpdateEngine:
         def seg1(c):
             return [(0, c, round_up(c, 4))]
 
+        def pk(weight, segments):
+            # the weight tensor's dtype selects the kernel in torch.ops.pfk.conv2d: fp32 [cout, ktot] or bf16 planes
+            if self.nsplit == 0:
+                return pack_conv_weight(weight, segments)
+            return split_bf16_planes(pack_conv_weight(weight, segments, kpad=64), self.nsplit)
+
         w: Dict[str, torch.Tensor] = {}
         real = s.hidden + s.x_channels
         self._real_cin = {"c1": s.corr_channels, "c2": s.c1, "f2": s.f1, "cv": (s.c2 if s.c2 else s.c1) + s.f2,
@@ -111,17 +126,17 @@ class UpdateEngine:
         for _, _, sfx in s.gru_passes:
             self._real_cin["zr" + sfx] = real
             self._real_cin["q" + sfx] = real
-        w["c1.w"] = pack_conv_weight(g("encoder.convc1.weight"), seg1(s.corr_channels))
+        w["c1.w"] = pk(g("encoder.convc1.weight"), seg1(s.corr_channels))
         w["c1.b"] = g("encoder.convc1.bias").contiguous()
         if s.c2:
-            w["c2.w"] = pack_conv_weight(g("encoder.convc2.weight"), seg1(s.c1))
+            w["c2.w"] = pk(g("encoder.convc2.weight"), seg1(s.c1))
             w["c2.b"] = g("encoder.convc2.bias").contiguous()
         w["f1.w"] = pack_cin2_weight(g("encoder.convf1.weight"))
         w["f1.b"] = g("encoder.convf1.bias").contiguous()
-        w["f2.w"] = pack_conv_weight(g("encoder.convf2.weight"), seg1(s.f1))
+        w["f2.w"] = pk(g("encoder.convf2.weight"), seg1(s.f1))
         w["f2.b"] = g("encoder.convf2.bias").contiguous()
         cf = (s.c2 if s.c2 else s.c1) + s.f2
-        w["cv.w"] = pack_conv_weight(g("encoder.conv.weight"), seg1(cf))
+        w["cv.w"] = pk(g("encoder.conv.weight"), seg1(cf))
         w["cv.b"] = g("encoder.conv.bias").contiguous()
         Ch = s.hidden
         hxc = s.hx_channels
@@ -130,21 +145,21 @@ class UpdateEngine:
             wz, wr, wq = (g(f"gru.conv{k}{sfx}.weight") for k in "zrq")
             bz, br, bq = (g(f"gru.conv{k}{sfx}.bias") for k in "zrq")
             # z|r: one source = the whole hx row (h | x), padded channels get zero weights
-            w[f"zr{sfx}.w"] = pack_conv_weight(torch.cat([wz, wr], 0), [(0, real, hxc)])
+            w[f"zr{sfx}.w"] = pk(torch.cat([wz, wr], 0), [(0, real, hxc)])
             w[f"zr{sfx}.b"] = torch.cat([bz, br]).contiguous()
             # q: sources r*h (own buffer) and x (hx slice)
-            w[f"q{sfx}.w"] = pack_conv_weight(wq, [(0, Ch, Ch), (Ch, real - Ch, hxc - Ch)])
+            w[f"q{sfx}.w"] = pk(wq, [(0, Ch, Ch), (Ch, real - Ch, hxc - Ch)])
             w[f"q{sfx}.b"] = bq.contiguous()
         if s.has_mask:
-            w["fm.w"] = pack_conv_weight(torch.cat([g("flow_head.conv1.weight"), g("mask.0.weight")], 0), seg1(Ch))
+            w["fm.w"] = pk(torch.cat([g("flow_head.conv1.weight"), g("mask.0.weight")], 0), seg1(Ch))
             w["fm.b"] = torch.cat([g("flow_head.conv1.bias"), g("mask.0.bias")]).contiguous()
-            w["mk.w"] = pack_conv_weight(g("mask.2.weight"), seg1(s.fh_hidden))
+            w["mk.w"] = pk(g("mask.2.weight"), seg1(s.fh_hidden))
             w["mk.b"] = g("mask.2.bias").contiguous()
         else:
-            w["fm.w"] = pack_conv_weight(g("flow_head.conv1.weight"), seg1(Ch))
+            w["fm.w"] = pk(g("flow_head.conv1.weight"), seg1(Ch))
             w["fm.b"] = g("flow_head.conv1.bias").contiguous()
         if s.aggregate:
-            w["tv.w"] = pack_conv_weight(g("aggregator.to_v.weight"), seg1(s.motion_channels))
+            w["tv.w"] = pk(g("aggregator.to_v.weight"), seg1(s.motion_channels))
             w["tv.b"] = None
             self.gamma = float(P["aggregator.gamma"].detach().float().cpu().item())   # one host read per (re)pack
             self._real_cin["tv"] = s.motion_channels
@@ -319,8 +334,9 @@ class PfkUpdateBlock(torch.nn.Module):
     The tensors handed back are views of the engine's buffers (net: channels-last strides); they are
     overwritten by the next call, which is how the reference loop uses them (raft.py:169-187)."""
 
-    def __init__(self, ref_block: torch.nn.Module, spec: UpdateSpec):
+    def __init__(self, ref_block: torch.nn.Module, spec: UpdateSpec, conv_precision: str = "fp32"):
         super().__init__()
+        self.conv_precision = conv_precision
         # keep the reference sub-modules so state_dict keys/checkpoints/optimizers are unchanged
         for name, child in ref_block.named_children():
             self.add_module(name, child)
@@ -336,7 +352,7 @@ class PfkUpdateBlock(torch.nn.Module):
     def _get_engine(self, device) -> UpdateEngine:
         v = self._param_versions()
         if self._engine is None or self._engine.device != device:
-            self._engine = UpdateEngine(dict(self.named_parameters()), self.spec, device)
+            self._engine = UpdateEngine(dict(self.named_parameters()), self.spec, device, self.conv_precision)
             self._versions = v
         elif v != self._versions:
             self._engine.pack(dict(self.named_parameters()))

@@ -1,0 +1,168 @@
+"""Parity of the split-bf16 convolution path (pfk_conv2d_bf16s, include/pfk.h) against the same oracle as the fp32 path.
+
+nsplit = number of bf16 planes per operand; kept product terms a_i*b_j with i + j < nsplit:
+  * nsplit 3 ("bf16x6"): fp32-grade — held to the fp32 kernels' tolerance (2e-5) and to the headline EPE gate (1e-3 px);
+  * nsplit 2 ("bf16x3"): ~2^-17 relative product error — 2e-4 on single convolutions;
+  * nsplit 1 ("bf16"):   plain bf16 operands, fp32 accumulate (what the reference computes under bf16 autocast) — the
+    bound is the operand rounding itself, 2^-8 relative per product; and EXACT-grade (fp32 tolerance) when the operands
+    are bf16-representable, which pins the indexing / padding / epilogue logic independently of rounding.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import raft_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+EPI_LINEAR, EPI_GRU_ZR, EPI_GRU_Q = 0, 1, 2
+TOL = {3: 2e-5, 2: 2e-4, 1: 4e-2}
+
+
+def close(a, b, rtol, atol):
+    a, b = a.float().cpu(), b.float().cpu()
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    assert bool((err <= tol).all()), f"max err {err.max().item():.3e} (ref max {b.abs().max().item():.3e})"
+
+
+def pm(x):
+    B, C, H, W = x.shape
+    return x.permute(0, 2, 3, 1).reshape(B * H * W, C).contiguous().cuda()
+
+
+def unpm(x, B, H, W):
+    return x.view(B, H, W, -1).permute(0, 3, 1, 2).cpu()
+
+
+def planes(weight, segs, nsplit):
+    from ptlflow_amd.packing import pack_conv_weight, split_bf16_planes
+    return split_bf16_planes(pack_conv_weight(weight, segs, kpad=64), nsplit).cuda()
+
+
+CASES = [
+    (1, 12, 20, 64, 96, 3, 3, True),
+    (2, 9, 7, 324, 256, 1, 1, True),      # convc1: 324 channels -> 6 K-steps of 64, the last one 4 channels wide
+    (1, 17, 33, 128, 126, 3, 3, True),    # cout not a multiple of 64
+    (1, 11, 19, 36, 40, 5, 1, False),     # a single partial K-step per tap
+    (1, 55, 128, 128, 64, 3, 3, True),
+]
+
+
+@pytest.mark.parametrize("nsplit", [1, 2, 3])
+@pytest.mark.parametrize("B,H,W,cin,cout,kh,kw,relu", CASES)
+def test_split_conv_linear(gpu, nsplit, B, H, W, cin, cout, kh, kw, relu):
+    torch.manual_seed(3)
+    x = torch.randn(B, cin, H, W)
+    wt = torch.randn(cout, cin, kh, kw) / math.sqrt(cin * kh * kw)
+    bias = torch.randn(cout)
+    ref = F.conv2d(x.double(), wt.double(), bias.double(), padding=(kh // 2, kw // 2))
+    if relu:
+        ref = F.relu(ref)
+    ref = (ref * 0.25).float()
+    M = B * H * W
+    buf = torch.full((M, cout + 12), 5.0, device=gpu)
+    out = buf[:, 4:4 + cout]
+    torch.ops.pfk.conv2d([pm(x)], B, H, W, kh, kw, planes(wt, [(0, cin, cin)], nsplit), bias.cuda(), cout, EPI_LINEAR, relu,
+                         0.25, out, None, None, None)
+    close(unpm(out, B, H, W), ref, rtol=TOL[nsplit], atol=TOL[nsplit])
+    assert bool((buf[:, :4] == 5.0).all()) and bool((buf[:, 4 + cout:] == 5.0).all()), "wrote outside its channel slice"
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,kh,kw,relu", CASES)
+def test_plain_bf16_is_exact_on_bf16_operands(gpu, B, H, W, cin, cout, kh, kw, relu):
+    """bf16-representable operands: products are exact in fp32, only the accumulation order differs."""
+    torch.manual_seed(4)
+    x = torch.randn(B, cin, H, W).bfloat16().float()
+    wt = (torch.randn(cout, cin, kh, kw) / math.sqrt(cin * kh * kw)).bfloat16().float()
+    bias = torch.randn(cout)
+    ref = F.conv2d(x.double(), wt.double(), bias.double(), padding=(kh // 2, kw // 2)).float()
+    if relu:
+        ref = F.relu(ref)
+    out = torch.zeros(B * H * W, cout, device=gpu)
+    torch.ops.pfk.conv2d([pm(x)], B, H, W, kh, kw, planes(wt, [(0, cin, cin)], 1), bias.cuda(), cout, EPI_LINEAR, relu, 1.0,
+                         out, None, None, None)
+    close(unpm(out, B, H, W), ref, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("nsplit", [2, 3])
+def test_split_conv_multi_source(gpu, nsplit):
+    torch.manual_seed(5)
+    B, H, W = 1, 14, 18
+    ca, cb, cc, cout = 96, 148, 32, 128
+    a, b, c = torch.randn(B, ca, H, W), torch.randn(B, cb, H, W), torch.randn(B, cc, H, W)
+    b[:, 146:] = 0
+    wt = torch.randn(cout, ca + 146 + cc, 3, 3) / 40
+    bias = torch.randn(cout)
+    ref = F.conv2d(torch.cat([a, b[:, :146], c], 1).double(), wt.double(), bias.double(), padding=1).float()
+    wide = torch.zeros(B * H * W, 300, device=gpu)
+    wide[:, 100:248] = pm(b)
+    w = planes(wt, [(0, ca, ca), (ca, 146, 148), (ca + 146, cc, cc)], nsplit)
+    out = torch.zeros(B * H * W, cout, device=gpu)
+    torch.ops.pfk.conv2d([pm(a), wide[:, 100:248], pm(c)], B, H, W, 3, 3, w, bias.cuda(), cout, EPI_LINEAR, False, 1.0,
+                         out, None, None, None)
+    close(unpm(out, B, H, W), ref, rtol=TOL[nsplit], atol=TOL[nsplit])
+
+
+@pytest.mark.parametrize("B,H,W,Ch,Cx,passes", [
+    (1, 12, 16, 128, 256, ((1, 5, "1"), (5, 1, "2"))),
+    (2, 10, 14, 96, 148, ((3, 3, ""),)),
+])
+def test_split_gru_bf16x6(gpu, B, H, W, Ch, Cx, passes):
+    torch.manual_seed(6)
+    P = {}
+    for kh, kw, sfx in passes:
+        for k in "zrq":
+            P[f"gru.conv{k}{sfx}.weight"] = torch.randn(Ch, Ch + Cx, kh, kw) / math.sqrt((Ch + Cx) * kh * kw)
+            P[f"gru.conv{k}{sfx}.bias"] = torch.randn(Ch) * 0.1
+    h = torch.tanh(torch.randn(B, Ch, H, W))
+    x = torch.randn(B, Cx, H, W)
+    ref = O.sepconv_gru(P, h, x) if len(passes) == 2 else O.conv_gru(P, h, x)
+    M = B * H * W
+    hx = torch.cat([pm(h), pm(x)], 1).contiguous()
+    z = torch.zeros(M, Ch, device=gpu)
+    rh = torch.zeros(M, Ch, device=gpu)
+    for kh, kw, sfx in passes:
+        wzr = planes(torch.cat([P[f"gru.convz{sfx}.weight"], P[f"gru.convr{sfx}.weight"]], 0), [(0, Ch + Cx, Ch + Cx)], 3)
+        bzr = torch.cat([P[f"gru.convz{sfx}.bias"], P[f"gru.convr{sfx}.bias"]]).cuda()
+        wq = planes(P[f"gru.convq{sfx}.weight"], [(0, Ch, Ch), (Ch, Cx, Cx)], 3)
+        bq = P[f"gru.convq{sfx}.bias"].cuda()
+        torch.ops.pfk.conv2d([hx], B, H, W, kh, kw, wzr, bzr, 2 * Ch, EPI_GRU_ZR, False, 1.0, None, hx[:, :Ch], z, rh)
+        torch.ops.pfk.conv2d([rh, hx[:, Ch:]], B, H, W, kh, kw, wq, bq, Ch, EPI_GRU_Q, False, 1.0, None, hx[:, :Ch], z, None)
+    close(unpm(hx[:, :Ch], B, H, W), ref, rtol=2e-5, atol=3e-5)
+
+
+def _epe(precisions, H, W, iters, small=False, seed=1234):
+    from ptlflow_amd.raft import RAFT
+    base = RAFT(small=small, iters=iters).load_synthetic(seed).eval()
+    P = {k: v.clone() for k, v in base.state_dict().items()}
+    x = O.smooth_pair(1, H, W, seed)
+    ref = O.raft_forward(P, x, iters=iters, small=small)
+    res = {}
+    for prec in precisions:
+        model = RAFT(small=small, iters=iters, conv_precision=prec).eval()
+        model.load_state_dict(P)
+        out = model.cuda()({"images": x.cuda()})
+        torch.cuda.synchronize()
+        res[prec] = O.epe(out["flows"][:, 0].cpu(), ref["flows"][:, 0])
+    return res
+
+
+@pytest.mark.parametrize("small", [False, True])
+def test_raft_bf16x6_meets_fp32_gate(gpu, small):
+    mean, mx = _epe(["bf16x6"], 184, 320, 12, small=small)["bf16x6"]
+    print(f"bf16x6 EPE mean {mean:.3e} max {mx:.3e}")
+    assert mean <= 1e-3 and mx <= 1e-2
+
+
+def test_raft_headline_split_modes(gpu):
+    """BASELINE.json configs[1] (436x1024, 32 iterations): EPE of each split mode against the fp32 CPU oracle.
+    bf16x6 is held to the north-star gate; bf16x3 / bf16 are reduced-precision modes and only bounded loosely."""
+    res = _epe(["bf16x6", "bf16x3", "bf16"], 436, 1024, 32)
+    for p, (mean, mx) in res.items():
+        print(f"headline EPE {p}: mean {mean:.3e} max {mx:.3e}")
+    assert res["bf16x6"][0] <= 1e-3 and res["bf16x6"][1] <= 1e-2
+    assert res["bf16x3"][0] <= 2e-2
+    assert res["bf16"][0] <= 2.0
