@@ -148,8 +148,8 @@ int pfk_conv2d_f32(const pfk_conv_desc* d, pfk_stream_t stream);
  *             model_benchmark.py:311 / base_model.py autocast), nsplit 2: ~2^-17 relative product error,
  *   nsplit 3: fp32-grade products at 6 bf16 MFMAs per 16 channels.
  * Activations are split by the kernel while staging; the caller pre-splits the weight:
- * weight_planes = bf16 [nsplit][cout][ktot], ktot = pfk_conv_ktot_bf16(d) = sum_s kh*kw*round_up(channels_s, 64)
- * (same k order as pfk_conv2d_f32, channels padded per tap to 64).  d->weight, d->workspace are ignored. */
+ * weight_planes = bf16 [nsplit][cout][ktot], ktot = pfk_conv_ktot_bf16(d) (= pfk_conv_ktot(d): the fp32 packed
+ * weight's k order and padding, split plane by plane).  d->weight, d->workspace are ignored. */
 int pfk_conv_ktot_bf16(const pfk_conv_desc* d);
 int pfk_conv2d_bf16s(const pfk_conv_desc* d, const void* weight_planes, int nsplit, pfk_stream_t stream);
 

@@ -30,8 +30,9 @@ struct GemmArgs {
   unsigned* sk_flags;      // stream-K: one ready flag per block (zeroed before every launch)
   int sk_steps;            // K-steps per tile (host-computed)
   long long sk_tiles;      // output tiles
-  const void* wbf;         // split-bf16 path: weight planes [nsplit][cout][ktot] bf16 (ktot padded per tap to 64 channels)
+  const void* wbf;         // split-bf16 path: weight planes [nsplit][cout][ktot] bf16, same k order as `weight`
   long long wbf_plane_bytes;
+  int dbg;                 // split-bf16 timing ablations (results are garbage): 1 no global loads, 2 no split + LDS stores, 4 no fragment reads + MFMAs
 };
 
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -101,7 +102,8 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[MT][NT]) {
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 }
 
-// pfk_gemm_bf.hip: split-bf16 implicit GEMM (nsplit 1..3) on 64x64 tiles
+// pfk_gemm_bf.hip: split-bf16 implicit GEMM (nsplit 1..3)
+extern int g_bf_cfg;
 int launch_bf(const GemmArgs& a, int epi, int nsplit, hipStream_t st);
 
 }  // namespace pfkg

@@ -788,13 +788,16 @@ int desc_to_args(const pfk_conv_desc* d, GemmArgs& a, int kpad) {
 
 extern "C" {
 
-void pfk_debug_set_tile(int cfg) { g_force_tile = cfg; }
+void pfk_debug_set_tile(int cfg) {
+  if (cfg >= 100) g_bf_cfg = cfg - 100;   // split-bf16 tile configuration (0 = heuristic)
+  else { g_force_tile = cfg; if (cfg < 0) g_bf_cfg = 0; }
+}
 
 long long pfk_conv_workspace_bytes(void) { return (long long)SK_WS_BYTES; }
 
 int pfk_conv_ktot(const pfk_conv_desc* d) { return conv_ktot(d, 32); }
 
-int pfk_conv_ktot_bf16(const pfk_conv_desc* d) { return conv_ktot(d, 64); }
+int pfk_conv_ktot_bf16(const pfk_conv_desc* d) { return conv_ktot(d, 32); }
 
 int pfk_conv2d_f32(const pfk_conv_desc* d, pfk_stream_t stream) {
   GemmArgs a{};
@@ -815,7 +818,7 @@ int pfk_conv2d_bf16s(const pfk_conv_desc* d, const void* weight_planes, int nspl
   GemmArgs a{};
   if (!d || !weight_planes || nsplit < 1 || nsplit > 3) return PFK_ERR_BAD_ARG;
   if (!pfk_aligned16(weight_planes)) return PFK_ERR_ALIGNMENT;
-  const int rc = desc_to_args(d, a, 64);
+  const int rc = desc_to_args(d, a, 32);
   if (rc != PFK_OK) return rc;
   a.wbf = weight_planes;
   a.wbf_plane_bytes = (long long)d->cout * a.ktot * 2;

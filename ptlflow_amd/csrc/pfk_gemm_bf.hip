@@ -7,14 +7,13 @@
 //   nsplit 1:  a0 b0                                   plain bf16 operands          (rel. product error ~2^-9)
 //   nsplit 2:  a0 b0 + a0 b1 + a1 b0                   3 MFMAs per K-block          (~2^-17)
 //   nsplit 3:  ... + a0 b2 + a1 b1 + a2 b0             6 MFMAs per K-block          (~2^-24: fp32-grade)
-// Terms of equal order i + j share an accumulator; the accumulators are added smallest first at the end.
 // The weights arrive pre-split (planes [nsplit][cout][ktot] bf16, host packing); the activations are split
-// while they are staged: global fp32 -> VGPR -> cvt/sub/cvt -> LDS bf16 planes, so HBM traffic is the fp32
-// path's and LDS holds K = 64 channels per 128-byte row.
+// while they are staged: global fp32 -> VGPR -> cvt/sub/cvt -> LDS bf16 planes, so HBM traffic is the fp32 path's.
+// All kept terms go into one fp32 accumulator (smallest first within a K-block).
 //
-// Same implicit-GEMM structure as pfk_gemm.hip: K-step = (source, tap, 64 channels), raw buffer loads with
-// hardware zero fill for the conv padding, un-padded LDS rows with the 16-byte chunk index XOR-swizzled by
-// (row >> 1) & 7 (conflict-free ds_read_b128 / ds_write_b128), two LDS stages, fused epilogues.
+// Same implicit-GEMM structure as pfk_gemm.hip: K sub-step = (source, tap, 32 channels) in the same order and padding
+// as the fp32 packed weight, raw buffer loads with hardware zero fill for the conv padding, un-padded 64-byte LDS rows
+// with the 16-byte chunk index XOR-swizzled, two LDS stages, fused epilogues.
 // Fragment use (32x32x16): lane l holds A[i = l & 31][k = 8*(l >> 5) .. +7] — one ds_read_b128 of chunk
 // kb*2 + (l >> 5) per plane per 16-channel K-block kb.
 #include "pfk_gemm.h"
@@ -25,9 +24,8 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int BKB = 64;            // channels per K-step
-constexpr int ROWB = 128;          // bytes per LDS row: 64 bf16
-constexpr int PLANE = 64 * ROWB;   // one 64-row operand plane, 8 KB
+constexpr int BKB = 32;            // channels per K sub-step (same K order / padding as the fp32 path's packed weight)
+constexpr int ROWB = 64;           // bytes per LDS row: 32 bf16
 
 template <int NS>
 __device__ __forceinline__ void split8(const f32x4& lo4, const f32x4& hi4, u32x4 (&out)[NS]) {
@@ -37,30 +35,34 @@ __device__ __forceinline__ void split8(const f32x4& lo4, const f32x4& hi4, u32x4
     bf16x8 h;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      h[e] = (__bf16)r[e];                       // round to nearest even (v_cvt_pk_bf16_f32)
+      h[e] = (__bf16)r[e];                         // round to nearest even (v_cvt_pk_bf16_f32)
       if (pl + 1 < NS) r[e] = r[e] - (float)h[e];  // exact
     }
     out[pl] = __builtin_bit_cast(u32x4, h);
   }
 }
 
-// 256 threads stage one K-step: thread t owns channels (t & 7)*8 .. +7 of rows (t >> 3) and (t >> 3) + 32 of
-// both operands.
-template <int NS>
+// 256 threads stage SUB K-sub-steps per barrier: thread t owns channels (t & 3)*8 .. +7 of rows (t >> 2) + 64*i of both
+// operands.  LDS rows are 64 bytes = four 16-byte chunks; chunk' = chunk ^ ((row >> 2) & 3) makes both the
+// ds_write_b128 (8 lanes = 2 rows) and the fragment ds_read_b128 (MI355X_MICROARCH.md lane groups) conflict-free.
+template <int NS, int BM, int BN, int SUB>
 struct StagerBF {
+  static constexpr int A_PT = BM / 64, B_PT = BN / 64;
+  static constexpr int A_PLANE = BM * ROWB, B_PLANE = BN * ROWB, SUBSTAGE = NS * (A_PLANE + B_PLANE);
   int H, W, kh, kw, ph, pw, nsrc;
   int ld0, ld1, ld2, ch0, ch1, ch2;
   __amdgpu_buffer_rsrc_t rs0, rs1, rs2, rsw, rs;
   int cld, cch;
   int plane_bytes;
   int seg = 0, ky = 0, kx = 0, c0 = 0, kofs = 0;
+  int pos = 0, total;
   int c8, r0;
-  unsigned sbyte;             // byte offset of this thread's 16-byte chunk inside a plane (row r0; row r0+32 = +32*ROWB)
-  int prow[2], py[2], px[2];
-  bool pok[2];
-  unsigned abase[2], aoff[2], wvoff[2];
-  f32x4 ra[2][2];
-  u32x4 rb[NS][2];
+  unsigned sbyte;             // byte offset of this thread's 16-byte chunk inside a plane (row r0; row r0 + 64*i: + i*64*ROWB)
+  int prow[A_PT], py[A_PT], px[A_PT];
+  bool pok[A_PT];
+  unsigned abase[A_PT], aoff[A_PT], wvoff[B_PT];
+  f32x4 ra[2][SUB][A_PT][2];   // two register sets: the loads of step j+2 are issued while step j+1's wait to be split
+  u32x4 rb[2][SUB][NS][B_PT];
 
   __device__ __forceinline__ StagerBF(const GemmArgs& a, long long m0, int n0, int t) {
     H = a.H; W = a.W; kh = a.kh; kw = a.kw; ph = a.kh >> 1; pw = a.kw >> 1; nsrc = a.nsrc;
@@ -70,17 +72,21 @@ struct StagerBF {
     rs2 = make_rsrc(a.src2);
     rsw = make_rsrc(a.wbf);
     plane_bytes = (int)a.wbf_plane_bytes;
-    c8 = (t & 7) * 8;
-    r0 = t >> 3;
-    sbyte = (unsigned)(r0 * ROWB + (((t & 7) ^ ((r0 >> 1) & 7)) << 4));
+    total = a.sk_steps;
+    c8 = (t & 3) * 8;
+    r0 = t >> 2;
+    sbyte = (unsigned)(r0 * ROWB + (((t & 3) ^ ((r0 >> 2) & 3)) << 4));
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const long long p = m0 + r0 + 32 * i;
+    for (int i = 0; i < A_PT; ++i) {
+      const long long p = m0 + r0 + 64 * i;
       pok[i] = p < a.M;
       prow[i] = (int)p;
       px[i] = (int)(p % a.W);
       py[i] = (int)((p / a.W) % a.H);
-      const int n = n0 + r0 + 32 * i;
+    }
+#pragma unroll
+    for (int i = 0; i < B_PT; ++i) {
+      const int n = n0 + r0 + 64 * i;
       wvoff[i] = n < a.b_rows ? (unsigned)(n * a.ktot + c8) * 2u : OOB;
     }
     set_segment(0);
@@ -92,44 +98,17 @@ struct StagerBF {
     else if (s == 1) { rs = rs1; cld = ld1; cch = ch1; }
     else { rs = rs2; cld = ld2; cch = ch2; }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) abase[i] = (unsigned)(prow[i] * cld + c8) * 4u;
+    for (int i = 0; i < A_PT; ++i) abase[i] = (unsigned)(prow[i] * cld + c8) * 4u;
   }
 
   __device__ __forceinline__ void set_tap() {
     const int dy = ky - ph, dx = kx - pw;
     const unsigned toff = (unsigned)((dy * W + dx) * cld * 4);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < A_PT; ++i) {
       const bool ok = pok[i] && (unsigned)(py[i] + dy) < (unsigned)H && (unsigned)(px[i] + dx) < (unsigned)W;
       aoff[i] = ok ? abase[i] + toff : OOB;
     }
-  }
-
-  __device__ __forceinline__ int total_steps() const {
-    const int taps = kh * kw;
-    int s = taps * ((ch0 + BKB - 1) / BKB);
-    if (nsrc > 1) s += taps * ((ch1 + BKB - 1) / BKB);
-    if (nsrc > 2) s += taps * ((ch2 + BKB - 1) / BKB);
-    return s;
-  }
-
-  // live = false: every A lane out of range (zeros), B parked on K-step 0 (valid memory) — branch-free last step
-  __device__ __forceinline__ void load(bool live) {
-    const int lim = live ? cch - c0 : 0;
-    const bool ok0 = c8 < lim, ok1 = c8 + 4 < lim;   // sources have a multiple of 4 channels
-    const int coff = c0 * 4;
-    const int koff = live ? kofs * 2 : 0;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const unsigned o = aoff[i];
-      ra[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok0 ? o : OOB, coff, 0));
-      ra[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (ok1 && o != OOB) ? o + 16u : OOB, coff, 0));
-    }
-#pragma unroll
-    for (int pl = 0; pl < NS; ++pl)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-        rb[pl][i] = __builtin_amdgcn_raw_buffer_load_b128(rsw, wvoff[i], koff + pl * plane_bytes, 0);
   }
 
   __device__ __forceinline__ void advance() {
@@ -149,111 +128,189 @@ struct StagerBF {
     }
   }
 
-  // stage layout: [A planes 0..NS-1][B planes 0..NS-1], each [64 rows][128 B]
+  // Issue the loads of the next SUB sub-steps.  Past the end of K every A lane is out of range (zeros) and B is
+  // parked on K-step 0 (valid memory, multiplied by zeros): the K loop stays branch-free.
+  template <int S>
+  __device__ __forceinline__ void load_all() {
+#pragma unroll
+    for (int u = 0; u < SUB; ++u) {
+      const bool live = pos < total;
+      const int lim = live ? cch - c0 : 0;
+      const bool ok0 = c8 < lim, ok1 = c8 + 4 < lim;   // sources have a multiple of 4 channels
+      const int coff = c0 * 4;
+      const int koff = live ? kofs * 2 : 0;
+#pragma unroll
+      for (int i = 0; i < A_PT; ++i) {
+        const unsigned o = aoff[i];
+        ra[S][u][i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok0 ? o : OOB, coff, 0));
+        ra[S][u][i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (ok1 && o != OOB) ? o + 16u : OOB, coff, 0));
+      }
+#pragma unroll
+      for (int pl = 0; pl < NS; ++pl)
+#pragma unroll
+        for (int i = 0; i < B_PT; ++i)
+          rb[S][u][pl][i] = __builtin_amdgcn_raw_buffer_load_b128(rsw, wvoff[i], koff + pl * plane_bytes, 0);
+      ++pos;
+      if (pos < total) advance();
+    }
+  }
+
+  // stage layout: [sub-step][A planes 0..NS-1][B planes 0..NS-1], planes [rows][64 B]
+  template <int S>
   __device__ __forceinline__ void store(char* stage) const {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      u32x4 pa[NS];
-      split8<NS>(ra[i][0], ra[i][1], pa);
+    for (int u = 0; u < SUB; ++u) {
 #pragma unroll
-      for (int pl = 0; pl < NS; ++pl) {
-        *reinterpret_cast<u32x4*>(stage + pl * PLANE + i * 32 * ROWB + sbyte) = pa[pl];
-        *reinterpret_cast<u32x4*>(stage + (NS + pl) * PLANE + i * 32 * ROWB + sbyte) = rb[pl][i];
+      for (int i = 0; i < A_PT; ++i) {
+        u32x4 pa[NS];
+        split8<NS>(ra[S][u][i][0], ra[S][u][i][1], pa);
+#pragma unroll
+        for (int pl = 0; pl < NS; ++pl)
+          *reinterpret_cast<u32x4*>(stage + u * SUBSTAGE + pl * A_PLANE + i * 64 * ROWB + sbyte) = pa[pl];
       }
+#pragma unroll
+      for (int pl = 0; pl < NS; ++pl)
+#pragma unroll
+        for (int i = 0; i < B_PT; ++i)
+          *reinterpret_cast<u32x4*>(stage + u * SUBSTAGE + NS * A_PLANE + pl * B_PLANE + i * 64 * ROWB + sbyte) = rb[S][u][pl][i];
     }
   }
 };
 
-template <int EPI, int NS>
-__global__ __launch_bounds__(256) void conv_gemm_bf_kernel(const GemmArgs a) {
-  constexpr int STAGE = 2 * NS * PLANE;
+// Block tile BM x BN, four waves as 2 x 2, wave tile (BM/2) x (BN/2) = MT x NT 32x32 MFMA blocks; two LDS stages of
+// SUB K-sub-steps each.  Big tiles amortise the split (VALU) and the LDS traffic over more MFMAs — per 16-channel
+// K-block a wave reads (MT + NT) * NS fragments for MT * NT * NS(NS+1)/2 MFMAs.
+// two resident blocks per CU (=> <= 256 registers) whenever two of them fit in the 160 KB of LDS
+constexpr int bf_blocks_per_cu(int ns, int bm, int bn, int sub) { return 2 * (2 * sub * ns * (bm + bn) * ROWB) <= 160 * 1024 ? 2 : 1; }
+
+template <int EPI, int NS, int BM, int BN, int SUB>
+__global__ __launch_bounds__(256, bf_blocks_per_cu(NS, BM, BN, SUB)) void conv_gemm_bf_kernel(const GemmArgs a) {
+  using St = StagerBF<NS, BM, BN, SUB>;
+  constexpr int MT = BM / 64, NT = BN / 64;
+  constexpr int A_PLANE = St::A_PLANE, B_PLANE = St::B_PLANE, SUBSTAGE = St::SUBSTAGE, STAGE = SUB * SUBSTAGE;
   extern __shared__ __attribute__((aligned(16))) char smem_bf[];   // [2][STAGE]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wid = tid >> 6;
-  const int wm0 = (wid >> 1) * 32;
-  const int wn0 = (wid & 1) * 32;
+  const int wm0 = (wid >> 1) * (BM / 2);
+  const int wn0 = (wid & 1) * (BN / 2);
 
   const int bid = pfk_xcd_remap(blockIdx.x, gridDim.x);
   const int tile_n = bid % a.tiles_n;
   const int tile_m = bid / a.tiles_n;
-  const long long m0 = (long long)tile_m * 64;
-  const int n0 = tile_n * 64;
+  const long long m0 = (long long)tile_m * BM;
+  const int n0 = tile_n * BN;
 
-  StagerBF<NS> st(a, m0, n0, tid);
-  const int total_steps = st.total_steps();
+  St st(a, m0, n0, tid);
+  const int nsteps = (st.total + SUB - 1) / SUB;
 
-  f32x16 acc[NS];   // acc[o]: products of order i + j = o
+  f32x16 acc[MT][NT];
 #pragma unroll
-  for (int o = 0; o < NS; ++o)
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[o][r] = 0.f;
-
-  st.load(true);
-  st.advance();
-  st.store(smem_bf);
-  __syncthreads();
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
   const int frow = lane & 31;
   const int hl = lane >> 5;
-  const int key = (frow >> 1) & 7;   // wave / tile row offsets are multiples of 32: same key
-  int ko[4];
-#pragma unroll
-  for (int kb = 0; kb < 4; ++kb) ko[kb] = ((kb * 2 + hl) ^ key) << 4;
+  const int key = (frow >> 2) & 3;   // wave / block row offsets are multiples of 32: same key
+  const int ko0 = ((0 + hl) ^ key) << 4, ko1 = ((2 + hl) ^ key) << 4;
+  const int a_row = (wm0 + frow) * ROWB;
+  const int b_row = NS * A_PLANE + (wn0 + frow) * ROWB;
 
-  for (int step = 0; step < total_steps; ++step) {
-    const int buf = step & 1;
-    const bool more = (step + 1) < total_steps;
-    const char* cA = smem_bf + buf * STAGE + (wm0 + frow) * ROWB;
-    const char* cB = smem_bf + buf * STAGE + NS * PLANE + (wn0 + frow) * ROWB;
-    st.load(more);
+  // MFMAs of one step on one LDS stage: all fragments of a sub-step are read up front, then the MFMAs run back to back
+  auto compute = [&](const char* stage) {
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-      bf16x8 fa[NS], fb[NS];
+    for (int u = 0; u < SUB; ++u) {
+      const char* cA = stage + u * SUBSTAGE + a_row;
+      const char* cB = stage + u * SUBSTAGE + b_row;
+      bf16x8 fa[2][MT][NS], fb[2][NT][NS];
 #pragma unroll
-      for (int pl = 0; pl < NS; ++pl) {
-        fa[pl] = *reinterpret_cast<const bf16x8*>(cA + pl * PLANE + ko[kb]);
-        fb[pl] = *reinterpret_cast<const bf16x8*>(cB + pl * PLANE + ko[kb]);
+      for (int kb = 0; kb < 2; ++kb) {
+        const int ko = kb ? ko1 : ko0;
+#pragma unroll
+        for (int pl = 0; pl < NS; ++pl) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) fa[kb][mt][pl] = *reinterpret_cast<const bf16x8*>(cA + pl * A_PLANE + mt * 32 * ROWB + ko);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) fb[kb][nt][pl] = *reinterpret_cast<const bf16x8*>(cB + pl * B_PLANE + nt * 32 * ROWB + ko);
+        }
       }
 #pragma unroll
-      for (int o = 0; o < NS; ++o)
+      for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int i = 0; i <= o; ++i)
-          acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[o - i], acc[o], 0, 0, 0);
+        for (int o = NS - 1; o >= 0; --o)     // smallest terms first
+#pragma unroll
+          for (int i = 0; i <= o; ++i)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kb][mt][i], fb[kb][nt][o - i], acc[mt][nt], 0, 0, 0);
     }
-    st.store(smem_bf + (buf ^ 1) * STAGE);   // last step: zeros / parked weights into the dead stage
-    if (more) st.advance();
+  };
+
+  // Pipeline: registers hold steps j+1 (loaded a whole step ago, split + stored into the other LDS stage during step j)
+  // and j+2 (just issued); LDS holds steps j and j+1.  Global latency gets a full step of MFMAs to land.
+  char* const stage0 = smem_bf;
+  char* const stage1 = smem_bf + STAGE;
+  st.template load_all<0>();
+  st.template load_all<1>();
+  st.template store<0>(stage0);
+  __syncthreads();
+  const bool do_load = !(a.dbg & 1), do_store = !(a.dbg & 2), do_mma = !(a.dbg & 4);
+  for (int step = 0; step < nsteps; step += 2) {
+    if (do_load) st.template load_all<0>();            // step + 2
+    if (do_mma) compute(stage0);                       // step
+    if (do_store) st.template store<1>(stage1);        // step + 1
+    __syncthreads();
+    if (step + 1 >= nsteps) break;
+    if (do_load) st.template load_all<1>();            // step + 3
+    if (do_mma) compute(stage1);                       // step + 1
+    if (do_store) st.template store<0>(stage0);        // step + 2
     __syncthreads();
   }
-
-  f32x16 sum[1][1];
-  sum[0][0] = acc[NS - 1];
-#pragma unroll
-  for (int o = NS - 2; o >= 0; --o) sum[0][0] += acc[o];
-  epilogue<1, 1, EPI, 0, 16>(a, sum, m0 + wm0, n0 + wn0, lane, 0);
+  epilogue<MT, NT, EPI, 0, 16>(a, acc, m0 + wm0, n0 + wn0, lane, 0);
 }
 
-template <int EPI, int NS>
-int launch_bf_one(const GemmArgs& g, dim3 grid, hipStream_t st) {
-  constexpr size_t smem = 2 * 2 * NS * PLANE;
+template <int EPI, int NS, int BM, int BN, int SUB>
+int launch_bf_one(const GemmArgs& a, hipStream_t st) {
+  GemmArgs g = a;
+  const long long tiles_m = (a.M + BM - 1) / BM;
+  g.tiles_n = (a.b_rows + BN - 1) / BN;
+  const long long nblk = tiles_m * g.tiles_n;
+  if (nblk <= 0 || nblk > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
+  constexpr size_t smem = 2 * (size_t)SUB * NS * (BM + BN) * ROWB;
   static_assert(smem <= 160 * 1024, "LDS budget");
-  auto kern = conv_gemm_bf_kernel<EPI, NS>;
+  auto kern = conv_gemm_bf_kernel<EPI, NS, BM, BN, SUB>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, g);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), smem, st, g);
   return pfk_launch_status();
 }
 
-template <int NS>
-int launch_bf_ns(const GemmArgs& g, int epi, dim3 grid, hipStream_t st) {
+template <int NS, int BM, int BN, int SUB>
+int launch_bf_epi(const GemmArgs& g, int epi, hipStream_t st) {
   switch (epi) {
-    case PFK_EPI_LINEAR: return launch_bf_one<PFK_EPI_LINEAR, NS>(g, grid, st);
-    case PFK_EPI_GRU_ZR: return launch_bf_one<PFK_EPI_GRU_ZR, NS>(g, grid, st);
-    case PFK_EPI_GRU_Q:  return launch_bf_one<PFK_EPI_GRU_Q, NS>(g, grid, st);
+    case PFK_EPI_LINEAR: return launch_bf_one<PFK_EPI_LINEAR, NS, BM, BN, SUB>(g, st);
+    case PFK_EPI_GRU_ZR: return launch_bf_one<PFK_EPI_GRU_ZR, NS, BM, BN, SUB>(g, st);
+    case PFK_EPI_GRU_Q:  return launch_bf_one<PFK_EPI_GRU_Q, NS, BM, BN, SUB>(g, st);
+    default: return PFK_ERR_BAD_ARG;
+  }
+}
+
+// tile configurations: 1 = 64x64 (two sub-steps per barrier), 2 = 128x64, 3 = 128x128
+template <int NS>
+int launch_bf_ns(const GemmArgs& g, int epi, int cfg, hipStream_t st) {
+  switch (cfg) {
+    case 1: return launch_bf_epi<NS, 64, 64, 2>(g, epi, st);
+    case 2: return launch_bf_epi<NS, 128, 64, 1>(g, epi, st);
+    case 3: return launch_bf_epi<NS, 128, 128, 1>(g, epi, st);
     default: return PFK_ERR_BAD_ARG;
   }
 }
@@ -262,17 +319,22 @@ int launch_bf_ns(const GemmArgs& g, int epi, dim3 grid, hipStream_t st) {
 
 namespace pfkg {
 
-int launch_bf(const GemmArgs& a, int epi, int nsplit, hipStream_t st) {
-  GemmArgs g = a;
-  const long long tiles_m = (a.M + 63) / 64;
-  g.tiles_n = (a.b_rows + 63) / 64;
-  const long long nblk = tiles_m * g.tiles_n;
-  if (nblk <= 0 || nblk > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
-  dim3 grid((unsigned)nblk);
+int g_bf_cfg = 0;   // debug/tuning knob (pfk_debug_set_tile(100 + cfg)); 0 = heuristic
+
+int launch_bf(const GemmArgs& a0, int epi, int nsplit, hipStream_t st) {
+  GemmArgs a = a0;
+  int cfg = g_bf_cfg % 10;
+  a.dbg = g_bf_cfg / 10;
+  if (cfg == 0) {
+    const long long blocks128 = ((a.M + 127) / 128) * ((a.b_rows + 127) / 128);
+    const int pad128 = (a.b_rows + 127) / 128 * 128;
+    if (blocks128 < 2 * 256) cfg = 1;                                   // small grids: more, smaller tiles
+    else cfg = (pad128 - a.b_rows) * 5 > a.b_rows ? 2 : 3;               // > 20 % padded columns with BN = 128
+  }
   switch (nsplit) {
-    case 1: return launch_bf_ns<1>(g, epi, grid, st);
-    case 2: return launch_bf_ns<2>(g, epi, grid, st);
-    case 3: return launch_bf_ns<3>(g, epi, grid, st);
+    case 1: return launch_bf_ns<1>(a, epi, cfg, st);
+    case 2: return launch_bf_ns<2>(a, epi, cfg, st);
+    case 3: return launch_bf_ns<3>(a, epi, cfg, st);
     default: return PFK_ERR_BAD_ARG;
   }
 }

@@ -117,7 +117,7 @@ class UpdateEngine:
             # the weight tensor's dtype selects the kernel in torch.ops.pfk.conv2d: fp32 [cout, ktot] or bf16 planes
             if self.nsplit == 0:
                 return pack_conv_weight(weight, segments)
-            return split_bf16_planes(pack_conv_weight(weight, segments, kpad=64), self.nsplit)
+            return split_bf16_planes(pack_conv_weight(weight, segments), self.nsplit)
 
         w: Dict[str, torch.Tensor] = {}
         real = s.hidden + s.x_channels

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Micro-benchmark + correctness of pfk::conv2d on the update-block shapes (GPU box).
     python scripts/conv_bench.py [--batch 1] [--cfgs -1,1,5] [--reps 30]
-cfg -1 = the library's own choice, 0..26 = a forced fp32 tile configuration, 101/102/103 = split-bf16 with 1/2/3 planes.
+cfg -1 = the library's own choice, 0..26 = a forced fp32 tile configuration; 100*n + t = split-bf16 with n planes (1..3) and
+tile configuration t (0 = heuristic, 1 = 64x64, 2 = 128x64, 3 = 128x128), e.g. 200, 203, 302;
++1000*d = timing ablation d of the split kernels (1 no global loads, 2 no split/LDS stores, 4 no MFMAs; results are garbage).
 Reference = torch conv2d on the same GPU (MIOpen fp32), only to catch wrong results quickly; the parity gate
 proper is tests/ against the CPU oracle."""
 import argparse
@@ -62,9 +64,10 @@ def main():
         flops = 2.0 * M * cout * kh * kw * cin
         line = f"{name:4s} cout={cout:3d} K={kh*kw*cin:5d} {flops/1e9:5.2f} GF |"
         for cfg in cfgs:
-            ops.debug_set_tile(cfg if cfg < 100 else -1)
+            ops.debug_set_tile(-1)
+            ops.debug_set_tile(cfg if cfg < 100 else 100 + cfg % 100 + 10 * (cfg // 1000))
             packed = (pack_conv_weight(wt, offs) if cfg < 100
-                      else split_bf16_planes(pack_conv_weight(wt, offs, kpad=64), cfg - 100))
+                      else split_bf16_planes(pack_conv_weight(wt, offs), (cfg // 100) % 10))
             out = torch.zeros(M, cout, device=dev)
             hbuf, zbuf, rh = hbuf0.clone(), zbuf0.clone(), torch.zeros(M, Ch, device=dev)
 
@@ -95,7 +98,7 @@ def main():
             torch.cuda.synchronize()
             us = 1e3 * e0.elapsed_time(e1) / args.reps
             tot[cfg] += us
-            line += f" cfg{cfg:3d}: {us:7.1f} us {flops/us/1e6:6.1f} TF err {err:.1e} |"
+            line += f" cfg{cfg:4d}: {us:7.1f} us {flops/us/1e6:6.1f} TF err {err:.1e} |"
         print(line, flush=True)
     ops.debug_set_tile(-1)
     print("sum us per iteration:", {c: round(v, 1) for c, v in tot.items()})

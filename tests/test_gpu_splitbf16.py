@@ -39,7 +39,7 @@ def unpm(x, B, H, W):
 
 def planes(weight, segs, nsplit):
     from ptlflow_amd.packing import pack_conv_weight, split_bf16_planes
-    return split_bf16_planes(pack_conv_weight(weight, segs, kpad=64), nsplit).cuda()
+    return split_bf16_planes(pack_conv_weight(weight, segs), nsplit).cuda()
 
 
 CASES = [
