@@ -71,6 +71,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-batch1", action="store_true")
+    ap.add_argument("--conv-precision", default="fp32", choices=["fp32", "bf16x6", "bf16x3", "bf16"],
+                    help="arithmetic of the update block's convolutions for the timed run: fp32 MFMA (default, the headline) "
+                         "or split-bf16 MFMA (include/pfk.h, pfk_conv2d_bf16s)")
+    ap.add_argument("--no-split-modes", action="store_true", help="skip the extra split-bf16 legs (`split_bf16` in the output)")
     ap.add_argument("--cpu-forwards", type=int, default=3)
     ap.add_argument("--cpu-budget-s", type=float, default=30.0, help="stop timing CPU forwards after this many seconds")
     return ap.parse_args()
@@ -119,9 +123,12 @@ def main():
         torch.backends.cudnn.benchmark = True
     small = args.model == "raft_small"
     if args.model == "gma":
-        model = GMA(iters=args.iters, upsample_every_iter=not args.skip_dead_upsample)
+        def make(prec):
+            return GMA(iters=args.iters, upsample_every_iter=not args.skip_dead_upsample, conv_precision=prec)
     else:
-        model = RAFT(small=small, iters=args.iters, upsample_every_iter=not args.skip_dead_upsample)
+        def make(prec):
+            return RAFT(small=small, iters=args.iters, upsample_every_iter=not args.skip_dead_upsample, conv_precision=prec)
+    model = make(args.conv_precision)
     model.load_synthetic(1234).eval()
     cpu_state = {k: v.clone() for k, v in model.state_dict().items()}
     model = model.to(dev)
@@ -162,10 +169,11 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "f32" if args.conv_precision == "fp32" else
+                 f"f32 storage/accumulate, update-block conv products as split bf16 ({args.conv_precision})",
         "data": "synthetic",
         "config": {"workload": f"{args.model} random-init (seeded), {args.height}x{args.width} frame pairs, {args.iters} iterations, "
-                               f"fp32, batch {args.batch}/GPU, eval forward incl. encoders, "
+                               f"{args.conv_precision}, batch {args.batch}/GPU, eval forward incl. encoders, "
                                + ("dead mask/upsample work skipped on non-final iterations" if args.skip_dead_upsample
                                   else "mask head + convex upsample on every iteration as the reference"),
                    "global_batch": args.batch * world, "parallelism": f"dp{world} (independent replicas, no collectives)"},
@@ -231,6 +239,38 @@ def main():
                                                 f"torch {torch.__version__} CPU, {cores} threads"}
             mean, mx = O.epe(out["flows"][:1, 0].float().cpu(), ref["flows"][:, 0])
             result["epe_vs_cpu"] = {"mean": mean, "max": mx, "gate": 1e-3}
+        else:
+            ref = None
+        if world == 1 and args.conv_precision == "fp32" and not args.no_split_modes:
+            # Same forward with the update block's convolutions on the bf16 matrix cores with split operands
+            # (reported beside the fp32 headline, never as `value`): throughput at the same batch and EPE against the same
+            # CPU forward (or, without it, against the fp32 GPU output).
+            modes = {}
+            base = out["flows"][:1, 0].float().cpu()
+            for prec in ("bf16x6", "bf16x3"):
+                m2 = make(prec).eval()
+                m2.load_state_dict(cpu_state)
+                m2 = m2.to(dev)
+                for _ in range(2):
+                    o2 = m2(inputs)
+                torch.cuda.synchronize()
+                s0 = time.perf_counter()
+                for _ in range(5):
+                    o2 = m2(inputs)
+                torch.cuda.synchronize()
+                ms = 1e3 * (time.perf_counter() - s0) / 5
+                if ref is not None:
+                    from oracle import raft_oracle as O
+                    mean, mx = O.epe(o2["flows"][:1, 0].float().cpu(), ref["flows"][:, 0])
+                    against = "cpu"
+                else:
+                    d = (o2["flows"][:1, 0].float().cpu() - base).pow(2).sum(1).sqrt()
+                    mean, mx, against = float(d.mean()), float(d.max()), "gpu_fp32"
+                modes[prec] = {"value": args.batch * 1e3 / ms, "unit": "frame-pairs/s", "ms_per_step": ms,
+                               "epe_mean": mean, "epe_max": mx, "epe_against": against}
+                del m2, o2
+                torch.cuda.empty_cache()
+            result["split_bf16"] = modes
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()

@@ -18,6 +18,8 @@
 // kb*2 + (l >> 5) per plane per 16-channel K-block kb.
 #include "pfk_gemm.h"
 
+#include <utility>
+
 using namespace pfkg;
 
 namespace {
@@ -26,21 +28,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int BKB = 32;            // channels per K sub-step (same K order / padding as the fp32 path's packed weight)
 constexpr int ROWB = 64;           // bytes per LDS row: 32 bf16
-
-template <int NS>
-__device__ __forceinline__ void split8(const f32x4& lo4, const f32x4& hi4, u32x4 (&out)[NS]) {
-  float r[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
-#pragma unroll
-  for (int pl = 0; pl < NS; ++pl) {
-    bf16x8 h;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      h[e] = (__bf16)r[e];                         // round to nearest even (v_cvt_pk_bf16_f32)
-      if (pl + 1 < NS) r[e] = r[e] - (float)h[e];  // exact
-    }
-    out[pl] = __builtin_bit_cast(u32x4, h);
-  }
-}
 
 // 256 threads stage SUB K-sub-steps per barrier: thread t owns channels (t & 3)*8 .. +7 of rows (t >> 2) + 64*i of both
 // operands.  LDS rows are 64 bytes = four 16-byte chunks; chunk' = chunk ^ ((row >> 2) & 3) makes both the
@@ -128,58 +115,194 @@ struct StagerBF {
     }
   }
 
-  // Issue the loads of the next SUB sub-steps.  Past the end of K every A lane is out of range (zeros) and B is
-  // parked on K-step 0 (valid memory, multiplied by zeros): the K loop stays branch-free.
-  template <int S>
-  __device__ __forceinline__ void load_all() {
+  // ---- the staging work of one step, cut into small "units" that the kernel places between MFMAs ----------------
+  // (a wave issues in order: whatever does not sit between two MFMAs in program order runs with the matrix pipe idle).
+  // Register set S receives the loads of step j+2 while set 1-S (loaded a whole step ago) is split and stored.
+  // All indices are template constants so every register array stays in registers.
+  bool p_ok0, p_ok1;
+  int p_coff, p_koff;
+  u32x4 pa[NS];   // planes of the row chunk being split
+
+  // Past the end of K every A lane is out of range (zeros) and B is parked on K-step 0 (valid memory, multiplied by
+  // zeros): the K loop stays branch-free.
+  __device__ __forceinline__ void load_setup() {
+    const bool live = pos < total;
+    const int lim = live ? cch - c0 : 0;
+    p_ok0 = c8 < lim; p_ok1 = c8 + 4 < lim;   // sources have a multiple of 4 channels
+    p_coff = c0 * 4;
+    p_koff = live ? kofs * 2 : 0;
+  }
+  template <int S, int U, int I, int Hf>
+  __device__ __forceinline__ void load_a() {
+    const unsigned o = aoff[I];
+    const unsigned off = Hf == 0 ? (p_ok0 ? o : OOB) : ((p_ok1 && o != OOB) ? o + 16u : OOB);
+    ra[S][U][I][Hf] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, p_coff, 0));
+  }
+  template <int S, int U, int PL, int I>
+  __device__ __forceinline__ void load_b() {
+    rb[S][U][PL][I] = __builtin_amdgcn_raw_buffer_load_b128(rsw, wvoff[I], p_koff + PL * plane_bytes, 0);
+  }
+  __device__ __forceinline__ void load_done() {
+    ++pos;
+    if (pos < total) advance();
+  }
+  // plane PL of half Hf (4 floats) of row chunk (U, I) of set S -> dwords 2*Hf, 2*Hf+1 of pa[PL]; the running
+  // residual lives in `sr` between the planes of one half
+  f32x4 sr;
+  template <int S, int U, int I, int Hf, int PL>
+  __device__ __forceinline__ void split_piece() {
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    if constexpr (PL == 0) sr = ra[S][U][I][Hf];
+    bf16x4 h;
 #pragma unroll
-    for (int u = 0; u < SUB; ++u) {
-      const bool live = pos < total;
-      const int lim = live ? cch - c0 : 0;
-      const bool ok0 = c8 < lim, ok1 = c8 + 4 < lim;   // sources have a multiple of 4 channels
-      const int coff = c0 * 4;
-      const int koff = live ? kofs * 2 : 0;
-#pragma unroll
-      for (int i = 0; i < A_PT; ++i) {
-        const unsigned o = aoff[i];
-        ra[S][u][i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok0 ? o : OOB, coff, 0));
-        ra[S][u][i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (ok1 && o != OOB) ? o + 16u : OOB, coff, 0));
-      }
-#pragma unroll
-      for (int pl = 0; pl < NS; ++pl)
-#pragma unroll
-        for (int i = 0; i < B_PT; ++i)
-          rb[S][u][pl][i] = __builtin_amdgcn_raw_buffer_load_b128(rsw, wvoff[i], koff + pl * plane_bytes, 0);
-      ++pos;
-      if (pos < total) advance();
+    for (int e = 0; e < 4; ++e) {
+      h[e] = (__bf16)sr[e];                           // round to nearest even (v_cvt_pk_bf16_f32)
+      if constexpr (PL + 1 < NS) sr[e] = sr[e] - (float)h[e];   // exact
     }
+    const u32x2 w = __builtin_bit_cast(u32x2, h);
+    pa[PL][2 * Hf] = w[0];
+    pa[PL][2 * Hf + 1] = w[1];
+  }
+  // stage layout: [sub-step][A planes 0..NS-1][B planes 0..NS-1], planes [rows][64 B]
+  template <int U, int I, int PL>
+  __device__ __forceinline__ void store_a(char* stage) const {
+    *reinterpret_cast<u32x4*>(stage + U * SUBSTAGE + PL * A_PLANE + I * 64 * ROWB + sbyte) = pa[PL];
+  }
+  template <int S, int U, int PL, int I>
+  __device__ __forceinline__ void store_b(char* stage) const {
+    *reinterpret_cast<u32x4*>(stage + U * SUBSTAGE + NS * A_PLANE + PL * B_PLANE + I * 64 * ROWB + sbyte) = rb[S][U][PL][I];
   }
 
-  // stage layout: [sub-step][A planes 0..NS-1][B planes 0..NS-1], planes [rows][64 B]
-  template <int S>
-  __device__ __forceinline__ void store(char* stage) const {
-#pragma unroll
-    for (int u = 0; u < SUB; ++u) {
-#pragma unroll
-      for (int i = 0; i < A_PT; ++i) {
-        u32x4 pa[NS];
-        split8<NS>(ra[S][u][i][0], ra[S][u][i][1], pa);
-#pragma unroll
-        for (int pl = 0; pl < NS; ++pl)
-          *reinterpret_cast<u32x4*>(stage + u * SUBSTAGE + pl * A_PLANE + i * 64 * ROWB + sbyte) = pa[pl];
-      }
-#pragma unroll
-      for (int pl = 0; pl < NS; ++pl)
-#pragma unroll
-        for (int i = 0; i < B_PT; ++i)
-          *reinterpret_cast<u32x4*>(stage + u * SUBSTAGE + NS * A_PLANE + pl * B_PLANE + i * 64 * ROWB + sbyte) = rb[S][u][pl][i];
+  // Unit X of a step, in order per sub-step: B stores | per row chunk: split pieces, A stores | load setup, A loads,
+  // B loads, iterator advance.
+  static constexpr int U_BST = NS * B_PT, U_ROW = 3 * NS, U_AST = A_PT * U_ROW, U_ALD = 2 * A_PT, U_BLD = NS * B_PT;
+  static constexpr int UNITS_PER_SUB = U_BST + U_AST + 1 + U_ALD + U_BLD + 1;
+  static constexpr int UNITS = SUB * UNITS_PER_SUB;
+  template <int S, int X>
+  __device__ __forceinline__ void unit(char* other) {
+    constexpr int U = X / UNITS_PER_SUB, x = X % UNITS_PER_SUB;
+    if constexpr (x < U_BST) {
+      store_b<1 - S, U, x / B_PT, x % B_PT>(other);
+    } else if constexpr (x < U_BST + U_AST) {
+      constexpr int y = x - U_BST, I = y / U_ROW, z = y % U_ROW;
+      if constexpr (z < 2 * NS) split_piece<1 - S, U, I, z / NS, z % NS>();
+      else store_a<U, I, z - 2 * NS>(other);
+    } else if constexpr (x == U_BST + U_AST) {
+      load_setup();
+    } else if constexpr (x < U_BST + U_AST + 1 + U_ALD) {
+      constexpr int y = x - (U_BST + U_AST + 1);
+      load_a<S, U, y / 2, y % 2>();
+    } else if constexpr (x < U_BST + U_AST + 1 + U_ALD + U_BLD) {
+      constexpr int y = x - (U_BST + U_AST + 1 + U_ALD);
+      load_b<S, U, y / B_PT, y % B_PT>();
+    } else {
+      load_done();
     }
+  }
+  template <int S, int... X>
+  __device__ __forceinline__ void units_plain(char* other, std::integer_sequence<int, X...>) {
+    (unit<S, X>(other), ...);
+  }
+  // prologue helpers (no interleaving needed)
+  template <int S>
+  __device__ __forceinline__ void load_all() {   // the load units of a step, nothing else
+    load_only<S>(std::make_integer_sequence<int, UNITS>{});
+  }
+  template <int S, int... X>
+  __device__ __forceinline__ void load_only(std::integer_sequence<int, X...>) {
+    ((X % UNITS_PER_SUB >= U_BST + U_AST ? unit<S, X>(nullptr) : (void)0), ...);
+  }
+  template <int S>
+  __device__ __forceinline__ void store_all(char* stage) {   // the split + store units of set S
+    store_only<1 - S>(stage, std::make_integer_sequence<int, UNITS>{});
+  }
+  template <int S, int... X>
+  __device__ __forceinline__ void store_only(char* stage, std::integer_sequence<int, X...>) {
+    ((X % UNITS_PER_SUB < U_BST + U_AST ? unit<S, X>(stage) : (void)0), ...);
   }
 };
 
 // Block tile BM x BN, four waves as 2 x 2, wave tile (BM/2) x (BN/2) = MT x NT 32x32 MFMA blocks; two LDS stages of
 // SUB K-sub-steps each.  Big tiles amortise the split (VALU) and the LDS traffic over more MFMAs — per 16-channel
 // K-block a wave reads (MT + NT) * NS fragments for MT * NT * NS(NS+1)/2 MFMAs.
+// t-th kept product term a_i * b_j (i + j < NS), smallest first
+template <int NS> constexpr int term_a(int t) {
+  int c = 0;
+  for (int o = NS - 1; o >= 0; --o)
+    for (int i = 0; i <= o; ++i) { if (c == t) return i; ++c; }
+  return 0;
+}
+template <int NS> constexpr int term_b(int t) {
+  int c = 0;
+  for (int o = NS - 1; o >= 0; --o)
+    for (int i = 0; i <= o; ++i) { if (c == t) return o - i; ++c; }
+  return 0;
+}
+
+// One K-step of a wave as a hand-placed instruction stream: MFMA, filler, MFMA, filler ...  (sched_barrier(0) after
+// every item pins the order).  A step has NB = 2*SUB 16-channel K-blocks of MPB = T*MT*NT MFMAs; fragments are
+// register double-buffered per K-block: the reads of block g+1 are the first fillers of block g; the staging units of
+// StagerBF::unit are spread evenly over all MFMA slots.  Only the first block's fragment reads (right after the
+// barrier) are exposed — the co-resident block's wave covers them.
+template <int EPI, int NS, int BM, int BN, int SUB>
+struct KStep {
+  using St = StagerBF<NS, BM, BN, SUB>;
+  static constexpr int MT = BM / 64, NT = BN / 64;
+  static constexpr int T = NS * (NS + 1) / 2;
+  static constexpr int NB = 2 * SUB, MPB = T * MT * NT, NM = NB * MPB;
+  static constexpr int NFR = (MT + NT) * NS;          // fragment reads per K-block
+  static constexpr int RU = (NFR + 1) / 2;            // ... as units of two
+  static_assert(RU <= MPB, "not enough MFMA slots for the fragment reads");
+  int a_row, b_row, ko0, ko1;
+  bf16x8 fa[2][MT][NS], fb[2][NT][NS];
+
+  template <int G, int E>
+  __device__ __forceinline__ void read_one(const char* stage) {
+    if constexpr (E < NFR) {
+      const char* base = stage + (G >> 1) * St::SUBSTAGE + ((G & 1) ? ko1 : ko0);
+      if constexpr (E < MT * NS)
+        fa[G & 1][E / NS][E % NS] = *reinterpret_cast<const bf16x8*>(base + a_row + (E % NS) * St::A_PLANE + (E / NS) * 32 * ROWB);
+      else
+        fb[G & 1][(E - MT * NS) / NS][(E - MT * NS) % NS] =
+            *reinterpret_cast<const bf16x8*>(base + b_row + ((E - MT * NS) % NS) * St::B_PLANE + ((E - MT * NS) / NS) * 32 * ROWB);
+    }
+  }
+  template <int G, int... E>
+  __device__ __forceinline__ void read_block(const char* stage, std::integer_sequence<int, E...>) {
+    (read_one<G, E>(stage), ...);
+  }
+
+  template <int S, int Q>
+  __device__ __forceinline__ void slot(f32x16 (&acc)[MT][NT], St& st, const char* cur, char* other) {
+    constexpr int G = Q / MPB, R = Q % MPB;
+    constexpr int t = R / (MT * NT), mt = (R / NT) % MT, nt = R % NT;
+    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[G & 1][mt][term_a<NS>(t)], fb[G & 1][nt][term_b<NS>(t)], acc[mt][nt], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (G + 1 < NB && R < RU) {       // next K-block's fragments, >= MPB - RU MFMAs ahead of their first use
+      read_one<G + 1, 2 * R>(cur);
+      read_one<G + 1, 2 * R + 1>(cur);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    constexpr int X0 = Q * St::UNITS / NM, X1 = (Q + 1) * St::UNITS / NM;
+    unit_range<S, X0>(st, other, std::make_integer_sequence<int, X1 - X0>{});
+  }
+  template <int S, int X0, int... D>
+  __device__ __forceinline__ void unit_range(St& st, char* other, std::integer_sequence<int, D...>) {
+    ((st.template unit<S, X0 + D>(other), __builtin_amdgcn_sched_barrier(0)), ...);
+  }
+  template <int S, int... Q>
+  __device__ __forceinline__ void slots(f32x16 (&acc)[MT][NT], St& st, const char* cur, char* other, std::integer_sequence<int, Q...>) {
+    (slot<S, Q>(acc, st, cur, other), ...);
+  }
+  template <int S>
+  __device__ __forceinline__ void run(f32x16 (&acc)[MT][NT], St& st, const char* cur, char* other) {
+    read_block<0>(cur, std::make_integer_sequence<int, NFR>{});
+    __builtin_amdgcn_sched_barrier(0);
+    slots<S>(acc, st, cur, other, std::make_integer_sequence<int, NM>{});
+  }
+};
+
 // two resident blocks per CU (=> <= 256 registers) whenever two of them fit in the 160 KB of LDS
 constexpr int bf_blocks_per_cu(int ns, int bm, int bn, int sub) { return 2 * (2 * sub * ns * (bm + bn) * ROWB) <= 160 * 1024 ? 2 : 1; }
 
@@ -187,7 +310,7 @@ template <int EPI, int NS, int BM, int BN, int SUB>
 __global__ __launch_bounds__(256, bf_blocks_per_cu(NS, BM, BN, SUB)) void conv_gemm_bf_kernel(const GemmArgs a) {
   using St = StagerBF<NS, BM, BN, SUB>;
   constexpr int MT = BM / 64, NT = BN / 64;
-  constexpr int A_PLANE = St::A_PLANE, B_PLANE = St::B_PLANE, SUBSTAGE = St::SUBSTAGE, STAGE = SUB * SUBSTAGE;
+  constexpr int A_PLANE = St::A_PLANE, STAGE = SUB * St::SUBSTAGE;
   extern __shared__ __attribute__((aligned(16))) char smem_bf[];   // [2][STAGE]
 
   const int tid = threadIdx.x;
@@ -220,56 +343,20 @@ __global__ __launch_bounds__(256, bf_blocks_per_cu(NS, BM, BN, SUB)) void conv_g
   const int a_row = (wm0 + frow) * ROWB;
   const int b_row = NS * A_PLANE + (wn0 + frow) * ROWB;
 
-  // MFMAs of one step on one LDS stage: all fragments of a sub-step are read up front, then the MFMAs run back to back
-  auto compute = [&](const char* stage) {
-#pragma unroll
-    for (int u = 0; u < SUB; ++u) {
-      const char* cA = stage + u * SUBSTAGE + a_row;
-      const char* cB = stage + u * SUBSTAGE + b_row;
-      bf16x8 fa[2][MT][NS], fb[2][NT][NS];
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        const int ko = kb ? ko1 : ko0;
-#pragma unroll
-        for (int pl = 0; pl < NS; ++pl) {
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) fa[kb][mt][pl] = *reinterpret_cast<const bf16x8*>(cA + pl * A_PLANE + mt * 32 * ROWB + ko);
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) fb[kb][nt][pl] = *reinterpret_cast<const bf16x8*>(cB + pl * B_PLANE + nt * 32 * ROWB + ko);
-        }
-      }
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int o = NS - 1; o >= 0; --o)     // smallest terms first
-#pragma unroll
-          for (int i = 0; i <= o; ++i)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-              for (int nt = 0; nt < NT; ++nt)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kb][mt][i], fb[kb][nt][o - i], acc[mt][nt], 0, 0, 0);
-    }
-  };
-
-  // Pipeline: registers hold steps j+1 (loaded a whole step ago, split + stored into the other LDS stage during step j)
-  // and j+2 (just issued); LDS holds steps j and j+1.  Global latency gets a full step of MFMAs to land.
+  // Pipeline: registers hold steps j+1 (loaded a whole step ago; split + stored into the other LDS stage during step j)
+  // and j+2 (issued during step j); LDS holds steps j and j+1; one barrier per step.
   char* const stage0 = smem_bf;
   char* const stage1 = smem_bf + STAGE;
+  KStep<EPI, NS, BM, BN, SUB> ks{a_row, b_row, ko0, ko1};
   st.template load_all<0>();
   st.template load_all<1>();
-  st.template store<0>(stage0);
+  st.template store_all<0>(stage0);
   __syncthreads();
-  const bool do_load = !(a.dbg & 1), do_store = !(a.dbg & 2), do_mma = !(a.dbg & 4);
   for (int step = 0; step < nsteps; step += 2) {
-    if (do_load) st.template load_all<0>();            // step + 2
-    if (do_mma) compute(stage0);                       // step
-    if (do_store) st.template store<1>(stage1);        // step + 1
+    ks.template run<0>(acc, st, stage0, stage1);   // MFMAs on stage0, loads -> set 0, set 1 -> stage1
     __syncthreads();
     if (step + 1 >= nsteps) break;
-    if (do_load) st.template load_all<1>();            // step + 3
-    if (do_mma) compute(stage1);                       // step + 1
-    if (do_store) st.template store<0>(stage0);        // step + 2
+    ks.template run<1>(acc, st, stage1, stage0);
     __syncthreads();
   }
   epilogue<MT, NT, EPI, 0, 16>(a, acc, m0 + wm0, n0 + wn0, lane, 0);
@@ -326,10 +413,15 @@ int launch_bf(const GemmArgs& a0, int epi, int nsplit, hipStream_t st) {
   int cfg = g_bf_cfg % 10;
   a.dbg = g_bf_cfg / 10;
   if (cfg == 0) {
-    const long long blocks128 = ((a.M + 127) / 128) * ((a.b_rows + 127) / 128);
+    // Measured on MI355X (scripts/conv_bench.py, batch 1 and 8, RAFT update-block shapes).  The kernels are bound by LDS
+    // traffic (ds_write_b128 moves ~80 B/clk/CU), so the biggest tile that still fills the chip wins; three planes only
+    // fit two resident blocks per CU up to 128x64.
+    const long long tm = (a.M + 127) / 128;
+    const long long b2 = tm * ((a.b_rows + 63) / 64), b3 = tm * ((a.b_rows + 127) / 128);
     const int pad128 = (a.b_rows + 127) / 128 * 128;
-    if (blocks128 < 2 * 256) cfg = 1;                                   // small grids: more, smaller tiles
-    else cfg = (pad128 - a.b_rows) * 5 > a.b_rows ? 2 : 3;               // > 20 % padded columns with BN = 128
+    if (nsplit == 3) cfg = b2 >= 160 ? 2 : 1;
+    else if (b3 >= 2 * 256) cfg = (pad128 - a.b_rows) * 10 > a.b_rows ? 2 : 3;   // > 10 % padded columns at BN = 128
+    else cfg = b2 >= 400 ? 2 : 1;
   }
   switch (nsplit) {
     case 1: return launch_bf_ns<1>(a, epi, cfg, st);
