@@ -53,7 +53,7 @@ enum pfk_status {
 };
 
 #define PFK_MAX_LEVELS 8
-#define PFK_ABI_VERSION 1
+#define PFK_ABI_VERSION 2
 
 int pfk_abi_version(void);
 const char* pfk_status_string(int status);
@@ -92,7 +92,7 @@ typedef struct {
 } pfk_lookup_desc;
 int pfk_corr_lookup_f32(const pfk_lookup_desc* d, pfk_stream_t stream);
 
-/* ---- K4-K6: stride-1 "same" convolution as an implicit GEMM on fp32 MFMA ---------------------
+/* ---- K4-K6: "same"-padded convolution (stride 1, or s for the encoders) as an implicit GEMM on fp32 MFMA ----
  * out[p][co] = epilogue( bias[co] + sum_{s, ky, kx, c} src[s][p + (ky-kh/2)*W + (kx-kw/2)][c]
  *                                                    * weight[co][k(s,ky,kx,c)] )
  * Input channels may come from up to 3 pixel-major sources (the reference's torch.cat operands).
@@ -117,7 +117,7 @@ typedef struct {
   pfk_conv_src src[3];
   int num_src;
   int B, H, W;
-  int kh, kw;            /* odd; padding kh/2, kw/2; stride 1 */
+  int kh, kw;            /* odd; padding kh/2, kw/2 */
   const float* weight;   /* packed [cout][ktot] */
   const float* bias;     /* [cout] or NULL */
   int cout;
@@ -132,6 +132,10 @@ typedef struct {
   float* aux_rh;         /* [M][Ch] */
   const float* residual; /* LINEAR only, optional: added after relu/scale (GMA's `fmap + gamma*out`, gma_utils.py:111) */
   int residual_ld;
+  int stride;            /* 0 or 1: "same" convolution; s > 1: output (yo, xo) reads input (yo*s + ky - kh/2, xo*s + kx - kw/2),
+                            Ho = (H-1)/s + 1, Wo = (W-1)/s + 1 (= PyTorch's Conv2d(k, stride=s, padding=k/2)); H, W are the
+                            INPUT dims, sources have B*H*W rows, out / h / aux / residual have B*Ho*Wo rows */
+  int relu_after_residual; /* LINEAR only: relu once more after the residual add (ResidualBlock, raft/extractor.py:53-61) */
   void* workspace;       /* optional: >= pfk_conv_workspace_bytes() of device memory, 16-byte aligned, private to
                             the stream; enables the stream-K schedule for small grids (deterministic).  NULL: tile grid */
   long long workspace_bytes;
@@ -198,6 +202,28 @@ int pfk_altcorr_forward_f32(const float* fmap1, const float* fmap2, const float*
 int pfk_altcorr_backward_f32(const float* fmap1, const float* fmap2, const float* coords,
                              const float* corr_grad, float* fmap1_grad, float* fmap2_grad, int B, int H1,
                              int W1, int H2, int W2, int C, int radius, pfk_stream_t stream);
+
+/* ---- encoder pieces (ptlflow/models/raft/extractor.py:122-194 BasicEncoder) -----------------
+ * The residual blocks' 3x3 / 1x1 convolutions (stride 1 and 2) are pfk_conv2d_f32 / pfk_conv2d_bf16s with `stride`
+ * and `relu_after_residual`; eval-mode BatchNorm is folded into their weights by the caller.  What is left:
+ *
+ * stem = Conv2d(3, cout, 7, stride=2, padding=3) (extractor.py:146) read from the NCHW image:
+ * img [B][3][H][W]; weight packed [49][3][cout] (tap ky*7+kx major); out pixel-major [B*Ho*Wo][out_ld], Ho=(H-1)/2+1. */
+int pfk_conv_stem_f32(const float* img, const float* weight, const float* bias, float* out, int out_ld, int B,
+                      int H, int W, int cout, int relu, pfk_stream_t stream);
+
+/* InstanceNorm2d statistics (extractor.py:136-140; affine=False, biased variance, eps inside the sqrt) over
+ * pixel-major x[B*HW][ld], channels [0, C): mean[b*C+c], rstd[b*C+c].  Deterministic two-pass reduction; needs
+ * pfk_instnorm_workspace_bytes(B, C) of device scratch. */
+long long pfk_instnorm_workspace_bytes(int B, int C);
+int pfk_instnorm_stats_f32(const float* x, int ld, int B, int HW, int C, float eps, float* mean, float* rstd,
+                           void* workspace, long long workspace_bytes, pfk_stream_t stream);
+
+/* out = relu?((x - mean) * rstd) ; if residual: out = relu?(residual + out)   — norm + relu (+ the ResidualBlock's
+ * `relu(x + y)`, extractor.py:53-61) in one pass.  out may alias x. */
+int pfk_norm_apply_f32(const float* x, int x_ld, const float* mean, const float* rstd, const float* residual,
+                       int residual_ld, float* out, int out_ld, int B, int HW, int C, int relu,
+                       int relu_after_residual, pfk_stream_t stream);
 
 /* NCHW [B][C][H][W] -> pixel-major [B*H*W][ld] (+ channel offset) and back. */
 int pfk_nchw_to_pm_f32(const float* in, float* out, int out_ld, int out_coff, int B, int C,

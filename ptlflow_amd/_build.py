@@ -35,6 +35,7 @@ HIP_SOURCES = [
     ("pfk_corr.hip", ["-ffp-contract=off"]),  # index-exact coordinate arithmetic
     ("pfk_misc.hip", ["-ffp-contract=off"]),
     ("pfk_altcorr.hip", []),
+    ("pfk_encoder.hip", []),
 ]
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
              f"-I{INCLUDE}", f"-I{CSRC}", "-Wall", "-Wno-unused-function"]

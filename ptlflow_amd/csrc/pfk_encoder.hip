@@ -1,0 +1,219 @@
+// Feature / context encoder pieces that are not implicit-GEMM convolutions (reference:
+// ptlflow/models/raft/extractor.py:122-194 BasicEncoder):
+//   * the stem: Conv2d(3, C, 7, stride 2, padding 3) read straight from the NCHW image (K = 147 is too thin for the
+//     32-channel K-steps of the MFMA kernels), VALU FMA kernel, output pixel-major;
+//   * instance-norm statistics (two-pass mean / variance per (image, channel), deterministic: per-chunk partials
+//     reduced in a fixed order, no atomics);
+//   * normalise + relu (+ residual add + relu) elementwise pass.
+// The 3x3 / 1x1 convolutions of the residual blocks (stride 1 and 2) run on pfk_conv2d_f32 / pfk_conv2d_bf16s;
+// batch-norm in eval mode is folded into their weights by the host (ptlflow_amd/encoder.py).
+#include "pfk_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------------------------
+// Stem.  One workgroup = 32 consecutive output pixels of one output row x all output channels; thread = one channel x
+// 8 pixels.  The 3 x 7 x 69 input patch (zero padding applied here) is staged once in LDS with row-contiguous loads;
+// per (channel, ky) a thread pulls its 21 patch columns into registers (LDS broadcast reads: the 64 lanes of a wave
+// share them) and reuses them across the 7 kx, so the inner loop is 56 FMAs per 7 coalesced weight loads.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int STEM_K = 7, STEM_R = 3, STEM_TP = 32, STEM_NP = 8;
+constexpr int STEM_PW = 2 * STEM_TP + STEM_K - 2;   // 69 input columns feed 32 stride-2 outputs
+
+__global__ __launch_bounds__(256) void conv_stem_kernel(const float* __restrict__ img, const float* __restrict__ wgt,
+                                                        const float* __restrict__ bias, float* __restrict__ out,
+                                                        int out_ld, int H, int W, int Ho, int Wo, int tiles_per_row,
+                                                        int cout, int relu) {
+  __shared__ float sp[3][STEM_K][STEM_PW + 3];
+  const int tile = blockIdx.x;
+  const int orow = tile / tiles_per_row;           // b*Ho + yo
+  const int xo0 = (tile - orow * tiles_per_row) * STEM_TP;
+  const int yo = orow % Ho;
+  const int b = orow / Ho;
+  const int iy0 = 2 * yo - STEM_R, ix0 = 2 * xo0 - STEM_R;
+  const float* src = img + (long long)b * 3 * H * W;
+  for (int e = threadIdx.x; e < 3 * STEM_K * STEM_PW; e += 256) {
+    const int ci = e / (STEM_K * STEM_PW);
+    const int r = e - ci * (STEM_K * STEM_PW);
+    const int ky = r / STEM_PW, xx = r - ky * STEM_PW;
+    const int gy = iy0 + ky, gx = ix0 + xx;
+    float v = 0.f;
+    if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) v = src[((long long)ci * H + gy) * W + gx];
+    sp[ci][ky][xx] = v;
+  }
+  __syncthreads();
+  const int g = threadIdx.x >> 6;                  // pixel group: 8 outputs
+  for (int c = threadIdx.x & 63; c < cout; c += 64) {
+    float acc[STEM_NP];
+    const float b0 = bias ? bias[c] : 0.f;
+#pragma unroll
+    for (int p = 0; p < STEM_NP; ++p) acc[p] = b0;
+#pragma unroll 1   // a fully unrolled body hoists all 147 weight loads: 512 VGPRs and scratch
+    for (int ky = 0; ky < STEM_K; ++ky) {
+#pragma unroll 1
+      for (int ci = 0; ci < 3; ++ci) {
+        float v[2 * STEM_NP + STEM_K - 2];
+#pragma unroll
+        for (int j = 0; j < 2 * STEM_NP + STEM_K - 2; ++j) v[j] = sp[ci][ky][2 * STEM_NP * g + j];
+#pragma unroll
+        for (int kx = 0; kx < STEM_K; ++kx) {
+          const float w = wgt[((ky * STEM_K + kx) * 3 + ci) * cout + c];
+#pragma unroll
+          for (int p = 0; p < STEM_NP; ++p) acc[p] = fmaf(v[2 * p + kx], w, acc[p]);
+        }
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < STEM_NP; ++p) {
+      const int xo = xo0 + g * STEM_NP + p;
+      if (xo < Wo) {
+        float r = acc[p];
+        if (relu) r = (r < 0.f) ? 0.f : r;
+        out[((long long)orow * Wo + xo) * out_ld + c] = r;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Instance-norm statistics over pixel-major x[B*HW][ld], channels [0, C), C % 4 == 0.
+// Pass 1: per (image, chunk) partial sums; pass 2: partial sums of (x - mean)^2 with the mean re-derived from pass 1's
+// partials in a fixed order; finalize: mean, rstd = 1/sqrt(var_biased + eps)  (F.instance_norm, extractor.py:136-140).
+// A thread owns 4 consecutive channels (float4) and every (256 / (C/4))-th row of the chunk.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int IN_CHUNKS = 32;
+
+template <bool CENTERED>
+__global__ __launch_bounds__(256) void instnorm_partial_kernel(const float* __restrict__ x, int ld, int C, int HW,
+                                                               const float* __restrict__ sums, float* __restrict__ part) {
+  __shared__ f32x4 red[256];
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int tpr = C >> 2;                   // threads per row
+  const int rpi = 256 / tpr;                // rows per iteration
+  const int t = threadIdx.x;
+  const int c4 = (t % tpr) * 4, rr = t / tpr;
+  const bool active = rr < rpi;
+  const int rows = (HW + IN_CHUNKS - 1) / IN_CHUNKS;
+  const int r0 = chunk * rows, r1 = min(HW, r0 + rows);
+  f32x4 mean = {0.f, 0.f, 0.f, 0.f};
+  if (CENTERED && active) {
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < IN_CHUNKS; ++k) s += *reinterpret_cast<const f32x4*>(sums + ((long long)b * IN_CHUNKS + k) * C + c4);
+    mean = s / (float)HW;
+  }
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (active) {
+    const float* base = x + (long long)b * HW * ld + c4;
+    for (int r = r0 + rr; r < r1; r += rpi) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(base + (long long)r * ld);
+      if (CENTERED) { v -= mean; acc += v * v; }
+      else acc += v;
+    }
+  }
+  red[t] = acc;
+  __syncthreads();
+  if (t < tpr) {
+    f32x4 s = red[t];
+    for (int k = 1; k < rpi; ++k) s += red[t + k * tpr];
+    *reinterpret_cast<f32x4*>(part + ((long long)b * IN_CHUNKS + chunk) * C + c4) = s;
+  }
+}
+
+__global__ void instnorm_finalize_kernel(const float* __restrict__ sums, const float* __restrict__ sq, int C, int HW,
+                                         float eps, float* __restrict__ mean, float* __restrict__ rstd, int total) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;   // b*C + c
+  if (i >= total) return;
+  const int b = i / C, c = i - b * C;
+  float s = 0.f, q = 0.f;
+  for (int k = 0; k < IN_CHUNKS; ++k) {
+    s += sums[((long long)b * IN_CHUNKS + k) * C + c];
+    q += sq[((long long)b * IN_CHUNKS + k) * C + c];
+  }
+  mean[i] = s / (float)HW;
+  rstd[i] = 1.0f / sqrtf(q / (float)HW + eps);
+}
+
+// y = (x - mean) * rstd ; relu? ; [y = residual + y ; relu?]   (float4 per thread)
+__global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict__ x, int x_ld, const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd, const float* __restrict__ residual,
+                                                         int res_ld, float* __restrict__ out, int out_ld, long long M, int HW,
+                                                         int C, int relu, int relu_after) {
+  const int tpr = C >> 2;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long p = idx / tpr;
+  if (p >= M) return;
+  const int c4 = (int)(idx - p * tpr) * 4;
+  const long long sidx = (p / HW) * C + c4;
+  const f32x4 m = *reinterpret_cast<const f32x4*>(mean + sidx);
+  const f32x4 r = *reinterpret_cast<const f32x4*>(rstd + sidx);
+  f32x4 v = *reinterpret_cast<const f32x4*>(x + p * x_ld + c4);
+  v = (v - m) * r;
+  if (relu) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (v[e] < 0.f) ? 0.f : v[e];
+  }
+  if (residual != nullptr) {
+    v = *reinterpret_cast<const f32x4*>(residual + p * res_ld + c4) + v;
+    if (relu_after) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (v[e] < 0.f) ? 0.f : v[e];
+    }
+  }
+  *reinterpret_cast<f32x4*>(out + p * out_ld + c4) = v;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pfk_conv_stem_f32(const float* img, const float* weight, const float* bias, float* out, int out_ld, int B,
+                      int H, int W, int cout, int relu, pfk_stream_t stream) {
+  if (!img || !weight || !out || B <= 0 || H <= 0 || W <= 0 || cout <= 0 || out_ld < cout) return PFK_ERR_BAD_ARG;
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const int tpr = (Wo + STEM_TP - 1) / STEM_TP;
+  const long long tiles = (long long)B * Ho * tpr;
+  if (tiles > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(conv_stem_kernel, dim3((unsigned)tiles), dim3(256), 0, static_cast<hipStream_t>(stream), img, weight,
+                     bias, out, out_ld, H, W, Ho, Wo, tpr, cout, relu);
+  return pfk_launch_status();
+}
+
+long long pfk_instnorm_workspace_bytes(int B, int C) { return (long long)B * IN_CHUNKS * C * 2 * (long long)sizeof(float); }
+
+int pfk_instnorm_stats_f32(const float* x, int ld, int B, int HW, int C, float eps, float* mean, float* rstd,
+                           void* workspace, long long workspace_bytes, pfk_stream_t stream) {
+  if (!x || !mean || !rstd || !workspace || B <= 0 || HW <= 0 || C <= 0 || ld < C) return PFK_ERR_BAD_ARG;
+  if ((C & 3) || (ld & 3) || C > 1024 || !pfk_aligned16(x) || !pfk_aligned16(workspace) || !pfk_aligned16(mean) ||
+      !pfk_aligned16(rstd))
+    return PFK_ERR_ALIGNMENT;
+  if (workspace_bytes < pfk_instnorm_workspace_bytes(B, C)) return PFK_ERR_BAD_ARG;
+  float* sums = static_cast<float*>(workspace);
+  float* sq = sums + (size_t)B * IN_CHUNKS * C;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  dim3 grid(IN_CHUNKS, (unsigned)B);
+  hipLaunchKernelGGL(instnorm_partial_kernel<false>, grid, dim3(256), 0, st, x, ld, C, HW, nullptr, sums);
+  hipLaunchKernelGGL(instnorm_partial_kernel<true>, grid, dim3(256), 0, st, x, ld, C, HW, sums, sq);
+  const int total = B * C;
+  hipLaunchKernelGGL(instnorm_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, st, sums, sq, C, HW, eps, mean,
+                     rstd, total);
+  return pfk_launch_status();
+}
+
+int pfk_norm_apply_f32(const float* x, int x_ld, const float* mean, const float* rstd, const float* residual,
+                       int residual_ld, float* out, int out_ld, int B, int HW, int C, int relu,
+                       int relu_after_residual, pfk_stream_t stream) {
+  if (!x || !mean || !rstd || !out || B <= 0 || HW <= 0 || C <= 0 || x_ld < C || out_ld < C) return PFK_ERR_BAD_ARG;
+  if ((C & 3) || (x_ld & 3) || (out_ld & 3) || !pfk_aligned16(x) || !pfk_aligned16(out) || !pfk_aligned16(mean) ||
+      !pfk_aligned16(rstd))
+    return PFK_ERR_ALIGNMENT;
+  if (residual && (residual_ld < C || (residual_ld & 3) || !pfk_aligned16(residual))) return PFK_ERR_ALIGNMENT;
+  const long long M = (long long)B * HW;
+  const long long threads = M * (C >> 2);
+  const long long blocks = (threads + 255) / 256;
+  if (blocks > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(norm_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, x_ld,
+                     mean, rstd, residual, residual_ld, out, out_ld, M, HW, C, relu, relu_after_residual);
+  return pfk_launch_status();
+}
+
+}  // extern "C"

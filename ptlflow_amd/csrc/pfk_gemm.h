@@ -10,7 +10,9 @@ struct GemmArgs {
   int ld0, ld1, ld2;
   int ch0, ch1, ch2;
   int nsrc;
-  int H, W;            // image dims for tap bounds (M = B*H*W rows, batch folded into M)
+  int H, W;            // input image dims for tap bounds (sources have B*H*W rows)
+  int Ho, Wo, stride;  // output dims (M = B*Ho*Wo rows, batch folded into M); output (yo, xo) reads input (yo*stride + dy, xo*stride + dx)
+  int relu2;           // LINEAR: relu again after the residual add (the residual blocks of raft/extractor.py)
   int kh, kw;
   const float* weight; // [b_rows][ktot]
   const float* bias;
@@ -67,6 +69,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& a, const f32x16 (&acc)[
           if (a.relu) v = (v < 0.f) ? 0.f : v;  // NaN-propagating like torch.relu (fmaxf would drop NaN)
           v *= a.scale;
           if (a.residual != nullptr) v = a.residual[p * a.residual_ld + n] + v;
+          if (a.relu2) v = (v < 0.f) ? 0.f : v;
           outp[p * a.out_ld + a.out_coff + n] = v;
         } else if constexpr (EPI == PFK_EPI_GRU_ZR) {
           const int ch = a.ch_hidden;

@@ -81,9 +81,10 @@ struct Stager {
     for (int i = 0; i < A_PT; ++i) {
       const long long p = m0 + r0 + 32 * i;
       pok[i] = p < a.M;
-      prow[i] = (int)p;
-      px[i] = (int)(p % a.W);
-      py[i] = (int)((p / a.W) % a.H);
+      const long long prow_o = p / a.Wo;                       // b*Ho + yo
+      px[i] = (int)(p - prow_o * a.Wo) * a.stride;             // input coordinates of the centre tap
+      py[i] = (int)(prow_o % a.Ho) * a.stride;
+      prow[i] = (int)(((prow_o / a.Ho) * a.H + py[i]) * a.W + px[i]);
     }
 #pragma unroll
     for (int i = 0; i < B_PT; ++i) {
@@ -751,14 +752,17 @@ int desc_to_args(const pfk_conv_desc* d, GemmArgs& a, int kpad) {
   if (d->num_src > 1) { a.src1 = s[1].ptr; a.ld1 = s[1].ld; a.ch1 = s[1].channels; }
   if (d->num_src > 2) { a.src2 = s[2].ptr; a.ld2 = s[2].ld; a.ch2 = s[2].channels; }
   a.nsrc = d->num_src;
+  const int stride = d->stride > 0 ? d->stride : 1;
   a.H = d->H; a.W = d->W; a.kh = d->kh; a.kw = d->kw;
+  a.stride = stride; a.Ho = (d->H - 1) / stride + 1; a.Wo = (d->W - 1) / stride + 1;
+  a.relu2 = d->relu_after_residual;
   a.bias = d->bias; a.b_rows = d->cout;
   a.ktot = conv_ktot(d, kpad);
   a.relu = d->relu; a.scale = d->scale;
-  a.M = (long long)d->B * d->H * d->W;
+  a.M = (long long)d->B * a.Ho * a.Wo;
   a.sk_steps = a.ktot / kpad;
   for (int i = 0; i < d->num_src; ++i)   // kernels address sources with 32-bit byte offsets
-    if (a.M * s[i].ld * 4 >= 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
+    if ((long long)d->B * d->H * d->W * s[i].ld * 4 >= 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
   switch (d->epilogue) {
     case PFK_EPI_LINEAR:
       if (!d->out || d->out_ld < d->out_coff + d->cout) return PFK_ERR_BAD_ARG;
@@ -836,7 +840,7 @@ int pfk_corr_volume_f32(const float* f1, int ld1, const float* f2, int ld2, floa
   if ((long long)N1 * ld1 * 4 >= 0x7fffffffLL || (long long)N2 * ld2 * 4 >= 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
   GemmArgs a{};
   a.src0 = f1; a.ld0 = ld1; a.ch0 = D; a.nsrc = 1;
-  a.H = 1; a.W = N1; a.kh = 1; a.kw = 1;
+  a.H = 1; a.W = N1; a.Ho = 1; a.Wo = N1; a.stride = 1; a.kh = 1; a.kw = 1;
   a.weight = f2; a.bias = nullptr; a.b_rows = N2; a.ktot = ld2;
   a.relu = 0; a.scale = scale;
   a.out = out; a.out_ld = N2; a.out_coff = 0;

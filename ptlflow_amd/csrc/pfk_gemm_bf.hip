@@ -67,9 +67,10 @@ struct StagerBF {
     for (int i = 0; i < A_PT; ++i) {
       const long long p = m0 + r0 + 64 * i;
       pok[i] = p < a.M;
-      prow[i] = (int)p;
-      px[i] = (int)(p % a.W);
-      py[i] = (int)((p / a.W) % a.H);
+      const long long prow_o = p / a.Wo;                       // b*Ho + yo
+      px[i] = (int)(p - prow_o * a.Wo) * a.stride;             // input coordinates of the centre tap
+      py[i] = (int)(prow_o % a.Ho) * a.stride;
+      prow[i] = (int)(((prow_o / a.Ho) * a.H + py[i]) * a.W + px[i]);
     }
 #pragma unroll
     for (int i = 0; i < B_PT; ++i) {

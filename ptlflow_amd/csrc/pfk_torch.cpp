@@ -86,13 +86,17 @@ void conv2d(at::TensorList srcs, int64_t B, int64_t H, int64_t W, int64_t kh, in
             const Tensor& weight, const c10::optional<Tensor>& bias, int64_t cout, int64_t epilogue,
             bool relu, double scale, const c10::optional<Tensor>& out, const c10::optional<Tensor>& h,
             const c10::optional<Tensor>& aux_z, const c10::optional<Tensor>& aux_rh,
-            const c10::optional<Tensor>& workspace, const c10::optional<Tensor>& residual) {
+            const c10::optional<Tensor>& workspace, const c10::optional<Tensor>& residual, int64_t stride,
+            bool relu_after_residual) {
   TORCH_CHECK(srcs.size() >= 1 && srcs.size() <= 3, "conv2d: 1..3 sources");
+  TORCH_CHECK(stride >= 1, "conv2d: stride");
   pfk_conv_desc d{};
-  const int64_t M = B * H * W;
+  d.stride = (int)stride;
+  d.relu_after_residual = relu_after_residual;
+  const int64_t M = B * ((H - 1) / stride + 1) * ((W - 1) / stride + 1);   // output rows
   for (size_t i = 0; i < srcs.size(); ++i) {
     check_pm(srcs[i], "src");
-    TORCH_CHECK(srcs[i].size(0) == M, "conv2d: src rows != B*H*W");
+    TORCH_CHECK(srcs[i].size(0) == B * H * W, "conv2d: src rows != B*H*W");
     d.src[i].ptr = fptr(srcs[i]); d.src[i].ld = srcs[i].stride(0); d.src[i].channels = srcs[i].size(1);
   }
   d.num_src = srcs.size();
@@ -250,6 +254,45 @@ void pm_to_cm(const Tensor& in, Tensor out) {
   check_ok(pfk_pm_to_cm_f32(fptr(in), in.stride(0), fptr(out), out.stride(1), B, C, N, cur_stream()), "pm_to_cm");
 }
 
+void conv_stem(const Tensor& img, const Tensor& weight, const c10::optional<Tensor>& bias, Tensor out, bool relu) {
+  check_dev_f32(img, "img"); check_dev_f32(weight, "weight"); check_pm(out, "out");
+  TORCH_CHECK(img.dim() == 4 && img.size(1) == 3 && img.is_contiguous(), "conv_stem: img [B,3,H,W] contiguous");
+  const int B = img.size(0), H = img.size(2), W = img.size(3), cout = out.size(1);
+  TORCH_CHECK(weight.is_contiguous() && weight.numel() == 49 * 3 * cout, "conv_stem: weight [49,3,cout]");
+  TORCH_CHECK(out.size(0) == (int64_t)B * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1), "conv_stem: out rows");
+  const float* b = nullptr;
+  if (bias.has_value()) { check_dev_f32(*bias, "bias"); TORCH_CHECK(bias->numel() == cout && bias->is_contiguous()); b = fptr(*bias); }
+  check_ok(pfk_conv_stem_f32(fptr(img), fptr(weight), b, fptr(out), out.stride(0), B, H, W, cout, relu, cur_stream()), "conv_stem");
+}
+
+int64_t instnorm_workspace_bytes(int64_t B, int64_t C) { return pfk_instnorm_workspace_bytes((int)B, (int)C); }
+
+void instnorm_stats(const Tensor& x, int64_t B, int64_t HW, double eps, Tensor mean, Tensor rstd, Tensor workspace) {
+  check_pm(x, "x"); check_dev_f32(mean, "mean"); check_dev_f32(rstd, "rstd");
+  const int C = x.size(1);
+  TORCH_CHECK(x.size(0) == B * HW, "instnorm_stats: rows");
+  TORCH_CHECK(mean.is_contiguous() && rstd.is_contiguous() && mean.numel() == B * C && rstd.numel() == B * C, "instnorm_stats: mean/rstd [B*C]");
+  TORCH_CHECK(workspace.is_cuda() && workspace.is_contiguous(), "instnorm_stats: workspace");
+  check_ok(pfk_instnorm_stats_f32(fptr(x), x.stride(0), (int)B, (int)HW, C, (float)eps, fptr(mean), fptr(rstd),
+                                  workspace.data_ptr(), (long long)workspace.nbytes(), cur_stream()), "instnorm_stats");
+}
+
+void norm_apply(const Tensor& x, const Tensor& mean, const Tensor& rstd, const c10::optional<Tensor>& residual, Tensor out,
+                int64_t B, int64_t HW, bool relu, bool relu_after_residual) {
+  check_pm(x, "x"); check_pm(out, "out"); check_dev_f32(mean, "mean"); check_dev_f32(rstd, "rstd");
+  const int C = x.size(1);
+  TORCH_CHECK(x.size(0) == B * HW && out.size(0) == B * HW && out.size(1) == C, "norm_apply: shapes");
+  TORCH_CHECK(mean.numel() == B * C && rstd.numel() == B * C, "norm_apply: mean/rstd [B*C]");
+  const float* r = nullptr; int r_ld = 0;
+  if (residual.has_value()) {
+    check_pm(*residual, "residual");
+    TORCH_CHECK(residual->size(0) == B * HW && residual->size(1) == C, "norm_apply: residual shape");
+    r = fptr(*residual); r_ld = residual->stride(0);
+  }
+  check_ok(pfk_norm_apply_f32(fptr(x), x.stride(0), fptr(mean), fptr(rstd), r, r_ld, fptr(out), out.stride(0), (int)B, (int)HW, C,
+                              relu, relu_after_residual, cur_stream()), "norm_apply");
+}
+
 int64_t abi_version() { return pfk_abi_version(); }
 int64_t conv_workspace_bytes() { return pfk_conv_workspace_bytes(); }
 void debug_set_tile(int64_t cfg) { pfk_debug_set_tile((int)cfg); }
@@ -258,13 +301,18 @@ void debug_set_tile(int64_t cfg) { pfk_debug_set_tile((int)cfg); }
 
 TORCH_LIBRARY(pfk, m) {
   m.def("abi_version() -> int", &abi_version);
+  m.def("instnorm_workspace_bytes(int B, int C) -> int", &instnorm_workspace_bytes);
+  m.def("conv_stem(Tensor img, Tensor weight, Tensor? bias, Tensor(a!) out, bool relu) -> ()");
+  m.def("instnorm_stats(Tensor x, int B, int HW, float eps, Tensor(a!) mean, Tensor(b!) rstd, Tensor(c!) workspace) -> ()");
+  m.def("norm_apply(Tensor x, Tensor mean, Tensor rstd, Tensor? residual, Tensor(a!) out, int B, int HW, bool relu, "
+        "bool relu_after_residual) -> ()");
   m.def("debug_set_tile(int cfg) -> ()", &debug_set_tile);
   m.def("corr_volume(Tensor f1, Tensor f2, float scale, Tensor(a!) out) -> ()");
   m.def("corr_pool2x2(Tensor inp, Tensor(a!) out) -> ()");
   m.def("corr_lookup(Tensor[] levels, Tensor coords, int radius, Tensor(a!) out) -> ()");
   m.def("conv2d(Tensor[] srcs, int B, int H, int W, int kh, int kw, Tensor weight, Tensor? bias, int cout, "
         "int epilogue, bool relu, float scale, Tensor(a!)? out, Tensor(b!)? h, Tensor(c!)? aux_z, Tensor(d!)? aux_rh, "
-        "Tensor(e!)? workspace=None, Tensor? residual=None) -> ()");
+        "Tensor(e!)? workspace=None, Tensor? residual=None, int stride=1, bool relu_after_residual=False) -> ()");
   m.def("conv_workspace_bytes() -> int", &conv_workspace_bytes);
   m.def("conv_cin2(Tensor inp, Tensor weight, Tensor? bias, Tensor(a!) out, int B, int H, int W, int k, bool relu) -> ()");
   m.def("flow_delta(Tensor inp, Tensor weight, Tensor? bias, Tensor coords0, Tensor(a!) coords1, Tensor(b!)? delta_out, "
@@ -294,4 +342,7 @@ TORCH_LIBRARY_IMPL(pfk, CUDA, m) {
   m.impl("nchw_to_pm", &nchw_to_pm);
   m.impl("pm_to_nchw", &pm_to_nchw);
   m.impl("pm_to_cm", &pm_to_cm);
+  m.impl("conv_stem", &conv_stem);
+  m.impl("instnorm_stats", &instnorm_stats);
+  m.impl("norm_apply", &norm_apply);
 }

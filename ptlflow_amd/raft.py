@@ -114,9 +114,14 @@ def _param_tree(shapes: Dict[str, tuple]) -> nn.Module:
 # ----------------------------------------------------------------------------- model
 class RAFT(nn.Module):
     def __init__(self, corr_levels: int = 4, corr_radius: Optional[int] = None, iters: int = 32, small: bool = False,
-                 upsample_every_iter: bool = True, conv_precision: str = "fp32"):
+                 upsample_every_iter: bool = True, conv_precision: str = "fp32", native_encoders: bool = True):
         super().__init__()
         self.small = small
+        # True: fnet / cnet run on libpfk kernels (ptlflow_amd/encoder.py; BasicEncoder only — raft_small's bottleneck
+        # encoder stays on torch/MIOpen); False: torch modules (MIOpen) as in round-1's first cut
+        self.native_encoders = native_encoders and not small
+        self._enc = None
+        self._enc_versions = None
         # "fp32" (default: fp32 matrix cores, the parity path) | "bf16x6" | "bf16x3" | "bf16": split-bf16 operands
         # for the update block's convolutions (include/pfk.h, pfk_conv2d_bf16s)
         self.conv_precision = conv_precision
@@ -165,6 +170,18 @@ class RAFT(nn.Module):
         self._versions = v
         return self._engine
 
+    def encoders(self, device):
+        """(fnet, cnet) callables: EncoderEngine pair on libpfk kernels, or the torch modules."""
+        if not self.native_encoders:
+            return self.fnet, self.cnet
+        from .encoder import EncoderEngine
+        v = tuple((p.data_ptr(), p._version) for m in (self.fnet, self.cnet) for p in list(m.parameters()) + list(m.buffers()))
+        if self._enc is None or self._enc[0].device != device or v != self._enc_versions:
+            self._enc = (EncoderEngine(self.fnet.state_dict(), "instance", device, self.conv_precision),
+                         EncoderEngine(self.cnet.state_dict(), "batch", device, self.conv_precision))
+            self._enc_versions = v
+        return self._enc
+
     # -- pre/post-processing (raft.py:127-135 -> base_model.py:207-247; utils/external/raft.py:57-84)
     @staticmethod
     def _pads(ht: int, wd: int, stride: int = 8):
@@ -199,9 +216,10 @@ class RAFT(nn.Module):
         image1, image2 = x[:, 0], x[:, 1]
         B = image1.shape[0]
 
-        fm = self.fnet(torch.cat([image1, image2], 0))
+        fnet, cnet_fn = self.encoders(x.device)
+        fm = fnet(torch.cat([image1, image2], 0))
         corr_fn = CorrBlock(fm[:B], fm[B:], num_levels=self.corr_levels, radius=self.corr_radius)
-        cnet = self.cnet(image1)
+        cnet = cnet_fn(image1)
         net, inp = torch.split(cnet, [self.hidden_dim, self.context_dim], dim=1)
         net, inp = torch.tanh(net), torch.relu(inp)
 

@@ -254,8 +254,13 @@ class UpdateEngine:
 
     def load_state(self, net: torch.Tensor, inp: torch.Tensor) -> None:
         """NCHW ``net`` / ``inp`` -> their hx slices (once per forward)."""
-        self.ops.nchw_to_pm(net.float().contiguous(), self.h_view)
-        self.ops.nchw_to_pm(inp.float().contiguous(), self.inp_view)
+        B, H, W = self._shape
+        for src, dst in ((net, self.h_view), (inp, self.inp_view)):
+            src = src.float()
+            if src.is_contiguous():       # NCHW producer (torch encoders, the drop-in seam): tiled transpose kernel
+                self.ops.nchw_to_pm(src, dst)
+            else:                         # channels-last producer (the native encoders): rows are already pixel-major
+                dst.view(B, H, W, dst.shape[1]).copy_(src.permute(0, 2, 3, 1))
 
     # ------------------------------------------------------------------ one iteration
     def _conv(self, srcs: List[torch.Tensor], kh, kw, key, cout, relu=True, scale=1.0, out=None,
