@@ -421,7 +421,7 @@ int launch_bf(const GemmArgs& a0, int epi, int nsplit, hipStream_t st) {
     const long long b2 = tm * ((a.b_rows + 63) / 64), b3 = tm * ((a.b_rows + 127) / 128);
     const int pad128 = (a.b_rows + 127) / 128 * 128;
     if (nsplit == 3) cfg = b2 >= 160 ? 2 : 1;
-    else if (b3 >= 2 * 256) cfg = (pad128 - a.b_rows) * 10 > a.b_rows ? 2 : 3;   // > 10 % padded columns at BN = 128
+    else if (b3 >= 384) cfg = (pad128 - a.b_rows) * 10 > a.b_rows ? 2 : 3;       // > 10 % padded columns at BN = 128
     else cfg = b2 >= 400 ? 2 : 1;
   }
   switch (nsplit) {

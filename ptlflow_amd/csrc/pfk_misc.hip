@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void conv_cin2_tiled_kernel(const float* __res
     const float b0 = bias ? bias[c] : 0.f;
 #pragma unroll
     for (int p = 0; p < NP; ++p) acc[p] = b0;
-#pragma unroll
+#pragma unroll 1   // unrolling ky as well hoists all K*K*2 weight loads (326 VGPRs at K = 7: one wave per SIMD)
     for (int ky = 0; ky < K; ++ky) {
       float fx[NP + K - 1], fy[NP + K - 1];
 #pragma unroll
