@@ -137,3 +137,45 @@ class EncoderEngine:
             h, w = _out(h, stride), _out(w, stride)
         y = self._conv(x, B, h, w, 1, "out", self.out_dim)
         return y.view(B, h, w, self.out_dim).permute(0, 3, 1, 2)
+
+
+class PfkEncoder(torch.nn.Module):
+    """Drop-in for ``model.fnet`` / ``model.cnet`` of a live ptlflow model (``BasicEncoder``, raft/extractor.py:122-194):
+    same ``forward(x)`` contract (a tensor, or a list of two images that is batched and split again, :172-193), same
+    parameters — the reference sub-modules are re-registered under their own names, so state_dict keys, checkpoints and
+    optimizers are untouched.  GPU inference goes to ``EncoderEngine``; training mode, gradient graphs, CPU tensors and
+    GroupNorm stay on the reference's own code."""
+
+    def __init__(self, ref: torch.nn.Module, conv_precision: str = "fp32"):
+        super().__init__()
+        for name, child in ref.named_children():
+            self.add_module(name, child)
+        self._ref = [ref]   # in a list: not registered twice in the module tree
+        self.norm_fn = ref.norm_fn
+        self.conv_precision = conv_precision
+        self._engine: Optional[EncoderEngine] = None
+        self._versions = None
+
+    def _get_engine(self, device) -> EncoderEngine:
+        ref = self._ref[0]
+        v = tuple((t.data_ptr(), t._version) for t in list(ref.parameters()) + list(ref.buffers()))
+        if self._engine is None or self._engine.device != device or v != self._versions:
+            self._engine = EncoderEngine(ref.state_dict(), self.norm_fn, device, self.conv_precision)
+            self._versions = v
+        return self._engine
+
+    def forward(self, x):
+        ref = self._ref[0]
+        is_list = isinstance(x, (tuple, list))
+        probe = x[0] if is_list else x
+        needs_graph = torch.is_grad_enabled() and (probe.requires_grad or any(p.requires_grad for p in ref.parameters()))
+        ref.training = self.training   # .train() / .eval() reach this wrapper and the shared children, not `ref` itself
+        if self.training or needs_graph or not probe.is_cuda or self.norm_fn not in ("instance", "batch", "none"):
+            return ref(x)
+        if is_list:
+            batch_dim = x[0].shape[0]
+            x = torch.cat(list(x), dim=0)
+        y = self._get_engine(x.device)(x)
+        if is_list:
+            y = torch.split(y, [batch_dim, batch_dim], dim=0)
+        return y

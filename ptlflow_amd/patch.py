@@ -10,7 +10,8 @@ What gets replaced:
   (`from .corr import get_corr_block`, raft.py:10, gma.py, sea_raft.py, ccmr.py, ms_raft_plus.py), so the
   patch target is the *model module's* global, not `corr.py`;
 * seam B3 — ``model.update_block`` is wrapped by `PfkUpdateBlock`, which keeps the original sub-modules
-  (state_dict keys, checkpoints and optimizers are untouched) and only overrides ``forward``.
+  (state_dict keys, checkpoints and optimizers are untouched) and only overrides ``forward``;
+* seam B4 — ``model.fnet`` / ``model.cnet`` (`BasicEncoder`) are wrapped by `PfkEncoder` the same way.
 
 Nothing in ptlflow is edited or copied; `restore(model)` undoes the patch.
 """
@@ -52,7 +53,7 @@ def _make_corr_hook(module_name: str, original):
 
 
 def accelerate(model: torch.nn.Module, corr: bool = True, update_block: bool = True,
-               conv_precision: str = "fp32") -> torch.nn.Module:
+               conv_precision: str = "fp32", encoders: bool = True) -> torch.nn.Module:
     """Patch seams B1/B3 of a ptlflow model instance in place and return it.
 
     ``conv_precision``: "fp32" (default, the parity path) or a split-bf16 mode of the update block's convolutions
@@ -70,6 +71,13 @@ def accelerate(model: torch.nn.Module, corr: bool = True, update_block: bool = T
         if factory is not None:
             spec: UpdateSpec = factory(model)
             model.update_block = PfkUpdateBlock(ub, spec, conv_precision)
+    if encoders:
+        # seam B4: the BasicEncoder feature / context networks (raft, gma, ... : `self.fnet`, `self.cnet`)
+        from .encoder import PfkEncoder
+        for attr in ("fnet", "cnet"):
+            enc = getattr(model, attr, None)
+            if enc is not None and type(enc).__name__ == "BasicEncoder" and getattr(enc, "norm_fn", None) in ("instance", "batch", "none"):
+                setattr(model, attr, PfkEncoder(enc, conv_precision))
     return model
 
 
@@ -81,4 +89,9 @@ def restore(model: torch.nn.Module) -> torch.nn.Module:
     ub = getattr(model, "update_block", None)
     if isinstance(ub, PfkUpdateBlock):
         model.update_block = ub._ref[0]
+    from .encoder import PfkEncoder
+    for attr in ("fnet", "cnet"):
+        enc = getattr(model, attr, None)
+        if isinstance(enc, PfkEncoder):
+            setattr(model, attr, enc._ref[0])
     return model

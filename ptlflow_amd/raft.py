@@ -80,6 +80,7 @@ class Encoder(nn.Module):
     def __init__(self, output_dim: int, norm_fn: str, small: bool):
         super().__init__()
         dims = (32, 32, 64, 96) if small else (64, 64, 96, 128)
+        self.norm_fn = norm_fn
         self.norm1 = _make_norm(norm_fn, dims[0])
         self.conv1 = nn.Conv2d(3, dims[0], 7, stride=2, padding=3)
         cin = dims[0]

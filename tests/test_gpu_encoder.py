@@ -125,3 +125,31 @@ def test_raft_torch_encoders_still_work(gpu):
     fa, fb = a({"images": x})["flows"], b({"images": x})["flows"]
     mean, mx = O.epe(fa[:, 0].cpu(), fb[:, 0].cpu())
     assert mean <= 1e-3 and mx <= 1e-2, f"EPE mean {mean:.2e} max {mx:.2e}"
+
+
+@pytest.mark.parametrize("kind", ["instance", "batch"])
+def test_pfk_encoder_wrapper_contract(gpu, kind):
+    """Seam B4: PfkEncoder around a BasicEncoder-shaped module — list-of-two-images contract (extractor.py:172-193),
+    state_dict keys unchanged, eval GPU inference on the kernels, training mode deferred to the wrapped module."""
+    from ptlflow_amd.encoder import PfkEncoder
+    from ptlflow_amd.raft import Encoder
+    ref = Encoder(256, kind, False)
+    ref.load_state_dict(_encoder_params(kind, 256, seed=21))
+    ref = ref.cuda().eval()
+    wrapped = PfkEncoder(ref, "fp32")
+    assert set(wrapped.state_dict()) == set(ref.state_dict())
+    x = (O.smooth_pair(2, 64, 96, seed=8) - 0.5) * 2.0
+    P = {k: v.cpu() for k, v in ref.state_dict().items()}
+    want1, want2 = O.encoder(P, x[:, 0], kind), O.encoder(P, x[:, 1], kind)
+    with torch.no_grad():
+        f1, f2 = wrapped([x[:, 0].cuda(), x[:, 1].cuda()])
+    scale = float(want1.abs().max())
+    if kind == "instance":      # per-image statistics: batching the two frames changes nothing
+        close(f1, want1, rtol=2e-4, atol=2e-4 * scale)
+        close(f2, want2, rtol=2e-4, atol=2e-4 * scale)
+    else:
+        close(f1, want1, rtol=2e-4, atol=2e-4 * scale)
+    assert wrapped._engine is not None
+    wrapped.train()
+    out = wrapped(x[:, 0].cuda())         # training mode: the wrapped module's own forward (autograd graph intact)
+    assert out.requires_grad

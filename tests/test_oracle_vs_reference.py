@@ -62,7 +62,7 @@ def test_mirror_state_dict_is_checkpoint_compatible(small):
 
 
 def test_patch_accelerate_keeps_checkpoint_keys_and_restores():
-    """Seams B1/B3 on the live reference model: patch, check the hooks landed where raft.py binds them,
+    """Seams B1/B3/B4 on the live reference model: patch, check the hooks landed where raft.py binds them,
     check state_dict keys are unchanged, check the CPU path still runs through the reference's own code
     (the hook only diverts GPU inference), restore."""
     import sys
@@ -79,8 +79,14 @@ def test_patch_accelerate_keeps_checkpoint_keys_and_restores():
         patch.accelerate(ref)
     except Exception as e:  # libs not built in this checkout
         pytest.skip(f"native libs unavailable: {e}")
+    from ptlflow_amd.encoder import PfkEncoder
     assert mod.get_corr_block is not orig_fn and isinstance(ref.update_block, PfkUpdateBlock)
+    assert isinstance(ref.fnet, PfkEncoder) and isinstance(ref.cnet, PfkEncoder)      # seam B4
     assert set(ref.state_dict()) == keys
+    xe = torch.randn(1, 3, 32, 48)
+    with torch.no_grad():   # CPU tensors: the encoder wrapper defers to the reference module, list contract included
+        a, b = ref.fnet([xe, xe])
+        assert torch.equal(a, ref.fnet._ref[0]([xe, xe])[0]) and torch.allclose(a, b, atol=1e-5)
     # CPU tensors: corr hook falls through to the reference; update block wrapper refuses (no CPU fallback)
     cb = mod.get_corr_block(torch.randn(1, 8, 16, 16), torch.randn(1, 8, 16, 16), num_levels=4, radius=4)
     assert type(cb).__module__.startswith("ptlflow.models.raft")
@@ -89,6 +95,7 @@ def test_patch_accelerate_keeps_checkpoint_keys_and_restores():
             ref({"images": x.clone()})
     patch.restore(ref)
     assert mod.get_corr_block is orig_fn and not isinstance(ref.update_block, PfkUpdateBlock)
+    assert not isinstance(ref.fnet, PfkEncoder) and not isinstance(ref.cnet, PfkEncoder)
     with torch.no_grad():
         assert torch.equal(ref({"images": x.clone()})["flows"], before)
 
