@@ -203,6 +203,13 @@ int pfk_altcorr_backward_f32(const float* fmap1, const float* fmap2, const float
                              const float* corr_grad, float* fmap1_grad, float* fmap2_grad, int B, int H1,
                              int W1, int H2, int W2, int C, int radius, pfk_stream_t stream);
 
+/* ---- warm start (second half) -------------------------------------------------------------------
+ * forward_interpolate (ptlflow/utils/external/raft.py:155-185, batched by utils/utils.py:454-478): flow [B][2][H][W] ->
+ * out [B][2][H][W]: every grid point takes the flow of the nearest forward-projected pixel that lands strictly inside the
+ * image (float64 distances, exact ties to the lowest source index; all-invalid -> 0).  Replaces the reference's per-sample
+ * host round trip through scipy.interpolate.griddata. */
+int pfk_forward_interpolate_f32(const float* flow, float* out, int B, int H, int W, pfk_stream_t stream);
+
 /* ---- encoder pieces (ptlflow/models/raft/extractor.py:122-194 BasicEncoder) -----------------
  * The residual blocks' 3x3 / 1x1 convolutions (stride 1 and 2) are pfk_conv2d_f32 / pfk_conv2d_bf16s with `stride`
  * and `relu_after_residual`; eval-mode BatchNorm is folded into their weights by the caller.  What is left:

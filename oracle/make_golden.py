@@ -149,6 +149,32 @@ def golden_gma():
     torch.save(out, os.path.join(OUT, "gma.pt"))
 
 
+def golden_warm_start():
+    """forward_interpolate (utils/external/raft.py:155-185, scipy griddata on the host) on random and structured flows,
+    and a warm-started RAFT forward (`prev_preds`, raft.py:162-167)."""
+    ext = ref_loader.ref_module("ptlflow.utils.external.raft")
+    gen = torch.Generator().manual_seed(61)
+    cases = {}
+    for tag, h, w, scale in (("55x128_s6", 55, 128, 6.0), ("20x33_s3", 20, 33, 3.0), ("16x24_s40_mostly_outside", 16, 24, 40.0)):
+        f = torch.randn(2, h, w, generator=gen) * scale
+        cases[tag] = {"flow": f, "out": ext.forward_interpolate(f)}
+    f = torch.zeros(2, 12, 20)
+    f[0] = 2.25
+    f[1] = -1.5
+    cases["12x20_constant"] = {"flow": f, "out": ext.forward_interpolate(f)}
+    ref = ref_loader.build_raft(small=False, iters=4)
+    shapes = {k: tuple(v.shape) for k, v in ref.state_dict().items() if not k.startswith("train_metrics")}
+    ref.load_state_dict(synth_state_dict(shapes, seed=63), strict=False)
+    x = O.smooth_pair(1, 128, 160, seed=65)
+    with torch.no_grad():
+        first = ref({"images": x.clone()})
+        second = ref({"images": x.clone(), "prev_preds": {"flow_small": first["flow_small"].clone()}})
+    out = {"interp": cases,
+           "forward": {"seed": 63, "shapes": shapes, "iters": 4, "images": x, "prev_flow_small": first["flow_small"].clone(),
+                       "flows": second["flows"].clone(), "flow_small": second["flow_small"].clone()}}
+    torch.save(out, os.path.join(OUT, "warm_start.pt"))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(4)
@@ -156,6 +182,7 @@ def main():
     golden_update()
     golden_forward()
     golden_gma()
+    golden_warm_start()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
 

@@ -415,6 +415,35 @@ def encoder(P: Params, x: Tensor, kind: str, small: bool = False) -> Tensor:
 
 
 # --------------------------------------------------------------------------------------
+# warm start                      ptlflow/utils/external/raft.py:155-185, utils/utils.py:454-478
+# --------------------------------------------------------------------------------------
+def forward_interpolate(flow: Tensor) -> Tensor:
+    """RAFT's warm-start projection for one sample ``[2,H,W]`` (utils/external/raft.py:155-185): every pixel is pushed
+    along its flow, the landing points strictly inside the image are kept, and each grid point takes the flow of its
+    NEAREST landing point (`scipy.interpolate.griddata(method="nearest")` = a cKDTree query in float64).  Restated as a
+    brute-force float64 arg-min; exact ties (which the k-d tree breaks by traversal order) go to the lowest source index."""
+    f = flow.detach().cpu().double()
+    ht, wd = f.shape[-2:]
+    ys, xs = torch.meshgrid(torch.arange(ht, dtype=torch.float64), torch.arange(wd, dtype=torch.float64), indexing="ij")
+    x1, y1 = (xs + f[0]).reshape(-1), (ys + f[1]).reshape(-1)
+    valid = (x1 > 0) & (x1 < wd) & (y1 > 0) & (y1 < ht)
+    out = torch.zeros(2, ht * wd, dtype=torch.float64)
+    if bool(valid.any()):
+        px, py = x1[valid], y1[valid]
+        src = torch.nonzero(valid).reshape(-1)
+        qx, qy = xs.reshape(-1, 1), ys.reshape(-1, 1)
+        d2 = (px[None, :] - qx) ** 2 + (py[None, :] - qy) ** 2          # [queries, points]
+        best = src[torch.argmin(d2, dim=1)]                              # argmin returns the first minimum
+        out = f.reshape(2, -1)[:, best]
+    return out.reshape(2, ht, wd).float()
+
+
+def forward_interpolate_batch(prev_flow: Tensor) -> Tensor:
+    """utils/utils.py:454-478."""
+    return torch.stack([forward_interpolate(prev_flow[i]) for i in range(prev_flow.shape[0])], 0).to(prev_flow.dtype)
+
+
+# --------------------------------------------------------------------------------------
 # whole forward                                             ptlflow/models/raft/raft.py:112-194
 # --------------------------------------------------------------------------------------
 def pad_amounts(ht: int, wd: int, stride: int = 8) -> Tuple[int, int, int, int]:
@@ -458,7 +487,7 @@ def upflow8(flow: Tensor) -> Tensor:
 @torch.no_grad()
 def raft_forward(P: Params, images: Tensor, iters: int = 32, small: bool = False,
                  corr_levels: int = 4, corr_radius: Optional[int] = None,
-                 return_trace: bool = False):
+                 return_trace: bool = False, prev_flow_small: Optional[Tensor] = None):
     """RAFT.forward / RAFTSmall.forward in eval mode (raft.py:125-194).
 
     `images`: [B, 2, 3, H, W] in [0, 1], BGR (what the scripts feed the model).
@@ -483,6 +512,8 @@ def raft_forward(P: Params, images: Tensor, iters: int = 32, small: bool = False
     h, w = image1.shape[-2] // 8, image1.shape[-1] // 8
     coords0 = coords_grid(B, h, w, x.dtype)
     coords1 = coords_grid(B, h, w, x.dtype)
+    if prev_flow_small is not None:      # warm start, raft.py:162-167
+        coords1 = coords1 + forward_interpolate_batch(prev_flow_small)
     U = sub(P, "update_block")
     step = small_update_block if small else basic_update_block
     trace = []

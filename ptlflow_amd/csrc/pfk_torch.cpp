@@ -293,6 +293,13 @@ void norm_apply(const Tensor& x, const Tensor& mean, const Tensor& rstd, const c
                               relu, relu_after_residual, cur_stream()), "norm_apply");
 }
 
+void forward_interpolate(const Tensor& flow, Tensor out) {
+  check_dev_f32(flow, "flow"); check_dev_f32(out, "out");
+  TORCH_CHECK(flow.dim() == 4 && flow.size(1) == 2 && flow.is_contiguous() && out.is_contiguous() && out.sizes() == flow.sizes(),
+              "forward_interpolate: flow/out [B,2,H,W] contiguous");
+  check_ok(pfk_forward_interpolate_f32(fptr(flow), fptr(out), flow.size(0), flow.size(2), flow.size(3), cur_stream()), "forward_interpolate");
+}
+
 int64_t abi_version() { return pfk_abi_version(); }
 int64_t conv_workspace_bytes() { return pfk_conv_workspace_bytes(); }
 void debug_set_tile(int64_t cfg) { pfk_debug_set_tile((int)cfg); }
@@ -301,6 +308,7 @@ void debug_set_tile(int64_t cfg) { pfk_debug_set_tile((int)cfg); }
 
 TORCH_LIBRARY(pfk, m) {
   m.def("abi_version() -> int", &abi_version);
+  m.def("forward_interpolate(Tensor flow, Tensor(a!) out) -> ()");
   m.def("instnorm_workspace_bytes(int B, int C) -> int", &instnorm_workspace_bytes);
   m.def("conv_stem(Tensor img, Tensor weight, Tensor? bias, Tensor(a!) out, bool relu) -> ()");
   m.def("instnorm_stats(Tensor x, int B, int HW, float eps, Tensor(a!) mean, Tensor(b!) rstd, Tensor(c!) workspace) -> ()");
@@ -343,6 +351,7 @@ TORCH_LIBRARY_IMPL(pfk, CUDA, m) {
   m.impl("pm_to_nchw", &pm_to_nchw);
   m.impl("pm_to_cm", &pm_to_cm);
   m.impl("conv_stem", &conv_stem);
+  m.impl("forward_interpolate", &forward_interpolate);
   m.impl("instnorm_stats", &instnorm_stats);
   m.impl("norm_apply", &norm_apply);
 }

@@ -230,8 +230,10 @@ class RAFT(nn.Module):
         coords0 = torch.stack([xs, ys], 0)[None].repeat(B, 1, 1, 1).contiguous()
         coords1 = coords0.clone()
         prev = inputs.get("prev_preds")
-        if prev is not None and prev.get("flow_small") is not None:
-            raise NotImplementedError("warm start (forward_interpolate, scipy on host) is outside the accelerated path")
+        if prev is not None and prev.get("flow_small") is not None:      # warm start, raft.py:162-167, on the device
+            fwd = torch.empty_like(coords1)
+            ops.forward_interpolate(prev["flow_small"].to(device=x.device, dtype=torch.float32).contiguous(), fwd)
+            coords1 = coords1 + fwd
 
         eng = self.engine(x.device)
         eng.bind(B, h, w)

@@ -104,3 +104,32 @@ def test_other_baseline_shapes(gpu, H, W, B, iters):
     assert out["flows"].shape == ref["flows"].shape == (B, 1, 2, H, W)
     mean, mx = O.epe(out["flows"][:, 0].cpu(), ref["flows"][:, 0])
     assert mean <= 1e-3 and mx <= 1e-2, f"EPE mean {mean:.2e} max {mx:.2e}"
+
+
+def test_warm_start_kernel_bit_exact(gpu):
+    """pfk_forward_interpolate_f32 vs the reference's scipy result (golden) and vs the oracle on fresh random flows."""
+    import os
+    g = torch.load(os.path.join(os.path.dirname(__file__), "golden", "warm_start.pt"), weights_only=False)
+    for tag, c in g["interp"].items():
+        f = c["flow"][None].contiguous().cuda()
+        out = torch.empty_like(f)
+        torch.ops.pfk.forward_interpolate(f, out)
+        assert torch.equal(out[0].cpu(), c["out"]), tag
+    gen = torch.Generator().manual_seed(5)
+    f = torch.randn(3, 2, 23, 41, generator=gen) * 5
+    out = torch.empty_like(f).cuda()
+    torch.ops.pfk.forward_interpolate(f.cuda(), out)
+    assert torch.equal(out.cpu(), O.forward_interpolate_batch(f))
+
+
+def test_warm_started_forward(gpu):
+    """`prev_preds` warm start (raft.py:162-167) through the device kernel vs the reference's own output (golden)."""
+    import os
+    from ptlflow_amd.raft import RAFT
+    from ptlflow_amd.synth import synth_state_dict
+    g = torch.load(os.path.join(os.path.dirname(__file__), "golden", "warm_start.pt"), weights_only=False)["forward"]
+    model = RAFT(iters=g["iters"]).eval()
+    model.load_state_dict(synth_state_dict(g["shapes"], seed=g["seed"]))
+    out = model.cuda()({"images": g["images"].cuda(), "prev_preds": {"flow_small": g["prev_flow_small"].cuda()}})
+    mean, mx = O.epe(out["flows"][:, 0].cpu(), g["flows"][:, 0])
+    assert mean <= 1e-3 and mx <= 1e-2, f"EPE mean {mean:.2e} max {mx:.2e}"
