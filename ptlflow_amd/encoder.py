@@ -151,6 +151,7 @@ class PfkEncoder(torch.nn.Module):
         for name, child in ref.named_children():
             self.add_module(name, child)
         self._ref = [ref]   # in a list: not registered twice in the module tree
+        self.training = ref.training
         self.norm_fn = ref.norm_fn
         self.conv_precision = conv_precision
         self._engine: Optional[EncoderEngine] = None

@@ -90,9 +90,14 @@ class Encoder(nn.Module):
         self.conv2 = nn.Conv2d(cin, output_dim, 1)
 
     def forward(self, x):
+        is_list = isinstance(x, (tuple, list))      # two frames batched and split again, extractor.py:173-193
+        if is_list:
+            batch_dim = x[0].shape[0]
+            x = torch.cat(list(x), dim=0)
         x = F.relu(self.norm1(self.conv1(x)))
         x = self.layer3(self.layer2(self.layer1(x)))
-        return self.conv2(x)
+        x = self.conv2(x)
+        return torch.split(x, [batch_dim, batch_dim], dim=0) if is_list else x
 
 
 # ----------------------------------------------------------------------------- parameter holder

@@ -346,6 +346,7 @@ class PfkUpdateBlock(torch.nn.Module):
         for name, child in ref_block.named_children():
             self.add_module(name, child)
         self._ref = [ref_block]  # in a list: not registered twice in the module tree
+        self.training = ref_block.training
         self.spec = spec
         self._engine: Optional[UpdateEngine] = None
         self._versions = None
