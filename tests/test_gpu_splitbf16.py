@@ -166,3 +166,30 @@ def test_raft_headline_split_modes(gpu):
     assert res["bf16x6"][0] <= 1e-3 and res["bf16x6"][1] <= 1e-2
     assert res["bf16x3"][0] <= 2e-2
     assert res["bf16"][0] <= 2.0
+
+
+def test_gma_split_modes(gpu):
+    """BASELINE.json configs[2] (gma, shared CorrBlock / GRU path): C_in = 512 SepConvGRU, to_v conv and both encoders on the
+    split kernels; bf16x6 inside the fp32 gate, plain bf16 (what bf16 autocast computes in its convolutions) loosely bounded."""
+    from ptlflow_amd.raft import GMA
+    base = GMA(iters=6).load_synthetic(77).eval()
+    P = {k: v.clone() for k, v in base.state_dict().items()}
+    x = O.smooth_pair(1, 184, 248, seed=9)
+    ref = O.gma_forward(P, x, iters=6)
+    res = {}
+    for prec in ("bf16x6", "bf16x3", "bf16"):
+        m = GMA(iters=6, conv_precision=prec).eval()
+        m.load_state_dict(P)
+        out = m.cuda()({"images": x.cuda()})
+        res[prec] = O.epe(out["flows"][:, 0].cpu(), ref["flows"][:, 0])
+        print(f"gma {prec}: EPE mean {res[prec][0]:.3e} max {res[prec][1]:.3e}")
+    assert res["bf16x6"][0] <= 1e-3 and res["bf16x6"][1] <= 1e-2
+    assert res["bf16x3"][0] <= 1e-2
+    assert res["bf16"][0] <= 2.0
+
+
+def test_kitti_shape_split(gpu):
+    """BASELINE.json configs[3] shape (1242x375 -> 47x156 grid, 7332 pixels per image: partial 128-row tiles), batch 2."""
+    res = _epe(["bf16x6", "bf16x3"], 375, 1242, 4)
+    assert res["bf16x6"][0] <= 1e-3 and res["bf16x6"][1] <= 1e-2
+    assert res["bf16x3"][0] <= 1e-2
