@@ -45,6 +45,7 @@ class EncoderEngine:
         self.device = device
         self.nsplit = CONV_PRECISIONS[conv_precision]
         self._ws: Optional[torch.Tensor] = None
+        self.max_matrix_bytes = 2 ** 31 - 1   # 32-bit byte offsets in the convolution kernels
         self.pack(params)
 
     # ------------------------------------------------------------------ weights
@@ -127,6 +128,11 @@ class EncoderEngine:
         img = img.float().contiguous()
         B, _, H, W = img.shape
         H1, W1 = _out(H, 2), _out(W, 2)
+        # the convolution kernels address a source with 32-bit byte offsets: keep every activation matrix under 2 GiB
+        per_image = H1 * W1 * 128 * 4
+        max_b = max(1, self.max_matrix_bytes // per_image)
+        if B > max_b:
+            return torch.cat([self(img[i:i + max_b]) for i in range(0, B, max_b)], 0)
         x = torch.empty(B * H1 * W1, self.stem_dim, device=self.device, dtype=torch.float32)
         self.ops.conv_stem(img, self.w["stem.w"], self.w["stem.b"], x, self.norm != "instance")
         if self.norm == "instance":

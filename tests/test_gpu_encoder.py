@@ -116,6 +116,17 @@ def test_basic_encoder(gpu, kind, B, H, W, precision, tol):
     close(out, ref, rtol=tol, atol=tol * scale)
 
 
+def test_encoder_batch_chunking(gpu):
+    """Batches whose activation matrices would exceed the kernels' 32-bit byte offsets are processed in chunks."""
+    from ptlflow_amd.encoder import EncoderEngine
+    P = _encoder_params("instance", 256, seed=13)
+    x = ((O.smooth_pair(3, 64, 96, seed=6)[:, 0]) - 0.5) * 2.0
+    eng = EncoderEngine(P, "instance", gpu)
+    whole = eng(x.cuda())
+    eng.max_matrix_bytes = 32 * 48 * 128 * 4          # one image per chunk
+    assert torch.equal(eng(x.cuda()), whole)
+
+
 def test_raft_torch_encoders_still_work(gpu):
     """native_encoders=False keeps the torch (MIOpen) encoders: same flow within the EPE gate."""
     from ptlflow_amd.raft import RAFT
