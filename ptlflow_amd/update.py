@@ -245,7 +245,9 @@ class UpdateEngine:
             if prof is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            self.ops.conv2d([src], 1, H, W, 1, 1, self.vT[b], None, mc, EPI_LINEAR, False, self.gamma,
+            # split modes: V^T changes every iteration, so its bf16 planes are cut here (three tiny elementwise kernels)
+            vt = self.vT[b] if self.nsplit == 0 else split_bf16_planes(self.vT[b], self.nsplit)
+            self.ops.conv2d([src], 1, H, W, 1, 1, vt, None, mc, EPI_LINEAR, False, self.gamma,
                             self.hx[rows, o + mc: o + 2 * mc], None, None, None, self.workspace, self.hx[rows, o: o + mc])
             if prof is not None:
                 e1.record()
@@ -347,6 +349,7 @@ class PfkUpdateBlock(torch.nn.Module):
             self.add_module(name, child)
         self._ref = [ref_block]  # in a list: not registered twice in the module tree
         self.training = ref_block.training
+        self.native_backward = True   # False: calls that need a gradient graph go to the wrapped reference module
         self.spec = spec
         self._engine: Optional[UpdateEngine] = None
         self._versions = None
@@ -368,7 +371,13 @@ class PfkUpdateBlock(torch.nn.Module):
     def forward(self, net, inp, corr, flow, attention=None):
         extra = () if attention is None else (attention,)
         if torch.is_grad_enabled() and (net.requires_grad or any(p.requires_grad for p in self.parameters())):
-            # training graph: the reference module keeps doing its own job (backward kernels are SURVEY §8 f4)
+            # training graph: every convolution forward / dgrad / wgrad on the MFMA kernel through the
+            # differentiable composition of ptlflow_amd/train.py; GMA's aggregate branch, CPU tensors and split-bf16
+            # modes keep the reference module's own autograd
+            if self.native_backward and net.is_cuda and not self.spec.aggregate and self.conv_precision == "fp32":
+                from .train import update_block_train
+                h, mask, delta = update_block_train(dict(self.named_parameters()), self.spec, net, inp, corr, flow)
+                return h.to(net.dtype), (None if mask is None else mask.to(net.dtype)), delta.to(net.dtype)
             return self._ref[0](net, inp, corr, flow, *extra)
         with torch.no_grad():
             return self._forward_kernels(net, inp, corr, flow, attention)
