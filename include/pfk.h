@@ -203,6 +203,17 @@ int pfk_altcorr_backward_f32(const float* fmap1, const float* fmap2, const float
                              const float* corr_grad, float* fmap1_grad, float* fmap2_grad, int B, int H1,
                              int W1, int H2, int W2, int C, int radius, pfk_stream_t stream);
 
+/* ---- weight gradient of the convolution above (torch.autograd of every nn.Conv2d in raft/update.py) ---
+ * dw_packed[co][k(s,tap,c)] = sum_p dy[p][co] * src_s[p + tap][c]   — the packed [cout][ktot] layout of pfk_conv2d_f32's weight.
+ * `d` describes the forward convolution (sources, B, H, W, kh, kw, cout; stride 1; weight/out/epilogue fields ignored);
+ * dy [B*H*W][dy_ld] is the gradient w.r.t. the convolution output, cout % 4 == 0.  The reduction runs over pixels, cut
+ * into slices whose partial results go through `workspace` (pfk_conv_wgrad_workspace_bytes(d) bytes, 16-byte aligned; may
+ * be NULL when that is 0) and are added in a fixed order: deterministic, no atomics.  (The data gradient needs no entry
+ * point of its own: it is pfk_conv2d_f32 of dy with the spatially flipped, transposed weight.) */
+long long pfk_conv_wgrad_workspace_bytes(const pfk_conv_desc* d);
+int pfk_conv_wgrad_f32(const pfk_conv_desc* d, const float* dy, int dy_ld, float* dw_packed, void* workspace,
+                       long long workspace_bytes, pfk_stream_t stream);
+
 /* ---- warm start (second half) -------------------------------------------------------------------
  * forward_interpolate (ptlflow/utils/external/raft.py:155-185, batched by utils/utils.py:454-478): flow [B][2][H][W] ->
  * out [B][2][H][W]: every grid point takes the flow of the nearest forward-projected pixel that lands strictly inside the

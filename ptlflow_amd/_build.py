@@ -36,6 +36,7 @@ HIP_SOURCES = [
     ("pfk_misc.hip", ["-ffp-contract=off"]),
     ("pfk_altcorr.hip", []),
     ("pfk_encoder.hip", []),
+    ("pfk_wgrad.hip", []),
 ]
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
              f"-I{INCLUDE}", f"-I{CSRC}", "-Wall", "-Wno-unused-function"]

@@ -705,8 +705,7 @@ int launch(const GemmArgs& a, int epi, int batches, hipStream_t st) {
     // >= 3 tiles per CU: the swizzled 48 KB layout (cfg 10) keeps three blocks resident; below that the padded rows'
     // immediate-offset fragment reads are a few % faster (cfg 4).
     // few output tiles, very long K (the weight-gradient GEMMs: K = all pixels of the batch): only stream-K fills the chip
-    const bool sk_long = a.sk_ws != nullptr && batches == 1 && blocks64 <= 256 && a.sk_steps >= 128 &&
-                         blocks64 * a.sk_steps >= 6LL * 512;
+    const bool sk_long = a.sk_ws != nullptr && batches == 1 && blocks64 <= 256 && a.sk_steps >= 128;
     cfg = (sk || sk_long) ? 9 : (a.sk_steps < 16 ? 0 : (blocks64 >= 3 * 256 ? 10 : 4));
   }
   switch (cfg) {

@@ -300,6 +300,28 @@ void forward_interpolate(const Tensor& flow, Tensor out) {
   check_ok(pfk_forward_interpolate_f32(fptr(flow), fptr(out), flow.size(0), flow.size(2), flow.size(3), cur_stream()), "forward_interpolate");
 }
 
+// weight gradient in the packed [cout, ktot] layout; dy [M, cout] (cout % 4 == 0)
+void conv_wgrad(at::TensorList srcs, const Tensor& dy, int64_t B, int64_t H, int64_t W, int64_t kh, int64_t kw, Tensor out) {
+  TORCH_CHECK(srcs.size() >= 1 && srcs.size() <= 3, "conv_wgrad: 1..3 sources");
+  check_pm(dy, "dy"); check_dev_f32(out, "out");
+  pfk_conv_desc d{};
+  const int64_t M = B * H * W;
+  for (size_t i = 0; i < srcs.size(); ++i) {
+    check_pm(srcs[i], "src");
+    TORCH_CHECK(srcs[i].size(0) == M, "conv_wgrad: src rows != B*H*W");
+    d.src[i].ptr = fptr(srcs[i]); d.src[i].ld = srcs[i].stride(0); d.src[i].channels = srcs[i].size(1);
+  }
+  d.num_src = srcs.size();
+  d.B = B; d.H = H; d.W = W; d.kh = kh; d.kw = kw; d.cout = dy.size(1);
+  TORCH_CHECK(dy.size(0) == M, "conv_wgrad: dy rows != B*H*W");
+  TORCH_CHECK(out.is_contiguous() && out.dim() == 2 && out.size(0) == d.cout && out.size(1) == pfk_conv_ktot(&d), "conv_wgrad: out [cout, ktot]");
+  const long long need = pfk_conv_wgrad_workspace_bytes(&d);
+  Tensor ws;
+  void* wsp = nullptr;
+  if (need > 0) { ws = at::empty({(int64_t)need}, dy.options().dtype(at::kByte)); wsp = ws.data_ptr(); }
+  check_ok(pfk_conv_wgrad_f32(&d, fptr(dy), dy.stride(0), fptr(out), wsp, need, cur_stream()), "conv_wgrad");
+}
+
 int64_t abi_version() { return pfk_abi_version(); }
 int64_t conv_workspace_bytes() { return pfk_conv_workspace_bytes(); }
 void debug_set_tile(int64_t cfg) { pfk_debug_set_tile((int)cfg); }
@@ -308,6 +330,7 @@ void debug_set_tile(int64_t cfg) { pfk_debug_set_tile((int)cfg); }
 
 TORCH_LIBRARY(pfk, m) {
   m.def("abi_version() -> int", &abi_version);
+  m.def("conv_wgrad(Tensor[] srcs, Tensor dy, int B, int H, int W, int kh, int kw, Tensor(a!) out) -> ()");
   m.def("forward_interpolate(Tensor flow, Tensor(a!) out) -> ()");
   m.def("instnorm_workspace_bytes(int B, int C) -> int", &instnorm_workspace_bytes);
   m.def("conv_stem(Tensor img, Tensor weight, Tensor? bias, Tensor(a!) out, bool relu) -> ()");
@@ -351,6 +374,7 @@ TORCH_LIBRARY_IMPL(pfk, CUDA, m) {
   m.impl("pm_to_nchw", &pm_to_nchw);
   m.impl("pm_to_cm", &pm_to_cm);
   m.impl("conv_stem", &conv_stem);
+  m.impl("conv_wgrad", &conv_wgrad);
   m.impl("forward_interpolate", &forward_interpolate);
   m.impl("instnorm_stats", &instnorm_stats);
   m.impl("norm_apply", &norm_apply);

@@ -1,0 +1,202 @@
+// Weight gradient of the implicit-GEMM convolution: the transposed product
+//
+//   dW[co][k] = sum_p dY[p][co] * A[p][k],     A[p][k = (source, tap, channel)] = src_s[p + tap][c]  (zero outside the image)
+//
+// on the fp32 matrix cores, straight from the pixel-major tensors of the forward pass — no im2col, no transposes.  The
+// reduction index is the PIXEL: a K-step is 32 consecutive pixels, staged as they lie in memory (dY: 32 rows x 128 output
+// channels, A: 32 rows x 32 input channels of one (source, tap, chunk), with the tap's zero padding done by out-of-range
+// buffer offsets exactly as in the forward kernel).  v_mfma_f32_32x32x2_f32 wants A[i = co][k = pixel] and B[k = pixel][j = c]:
+// lane l reads LDS element [pixel 2j + (l >> 5)][l & 31] with ds_read_b32 — each half-wave reads 32 consecutive floats of
+// one row, conflict-free — one read pair per MFMA.
+//
+// Grid: (cout/128 tiles) x (ktot/32 chunks) x (pixel splits).  The output has few tiles and a very long reduction
+// (zr of RAFT: 2 x 60 tiles, 22 816+ pixels), so the pixel range is cut into `splits` slices that write partial tiles to a
+// workspace; a second kernel adds the slices in a fixed order (deterministic, no atomics) into the packed [cout][ktot]
+// layout of the forward weight.
+#include "pfk_common.h"
+
+namespace {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB = 0x80000000u;
+
+struct WgradArgs {
+  const float* src0; const float* src1; const float* src2;
+  int ld0, ld1, ld2, ch0, ch1, ch2, nsrc;
+  const float* dy; int dy_ld; int cout;
+  int H, W, kh, kw;
+  long long M;
+  float* part;            // [splits][cout][ktot]  (== the output when splits == 1)
+  int ktot, chunks, tiles_m;
+  long long px_per_split; // multiple of 32
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
+}
+
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
+  __shared__ __attribute__((aligned(16))) float sY[2][32][128];
+  __shared__ __attribute__((aligned(16))) float sX[2][32][32];
+
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+  const int chunk = blockIdx.x % a.chunks;
+  const int tile_m = blockIdx.x / a.chunks;
+  const int split = blockIdx.y;
+  const int co0 = tile_m * 128;
+
+  // chunk -> (source, tap, first channel): same enumeration as the forward kernel's K iterator
+  const int taps = a.kh * a.kw;
+  int r = chunk, cps = (a.ch0 + 31) >> 5;
+  const float* src = a.src0; int ld = a.ld0, cch = a.ch0;
+  if (a.nsrc > 1 && r >= taps * cps) {
+    r -= taps * cps; cps = (a.ch1 + 31) >> 5; src = a.src1; ld = a.ld1; cch = a.ch1;
+    if (a.nsrc > 2 && r >= taps * cps) { r -= taps * cps; cps = (a.ch2 + 31) >> 5; src = a.src2; ld = a.ld2; cch = a.ch2; }
+  }
+  const int tap = r / cps, c0 = (r - tap * cps) * 32;
+  const int dy_ = tap / a.kw - (a.kh >> 1), dx_ = tap % a.kw - (a.kw >> 1);
+
+  const __amdgpu_buffer_rsrc_t rsx = rsrc_of(src), rsy = rsrc_of(a.dy);
+  const long long p_begin = (long long)split * a.px_per_split;
+  const long long p_end = min(a.M, p_begin + a.px_per_split);
+  const int steps = p_end > p_begin ? (int)((p_end - p_begin + 31) >> 5) : 0;
+
+  // this thread stages row (t >> 3) of every step: float4 q of the A chunk, float4 q + 8*i of the dY tile
+  const int row = t >> 3, q = t & 7;
+  long long p = p_begin + row;
+  int x = (int)(p % a.W), y = (int)((p / a.W) % a.H);
+  const bool c_ok = c0 + q * 4 < cch;
+  const int tap_off = (dy_ * a.W + dx_) * ld + c0 + q * 4;
+  bool yok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) yok[i] = co0 + q * 4 + 32 * i < a.cout;
+
+  u32x4 rx, ry[4];
+  auto load = [&](void) {
+    const bool in = p < p_end;
+    const bool ok = in && c_ok && (unsigned)(y + dy_) < (unsigned)a.H && (unsigned)(x + dx_) < (unsigned)a.W;
+    rx = __builtin_amdgcn_raw_buffer_load_b128(rsx, ok ? (unsigned)((int)p * ld + tap_off) * 4u : OOB, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      ry[i] = __builtin_amdgcn_raw_buffer_load_b128(rsy, (in && yok[i]) ? (unsigned)((int)p * a.dy_ld + co0 + q * 4 + 32 * i) * 4u : OOB, 0, 0);
+    p += 32;
+    x += 32;
+    while (x >= a.W) { x -= a.W; if (++y == a.H) y = 0; }
+  };
+  auto store = [&](int buf) {
+    *reinterpret_cast<u32x4*>(&sX[buf][row][q * 4]) = rx;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(&sY[buf][row][q * 4 + 32 * i]) = ry[i];
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+
+  if (steps > 0) {
+    load();
+    store(0);
+  }
+  __syncthreads();
+  const int l31 = lane & 31, hl = lane >> 5;
+  for (int s = 0; s < steps; ++s) {
+    const int buf = s & 1;
+    const bool more = s + 1 < steps;
+    if (more) load();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float av = sY[buf][2 * j + hl][wid * 32 + l31];
+      const float bv = sX[buf][2 * j + hl][l31];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+    if (more) store(buf ^ 1);
+    __syncthreads();
+  }
+
+  // D: column j = lane & 31 (input channel), rows i = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) (output channel)
+  float* out = a.part + (long long)split * a.cout * a.ktot;
+  const int kcol = chunk * 32 + l31;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int co = co0 + wid * 32 + (e & 3) + 8 * (e >> 2) + 4 * hl;
+    if (co < a.cout) out[(long long)co * a.ktot + kcol] = acc[e];
+  }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                           long long n, int splits) {
+  const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= n) return;
+  f32x4 s = *reinterpret_cast<const f32x4*>(part + i);
+  for (int k = 1; k < splits; ++k) s += *reinterpret_cast<const f32x4*>(part + (long long)k * n + i);
+  *reinterpret_cast<f32x4*>(out + i) = s;
+}
+
+int pick_splits(long long tiles, long long M) {
+  long long s = 1024 / (tiles > 0 ? tiles : 1);
+  const long long max_s = M / 512 > 0 ? M / 512 : 1;     // >= 16 K-steps per slice
+  if (s > max_s) s = max_s;
+  if (s > 64) s = 64;
+  return s < 1 ? 1 : (int)s;
+}
+
+inline int ktot_of(const pfk_conv_desc* d) {
+  int k = 0;
+  for (int s = 0; s < d->num_src; ++s) k += d->kh * d->kw * ((d->src[s].channels + 31) / 32 * 32);
+  return k;
+}
+
+}  // namespace
+
+extern "C" {
+
+long long pfk_conv_wgrad_workspace_bytes(const pfk_conv_desc* d) {
+  if (!d || d->num_src < 1 || d->num_src > 3 || d->cout <= 0) return 0;
+  const int ktot = ktot_of(d);
+  const long long M = (long long)d->B * d->H * d->W;
+  const int splits = pick_splits((long long)((d->cout + 127) / 128) * (ktot / 32), M);
+  return splits > 1 ? (long long)splits * d->cout * ktot * (long long)sizeof(float) : 0;
+}
+
+int pfk_conv_wgrad_f32(const pfk_conv_desc* d, const float* dy, int dy_ld, float* dw_packed, void* workspace,
+                       long long workspace_bytes, pfk_stream_t stream) {
+  if (!d || !dy || !dw_packed || d->num_src < 1 || d->num_src > 3) return PFK_ERR_BAD_ARG;
+  if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->cout <= 0 || dy_ld < d->cout) return PFK_ERR_BAD_ARG;
+  if (d->kh <= 0 || d->kw <= 0 || !(d->kh & 1) || !(d->kw & 1) || d->stride > 1) return PFK_ERR_BAD_ARG;
+  if ((d->cout & 3) || (dy_ld & 3) || !pfk_aligned16(dy) || !pfk_aligned16(dw_packed)) return PFK_ERR_ALIGNMENT;
+  WgradArgs a{};
+  const pfk_conv_src* s = d->src;
+  const long long M = (long long)d->B * d->H * d->W;
+  for (int i = 0; i < d->num_src; ++i) {
+    if (!s[i].ptr || s[i].channels <= 0 || s[i].ld < s[i].channels) return PFK_ERR_BAD_ARG;
+    if (!pfk_aligned16(s[i].ptr) || (s[i].ld & 3) || (s[i].channels & 3)) return PFK_ERR_ALIGNMENT;
+    if (M * s[i].ld * 4 >= 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
+  }
+  if (M * dy_ld * 4 >= 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
+  a.src0 = s[0].ptr; a.ld0 = s[0].ld; a.ch0 = s[0].channels;
+  if (d->num_src > 1) { a.src1 = s[1].ptr; a.ld1 = s[1].ld; a.ch1 = s[1].channels; }
+  if (d->num_src > 2) { a.src2 = s[2].ptr; a.ld2 = s[2].ld; a.ch2 = s[2].channels; }
+  a.nsrc = d->num_src;
+  a.dy = dy; a.dy_ld = dy_ld; a.cout = d->cout;
+  a.H = d->H; a.W = d->W; a.kh = d->kh; a.kw = d->kw; a.M = M;
+  a.ktot = ktot_of(d);
+  a.chunks = a.ktot / 32;
+  a.tiles_m = (d->cout + 127) / 128;
+  const int splits = pick_splits((long long)a.tiles_m * a.chunks, M);
+  a.px_per_split = ((M + splits - 1) / splits + 31) / 32 * 32;
+  const long long n = (long long)d->cout * a.ktot;
+  if (splits > 1) {
+    if (!workspace || workspace_bytes < splits * n * (long long)sizeof(float) || !pfk_aligned16(workspace)) return PFK_ERR_BAD_ARG;
+    a.part = static_cast<float*>(workspace);
+  } else {
+    a.part = dw_packed;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)(a.tiles_m * a.chunks), (unsigned)splits), dim3(256), 0, st, a);
+  if (splits > 1)
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st,
+                       static_cast<const float*>(workspace), dw_packed, n, splits);
+  return pfk_launch_status();
+}
+
+}  // extern "C"

@@ -350,6 +350,7 @@ class PfkUpdateBlock(torch.nn.Module):
         self._ref = [ref_block]  # in a list: not registered twice in the module tree
         self.training = ref_block.training
         self.native_backward = True   # False: calls that need a gradient graph go to the wrapped reference module
+        self._train_cache: dict = {}  # packed weights of the training path, keyed by parameter versions
         self.spec = spec
         self._engine: Optional[UpdateEngine] = None
         self._versions = None
@@ -376,7 +377,7 @@ class PfkUpdateBlock(torch.nn.Module):
             # modes keep the reference module's own autograd
             if self.native_backward and net.is_cuda and not self.spec.aggregate and self.conv_precision == "fp32":
                 from .train import update_block_train
-                h, mask, delta = update_block_train(dict(self.named_parameters()), self.spec, net, inp, corr, flow)
+                h, mask, delta = update_block_train(dict(self.named_parameters()), self.spec, net, inp, corr, flow, self._train_cache)
                 return h.to(net.dtype), (None if mask is None else mask.to(net.dtype)), delta.to(net.dtype)
             return self._ref[0](net, inp, corr, flow, *extra)
         with torch.no_grad():
