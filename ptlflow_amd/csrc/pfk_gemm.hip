@@ -704,8 +704,8 @@ int launch(const GemmArgs& a, int epi, int batches, hipStream_t st) {
                     a.sk_steps >= 24;
     // >= 3 tiles per CU: the swizzled 48 KB layout (cfg 10) keeps three blocks resident; below that the padded rows'
     // immediate-offset fragment reads are a few % faster (cfg 4).
-    // few output tiles, very long K (the weight-gradient GEMMs: K = all pixels of the batch): only stream-K fills the chip
-    const bool sk_long = a.sk_ws != nullptr && batches == 1 && blocks64 <= 256 && a.sk_steps >= 128;
+    // a handful of output tiles with a very long K (GEMM-shaped callers with a tall reduction): only stream-K fills the chip
+    const bool sk_long = a.sk_ws != nullptr && batches == 1 && blocks64 <= 64 && a.sk_steps >= 128;
     cfg = (sk || sk_long) ? 9 : (a.sk_steps < 16 ? 0 : (blocks64 >= 3 * 256 ? 10 : 4));
   }
   switch (cfg) {
@@ -748,9 +748,7 @@ int desc_to_args(const pfk_conv_desc* d, GemmArgs& a, int kpad) {
   const pfk_conv_src* s = d->src;
   for (int i = 0; i < d->num_src; ++i) {
     if (!s[i].ptr || s[i].channels <= 0 || s[i].ld < s[i].channels) return PFK_ERR_BAD_ARG;
-    // rows are fetched with dword-aligned buffer_load_dwordx4: the base may sit on any 4-byte boundary (the weight-gradient
-    // GEMMs read channel-major activations shifted by a tap offset), 16-byte bases are simply the fast case
-    if ((reinterpret_cast<uintptr_t>(s[i].ptr) & 3u) || (s[i].ld & 3) || (s[i].channels & 3)) return PFK_ERR_ALIGNMENT;
+    if (!pfk_aligned16(s[i].ptr) || (s[i].ld & 3) || (s[i].channels & 3)) return PFK_ERR_ALIGNMENT;
   }
   a.src0 = s[0].ptr; a.ld0 = s[0].ld; a.ch0 = s[0].channels;
   if (d->num_src > 1) { a.src1 = s[1].ptr; a.ld1 = s[1].ld; a.ch1 = s[1].channels; }
