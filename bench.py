@@ -158,7 +158,7 @@ def main():
 
     pairs = args.batch * args.steps * world
     result = {
-        "metric": "frame-pairs/sec, RAFT 32-iter 436x1024" if (not small and args.iters == 32 and (args.height, args.width) == (436, 1024))
+        "metric": "frame-pairs/sec, RAFT 32-iter 436x1024" if (args.model == "raft" and args.iters == 32 and (args.height, args.width) == (436, 1024))
                   else f"frame-pairs/sec, {args.model} {args.iters}-iter {args.height}x{args.width}",
         "value": pairs / elapsed,
         "unit": "frame-pairs/s",
