@@ -214,6 +214,22 @@ long long pfk_conv_wgrad_workspace_bytes(const pfk_conv_desc* d);
 int pfk_conv_wgrad_f32(const pfk_conv_desc* d, const float* dy, int dy_ld, float* dw_packed, void* workspace,
                        long long workspace_bytes, pfk_stream_t stream);
 
+/* Gate arithmetic of one ConvGRU / SepConvGRU pass for the training path (raft/update.py:24-32, 58-73), pixel-major
+ * [M][C] tensors, C % 4 == 0; z, r, rh, q, h_new, da_q, dh are contiguous [M][C], a_zr / da_zr contiguous [M][2C]
+ * (z half first), h / dh_new have their own row stride.
+ *   gates_zr:     z = sigmoid(a_zr[:, :C]), r = sigmoid(a_zr[:, C:]), rh = r * h
+ *   gates_q:      q = tanh(a_q), h_new = (1 - z) * h + z * q
+ *   backward_q:   da_q = dh_new * z * (1 - q^2);  da_zr[:, :C] = dh_new * (q - h) * z * (1 - z);  dh = dh_new * (1 - z)
+ *   backward_zr:  da_zr[:, C:] = d_rh * h * r * (1 - r);  dh += d_rh * r */
+int pfk_gru_gates_zr_f32(const float* a_zr, const float* h, int h_ld, float* z, float* r, float* rh, long long M, int C,
+                         pfk_stream_t stream);
+int pfk_gru_gates_q_f32(const float* a_q, const float* z, const float* h, int h_ld, float* q, float* h_new, long long M, int C,
+                        pfk_stream_t stream);
+int pfk_gru_backward_q_f32(const float* dh_new, int dh_new_ld, const float* z, const float* q, const float* h, int h_ld,
+                           float* da_q, float* da_zr, float* dh, long long M, int C, pfk_stream_t stream);
+int pfk_gru_backward_zr_f32(const float* d_rh, const float* h, int h_ld, const float* r, float* da_zr, float* dh, long long M,
+                            int C, pfk_stream_t stream);
+
 /* ---- warm start (second half) -------------------------------------------------------------------
  * forward_interpolate (ptlflow/utils/external/raft.py:155-185, batched by utils/utils.py:454-478): flow [B][2][H][W] ->
  * out [B][2][H][W]: every grid point takes the flow of the nearest forward-projected pixel that lands strictly inside the

@@ -322,6 +322,33 @@ void conv_wgrad(at::TensorList srcs, const Tensor& dy, int64_t B, int64_t H, int
   check_ok(pfk_conv_wgrad_f32(&d, fptr(dy), dy.stride(0), fptr(out), wsp, need, cur_stream()), "conv_wgrad");
 }
 
+void gru_gates_zr(const Tensor& a_zr, const Tensor& h, Tensor z, Tensor r, Tensor rh) {
+  check_pm(h, "h"); check_dev_f32(a_zr, "a_zr");
+  const int64_t M = h.size(0); const int C = h.size(1);
+  TORCH_CHECK(a_zr.is_contiguous() && a_zr.size(0) == M && a_zr.size(1) == 2 * C && z.is_contiguous() && r.is_contiguous() && rh.is_contiguous());
+  check_ok(pfk_gru_gates_zr_f32(fptr(a_zr), fptr(h), h.stride(0), fptr(z), fptr(r), fptr(rh), M, C, cur_stream()), "gru_gates_zr");
+}
+void gru_gates_q(const Tensor& a_q, const Tensor& z, const Tensor& h, Tensor q, Tensor h_new) {
+  check_pm(h, "h");
+  const int64_t M = h.size(0); const int C = h.size(1);
+  TORCH_CHECK(a_q.is_contiguous() && a_q.size(0) == M && a_q.size(1) == C && z.is_contiguous() && q.is_contiguous() && h_new.is_contiguous());
+  check_ok(pfk_gru_gates_q_f32(fptr(a_q), fptr(z), fptr(h), h.stride(0), fptr(q), fptr(h_new), M, C, cur_stream()), "gru_gates_q");
+}
+void gru_backward_q(const Tensor& dh_new, const Tensor& z, const Tensor& q, const Tensor& h, Tensor da_q, Tensor da_zr, Tensor dh) {
+  check_pm(h, "h"); check_pm(dh_new, "dh_new");
+  const int64_t M = h.size(0); const int C = h.size(1);
+  TORCH_CHECK(z.is_contiguous() && q.is_contiguous() && da_q.is_contiguous() && da_zr.is_contiguous() && dh.is_contiguous() &&
+              da_zr.size(1) == 2 * C && dh_new.size(1) == C);
+  check_ok(pfk_gru_backward_q_f32(fptr(dh_new), dh_new.stride(0), fptr(z), fptr(q), fptr(h), h.stride(0), fptr(da_q), fptr(da_zr),
+                                  fptr(dh), M, C, cur_stream()), "gru_backward_q");
+}
+void gru_backward_zr(const Tensor& d_rh, const Tensor& h, const Tensor& r, Tensor da_zr, Tensor dh) {
+  check_pm(h, "h");
+  const int64_t M = h.size(0); const int C = h.size(1);
+  TORCH_CHECK(d_rh.is_contiguous() && r.is_contiguous() && da_zr.is_contiguous() && dh.is_contiguous() && da_zr.size(1) == 2 * C);
+  check_ok(pfk_gru_backward_zr_f32(fptr(d_rh), fptr(h), h.stride(0), fptr(r), fptr(da_zr), fptr(dh), M, C, cur_stream()), "gru_backward_zr");
+}
+
 int64_t abi_version() { return pfk_abi_version(); }
 int64_t conv_workspace_bytes() { return pfk_conv_workspace_bytes(); }
 void debug_set_tile(int64_t cfg) { pfk_debug_set_tile((int)cfg); }
@@ -330,6 +357,10 @@ void debug_set_tile(int64_t cfg) { pfk_debug_set_tile((int)cfg); }
 
 TORCH_LIBRARY(pfk, m) {
   m.def("abi_version() -> int", &abi_version);
+  m.def("gru_gates_zr(Tensor a_zr, Tensor h, Tensor(a!) z, Tensor(b!) r, Tensor(c!) rh) -> ()");
+  m.def("gru_gates_q(Tensor a_q, Tensor z, Tensor h, Tensor(a!) q, Tensor(b!) h_new) -> ()");
+  m.def("gru_backward_q(Tensor dh_new, Tensor z, Tensor q, Tensor h, Tensor(a!) da_q, Tensor(b!) da_zr, Tensor(c!) dh) -> ()");
+  m.def("gru_backward_zr(Tensor d_rh, Tensor h, Tensor r, Tensor(a!) da_zr, Tensor(b!) dh) -> ()");
   m.def("conv_wgrad(Tensor[] srcs, Tensor dy, int B, int H, int W, int kh, int kw, Tensor(a!) out) -> ()");
   m.def("forward_interpolate(Tensor flow, Tensor(a!) out) -> ()");
   m.def("instnorm_workspace_bytes(int B, int C) -> int", &instnorm_workspace_bytes);
@@ -374,6 +405,10 @@ TORCH_LIBRARY_IMPL(pfk, CUDA, m) {
   m.impl("pm_to_nchw", &pm_to_nchw);
   m.impl("pm_to_cm", &pm_to_cm);
   m.impl("conv_stem", &conv_stem);
+  m.impl("gru_gates_zr", &gru_gates_zr);
+  m.impl("gru_gates_q", &gru_gates_q);
+  m.impl("gru_backward_q", &gru_backward_q);
+  m.impl("gru_backward_zr", &gru_backward_zr);
   m.impl("conv_wgrad", &conv_wgrad);
   m.impl("forward_interpolate", &forward_interpolate);
   m.impl("instnorm_stats", &instnorm_stats);

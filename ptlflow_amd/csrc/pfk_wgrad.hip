@@ -132,6 +132,77 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   *reinterpret_cast<f32x4*>(out + i) = s;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Gate arithmetic of one (Sep)ConvGRU pass for the training path (raft/update.py:24-32, 58-73), float4 per thread over
+// pixel-major [M][C] tensors.  Forward keeps what the backward needs (z, r, q); the derivative kernels produce the
+// pre-activation gradients the dgrad / wgrad convolutions consume.
+//   f1: z = s(a_z), r = s(a_r), rh = r*h               f2: q = tanh(a_q), h' = (1-z)*h + z*q
+//   b1: da_q = dh'*z*(1-q^2), da_z = dh'*(q-h)*z*(1-z), dh = dh'*(1-z)
+//   b2: da_r = d(rh)*h*r*(1-r), dh += d(rh)*r
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x4 sigmoid4(f32x4 v) {
+  f32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = 1.0f / (1.0f + expf(-v[e]));
+  return o;
+}
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+__global__ __launch_bounds__(256) void gru_f1_kernel(const float* __restrict__ azr, const float* __restrict__ h, int h_ld,
+                                                     float* __restrict__ z, float* __restrict__ r, float* __restrict__ rh,
+                                                     long long M, int C) {
+  const int tpr = C >> 2;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x, p = idx / tpr;
+  if (p >= M) return;
+  const int c = (int)(idx - p * tpr) * 4;
+  const f32x4 zz = sigmoid4(ld4(azr + p * 2 * C + c)), rr = sigmoid4(ld4(azr + p * 2 * C + C + c));
+  st4(z + p * C + c, zz);
+  st4(r + p * C + c, rr);
+  st4(rh + p * C + c, rr * ld4(h + p * h_ld + c));
+}
+
+__global__ __launch_bounds__(256) void gru_f2_kernel(const float* __restrict__ aq, const float* __restrict__ z,
+                                                     const float* __restrict__ h, int h_ld, float* __restrict__ q,
+                                                     float* __restrict__ hn, long long M, int C) {
+  const int tpr = C >> 2;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x, p = idx / tpr;
+  if (p >= M) return;
+  const int c = (int)(idx - p * tpr) * 4;
+  const f32x4 a = ld4(aq + p * C + c), zz = ld4(z + p * C + c), hh = ld4(h + p * h_ld + c);
+  f32x4 qq;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) qq[e] = tanhf(a[e]);
+  st4(q + p * C + c, qq);
+  st4(hn + p * C + c, (1.0f - zz) * hh + zz * qq);
+}
+
+__global__ __launch_bounds__(256) void gru_b1_kernel(const float* __restrict__ dhn, int dhn_ld, const float* __restrict__ z,
+                                                     const float* __restrict__ q, const float* __restrict__ h, int h_ld,
+                                                     float* __restrict__ daq, float* __restrict__ dazr, float* __restrict__ dh,
+                                                     long long M, int C) {
+  const int tpr = C >> 2;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x, p = idx / tpr;
+  if (p >= M) return;
+  const int c = (int)(idx - p * tpr) * 4;
+  const f32x4 g = ld4(dhn + p * dhn_ld + c), zz = ld4(z + p * C + c), qq = ld4(q + p * C + c), hh = ld4(h + p * h_ld + c);
+  st4(daq + p * C + c, g * zz * (1.0f - qq * qq));
+  st4(dazr + p * 2 * C + c, g * (qq - hh) * zz * (1.0f - zz));
+  st4(dh + p * C + c, g * (1.0f - zz));
+}
+
+__global__ __launch_bounds__(256) void gru_b2_kernel(const float* __restrict__ drh, const float* __restrict__ h, int h_ld,
+                                                     const float* __restrict__ r, float* __restrict__ dazr, float* __restrict__ dh,
+                                                     long long M, int C) {
+  const int tpr = C >> 2;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x, p = idx / tpr;
+  if (p >= M) return;
+  const int c = (int)(idx - p * tpr) * 4;
+  const f32x4 g = ld4(drh + p * C + c), hh = ld4(h + p * h_ld + c), rr = ld4(r + p * C + c);
+  st4(dazr + p * 2 * C + C + c, g * hh * rr * (1.0f - rr));
+  st4(dh + p * C + c, ld4(dh + p * C + c) + g * rr);
+}
+
 int pick_splits(long long tiles, long long M) {
   long long s = 1024 / (tiles > 0 ? tiles : 1);
   const long long max_s = M / 512 > 0 ? M / 512 : 1;     // >= 16 K-steps per slice
@@ -196,6 +267,55 @@ int pfk_conv_wgrad_f32(const pfk_conv_desc* d, const float* dy, int dy_ld, float
   if (splits > 1)
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st,
                        static_cast<const float*>(workspace), dw_packed, n, splits);
+  return pfk_launch_status();
+}
+
+static int gru_grid(long long M, int C, dim3* grid) {
+  if (M <= 0 || C <= 0 || (C & 3)) return PFK_ERR_BAD_ARG;
+  const long long blocks = (M * (C >> 2) + 255) / 256;
+  if (blocks > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
+  *grid = dim3((unsigned)blocks);
+  return PFK_OK;
+}
+
+int pfk_gru_gates_zr_f32(const float* a_zr, const float* h, int h_ld, float* z, float* r, float* rh, long long M, int C,
+                         pfk_stream_t stream) {
+  dim3 grid;
+  if (!a_zr || !h || !z || !r || !rh || (h_ld & 3) || h_ld < C) return PFK_ERR_BAD_ARG;
+  const int rc = gru_grid(M, C, &grid);
+  if (rc != PFK_OK) return rc;
+  hipLaunchKernelGGL(gru_f1_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a_zr, h, h_ld, z, r, rh, M, C);
+  return pfk_launch_status();
+}
+
+int pfk_gru_gates_q_f32(const float* a_q, const float* z, const float* h, int h_ld, float* q, float* h_new, long long M, int C,
+                        pfk_stream_t stream) {
+  dim3 grid;
+  if (!a_q || !z || !h || !q || !h_new || (h_ld & 3) || h_ld < C) return PFK_ERR_BAD_ARG;
+  const int rc = gru_grid(M, C, &grid);
+  if (rc != PFK_OK) return rc;
+  hipLaunchKernelGGL(gru_f2_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a_q, z, h, h_ld, q, h_new, M, C);
+  return pfk_launch_status();
+}
+
+int pfk_gru_backward_q_f32(const float* dh_new, int dh_new_ld, const float* z, const float* q, const float* h, int h_ld,
+                           float* da_q, float* da_zr, float* dh, long long M, int C, pfk_stream_t stream) {
+  dim3 grid;
+  if (!dh_new || !z || !q || !h || !da_q || !da_zr || !dh || (h_ld & 3) || (dh_new_ld & 3)) return PFK_ERR_BAD_ARG;
+  const int rc = gru_grid(M, C, &grid);
+  if (rc != PFK_OK) return rc;
+  hipLaunchKernelGGL(gru_b1_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), dh_new, dh_new_ld, z, q, h, h_ld, da_q,
+                     da_zr, dh, M, C);
+  return pfk_launch_status();
+}
+
+int pfk_gru_backward_zr_f32(const float* d_rh, const float* h, int h_ld, const float* r, float* da_zr, float* dh, long long M,
+                            int C, pfk_stream_t stream) {
+  dim3 grid;
+  if (!d_rh || !h || !r || !da_zr || !dh || (h_ld & 3)) return PFK_ERR_BAD_ARG;
+  const int rc = gru_grid(M, C, &grid);
+  if (rc != PFK_OK) return rc;
+  hipLaunchKernelGGL(gru_b2_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), d_rh, h, h_ld, r, da_zr, dh, M, C);
   return pfk_launch_status();
 }
 

@@ -3,8 +3,8 @@
 The inference path fuses gates and concatenations into convolution epilogues and keeps its state in place, which autograd
 cannot see.  For training the update block (ptlflow/models/raft/update.py:6-153) is re-composed from ONE differentiable
 primitive, ``conv_pm`` — a "same" convolution over pixel-major ``[B*H*W, C]`` tensors whose forward, data gradient and weight
-gradient all run on fp32-MFMA implicit-GEMM kernels — plus torch elementwise ops for the gates
-(sigmoid, tanh, the GRU blend), which autograd differentiates by itself:
+gradient all run on fp32-MFMA implicit-GEMM kernels — plus one fused autograd node per GRU pass (``_GruPass``: gate
+arithmetic and its derivatives in four small kernels, ``pfk_gru_*``):
 
 * forward   ``out = conv(srcs, W) + b`` (relu fused)                              -> ``pfk_conv2d_f32``
 * dgrad     ``dX_s = conv(dY, flip(W_s)^T)``  — a convolution again                -> ``pfk_conv2d_f32`` (re-packed weight)
@@ -85,10 +85,8 @@ class _ConvPM(torch.autograd.Function):
         srcs = [s.contiguous() if s.stride(1) != 1 else s for s in srcs]
         cout = weight.shape[0]
         M = g.B * g.H * g.W
-        if packs.fwd is None:
-            packs.fwd = pack_conv_weight(weight.detach().float(), _segments(srcs, real))
         out = torch.empty(M, cout, device=srcs[0].device, dtype=torch.float32)
-        ops.conv2d(list(srcs), g.B, g.H, g.W, g.kh, g.kw, packs.fwd, None if bias is None else bias.detach().float().contiguous(),
+        ops.conv2d(list(srcs), g.B, g.H, g.W, g.kh, g.kw, _fwd_pack(packs, weight, _segments(srcs, real)), None if bias is None else bias.detach().float().contiguous(),
                    cout, EPI_LINEAR, relu, 1.0, out, None, None, None, _workspace(out.device))
         ctx.g, ctx.relu, ctx.real, ctx.has_bias, ctx.packs = g, relu, real, bias is not None, packs
         ctx.save_for_backward(weight, out if relu else None, *srcs)
@@ -115,13 +113,9 @@ class _ConvPM(torch.autograd.Function):
         for i, (first, n, n_buf) in enumerate(segs):
             if not need[6 + i]:
                 continue
-            if i not in packs.dgrad:
-                wt = weight.detach().float()[:, first:first + n].permute(1, 0, 2, 3).flip(2, 3)   # [n, cout, kh, kw]
-                if n_buf > n:
-                    wt = F.pad(wt, (0, 0, 0, 0, 0, 0, 0, n_buf - n))                              # padded channels: zero gradient
-                packs.dgrad[i] = pack_conv_weight(wt.contiguous(), [(0, cout, dY_src.shape[1])])
             dx = torch.empty(M, n_buf, device=dY.device, dtype=torch.float32)
-            ops.conv2d([dY_src], g.B, g.H, g.W, g.kh, g.kw, packs.dgrad[i], None, n_buf, EPI_LINEAR, False, 1.0, dx, None, None, None, ws)
+            ops.conv2d([dY_src], g.B, g.H, g.W, g.kh, g.kw, _dgrad_pack(packs, i, weight, (first, n, n_buf), dY_src.shape[1]), None, n_buf,
+                       EPI_LINEAR, False, 1.0, dx, None, None, None, ws)
             dsrcs[i] = dx
         # ---- wgrad: one launch (+ a deterministic slice reduction) straight from the pixel-major tensors, written in the packed
         # [cout, ktot] layout of the forward weight and un-packed here (the inverse of pack_conv_weight)
@@ -130,17 +124,116 @@ class _ConvPM(torch.autograd.Function):
             ktot = sum(taps * round_up(n_buf, 32) for _, _, n_buf in segs)
             packed = torch.empty(dY_src.shape[1], ktot, device=dY.device, dtype=torch.float32)
             ops.conv_wgrad(list(srcs), dY_src, g.B, g.H, g.W, g.kh, g.kw, packed)
-            dW = torch.empty(weight.shape, device=dY.device, dtype=torch.float32)
-            k0 = 0
-            for first, n, n_buf in segs:
-                cpad = round_up(n_buf, 32)
-                blk = packed[:cout, k0:k0 + taps * cpad].view(cout, g.kh, g.kw, cpad)[..., :n]
-                dW[:, first:first + n] = blk.permute(0, 3, 1, 2)
-                k0 += taps * cpad
+            dW = _unpack_wgrad(packed, weight.shape, segs, g)
             dW = dW.to(weight.dtype)
         if ctx.has_bias and need[1]:
             db = dY.sum(0)
         return (dW, db, None, None, None, None, *dsrcs)
+
+
+def _fwd_pack(packs: ConvPacks, weight: torch.Tensor, segs) -> torch.Tensor:
+    if packs.fwd is None:
+        packs.fwd = pack_conv_weight(weight.detach().float(), segs)
+    return packs.fwd
+
+
+def _dgrad_pack(packs: ConvPacks, i: int, weight: torch.Tensor, seg, dy_channels: int) -> torch.Tensor:
+    """Packed weight of the data-gradient convolution w.r.t. source i: W[:, seg] with in/out swapped and taps flipped."""
+    if i not in packs.dgrad:
+        first, n, n_buf = seg
+        cout = weight.shape[0]
+        wt = weight.detach().float()[:, first:first + n].permute(1, 0, 2, 3).flip(2, 3)        # [n, cout, kh, kw]
+        if n_buf > n:
+            wt = F.pad(wt, (0, 0, 0, 0, 0, 0, 0, n_buf - n))                                   # padded channels: zero gradient
+        packs.dgrad[i] = pack_conv_weight(wt.contiguous(), [(0, cout, dy_channels)])
+    return packs.dgrad[i]
+
+
+def _unpack_wgrad(packed: torch.Tensor, weight_shape, segs, g: _Geometry) -> torch.Tensor:
+    """packed [cout(+pad), ktot] (the forward weight's layout) -> PyTorch layout [cout, cin, kh, kw]."""
+    cout = weight_shape[0]
+    taps = g.kh * g.kw
+    dW = torch.empty(weight_shape, device=packed.device, dtype=torch.float32)
+    k0 = 0
+    for first, n, n_buf in segs:
+        cpad = round_up(n_buf, 32)
+        blk = packed[:cout, k0:k0 + taps * cpad].view(cout, g.kh, g.kw, cpad)[..., :n]
+        dW[:, first:first + n] = blk.permute(0, 3, 1, 2)
+        k0 += taps * cpad
+    return dW
+
+
+class _GruPass(torch.autograd.Function):
+    """One ConvGRU / SepConvGRU pass (raft/update.py:24-32, 58-73) as a single autograd node:
+        z, r = sigmoid(conv([h, x], Wz|Wr));  q = tanh(conv([r*h, x], Wq));  h' = (1 - z) h + z q
+    two convolutions + two fused gate kernels forward; backward = two gate-derivative kernels, four data-gradient
+    convolutions (the second pair accumulates into the first pair's results through the epilogue's residual input) and two
+    weight-gradient launches."""
+
+    @staticmethod
+    def forward(ctx, h, x, wz, wr, wq, bz, br, bq, g: _Geometry, x_real: int, pk_zr: ConvPacks, pk_q: ConvPacks):
+        ops = torch.ops.pfk
+        h = h.float().contiguous()
+        x = x.float().contiguous()
+        M, C = h.shape
+        dev = h.device
+        ws = _workspace(dev)
+        wzr = torch.cat([wz.detach(), wr.detach()], 0).float()
+        bzr = torch.cat([bz.detach(), br.detach()], 0).float().contiguous()
+        segs = [(0, C, C), (C, x_real, x.shape[1])]
+        a_zr = torch.empty(M, 2 * C, device=dev, dtype=torch.float32)
+        ops.conv2d([h, x], g.B, g.H, g.W, g.kh, g.kw, _fwd_pack(pk_zr, wzr, segs), bzr, 2 * C, EPI_LINEAR, False, 1.0, a_zr,
+                   None, None, None, ws)
+        z, r, rh = (torch.empty(M, C, device=dev, dtype=torch.float32) for _ in range(3))
+        ops.gru_gates_zr(a_zr, h, z, r, rh)
+        a_q = torch.empty(M, C, device=dev, dtype=torch.float32)
+        ops.conv2d([rh, x], g.B, g.H, g.W, g.kh, g.kw, _fwd_pack(pk_q, wq, segs), bq.detach().float().contiguous(), C, EPI_LINEAR,
+                   False, 1.0, a_q, None, None, None, ws)
+        q, hn = torch.empty_like(a_q), torch.empty_like(a_q)
+        ops.gru_gates_q(a_q, z, h, q, hn)
+        ctx.g, ctx.x_real, ctx.pk_zr, ctx.pk_q, ctx.wzr = g, x_real, pk_zr, pk_q, wzr
+        ctx.save_for_backward(h, x, z, r, q, rh, wq)
+        return hn
+
+    @staticmethod
+    def backward(ctx, dhn):
+        ops = torch.ops.pfk
+        h, x, z, r, q, rh, wq = ctx.saved_tensors
+        g, x_real, pk_zr, pk_q, wzr = ctx.g, ctx.x_real, ctx.pk_zr, ctx.pk_q, ctx.wzr
+        M, C = h.shape
+        Cx = x.shape[1]
+        dev = h.device
+        ws = _workspace(dev)
+        segs = [(0, C, C), (C, x_real, Cx)]
+        dhn = dhn.float()
+        if dhn.stride(1) != 1:
+            dhn = dhn.contiguous()
+        da_q = torch.empty(M, C, device=dev, dtype=torch.float32)
+        da_zr = torch.empty(M, 2 * C, device=dev, dtype=torch.float32)
+        dh = torch.empty(M, C, device=dev, dtype=torch.float32)
+        ops.gru_backward_q(dhn, z, q, h, da_q, da_zr, dh)
+
+        def dgrad(dy, packs, weight, i, n_out, residual=None):
+            out = torch.empty(M, n_out, device=dev, dtype=torch.float32)
+            ops.conv2d([dy], g.B, g.H, g.W, g.kh, g.kw, _dgrad_pack(packs, i, weight, segs[i], dy.shape[1]), None, n_out, EPI_LINEAR,
+                       False, 1.0, out, None, None, None, ws, residual)
+            return out
+
+        d_rh = dgrad(da_q, pk_q, wq, 0, C)
+        dx = dgrad(da_q, pk_q, wq, 1, Cx)
+        ops.gru_backward_zr(d_rh, h, r, da_zr, dh)
+        dh = dgrad(da_zr, pk_zr, wzr, 0, C, residual=dh)          # + dh through the epilogue
+        dx = dgrad(da_zr, pk_zr, wzr, 1, Cx, residual=dx)
+        taps = g.kh * g.kw
+        ktot = taps * (round_up(C, 32) + round_up(Cx, 32))
+        pq = torch.empty(C, ktot, device=dev, dtype=torch.float32)
+        ops.conv_wgrad([rh, x], da_q, g.B, g.H, g.W, g.kh, g.kw, pq)
+        pzr = torch.empty(2 * C, ktot, device=dev, dtype=torch.float32)
+        ops.conv_wgrad([h, x], da_zr, g.B, g.H, g.W, g.kh, g.kw, pzr)
+        dwq = _unpack_wgrad(pq, wq.shape, segs, g)
+        dwzr = _unpack_wgrad(pzr, wzr.shape, segs, g)
+        dbzr = da_zr.sum(0)
+        return (dh, dx, dwzr[:C], dwzr[C:], dwq, dbzr[:C], dbzr[C:], da_q.sum(0), None, None, None, None)
 
 
 def conv_pm(srcs: Sequence[torch.Tensor], weight: torch.Tensor, bias: Optional[torch.Tensor], B: int, H: int, W: int,
@@ -193,16 +286,13 @@ def update_block_train(P: Dict[str, torch.Tensor], spec, net, inp, corr, flow, c
     motion = torch.cat([out, f], 1)                      # enc_out + 2
     x = _pad4(torch.cat([i, motion], 1))
     x_real = spec.context + spec.motion_channels
-    # GRU passes (update.py:58-73 / :24-32): z and r share one convolution (weights concatenated on the output axis)
-    for _kh, _kw, sfx in spec.gru_passes:
-        wzr = torch.cat([P[f"gru.convz{sfx}.weight"], P[f"gru.convr{sfx}.weight"]], 0)
-        bzr = torch.cat([P[f"gru.convz{sfx}.bias"], P[f"gru.convr{sfx}.bias"]], 0)
-        zr = torch.sigmoid(conv_pm([h, x], wzr, bzr, B, H, W, False, [spec.hidden, x_real],
-                                   packs_for(cache, "zr" + sfx, [P[f"gru.convz{sfx}.weight"], P[f"gru.convr{sfx}.weight"]])))
-        z, r = zr[:, : spec.hidden], zr[:, spec.hidden:]
-        q = torch.tanh(conv_pm([(r * h).contiguous(), x], P[f"gru.convq{sfx}.weight"], P[f"gru.convq{sfx}.bias"], B, H, W, False,
-                               [spec.hidden, x_real], packs_for(cache, "q" + sfx, [P[f"gru.convq{sfx}.weight"]])))
-        h = (1 - z) * h + z * q
+    # GRU passes (update.py:58-73 / :24-32): one fused autograd node per pass (z and r share a convolution)
+    for kh, kw, sfx in spec.gru_passes:
+        names = [f"gru.conv{k}{sfx}" for k in "zrq"]
+        h = _GruPass.apply(h, x, *(P[n + ".weight"] for n in names), *(P[n + ".bias"] for n in names),
+                           _Geometry(B, H, W, kh, kw), x_real,
+                           packs_for(cache, "zr" + sfx, [P[names[0] + ".weight"], P[names[1] + ".weight"]]),
+                           packs_for(cache, "q" + sfx, [P[names[2] + ".weight"]]))
     # heads (update.py:6-14, 138-142, 152)
     delta = conv([conv([h], "flow_head.conv1", True)], "flow_head.conv2")
     mask = None
