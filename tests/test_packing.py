@@ -56,3 +56,36 @@ def test_small_kernel_layouts():
     w = torch.arange(2 * 256 * 9, dtype=torch.float32).view(2, 256, 3, 3)
     p = pack_flow_head_weight(w)
     assert p.shape == (9, 2, 256) and p[1 * 3 + 2, 1, 77] == w[1, 77, 1, 2]
+
+
+def test_split_bf16_planes_reconstruct_the_weight():
+    """plane 0 = bf16(w), plane k = bf16(residual): the planes' sum approaches w by ~2^-8 per plane, every plane is the
+    round-to-nearest of what is left, and a bf16-representable weight needs exactly one plane."""
+    from ptlflow_amd.packing import split_bf16_planes
+    torch.manual_seed(1)
+    w = torch.randn(24, 96) * 0.3
+    prev = None
+    for n in (1, 2, 3):
+        planes = split_bf16_planes(w, n)
+        assert planes.dtype == torch.bfloat16 and tuple(planes.shape) == (n, 24, 96)
+        err = (w - planes.float().sum(0)).abs().max().item()
+        assert err <= float(w.abs().max()) * 2.0 ** (-8 * n) , (n, err)
+        if prev is not None:
+            assert torch.equal(planes[: n - 1], prev)          # adding a plane never changes the earlier ones
+        prev = planes
+    exact = split_bf16_planes(w.bfloat16().float(), 2)
+    assert torch.equal(exact[0].float(), w.bfloat16().float()) and bool((exact[1] == 0).all())
+
+
+def test_unpack_wgrad_is_the_inverse_of_pack():
+    """The weight gradient comes back from the kernel in the packed [cout, ktot] layout of the forward weight;
+    train._unpack_wgrad must undo pack_conv_weight exactly (multi-source, padded channels, cout padded to 4)."""
+    from ptlflow_amd.train import _Geometry, _unpack_wgrad
+    torch.manual_seed(2)
+    cout, kh, kw = 6, 1, 5
+    segs = [(0, 96, 96), (96, 146, 148)]
+    w = torch.randn(cout, 96 + 146, kh, kw)
+    packed = pack_conv_weight(w, segs)
+    padded = F.pad(packed, (0, 0, 0, 2))                       # the kernel's output has cout rounded up to a multiple of 4
+    back = _unpack_wgrad(padded, w.shape, segs, _Geometry(1, 4, 4, kh, kw))
+    assert torch.equal(back, w)
