@@ -8,7 +8,8 @@ eval), and the same ``state_dict`` key names / shapes as the reference classes, 
 tests/test_oracle_vs_reference.py).
 
 What runs where:
-* encoders (fnet / cnet, raft/extractor.py) — torch ops on the GPU (MIOpen); SURVEY.md §8(f3) "next";
+* encoders (fnet / cnet, raft/extractor.py BasicEncoder) — libpfk kernels through `EncoderEngine` (ptlflow_amd/encoder.py);
+  raft_small's bottleneck SmallEncoder and `native_encoders=False` keep the torch modules;
 * correlation volume, pyramid, per-iteration lookup, the whole update block, coordinate update and
   convex upsampling — libpfk kernels through torch.ops.pfk, state kept pixel-major across all
   iterations (no NCHW round trips inside the loop).
@@ -124,7 +125,7 @@ class RAFT(nn.Module):
         super().__init__()
         self.small = small
         # True: fnet / cnet run on libpfk kernels (ptlflow_amd/encoder.py; BasicEncoder only — raft_small's bottleneck
-        # encoder stays on torch/MIOpen); False: torch modules (MIOpen) as in round-1's first cut
+        # encoder stays on torch); False: the torch modules
         self.native_encoders = native_encoders and not small
         self._enc = None
         self._enc_versions = None
