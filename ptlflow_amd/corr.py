@@ -111,10 +111,41 @@ class CorrBlock:
         return res
 
 
+class AlternateCorrBlock:
+    """On-demand correlation (ptlflow/models/raft/corr.py:67-101): no N x N volume is materialised; every call computes,
+    per pyramid level of ``fmap2`` (avg-pooled), the (2r+1)^2 window around ``coords / 2^l`` with the gfx950 kernel behind
+    the ``alt_cuda_corr`` ABI (``pfk_altcorr_forward_f32``).  Same channel layout and ``/ sqrt(dim)`` as the reference."""
+
+    def __init__(self, fmap1: torch.Tensor, fmap2: torch.Tensor, num_levels: int = 4, radius: int = 4):
+        if not fmap1.is_cuda:
+            raise RuntimeError("ptlflow_amd.AlternateCorrBlock needs GPU tensors (no CPU fallback)")
+        _ops()
+        self.num_levels, self.radius = num_levels, radius
+        self.out_dtype = fmap1.dtype
+        self.dim = fmap1.shape[1]
+        self.f1 = fmap1.float().permute(0, 2, 3, 1).contiguous()                 # NHWC, what the kernel reads
+        self.f2 = []
+        f2 = fmap2.float()
+        for _ in range(num_levels):
+            self.f2.append(f2.permute(0, 2, 3, 1).contiguous())
+            f2 = F.avg_pool2d(f2, 2, stride=2)
+
+    def __call__(self, coords: torch.Tensor) -> torch.Tensor:
+        from . import altcorr
+        c = coords.float().permute(0, 2, 3, 1)
+        B, H, W, _ = c.shape
+        out = []
+        for l in range(self.num_levels):
+            ci = (c / 2 ** l).reshape(B, 1, H, W, 2).contiguous()
+            (corr,) = altcorr.forward(self.f1, self.f2[l], ci, self.radius)
+            out.append(corr.squeeze(1))
+        corr = torch.stack(out, dim=1).reshape(B, -1, H, W) / math.sqrt(self.dim)
+        return corr if self.out_dtype == torch.float32 else corr.to(self.out_dtype)
+
+
 def get_corr_block(fmap1: torch.Tensor, fmap2: torch.Tensor, num_levels: int = 4, radius: int = 4,
                    alternate_corr: bool = False, pyramid: str = "avgpool"):
-    """Same signature as ptlflow/models/raft/corr.py:104-118.  ``alternate_corr=True`` (the on-demand
-    ``alt_cuda_corr`` variant) is a later row of SURVEY.md §8(f); it is refused, not emulated."""
+    """Same signature as ptlflow/models/raft/corr.py:104-118; ``alternate_corr=True`` selects the on-demand block."""
     if alternate_corr:
-        raise NotImplementedError("alternate_corr (on-demand correlation) is not built yet; use alternate_corr=False")
+        return AlternateCorrBlock(fmap1, fmap2, num_levels=num_levels, radius=radius)
     return CorrBlock(fmap1, fmap2, num_levels=num_levels, radius=radius, pyramid=pyramid)

@@ -104,6 +104,22 @@ def test_alt_cuda_corr_abi(gpu, B, H1, W1, H2, W2, C, r):
         mod.forward(f1.cuda().permute(0, 2, 1, 3), f2.cuda(), coords.cuda(), r)   # CHECK_CONTIGUOUS
 
 
+@pytest.mark.parametrize("B,C,H,W,L,r", [(1, 256, 16, 24, 4, 4), (2, 128, 24, 40, 2, 4), (1, 64, 18, 22, 3, 3)])
+def test_alternate_corr_block(gpu, B, C, H, W, L, r):
+    """`get_corr_block(alternate_corr=True)` (raft/corr.py:67-101, the default of ccmr / ms_raft_p): pooled fmap2 per level,
+    on-demand windows, same channel layout and scaling as the oracle's restatement."""
+    from ptlflow_amd.corr import AlternateCorrBlock, get_corr_block
+    g = torch.Generator().manual_seed(12)
+    f1, f2 = torch.randn(B, C, H, W, generator=g), torch.randn(B, C, H, W, generator=g)
+    coords = O.coords_grid(B, H, W) + torch.randn(B, 2, H, W, generator=g) * 4
+    ref = O.alternate_corr_block(f1, f2, coords, L, r)
+    blk = get_corr_block(fmap1=f1.cuda(), fmap2=f2.cuda(), num_levels=L, radius=r, alternate_corr=True)
+    assert isinstance(blk, AlternateCorrBlock)
+    got = blk(coords.cuda()).cpu()
+    assert got.shape == ref.shape == (B, L * (2 * r + 1) ** 2, H, W)
+    assert (got - ref).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item())
+
+
 def test_gma_update_block_dropin(gpu):
     """Seam B3 with GMA's five-argument forward(net, inp, corr, flow, attention) (gma/update.py:148)."""
     from ptlflow_amd.raft import _param_tree
