@@ -142,6 +142,12 @@ class AlternateCorrBlock:
         corr = torch.stack(out, dim=1).reshape(B, -1, H, W) / math.sqrt(self.dim)
         return corr if self.out_dtype == torch.float32 else corr.to(self.out_dtype)
 
+    def lookup_pm(self, coords: torch.Tensor) -> torch.Tensor:
+        """Pixel-major ``[B*h*w, C]`` form for the update engine (same contract as ``CorrBlock.lookup_pm``)."""
+        corr = self(coords).float()
+        B, C, H, W = corr.shape
+        return corr.permute(0, 2, 3, 1).reshape(B * H * W, C).contiguous()
+
 
 def get_corr_block(fmap1: torch.Tensor, fmap2: torch.Tensor, num_levels: int = 4, radius: int = 4,
                    alternate_corr: bool = False, pyramid: str = "avgpool"):

@@ -25,7 +25,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import load_native
-from .corr import CorrBlock
+from .corr import AlternateCorrBlock, CorrBlock
 from .update import UpdateEngine, UpdateSpec, basic_spec, gma_spec, small_spec
 from .synth import synth_state_dict, update_block_shapes
 
@@ -121,9 +121,13 @@ def _param_tree(shapes: Dict[str, tuple]) -> nn.Module:
 # ----------------------------------------------------------------------------- model
 class RAFT(nn.Module):
     def __init__(self, corr_levels: int = 4, corr_radius: Optional[int] = None, iters: int = 32, small: bool = False,
-                 upsample_every_iter: bool = True, conv_precision: str = "fp32", native_encoders: bool = True):
+                 upsample_every_iter: bool = True, conv_precision: str = "fp32", native_encoders: bool = True,
+                 alternate_corr: bool = False):
         super().__init__()
         self.small = small
+        # True: never materialise the N x N volume, compute the lookup windows on demand (raft.py `alternate_corr`,
+        # raft/corr.py:67-101) — the memory / time trade for high resolutions
+        self.alternate_corr = alternate_corr
         # True: fnet / cnet run on libpfk kernels (ptlflow_amd/encoder.py; BasicEncoder only — raft_small's bottleneck
         # encoder stays on torch); False: the torch modules
         self.native_encoders = native_encoders and not small
@@ -225,7 +229,8 @@ class RAFT(nn.Module):
 
         fnet, cnet_fn = self.encoders(x.device)
         fm = fnet(torch.cat([image1, image2], 0))
-        corr_fn = CorrBlock(fm[:B], fm[B:], num_levels=self.corr_levels, radius=self.corr_radius)
+        corr_cls = AlternateCorrBlock if self.alternate_corr else CorrBlock
+        corr_fn = corr_cls(fm[:B], fm[B:], num_levels=self.corr_levels, radius=self.corr_radius)
         cnet = cnet_fn(image1)
         net, inp = torch.split(cnet, [self.hidden_dim, self.context_dim], dim=1)
         net, inp = torch.tanh(net), torch.relu(inp)
