@@ -52,43 +52,55 @@ class CorrBlock:
             raise RuntimeError("ptlflow_amd.CorrBlock needs GPU tensors (no CPU fallback)")
         if not 1 <= radius <= 4:
             raise RuntimeError("radius must be in 1..4")
-        ops = _ops()
+        _ops()
         self.num_levels = num_levels
         self.radius = radius
+        self.pyramid_mode = pyramid
+        if pyramid not in ("avgpool", "bilinear_f2"):
+            raise ValueError(f"unknown pyramid mode {pyramid!r}")
+        n = 2 * radius + 1
+        self.channels = num_levels * n * n
+        self._out: Optional[torch.Tensor] = None
+        self.corr_pyramid: List[torch.Tensor] = []
+        self._shape = None
+        self.update(fmap1, fmap2)
+
+    def update(self, fmap1: torch.Tensor, fmap2: torch.Tensor) -> "CorrBlock":
+        """(Re)build the pyramid for a new frame pair.  Feature maps of the same shape as last time are written into the
+        SAME level tensors (same addresses), which is what lets the iteration loop live in a captured hipGraph."""
+        ops = _ops()
         self.out_dtype = fmap1.dtype
         B, D, h, w = fmap1.shape
         self.B, self.h, self.w = B, h, w
         N = h * w
         f1 = to_pixel_major(fmap1)
         scale = 1.0 / math.sqrt(D)
-        self.corr_pyramid: List[torch.Tensor] = []
-        if pyramid == "avgpool":  # raft/corr.py:19-27
+        shape = (B, D, h, w, tuple(fmap2.shape), fmap1.device)
+        fresh = shape != self._shape
+        if fresh:
+            self.corr_pyramid, self._out, self._shape = [], None, shape
+        dev = f1.device
+        if self.pyramid_mode == "avgpool":  # raft/corr.py:19-27
             f2 = to_pixel_major(fmap2)
-            vol = torch.empty(B, N, N, device=f1.device, dtype=torch.float32)
-            ops.corr_volume(f1, f2, scale, vol)
-            lvl = vol.view(B * N, h, w)
-            self.corr_pyramid.append(lvl)
-            for _ in range(num_levels - 1):
-                hl, wl = lvl.shape[1] // 2, lvl.shape[2] // 2
-                nxt = torch.empty(B * N, hl, wl, device=f1.device, dtype=torch.float32)
-                ops.corr_pool2x2(lvl, nxt)
-                self.corr_pyramid.append(nxt)
-                lvl = nxt
-        elif pyramid == "bilinear_f2":  # sea_raft/corr.py:77-84: one GEMM per level
+            if fresh:
+                hl, wl = h, w
+                for _ in range(self.num_levels):
+                    self.corr_pyramid.append(torch.empty(B * N, hl, wl, device=dev, dtype=torch.float32))
+                    hl, wl = hl // 2, wl // 2
+            ops.corr_volume(f1, f2, scale, self.corr_pyramid[0].view(B, N, N))
+            for l in range(1, self.num_levels):
+                ops.corr_pool2x2(self.corr_pyramid[l - 1], self.corr_pyramid[l])
+        else:  # sea_raft/corr.py:77-84: one GEMM per level
             f2n = fmap2.float()
-            for l in range(num_levels):
+            for l in range(self.num_levels):
                 if l > 0:
                     f2n = F.interpolate(f2n, scale_factor=0.5, mode="bilinear", align_corners=False)
                 h2, w2 = f2n.shape[-2:]
                 f2 = to_pixel_major(f2n)
-                vol = torch.empty(B, N, h2 * w2, device=f1.device, dtype=torch.float32)
-                ops.corr_volume(f1, f2, scale, vol)
-                self.corr_pyramid.append(vol.view(B * N, h2, w2))
-        else:
-            raise ValueError(f"unknown pyramid mode {pyramid!r}")
-        n = 2 * radius + 1
-        self.channels = num_levels * n * n
-        self._out: Optional[torch.Tensor] = None
+                if fresh:
+                    self.corr_pyramid.append(torch.empty(B * N, h2, w2, device=dev, dtype=torch.float32))
+                ops.corr_volume(f1, f2, scale, self.corr_pyramid[l].view(B, N, h2 * w2))
+        return self
 
     def lookup_pm(self, coords: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Lookup into a pixel-major ``[B*h*w, C]`` buffer (allocated once and reused unless given)."""

@@ -122,9 +122,15 @@ def _param_tree(shapes: Dict[str, tuple]) -> nn.Module:
 class RAFT(nn.Module):
     def __init__(self, corr_levels: int = 4, corr_radius: Optional[int] = None, iters: int = 32, small: bool = False,
                  upsample_every_iter: bool = True, conv_precision: str = "fp32", native_encoders: bool = True,
-                 alternate_corr: bool = False):
+                 alternate_corr: bool = False, use_graph: bool = False):
         super().__init__()
         self.small = small
+        # True: the 32-iteration loop (lookup, update block, upsampling: ~20 launches per iteration) is captured once per
+        # input shape into a hipGraph (torch.cuda.CUDAGraph) and replayed — it runs entirely on buffers with fixed addresses.
+        # Pays when the forward is launch-bound (small frames, batch 1); models with a mask head and the materialised
+        # volume only (no GMA aggregate, no alternate_corr).
+        self.use_graph = use_graph
+        self._graphs: Dict[tuple, dict] = {}
         # True: never materialise the N x N volume, compute the lookup windows on demand (raft.py `alternate_corr`,
         # raft/corr.py:67-101) — the memory / time trade for high resolutions
         self.alternate_corr = alternate_corr
@@ -229,30 +235,60 @@ class RAFT(nn.Module):
 
         fnet, cnet_fn = self.encoders(x.device)
         fm = fnet(torch.cat([image1, image2], 0))
-        corr_cls = AlternateCorrBlock if self.alternate_corr else CorrBlock
-        corr_fn = corr_cls(fm[:B], fm[B:], num_levels=self.corr_levels, radius=self.corr_radius)
+        h, w = image1.shape[-2] // 8, image1.shape[-1] // 8
+        eng = self.engine(x.device)
+        eng.bind(B, h, w)
+        graphable = self.use_graph and self.spec.has_mask and not self.spec.aggregate and not self.alternate_corr
+        st = self._graphs.get((B, h, w, x.device)) if graphable else None
+        if st is not None and (st["engine"] is not eng or st["hx_ptr"] != eng.hx.data_ptr()):
+            st = None      # a new engine, or its buffers were re-bound for another shape in between: the recorded addresses are stale
+        if st is None:
+            corr_cls = AlternateCorrBlock if self.alternate_corr else CorrBlock
+            corr_fn = corr_cls(fm[:B], fm[B:], num_levels=self.corr_levels, radius=self.corr_radius)
+            ys, xs = torch.meshgrid(torch.arange(h, device=x.device, dtype=torch.float32),
+                                    torch.arange(w, device=x.device, dtype=torch.float32), indexing="ij")
+            coords0 = torch.stack([xs, ys], 0)[None].repeat(B, 1, 1, 1).contiguous()
+            coords1 = coords0.clone()
+            flow_up = torch.empty(B, 2, 8 * h, 8 * w, device=x.device, dtype=torch.float32) if self.spec.has_mask else None
+        else:
+            corr_fn, coords0, coords1, flow_up = st["corr"].update(fm[:B], fm[B:]), st["coords0"], st["coords1"], st["flow_up"]
+            coords1.copy_(coords0)
         cnet = cnet_fn(image1)
         net, inp = torch.split(cnet, [self.hidden_dim, self.context_dim], dim=1)
         net, inp = torch.tanh(net), torch.relu(inp)
 
-        h, w = image1.shape[-2] // 8, image1.shape[-1] // 8
-        ys, xs = torch.meshgrid(torch.arange(h, device=x.device, dtype=torch.float32),
-                                torch.arange(w, device=x.device, dtype=torch.float32), indexing="ij")
-        coords0 = torch.stack([xs, ys], 0)[None].repeat(B, 1, 1, 1).contiguous()
-        coords1 = coords0.clone()
         prev = inputs.get("prev_preds")
         if prev is not None and prev.get("flow_small") is not None:      # warm start, raft.py:162-167, on the device
             fwd = torch.empty_like(coords1)
             ops.forward_interpolate(prev["flow_small"].to(device=x.device, dtype=torch.float32).contiguous(), fwd)
-            coords1 = coords1 + fwd
+            coords1.add_(fwd)
 
-        eng = self.engine(x.device)
-        eng.bind(B, h, w)
         eng.load_state(net, inp)
         self._after_context(eng, inp)
         ops.flow_from_coords(coords0, coords1, eng.flow_view)
+        if st is not None:
+            st["graph"].replay()
+        else:
+            flow_up = self._iterate(corr_fn, eng, coords0, coords1, flow_up)
+            if graphable:
+                # the eager pass above produced this forward's result and warmed every kernel up; record the same loop for
+                # the next forwards of this shape (capture does not execute, state is left as the eager pass wrote it)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    self._iterate(corr_fn, eng, coords0, coords1, flow_up)
+                self._graphs[(B, h, w, x.device)] = {"graph": graph, "corr": corr_fn, "coords0": coords0, "coords1": coords1,
+                                                     "flow_up": flow_up, "engine": eng, "hx_ptr": eng.hx.data_ptr()}
+        out_up = self.unpad(flow_up, pads)
+        flow_small = coords1 - coords0
+        if graphable:      # the buffers behind these results are overwritten by the next forward
+            out_up = out_up.clone()
+        return {"flows": out_up[:, None], "flow_small": flow_small}
+
+    def _iterate(self, corr_fn, eng: UpdateEngine, coords0, coords1, flow_up):
+        """The recurrent loop of raft.py:169-187 on fixed buffers: lookup -> update block -> coordinate update -> upsampling."""
+        ops = torch.ops.pfk
         has_mask = self.spec.has_mask
-        flow_up = torch.empty(B, 2, 8 * h, 8 * w, device=x.device, dtype=torch.float32) if has_mask else None
+        h, w = coords0.shape[-2:]
         for it in range(self.iters):
             last = it == self.iters - 1
             corr_pm = corr_fn.lookup_pm(coords1)
@@ -263,8 +299,7 @@ class RAFT(nn.Module):
                     ops.convex_upsample_pm(eng.flow_view, eng.mask, flow_up)
                 else:          # raft_small: upflow8 (raft/utils.py:94-96)
                     flow_up = 8 * F.interpolate(coords1 - coords0, size=(8 * h, 8 * w), mode="bilinear", align_corners=True)
-        out_up = self.unpad(flow_up, pads)
-        return {"flows": out_up[:, None], "flow_small": coords1 - coords0}
+        return flow_up
 
 
 class RAFTSmall(RAFT):

@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Eager vs hipGraph-replayed iteration loop (GPU box).  python scripts/graph_bench.py [--height 436 --width 1024 --batch 1]"""
+import argparse, os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ptlflow_amd.raft import RAFT  # noqa: E402
+from ptlflow_amd.synth import smooth_pair  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--height", type=int, default=436)
+ap.add_argument("--width", type=int, default=1024)
+ap.add_argument("--batch", type=int, default=1)
+ap.add_argument("--conv-precision", default="fp32")
+args = ap.parse_args()
+x = smooth_pair(args.batch, args.height, args.width, seed=1).cuda()
+for use_graph in (False, True):
+    m = RAFT(use_graph=use_graph, conv_precision=args.conv_precision).load_synthetic(1).eval().cuda()
+    for _ in range(3):
+        m({"images": x})
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        m({"images": x})
+    torch.cuda.synchronize()
+    ms = 1e2 * (time.perf_counter() - t0)
+    print(f"{args.height}x{args.width} batch {args.batch} {args.conv_precision} use_graph={use_graph}: {ms:.2f} ms / forward ({args.batch * 1e3 / ms:.1f} pairs/s)")

@@ -146,3 +146,22 @@ def test_alternate_corr_forward(gpu):
     fa, fb = a({"images": x})["flows"], b({"images": x})["flows"]
     mean, mx = O.epe(fa[:, 0].cpu(), fb[:, 0].cpu())
     assert mean <= 5e-3 and mx <= 5e-2, f"EPE mean {mean:.2e} max {mx:.2e}"
+
+
+def test_graph_replay_matches_eager(gpu):
+    """use_graph=True: the iteration loop recorded into a hipGraph must reproduce the eager forward bit for bit, for new inputs
+    of the same shape, after a shape change in between, and with a warm start."""
+    from ptlflow_amd.raft import RAFT
+    eager = RAFT(iters=5).load_synthetic(11).eval().cuda()
+    graph = RAFT(iters=5, use_graph=True).load_synthetic(11).eval().cuda()
+    xs = [O.smooth_pair(1, 128, 192, seed=s).cuda() for s in (1, 2, 3)]
+    other = O.smooth_pair(1, 136, 160, seed=7).cuda()
+    prev = None
+    for i, x in enumerate(xs + [other] + xs[:2]):
+        inp = {"images": x}
+        if i == 2 and prev is not None:
+            inp["prev_preds"] = {"flow_small": prev}
+        a, b = eager(dict(inp)), graph(dict(inp))
+        assert torch.equal(a["flows"], b["flows"]) and torch.equal(a["flow_small"], b["flow_small"]), f"forward {i}"
+        prev = a["flow_small"] if x.shape == xs[0].shape else None
+    assert len(graph._graphs) == 2
