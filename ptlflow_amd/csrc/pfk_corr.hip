@@ -53,20 +53,26 @@ __device__ __forceinline__ int safe_base(float v) {
 // PIX consecutive source pixels per workgroup: the kernel is a chain of dependent latencies (coords -> patch
 // loads -> LDS -> outputs), so each wave keeps PIX independent patches in flight instead of one — 4x fewer,
 // 4x fatter workgroups, one resident round on the chip at 55x128.
+// Every wave works on its own LDS region (its level's patches and tap tables), so the only synchronisation needed between
+// staging and sampling is within the wave: LDS operations of a wave complete in order, `s_waitcnt lgkmcnt(0)` (also a
+// compiler barrier) is enough — no workgroup barrier couples the four levels' very different amounts of work.
+__device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 constexpr int PIX = 4;
 
+// R = radius (compile-time: the (2R+1)^2 sample enumeration divides by constants), PIX pixels per workgroup.
+template <int PIX, int R>
 __global__ __launch_bounds__(256) void lookup_kernel(const LookupArgs a) {
+  constexpr int n = 2 * R + 1, nn = n * n;
   __shared__ float s_patch[4][PIX][PATCH * PATCH_LD];
-  __shared__ float s_x0[4][PIX][12], s_wx[4][PIX][12], s_y0[4][PIX][12], s_wy[4][PIX][12];
+  __shared__ float s_wx[4][PIX][12], s_wy[4][PIX][12];
+  __shared__ int s_rx[4][PIX][12], s_ry[4][PIX][12];   // per window index: patch column / row (x 13) of the north-west tap
 
   const int lane = threadIdx.x & 63;
   const int wid = threadIdx.x >> 6;
   const long long M = (long long)a.B * a.h * a.w;
   const long long p0 = (long long)blockIdx.x * PIX;
   const int N = a.h * a.w;
-  const int r = a.r;
-  const int n = 2 * r + 1;
-  const int nn = n * n;
 
   float cx0[PIX], cy0[PIX];
 #pragma unroll
@@ -85,7 +91,6 @@ __global__ __launch_bounds__(256) void lookup_kernel(const LookupArgs a) {
   for (int it = 0; it < rounds; ++it) {
     const int l = it * 4 + wid;
     const bool active = l < a.L;
-    float xb[PIX], yb[PIX];
     if (active) {
       const int Hl = a.lh[l], Wl = a.lw[l];
       const float inv = 1.0f / (float)(1 << l);   // coords / 2**l is exact (corr.py:45)
@@ -93,19 +98,20 @@ __global__ __launch_bounds__(256) void lookup_kernel(const LookupArgs a) {
 #pragma unroll
       for (int q = 0; q < PIX; ++q) {
         const float cx = cx0[q] * inv, cy = cy0[q] * inv;
-        xb[q] = floorf(cx) - (float)(r + 1);
-        yb[q] = floorf(cy) - (float)(r + 1);
+        const float xb = floorf(cx) - (float)(R + 1);
+        const float yb = floorf(cy) - (float)(R + 1);
         if (lane < n) {
-          const float off = (float)(lane - r);
+          const float off = (float)(lane - R);
           const float ix = roundtrip(cx + off, (float)(Wl - 1), (float)(Wl - 1) * 0.5f);
           const float iy = roundtrip(cy + off, (float)(Hl - 1), (float)(Hl - 1) * 0.5f);
           const float x0 = floorf(ix), y0 = floorf(iy);
-          s_x0[wid][q][lane] = x0;
+          const float dxf = x0 - xb, dyf = y0 - yb;   // position of the tap inside the staged patch (absurd / NaN -> 0)
+          s_rx[wid][q][lane] = (dxf >= 0.f && dxf <= (float)(PATCH - 2)) ? (int)dxf : 0;
+          s_ry[wid][q][lane] = ((dyf >= 0.f && dyf <= (float)(PATCH - 2)) ? (int)dyf : 0) * PATCH_LD;
           s_wx[wid][q][lane] = ix - x0;
-          s_y0[wid][q][lane] = y0;
           s_wy[wid][q][lane] = iy - y0;
         }
-        const int xbi = safe_base(xb[q]), ybi = safe_base(yb[q]);
+        const int xbi = safe_base(xb), ybi = safe_base(yb);
         const bool pl = (p0 + q) < M;
         const float* vol = a.lv[l] + (p0 + q) * (long long)Hl * Wl;
 #pragma unroll
@@ -130,32 +136,27 @@ __global__ __launch_bounds__(256) void lookup_kernel(const LookupArgs a) {
           }
         }
     }
-    __syncthreads();
+    wave_lds_sync();
     if (active) {
-#pragma unroll
-      for (int q = 0; q < PIX; ++q) {
-        if (p0 + q >= M) break;
-        float* o = a.out + (p0 + q) * a.out_ld + l * nn;
-        for (int k = lane; k < nn; k += 64) {
-          const int i = k / n, j = k - i * n;
-          const float x0 = s_x0[wid][q][i], wx = s_wx[wid][q][i];
-          const float y0 = s_y0[wid][q][j], wy = s_wy[wid][q][j];
-          const float dxf = x0 - xb[q], dyf = y0 - yb[q];
-          const int rx = (dxf >= 0.f && dxf <= (float)(PATCH - 2)) ? (int)dxf : 0;
-          const int ry = (dyf >= 0.f && dyf <= (float)(PATCH - 2)) ? (int)dyf : 0;
-          const float* pq = &s_patch[wid][q][ry * PATCH_LD + rx];
-          const float nw = pq[0], ne = pq[1], sw = pq[PATCH_LD], se = pq[PATCH_LD + 1];
-          const float ex = 1.0f - wx, sy = 1.0f - wy;
-          const float w_nw = sy * ex, w_ne = sy * wx, w_sw = wy * ex, w_se = wy * wx;
-          float t = nw * w_nw;
-          t = fmaf(ne, w_ne, t);
-          t = fmaf(sw, w_sw, t);
-          t = fmaf(se, w_se, t);
-          o[k] = t;
-        }
+      // the PIX * (2R+1)^2 samples of this level as one flat list over the lanes (324 = 5.06 wave-iterations at R = 4
+      // instead of 4 x 2 with 47 idle lanes in every second one)
+      for (int idx = lane; idx < PIX * nn; idx += 64) {
+        const int q = idx / nn, k = idx - q * nn;
+        if (p0 + q >= M) continue;
+        const int i = k / n, j = k - i * n;
+        const float wx = s_wx[wid][q][i], wy = s_wy[wid][q][j];
+        const float* pq = &s_patch[wid][q][s_ry[wid][q][j] + s_rx[wid][q][i]];
+        const float nw = pq[0], ne = pq[1], sw = pq[PATCH_LD], se = pq[PATCH_LD + 1];
+        const float ex = 1.0f - wx, sy = 1.0f - wy;
+        const float w_nw = sy * ex, w_ne = sy * wx, w_sw = wy * ex, w_se = wy * wx;
+        float t = nw * w_nw;
+        t = fmaf(ne, w_ne, t);
+        t = fmaf(sw, w_sw, t);
+        t = fmaf(se, w_se, t);
+        a.out[(p0 + q) * a.out_ld + l * nn + k] = t;
       }
     }
-    __syncthreads();
+    wave_lds_sync();   // the next round restages this wave's region
   }
 }
 
@@ -197,8 +198,14 @@ int pfk_corr_lookup_f32(const pfk_lookup_desc* d, pfk_stream_t stream) {
   a.coords = d->coords; a.out = d->out; a.out_ld = d->out_ld;
   const long long blocks = ((long long)d->B * d->h * d->w + PIX - 1) / PIX;
   if (blocks > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(lookup_kernel, dim3((unsigned)blocks), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), a);
+  const dim3 grid((unsigned)blocks), block(256);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (d->radius) {
+    case 1: hipLaunchKernelGGL((lookup_kernel<PIX, 1>), grid, block, 0, st, a); break;
+    case 2: hipLaunchKernelGGL((lookup_kernel<PIX, 2>), grid, block, 0, st, a); break;
+    case 3: hipLaunchKernelGGL((lookup_kernel<PIX, 3>), grid, block, 0, st, a); break;
+    default: hipLaunchKernelGGL((lookup_kernel<PIX, 4>), grid, block, 0, st, a); break;
+  }
   return pfk_launch_status();
 }
 
