@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--conv-precision", default="fp32")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--torch-encoders", action="store_true")
+    ap.add_argument("--corr-tile", type=int, default=-1, help="force a GEMM tile configuration while timing the correlation volume")
     args = ap.parse_args()
     dev = torch.device("cuda")
     m = RAFT(conv_precision=args.conv_precision, native_encoders=not args.torch_encoders).load_synthetic(1234).eval().to(dev)
@@ -44,7 +45,9 @@ def main():
         t_f, fm = timed(lambda: fnet(both), args.reps)
         t_c, _ = timed(lambda: cnet(i1), args.reps)
         B = args.batch
+        torch.ops.pfk.debug_set_tile(args.corr_tile)
         t_corr, _ = timed(lambda: CorrBlock(fm[:B], fm[B:], num_levels=4, radius=4), args.reps)
+        torch.ops.pfk.debug_set_tile(-1)
         t_all, _ = timed(lambda: m({"images": x}), args.reps)
     rest = t_all - t_pre - t_f - t_c - t_corr
     print(f"batch {B} {args.conv_precision}: forward {t_all:.2f} ms = preprocess {t_pre:.2f} + fnet {t_f:.2f} + cnet {t_c:.2f} "
