@@ -117,50 +117,64 @@ __device__ __forceinline__ float wave_sum(float v) {
 // FlowHead.conv2 (3x3, cin -> 2; raft/update.py:10,14) + RAFT loop bookkeeping (raft.py:174,178).
 // One wave per pixel: lanes split the input channels (float4 each, coalesced 1 KiB rows), two
 // butterfly reductions, lane 0 applies coords1 += delta and flow = coords1 - coords0.
+constexpr int FD_PIX = 4;   // consecutive pixels per wave: the tap's weights are loaded once for all of them
+
 __global__ __launch_bounds__(256) void flow_delta_kernel(
     const float* __restrict__ in, int in_ld, int cin, const float* __restrict__ wgt,
     const float* __restrict__ bias, const float* __restrict__ coords0, float* coords1,
     float* delta_out, float* flow_out, int flow_ld, long long M, int H, int W) {
   const int lane = threadIdx.x & 63;
-  const long long p = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (p >= M) return;
-  const int x = (int)(p % W);
-  const int y = (int)((p / W) % H);
-  float s0 = 0.f, s1 = 0.f;
-  for (int ky = 0; ky < 3; ++ky) {
-    const int yy = y + ky - 1;
-    if ((unsigned)yy >= (unsigned)H) continue;
-    for (int kx = 0; kx < 3; ++kx) {
-      const int xx = x + kx - 1;
-      if ((unsigned)xx >= (unsigned)W) continue;
-      const float* src = in + (p + (long long)(ky - 1) * W + (kx - 1)) * in_ld;
-      const float* w0 = wgt + (long long)((ky * 3 + kx) * 2) * cin;
-      const float* w1 = w0 + cin;
-      for (int c = lane * 4; c < cin; c += 256) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(src + c);
+  const long long p0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * FD_PIX;
+  if (p0 >= M) return;
+  int x[FD_PIX], y[FD_PIX];
+#pragma unroll
+  for (int q = 0; q < FD_PIX; ++q) {
+    const long long p = p0 + q;
+    x[q] = (int)(p % W);
+    y[q] = (p < M) ? (int)((p / W) % H) : -4;        // past the end: every tap out of range
+  }
+  float s0[FD_PIX], s1[FD_PIX];
+#pragma unroll
+  for (int q = 0; q < FD_PIX; ++q) { s0[q] = 0.f; s1[q] = 0.f; }
+  for (int c = lane * 4; c < cin; c += 256) {
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const float* w0 = wgt + (long long)((ky * 3 + kx) * 2) * cin;
         const f32x4 a = *reinterpret_cast<const f32x4*>(w0 + c);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(w1 + c);
-        s0 = fmaf(v.x, a.x, fmaf(v.y, a.y, fmaf(v.z, a.z, fmaf(v.w, a.w, s0))));
-        s1 = fmaf(v.x, b.x, fmaf(v.y, b.y, fmaf(v.z, b.z, fmaf(v.w, b.w, s1))));
+        const f32x4 b = *reinterpret_cast<const f32x4*>(w0 + cin + c);
+#pragma unroll
+        for (int q = 0; q < FD_PIX; ++q) {
+          const int yy = y[q] + ky - 1, xx = x[q] + kx - 1;
+          if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {   // zero padding: the tap simply does not contribute
+            const f32x4 v = *reinterpret_cast<const f32x4*>(in + (p0 + q + (long long)(ky - 1) * W + (kx - 1)) * in_ld + c);
+            s0[q] = fmaf(v.x, a.x, fmaf(v.y, a.y, fmaf(v.z, a.z, fmaf(v.w, a.w, s0[q]))));
+            s1[q] = fmaf(v.x, b.x, fmaf(v.y, b.y, fmaf(v.z, b.z, fmaf(v.w, b.w, s1[q]))));
+          }
+        }
       }
     }
   }
-  s0 = wave_sum(s0);
-  s1 = wave_sum(s1);
-  if (lane == 0) {
-    const long long hw = (long long)H * W;
-    const long long b = p / hw, pix = p - b * hw;
-    const long long ix = (b * 2 + 0) * hw + pix, iy = (b * 2 + 1) * hw + pix;
-    const float dx = s0 + (bias ? bias[0] : 0.f);
-    const float dy = s1 + (bias ? bias[1] : 0.f);
-    const float c1x = __fadd_rn(coords1[ix], dx);
-    const float c1y = __fadd_rn(coords1[iy], dy);
-    coords1[ix] = c1x;
-    coords1[iy] = c1y;
-    if (delta_out) { delta_out[ix] = dx; delta_out[iy] = dy; }
-    if (flow_out) {
-      flow_out[p * flow_ld + 0] = __fsub_rn(c1x, coords0[ix]);
-      flow_out[p * flow_ld + 1] = __fsub_rn(c1y, coords0[iy]);
+  const long long hw = (long long)H * W;
+#pragma unroll
+  for (int q = 0; q < FD_PIX; ++q) {
+    const float t0 = wave_sum(s0[q]), t1 = wave_sum(s1[q]);
+    const long long p = p0 + q;
+    if (lane == 0 && p < M) {
+      const long long b = p / hw, pix = p - b * hw;
+      const long long ix = (b * 2 + 0) * hw + pix, iy = (b * 2 + 1) * hw + pix;
+      const float dx = t0 + (bias ? bias[0] : 0.f);
+      const float dy = t1 + (bias ? bias[1] : 0.f);
+      const float c1x = __fadd_rn(coords1[ix], dx);
+      const float c1y = __fadd_rn(coords1[iy], dy);
+      coords1[ix] = c1x;
+      coords1[iy] = c1y;
+      if (delta_out) { delta_out[ix] = dx; delta_out[iy] = dy; }
+      if (flow_out) {
+        flow_out[p * flow_ld + 0] = __fsub_rn(c1x, coords0[ix]);
+        flow_out[p * flow_ld + 1] = __fsub_rn(c1y, coords0[iy]);
+      }
     }
   }
 }
@@ -361,7 +375,7 @@ int pfk_flow_delta_f32(const float* in, int in_ld, int cin, const float* weight,
   if (!pfk_aligned16(in) || !pfk_aligned16(weight) || (in_ld & 3) || (cin & 3))
     return PFK_ERR_ALIGNMENT;
   const long long M = (long long)B * H * W;
-  const long long blocks = (M + 3) / 4;
+  const long long blocks = (M + 4 * FD_PIX - 1) / (4 * FD_PIX);
   if (blocks > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(flow_delta_kernel, dim3((unsigned)blocks), dim3(256), 0,
                      static_cast<hipStream_t>(stream), in, in_ld, cin, weight, bias, coords0,
