@@ -101,6 +101,7 @@ class UpdateEngine:
         # optional per-launch instrumentation: key -> [(start_event, end_event)], and key -> algorithmic FLOPs
         self.profile: Optional[Dict[str, list]] = None
         self.flops: Dict[str, float] = {}
+        self.bytes: Dict[str, float] = {}
         self.pack(params)
 
     # ------------------------------------------------------------------ weights
@@ -279,6 +280,8 @@ class UpdateEngine:
             prof.setdefault(key, []).append((e0, e1))
             # algorithmic work: 2 * pixels * cout * taps * real input channels (padding is not work)
             self.flops[key] = 2.0 * B * H * W * cout * kh * kw * self._real_cin[key]
+            # algorithmic HBM bytes: every input channel read once, every output written once, the weight once (fp32)
+            self.bytes[key] = 4.0 * (B * H * W * (self._real_cin[key] + cout) + cout * kh * kw * self._real_cin[key])
 
     def motion_and_gru(self, corr_pm: torch.Tensor) -> None:
         """update.py:104-112 (encoder) + :58-73 / :24-32 (GRU); `flow` must already be in hx."""
