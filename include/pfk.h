@@ -208,10 +208,12 @@ int pfk_altcorr_backward_f32(const float* fmap1, const float* fmap2, const float
  * `d` describes the forward convolution (sources, B, H, W, kh, kw, cout; stride 1; weight/out/epilogue fields ignored);
  * dy [B*H*W][dy_ld] is the gradient w.r.t. the convolution output, cout % 4 == 0.  The reduction runs over pixels, cut
  * into slices whose partial results go through `workspace` (pfk_conv_wgrad_workspace_bytes(d) bytes, 16-byte aligned; may
- * be NULL when that is 0) and are added in a fixed order: deterministic, no atomics.  (The data gradient needs no entry
+ * be NULL when that is 0) and are added in a fixed order: deterministic, no atomics.  with_bias != 0 appends 32 columns to
+ * every row of dw_packed ([cout][ktot + 32]); column ktot is the bias gradient sum_p dy[p][co] (computed as one more chunk
+ * whose A operand is a column of ones), the other 31 are zero.  (The data gradient needs no entry
  * point of its own: it is pfk_conv2d_f32 of dy with the spatially flipped, transposed weight.) */
-long long pfk_conv_wgrad_workspace_bytes(const pfk_conv_desc* d);
-int pfk_conv_wgrad_f32(const pfk_conv_desc* d, const float* dy, int dy_ld, float* dw_packed, void* workspace,
+long long pfk_conv_wgrad_workspace_bytes(const pfk_conv_desc* d, int with_bias);
+int pfk_conv_wgrad_f32(const pfk_conv_desc* d, const float* dy, int dy_ld, float* dw_packed, int with_bias, void* workspace,
                        long long workspace_bytes, pfk_stream_t stream);
 
 /* Gate arithmetic of one ConvGRU / SepConvGRU pass for the training path (raft/update.py:24-32, 58-73), pixel-major

@@ -301,7 +301,8 @@ void forward_interpolate(const Tensor& flow, Tensor out) {
 }
 
 // weight gradient in the packed [cout, ktot] layout; dy [M, cout] (cout % 4 == 0)
-void conv_wgrad(at::TensorList srcs, const Tensor& dy, int64_t B, int64_t H, int64_t W, int64_t kh, int64_t kw, Tensor out) {
+void conv_wgrad(at::TensorList srcs, const Tensor& dy, int64_t B, int64_t H, int64_t W, int64_t kh, int64_t kw, Tensor out,
+                bool with_bias) {
   TORCH_CHECK(srcs.size() >= 1 && srcs.size() <= 3, "conv_wgrad: 1..3 sources");
   check_pm(dy, "dy"); check_dev_f32(out, "out");
   pfk_conv_desc d{};
@@ -314,12 +315,13 @@ void conv_wgrad(at::TensorList srcs, const Tensor& dy, int64_t B, int64_t H, int
   d.num_src = srcs.size();
   d.B = B; d.H = H; d.W = W; d.kh = kh; d.kw = kw; d.cout = dy.size(1);
   TORCH_CHECK(dy.size(0) == M, "conv_wgrad: dy rows != B*H*W");
-  TORCH_CHECK(out.is_contiguous() && out.dim() == 2 && out.size(0) == d.cout && out.size(1) == pfk_conv_ktot(&d), "conv_wgrad: out [cout, ktot]");
-  const long long need = pfk_conv_wgrad_workspace_bytes(&d);
+  TORCH_CHECK(out.is_contiguous() && out.dim() == 2 && out.size(0) == d.cout && out.size(1) == pfk_conv_ktot(&d) + (with_bias ? 32 : 0),
+              "conv_wgrad: out [cout, ktot (+32 with the bias column)]");
+  const long long need = pfk_conv_wgrad_workspace_bytes(&d, with_bias);
   Tensor ws;
   void* wsp = nullptr;
   if (need > 0) { ws = at::empty({(int64_t)need}, dy.options().dtype(at::kByte)); wsp = ws.data_ptr(); }
-  check_ok(pfk_conv_wgrad_f32(&d, fptr(dy), dy.stride(0), fptr(out), wsp, need, cur_stream()), "conv_wgrad");
+  check_ok(pfk_conv_wgrad_f32(&d, fptr(dy), dy.stride(0), fptr(out), with_bias, wsp, need, cur_stream()), "conv_wgrad");
 }
 
 void gru_gates_zr(const Tensor& a_zr, const Tensor& h, Tensor z, Tensor r, Tensor rh) {
@@ -361,7 +363,7 @@ TORCH_LIBRARY(pfk, m) {
   m.def("gru_gates_q(Tensor a_q, Tensor z, Tensor h, Tensor(a!) q, Tensor(b!) h_new) -> ()");
   m.def("gru_backward_q(Tensor dh_new, Tensor z, Tensor q, Tensor h, Tensor(a!) da_q, Tensor(b!) da_zr, Tensor(c!) dh) -> ()");
   m.def("gru_backward_zr(Tensor d_rh, Tensor h, Tensor r, Tensor(a!) da_zr, Tensor(b!) dh) -> ()");
-  m.def("conv_wgrad(Tensor[] srcs, Tensor dy, int B, int H, int W, int kh, int kw, Tensor(a!) out) -> ()");
+  m.def("conv_wgrad(Tensor[] srcs, Tensor dy, int B, int H, int W, int kh, int kw, Tensor(a!) out, bool with_bias=False) -> ()");
   m.def("forward_interpolate(Tensor flow, Tensor(a!) out) -> ()");
   m.def("instnorm_workspace_bytes(int B, int C) -> int", &instnorm_workspace_bytes);
   m.def("conv_stem(Tensor img, Tensor weight, Tensor? bias, Tensor(a!) out, bool relu) -> ()");

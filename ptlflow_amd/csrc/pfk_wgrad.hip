@@ -27,7 +27,8 @@ struct WgradArgs {
   int H, W, kh, kw;
   long long M;
   float* part;            // [splits][cout][ktot]  (== the output when splits == 1)
-  int ktot, chunks, tiles_m;
+  int ktot, chunks, tiles_m;   // ktot / chunks include the bias chunk when with_bias
+  int with_bias;               // one extra 32-column chunk whose column 0 is sum_p dY[p][co] (A = a column of ones): the bias gradient
   long long px_per_split; // multiple of 32
 };
 
@@ -53,8 +54,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     r -= taps * cps; cps = (a.ch1 + 31) >> 5; src = a.src1; ld = a.ld1; cch = a.ch1;
     if (a.nsrc > 2 && r >= taps * cps) { r -= taps * cps; cps = (a.ch2 + 31) >> 5; src = a.src2; ld = a.ld2; cch = a.ch2; }
   }
-  const int tap = r / cps, c0 = (r - tap * cps) * 32;
-  const int dy_ = tap / a.kw - (a.kh >> 1), dx_ = tap % a.kw - (a.kw >> 1);
+  const bool bias_chunk = a.with_bias && chunk == a.chunks - 1;
+  const int tap = bias_chunk ? 0 : r / cps, c0 = bias_chunk ? 0 : (r - tap * cps) * 32;
+  const int dy_ = bias_chunk ? 0 : tap / a.kw - (a.kh >> 1), dx_ = bias_chunk ? 0 : tap % a.kw - (a.kw >> 1);
 
   const __amdgpu_buffer_rsrc_t rsx = rsrc_of(src), rsy = rsrc_of(a.dy);
   const long long p_begin = (long long)split * a.px_per_split;
@@ -75,7 +77,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
   auto load = [&](void) {
     const bool in = p < p_end;
     const bool ok = in && c_ok && (unsigned)(y + dy_) < (unsigned)a.H && (unsigned)(x + dx_) < (unsigned)a.W;
-    rx = __builtin_amdgcn_raw_buffer_load_b128(rsx, ok ? (unsigned)((int)p * ld + tap_off) * 4u : OOB, 0, 0);
+    if (bias_chunk) {   // A = [1 0 0 ...] for every live pixel
+      rx = u32x4{(in && q == 0) ? 0x3f800000u : 0u, 0u, 0u, 0u};
+    } else {
+      rx = __builtin_amdgcn_raw_buffer_load_b128(rsx, ok ? (unsigned)((int)p * ld + tap_off) * 4u : OOB, 0, 0);
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       ry[i] = __builtin_amdgcn_raw_buffer_load_b128(rsy, (in && yok[i]) ? (unsigned)((int)p * a.dy_ld + co0 + q * 4 + 32 * i) * 4u : OOB, 0, 0);
@@ -221,15 +227,15 @@ inline int ktot_of(const pfk_conv_desc* d) {
 
 extern "C" {
 
-long long pfk_conv_wgrad_workspace_bytes(const pfk_conv_desc* d) {
+long long pfk_conv_wgrad_workspace_bytes(const pfk_conv_desc* d, int with_bias) {
   if (!d || d->num_src < 1 || d->num_src > 3 || d->cout <= 0) return 0;
-  const int ktot = ktot_of(d);
+  const int ktot = ktot_of(d) + (with_bias ? 32 : 0);
   const long long M = (long long)d->B * d->H * d->W;
   const int splits = pick_splits((long long)((d->cout + 127) / 128) * (ktot / 32), M);
   return splits > 1 ? (long long)splits * d->cout * ktot * (long long)sizeof(float) : 0;
 }
 
-int pfk_conv_wgrad_f32(const pfk_conv_desc* d, const float* dy, int dy_ld, float* dw_packed, void* workspace,
+int pfk_conv_wgrad_f32(const pfk_conv_desc* d, const float* dy, int dy_ld, float* dw_packed, int with_bias, void* workspace,
                        long long workspace_bytes, pfk_stream_t stream) {
   if (!d || !dy || !dw_packed || d->num_src < 1 || d->num_src > 3) return PFK_ERR_BAD_ARG;
   if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->cout <= 0 || dy_ld < d->cout) return PFK_ERR_BAD_ARG;
@@ -250,7 +256,8 @@ int pfk_conv_wgrad_f32(const pfk_conv_desc* d, const float* dy, int dy_ld, float
   a.nsrc = d->num_src;
   a.dy = dy; a.dy_ld = dy_ld; a.cout = d->cout;
   a.H = d->H; a.W = d->W; a.kh = d->kh; a.kw = d->kw; a.M = M;
-  a.ktot = ktot_of(d);
+  a.with_bias = with_bias ? 1 : 0;
+  a.ktot = ktot_of(d) + (with_bias ? 32 : 0);
   a.chunks = a.ktot / 32;
   a.tiles_m = (d->cout + 127) / 128;
   const int splits = pick_splits((long long)a.tiles_m * a.chunks, M);

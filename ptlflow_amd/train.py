@@ -119,14 +119,16 @@ class _ConvPM(torch.autograd.Function):
             dsrcs[i] = dx
         # ---- wgrad: one launch (+ a deterministic slice reduction) straight from the pixel-major tensors, written in the packed
         # [cout, ktot] layout of the forward weight and un-packed here (the inverse of pack_conv_weight)
+        want_b = ctx.has_bias and need[1]
         if need[0]:
             taps = g.kh * g.kw
             ktot = sum(taps * round_up(n_buf, 32) for _, _, n_buf in segs)
-            packed = torch.empty(dY_src.shape[1], ktot, device=dY.device, dtype=torch.float32)
-            ops.conv_wgrad(list(srcs), dY_src, g.B, g.H, g.W, g.kh, g.kw, packed)
-            dW = _unpack_wgrad(packed, weight.shape, segs, g)
-            dW = dW.to(weight.dtype)
-        if ctx.has_bias and need[1]:
+            packed = torch.empty(dY_src.shape[1], ktot + (32 if want_b else 0), device=dY.device, dtype=torch.float32)
+            ops.conv_wgrad(list(srcs), dY_src, g.B, g.H, g.W, g.kh, g.kw, packed, want_b)   # bias gradient = one more column
+            dW = _unpack_wgrad(packed, weight.shape, segs, g).to(weight.dtype)
+            if want_b:
+                db = packed[:cout, ktot].clone()
+        elif want_b:
             db = dY.sum(0)
         return (dW, db, None, None, None, None, *dsrcs)
 
@@ -226,14 +228,14 @@ class _GruPass(torch.autograd.Function):
         dx = dgrad(da_zr, pk_zr, wzr, 1, Cx, residual=dx)
         taps = g.kh * g.kw
         ktot = taps * (round_up(C, 32) + round_up(Cx, 32))
-        pq = torch.empty(C, ktot, device=dev, dtype=torch.float32)
-        ops.conv_wgrad([rh, x], da_q, g.B, g.H, g.W, g.kh, g.kw, pq)
-        pzr = torch.empty(2 * C, ktot, device=dev, dtype=torch.float32)
-        ops.conv_wgrad([h, x], da_zr, g.B, g.H, g.W, g.kh, g.kw, pzr)
+        pq = torch.empty(C, ktot + 32, device=dev, dtype=torch.float32)
+        ops.conv_wgrad([rh, x], da_q, g.B, g.H, g.W, g.kh, g.kw, pq, True)
+        pzr = torch.empty(2 * C, ktot + 32, device=dev, dtype=torch.float32)
+        ops.conv_wgrad([h, x], da_zr, g.B, g.H, g.W, g.kh, g.kw, pzr, True)
         dwq = _unpack_wgrad(pq, wq.shape, segs, g)
         dwzr = _unpack_wgrad(pzr, wzr.shape, segs, g)
-        dbzr = da_zr.sum(0)
-        return (dh, dx, dwzr[:C], dwzr[C:], dwq, dbzr[:C], dbzr[C:], da_q.sum(0), None, None, None, None)
+        dbzr, dbq = pzr[:, ktot], pq[:, ktot].clone()
+        return (dh, dx, dwzr[:C], dwzr[C:], dwq, dbzr[:C].clone(), dbzr[C:].clone(), dbq, None, None, None, None)
 
 
 def conv_pm(srcs: Sequence[torch.Tensor], weight: torch.Tensor, bias: Optional[torch.Tensor], B: int, H: int, W: int,
