@@ -23,6 +23,7 @@
 // slices of pixel-major buffers (no torch.cat).
 #include "pfk_gemm.h"
 
+#include <mutex>
 #include <utility>
 
 using namespace pfkg;
@@ -654,12 +655,11 @@ int launch_one(const GemmArgs& g, dim3 grid, hipStream_t st) {
     constexpr int G = VARIANT % 10, ABL = (VARIANT / 10) % 10, LD = VARIANT >= 100 ? LDS_LDX : LDS_LD;
     constexpr size_t smem = (size_t)G * 3 * (BM + BN) * LD * sizeof(float);
     static_assert(smem <= 160 * 1024, "LDS budget");
-    static bool attr_set = false;
     auto kern = conv_gemm_v3_kernel<BM, BN, WM, WN, EPI, G, ABL, LD>;
-    if (!attr_set) {
+    static std::once_flag attr_once;   // one flag per template instantiation; safe with several host threads
+    std::call_once(attr_once, [&] {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      attr_set = true;
-    }
+    });
     hipLaunchKernelGGL(kern, grid, dim3(256 * G), smem, st, g);
   }
   return pfk_launch_status();

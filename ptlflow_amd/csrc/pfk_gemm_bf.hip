@@ -18,6 +18,7 @@
 // kb*2 + (l >> 5) per plane per 16-channel K-block kb.
 #include "pfk_gemm.h"
 
+#include <mutex>
 #include <utility>
 
 using namespace pfkg;
@@ -373,11 +374,10 @@ int launch_bf_one(const GemmArgs& a, hipStream_t st) {
   constexpr size_t smem = 2 * (size_t)SUB * NS * (BM + BN) * ROWB;
   static_assert(smem <= 160 * 1024, "LDS budget");
   auto kern = conv_gemm_bf_kernel<EPI, NS, BM, BN, SUB>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::once_flag attr_once;   // one flag per template instantiation; safe with several host threads
+  std::call_once(attr_once, [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_set = true;
-  }
+  });
   hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), smem, st, g);
   return pfk_launch_status();
 }
