@@ -142,6 +142,10 @@ typedef struct {
 } pfk_conv_desc;
 
 long long pfk_conv_workspace_bytes(void);
+/* Byte offset, inside a conv workspace, of a 32-bit counter of stream-K fix-ups that timed out (a partner block's partial
+ * tile never became visible within the bounded spin).  The caller zero-initialises the workspace once; the kernels only
+ * ever increment the word, and the affected output tile is written as NaN.  0 = every result so far is complete. */
+long long pfk_conv_workspace_fault_offset(void);
 int pfk_conv_ktot(const pfk_conv_desc* d);
 int pfk_conv2d_f32(const pfk_conv_desc* d, pfk_stream_t stream);
 

@@ -77,6 +77,51 @@ def _install_stubs() -> None:
         tm.Metric = Metric
         sys.modules["torchmetrics"] = tm
 
+    # ccmr/xcit.py needs four helpers of timm, ccmr|ms_raft_plus/extractor.py import torchvision's functional transforms
+    # at module level; neither package is installed here.  Minimal stand-ins (enough to CONSTRUCT those models on CPU
+    # for the patch-dispatch tests — nothing on the measured path uses them).
+    if "timm" not in sys.modules:
+        import collections.abc
+        from itertools import repeat
+
+        timm = types.ModuleType("timm")
+        tmodels = types.ModuleType("timm.models")
+        vit = types.ModuleType("timm.models.vision_transformer")
+        layers = types.ModuleType("timm.models.layers")
+
+        class Mlp(nn.Module):
+            def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.0):
+                super().__init__()
+                self.fc1 = nn.Linear(in_features, hidden_features or in_features)
+                self.act = act_layer()
+                self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
+                self.drop = nn.Dropout(drop)
+
+            def forward(self, x):
+                return self.drop(self.fc2(self.drop(self.act(self.fc1(x)))))
+
+        class DropPath(nn.Module):
+            def __init__(self, drop_prob=0.0):
+                super().__init__()
+
+            def forward(self, x):
+                return x
+
+        def to_2tuple(x):
+            return tuple(x) if isinstance(x, collections.abc.Iterable) and not isinstance(x, str) else tuple(repeat(x, 2))
+
+        vit.Mlp = Mlp
+        layers.DropPath, layers.trunc_normal_, layers.to_2tuple = DropPath, nn.init.trunc_normal_, to_2tuple
+        timm.models, tmodels.vision_transformer, tmodels.layers = tmodels, vit, layers
+        sys.modules.update({"timm": timm, "timm.models": tmodels, "timm.models.vision_transformer": vit,
+                            "timm.models.layers": layers})
+    if "torchvision" not in sys.modules:
+        tv = types.ModuleType("torchvision")
+        tvt = types.ModuleType("torchvision.transforms")
+        tvf = types.ModuleType("torchvision.transforms.functional")
+        tv.transforms, tvt.functional = tvt, tvf
+        sys.modules.update({"torchvision": tv, "torchvision.transforms": tvt, "torchvision.transforms.functional": tvf})
+
 
 def _namespace(name: str, path: str) -> None:
     if name in sys.modules:

@@ -12,6 +12,22 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static inline bool pfk_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// hipFuncSetAttribute is per DEVICE: a process that drives several GPUs (model.to("cuda:1"), DataParallel) must raise the
+// dynamic-LDS limit of a kernel on each of them.  One flag per (kernel instantiation, device), lock-free after the first call.
+#include <atomic>
+constexpr int PFK_MAX_DEVICES = 64;
+struct pfk_device_once {
+  std::atomic<unsigned char> done[PFK_MAX_DEVICES] = {};
+  template <class F>
+  void run(F&& f) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= PFK_MAX_DEVICES) { f(); return; }
+    if (done[dev].load(std::memory_order_acquire)) return;
+    f();   // idempotent: two threads racing here both set the same attribute value
+    done[dev].store(1, std::memory_order_release);
+  }
+};
+
 static inline int pfk_launch_status() {
   return hipGetLastError() == hipSuccess ? PFK_OK : PFK_ERR_LAUNCH;
 }

@@ -530,6 +530,7 @@ __global__ __launch_bounds__(256 * GROUPS) void conv_gemm_v3_kernel(const GemmAr
 // hipMemsetAsync in front of every launch; the spin is bounded.
 // -------------------------------------------------------------------------------------------------
 constexpr int SK_MAX_BLOCKS = 512;
+constexpr int SK_FAULT_SLOT = 1024;   // u32 index in the flag region (flags use [0, 512)): sticky count of timed-out fix-ups
 constexpr size_t SK_WS_BYTES = (size_t)SK_MAX_BLOCKS * (64 * 64 * 4 + 64);   // partials + flags (flags after the partials)
 
 template <int EPI>
@@ -547,6 +548,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_sk_kernel(const GemmArgs a) 
   int ko[4];
   frag_offsets<LDS_LD>(ko, lane);
 
+  __shared__ int s_lost;   // set by thread 0 when a partner's contribution timed out (read after the next barrier)
+  if (threadIdx.x == 0) s_lost = 0;
   const long long G = gridDim.x;
   // NO XCD remap here: a block may only wait on blocks with a LOWER dispatch index (those are running or done whatever
   // the residency), so the logical order of the unit ranges must be the dispatch order.
@@ -607,7 +610,14 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_sk_kernel(const GemmArgs a) 
             unsigned spins = 0;
             while (__hip_atomic_load(a.sk_flags + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
               __builtin_amdgcn_s_sleep(4);
-              if (++spins > (1u << 24)) break;   // bounded: a lost contribution shows up as a wrong result, not a hang
+              if (++spins > (1u << 24)) {
+                // bounded spin (no hang under preemption / a debugger) — but a contribution that never arrived must not pass
+                // for a result: count it in the workspace's sticky fault word (pfk_conv_workspace_fault_offset) and poison
+                // this tile with NaN, which every consumer downstream propagates into the flow.
+                atomicAdd(a.sk_flags + SK_FAULT_SLOT, 1u);
+                s_lost = 1;
+                break;
+              }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
           }
@@ -616,6 +626,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_sk_kernel(const GemmArgs a) 
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[0][0][r] += theirs[r * 64];
           if (k * U / G <= tbeg) break;   // block k's range starts at or before the tile: it was the last contributor
+        }
+        if (s_lost) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[0][0][r] = __builtin_nanf("");
         }
       }
       epilogue<MT, NT, EPI, 0, 16>(a, acc, m0 + wm0, n0 + wn0, lane, 0);
@@ -656,8 +670,8 @@ int launch_one(const GemmArgs& g, dim3 grid, hipStream_t st) {
     constexpr size_t smem = (size_t)G * 3 * (BM + BN) * LD * sizeof(float);
     static_assert(smem <= 160 * 1024, "LDS budget");
     auto kern = conv_gemm_v3_kernel<BM, BN, WM, WN, EPI, G, ABL, LD>;
-    static std::once_flag attr_once;   // one flag per template instantiation; safe with several host threads
-    std::call_once(attr_once, [&] {
+    static pfk_device_once attr_once;   // one per template instantiation and device; safe with several host threads
+    attr_once.run([&] {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     });
     hipLaunchKernelGGL(kern, grid, dim3(256 * G), smem, st, g);
@@ -802,6 +816,8 @@ void pfk_debug_set_tile(int cfg) {
 }
 
 long long pfk_conv_workspace_bytes(void) { return (long long)SK_WS_BYTES; }
+
+long long pfk_conv_workspace_fault_offset(void) { return (long long)SK_MAX_BLOCKS * 64 * 64 * 4 + (long long)SK_FAULT_SLOT * 4; }
 
 int pfk_conv_ktot(const pfk_conv_desc* d) { return conv_ktot(d, 32); }
 

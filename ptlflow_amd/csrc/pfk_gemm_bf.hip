@@ -374,8 +374,8 @@ int launch_bf_one(const GemmArgs& a, hipStream_t st) {
   constexpr size_t smem = 2 * (size_t)SUB * NS * (BM + BN) * ROWB;
   static_assert(smem <= 160 * 1024, "LDS budget");
   auto kern = conv_gemm_bf_kernel<EPI, NS, BM, BN, SUB>;
-  static std::once_flag attr_once;   // one flag per template instantiation; safe with several host threads
-  std::call_once(attr_once, [&] {
+  static pfk_device_once attr_once;   // one per template instantiation and device; safe with several host threads
+  attr_once.run([&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   });
   hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), smem, st, g);

@@ -9,6 +9,7 @@
 // Pixel-major activations are passed as 2-D tensors [M, C] whose row stride is the buffer's
 // `ld` — a channel slice of a wider buffer (buf[:, 128:384]) is just a view.
 #include <ATen/ATen.h>
+#include <c10/hip/HIPGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
 
@@ -24,10 +25,29 @@ void check_ok(int status, const char* what) {
   TORCH_CHECK(status == PFK_OK, "pfk::", what, " failed: ", pfk_status_string(status), " (", status, ")");
 }
 
+// Every op opens an OpScope on one of its tensors: the HIP device becomes that tensor's device for the duration of the
+// op (kernels, torch's current stream and any at::empty are then on the GPU that owns the data, whatever the caller's
+// current device is — model.to("cuda:1") with device 0 current), and every tensor checked afterwards must live there too.
+thread_local const c10::Device* tl_op_device = nullptr;
+struct OpScope {
+  c10::Device dev;
+  c10::hip::HIPGuard guard;
+  explicit OpScope(const Tensor& t) : dev(t.device()), guard(t.device()) {
+    TORCH_CHECK(t.is_cuda(), "pfk ops need GPU tensors");
+    tl_op_device = &dev;
+  }
+  ~OpScope() { tl_op_device = nullptr; }
+};
+
 pfk_stream_t cur_stream() { return static_cast<pfk_stream_t>(c10::hip::getCurrentHIPStream().stream()); }
 
-void check_dev_f32(const Tensor& t, const char* name) {
+void check_dev(const Tensor& t, const char* name) {
   TORCH_CHECK(t.is_cuda(), name, " must be a GPU tensor");
+  TORCH_CHECK(tl_op_device == nullptr || t.device() == *tl_op_device, name, " is on ", t.device(), " but the op runs on ", *tl_op_device);
+}
+
+void check_dev_f32(const Tensor& t, const char* name) {
+  check_dev(t, name);
   TORCH_CHECK(t.scalar_type() == at::kFloat, name, " must be float32");
 }
 
@@ -42,6 +62,7 @@ float* fptr(const Tensor& t) { return t.data_ptr<float>(); }
 
 // out[b,i,j] = scale * <f1[b,i,:], f2[b,j,:]>
 void corr_volume(const Tensor& f1, const Tensor& f2, double scale, Tensor out) {
+  OpScope scope(f1);
   check_dev_f32(f1, "f1"); check_dev_f32(f2, "f2"); check_dev_f32(out, "out");
   TORCH_CHECK(f1.dim() == 3 && f2.dim() == 3 && out.dim() == 3, "corr_volume: [B,N,D] inputs, [B,N1,N2] out");
   TORCH_CHECK(f1.is_contiguous() && f2.is_contiguous() && out.is_contiguous(), "corr_volume: contiguous tensors");
@@ -53,6 +74,7 @@ void corr_volume(const Tensor& f1, const Tensor& f2, double scale, Tensor out) {
 }
 
 void corr_pool2x2(const Tensor& in, Tensor out) {
+  OpScope scope(in);
   check_dev_f32(in, "in"); check_dev_f32(out, "out");
   TORCH_CHECK(in.dim() == 3 && in.is_contiguous() && out.is_contiguous(), "corr_pool2x2: [M,H,W] contiguous");
   const int64_t M = in.size(0); const int H = in.size(1), W = in.size(2);
@@ -62,6 +84,7 @@ void corr_pool2x2(const Tensor& in, Tensor out) {
 }
 
 void corr_lookup(at::TensorList levels, const Tensor& coords, int64_t radius, Tensor out) {
+  OpScope scope(coords);
   check_dev_f32(coords, "coords"); check_pm(out, "out");
   TORCH_CHECK(coords.dim() == 4 && coords.size(1) == 2 && coords.is_contiguous(), "corr_lookup: coords [B,2,h,w] contiguous");
   TORCH_CHECK(levels.size() >= 1 && levels.size() <= PFK_MAX_LEVELS, "corr_lookup: 1..8 levels");
@@ -88,6 +111,7 @@ void conv2d(at::TensorList srcs, int64_t B, int64_t H, int64_t W, int64_t kh, in
             const c10::optional<Tensor>& aux_z, const c10::optional<Tensor>& aux_rh,
             const c10::optional<Tensor>& workspace, const c10::optional<Tensor>& residual, int64_t stride,
             bool relu_after_residual) {
+  OpScope scope(weight);
   TORCH_CHECK(srcs.size() >= 1 && srcs.size() <= 3, "conv2d: 1..3 sources");
   TORCH_CHECK(stride >= 1, "conv2d: stride");
   pfk_conv_desc d{};
@@ -105,7 +129,8 @@ void conv2d(at::TensorList srcs, int64_t B, int64_t H, int64_t W, int64_t kh, in
   // fp32 packed weight [cout, ktot] -> fp32 MFMA path; bf16 planes [nsplit, cout, ktot64] -> split-bf16 path
   const bool split = weight.scalar_type() == at::kBFloat16;
   if (split) {
-    TORCH_CHECK(weight.is_cuda() && weight.is_contiguous() && weight.dim() == 3 && weight.size(1) == cout &&
+    check_dev(weight, "weight");
+    TORCH_CHECK(weight.is_contiguous() && weight.dim() == 3 && weight.size(1) == cout &&
                 weight.size(0) >= 1 && weight.size(0) <= 3, "conv2d: bf16 weight planes [nsplit, cout, ktot]");
     TORCH_CHECK(weight.size(2) == pfk_conv_ktot_bf16(&d), "conv2d: bf16 weight planes have ktot ", weight.size(2),
                 ", expected ", pfk_conv_ktot_bf16(&d));
@@ -130,7 +155,8 @@ void conv2d(at::TensorList srcs, int64_t B, int64_t H, int64_t W, int64_t kh, in
     d.residual = fptr(*residual); d.residual_ld = residual->stride(0);
   }
   if (workspace.has_value()) {
-    TORCH_CHECK(workspace->is_cuda() && workspace->is_contiguous(), "conv2d: workspace must be a contiguous GPU tensor");
+    check_dev(*workspace, "workspace");
+    TORCH_CHECK(workspace->is_contiguous(), "conv2d: workspace must be a contiguous GPU tensor");
     d.workspace = workspace->data_ptr(); d.workspace_bytes = (long long)workspace->nbytes();
   }
   if (split) check_ok(pfk_conv2d_bf16s(&d, weight.data_ptr(), (int)weight.size(0), cur_stream()), "conv2d (split bf16)");
@@ -139,6 +165,7 @@ void conv2d(at::TensorList srcs, int64_t B, int64_t H, int64_t W, int64_t kh, in
 
 void conv_cin2(const Tensor& in, const Tensor& weight, const c10::optional<Tensor>& bias, Tensor out,
                int64_t B, int64_t H, int64_t W, int64_t k, bool relu) {
+  OpScope scope(in);
   check_pm(in, "in"); check_pm(out, "out"); check_dev_f32(weight, "weight");
   const int cout = out.size(1);
   TORCH_CHECK(weight.is_contiguous() && weight.numel() == k * k * 2 * cout, "conv_cin2: weight [k*k,2,cout]");
@@ -151,6 +178,7 @@ void conv_cin2(const Tensor& in, const Tensor& weight, const c10::optional<Tenso
 
 void flow_delta(const Tensor& in, const Tensor& weight, const c10::optional<Tensor>& bias, const Tensor& coords0,
                 Tensor coords1, const c10::optional<Tensor>& delta_out, const c10::optional<Tensor>& flow_out) {
+  OpScope scope(in);
   check_pm(in, "in"); check_dev_f32(weight, "weight"); check_dev_f32(coords0, "coords0"); check_dev_f32(coords1, "coords1");
   TORCH_CHECK(coords0.dim() == 4 && coords0.size(1) == 2 && coords0.is_contiguous() && coords1.is_contiguous() &&
               coords1.sizes() == coords0.sizes(), "flow_delta: coords [B,2,h,w] contiguous");
@@ -165,6 +193,7 @@ void flow_delta(const Tensor& in, const Tensor& weight, const c10::optional<Tens
 }
 
 void flow_from_coords(const Tensor& coords0, const Tensor& coords1, Tensor flow_out) {
+  OpScope scope(coords0);
   check_dev_f32(coords0, "coords0"); check_dev_f32(coords1, "coords1"); check_pm(flow_out, "flow_out");
   TORCH_CHECK(coords0.dim() == 4 && coords0.is_contiguous() && coords1.is_contiguous() && coords1.sizes() == coords0.sizes());
   check_ok(pfk_flow_from_coords_f32(fptr(coords0), fptr(coords1), fptr(flow_out), flow_out.stride(0), coords0.size(0),
@@ -172,6 +201,7 @@ void flow_from_coords(const Tensor& coords0, const Tensor& coords1, Tensor flow_
 }
 
 void convex_upsample(const Tensor& flow, const Tensor& mask, Tensor out) {
+  OpScope scope(flow);
   check_dev_f32(flow, "flow"); check_pm(mask, "mask"); check_dev_f32(out, "out");
   TORCH_CHECK(flow.dim() == 4 && flow.size(1) == 2 && flow.is_contiguous() && out.is_contiguous());
   const int B = flow.size(0), H = flow.size(2), W = flow.size(3);
@@ -181,6 +211,7 @@ void convex_upsample(const Tensor& flow, const Tensor& mask, Tensor out) {
 }
 
 void convex_upsample_pm(const Tensor& flow_pm, const Tensor& mask, Tensor out) {
+  OpScope scope(flow_pm);
   check_pm(flow_pm, "flow_pm"); check_pm(mask, "mask"); check_dev_f32(out, "out");
   TORCH_CHECK(out.dim() == 4 && out.size(1) == 2 && out.is_contiguous() && out.size(2) % 8 == 0 && out.size(3) % 8 == 0);
   const int B = out.size(0), H = out.size(2) / 8, W = out.size(3) / 8;
@@ -191,6 +222,7 @@ void convex_upsample_pm(const Tensor& flow_pm, const Tensor& mask, Tensor out) {
 
 // alt_cuda_corr.forward semantics (correlation.cpp:23-37): returns [B, N, (2r+1)^2, H1, W1], unscaled
 Tensor altcorr_forward(const Tensor& fmap1, const Tensor& fmap2, const Tensor& coords, int64_t radius) {
+  OpScope scope(fmap1);
   check_dev_f32(fmap1, "fmap1"); check_dev_f32(fmap2, "fmap2"); check_dev_f32(coords, "coords");
   TORCH_CHECK(fmap1.dim() == 4 && fmap2.dim() == 4 && coords.dim() == 5 && coords.size(4) == 2, "altcorr_forward: fmap [B,H,W,C], coords [B,N,H1,W1,2]");
   TORCH_CHECK(fmap1.is_contiguous() && fmap2.is_contiguous() && coords.is_contiguous(), "altcorr_forward: contiguous inputs");  // CHECK_CONTIGUOUS in the reference
@@ -212,6 +244,7 @@ Tensor altcorr_forward(const Tensor& fmap1, const Tensor& fmap2, const Tensor& c
 // alt_cuda_corr.backward semantics (correlation.cpp:39-49): returns {fmap1_grad, fmap2_grad, coords_grad (zeros)}
 std::vector<Tensor> altcorr_backward(const Tensor& fmap1, const Tensor& fmap2, const Tensor& coords, const Tensor& corr_grad,
                                      int64_t radius) {
+  OpScope scope(fmap1);
   check_dev_f32(fmap1, "fmap1"); check_dev_f32(fmap2, "fmap2"); check_dev_f32(coords, "coords"); check_dev_f32(corr_grad, "corr_grad");
   TORCH_CHECK(fmap1.is_contiguous() && fmap2.is_contiguous() && coords.is_contiguous() && corr_grad.is_contiguous(),
               "altcorr_backward: contiguous inputs");
@@ -228,6 +261,7 @@ std::vector<Tensor> altcorr_backward(const Tensor& fmap1, const Tensor& fmap2, c
 }
 
 void nchw_to_pm(const Tensor& in, Tensor out) {
+  OpScope scope(in);
   check_dev_f32(in, "in"); check_pm(out, "out");
   TORCH_CHECK(in.dim() == 4 && in.is_contiguous());
   const int B = in.size(0), C = in.size(1), H = in.size(2), W = in.size(3);
@@ -236,6 +270,7 @@ void nchw_to_pm(const Tensor& in, Tensor out) {
 }
 
 void pm_to_nchw(const Tensor& in, Tensor out) {
+  OpScope scope(in);
   check_pm(in, "in"); check_dev_f32(out, "out");
   TORCH_CHECK(out.dim() == 4 && out.is_contiguous());
   const int B = out.size(0), C = out.size(1), H = out.size(2), W = out.size(3);
@@ -245,6 +280,7 @@ void pm_to_nchw(const Tensor& in, Tensor out) {
 
 // in [B*N, C] pixel-major view -> out [B, C, Npad] channel-major (row stride = out.stride(1))
 void pm_to_cm(const Tensor& in, Tensor out) {
+  OpScope scope(in);
   check_pm(in, "in"); check_dev_f32(out, "out");
   TORCH_CHECK(out.dim() == 3 && out.stride(2) == 1 && out.stride(0) == out.size(1) * out.stride(1), "pm_to_cm: out [B,C,Npad]");
   const int B = out.size(0), C = out.size(1);
@@ -255,6 +291,7 @@ void pm_to_cm(const Tensor& in, Tensor out) {
 }
 
 void conv_stem(const Tensor& img, const Tensor& weight, const c10::optional<Tensor>& bias, Tensor out, bool relu) {
+  OpScope scope(img);
   check_dev_f32(img, "img"); check_dev_f32(weight, "weight"); check_pm(out, "out");
   TORCH_CHECK(img.dim() == 4 && img.size(1) == 3 && img.is_contiguous(), "conv_stem: img [B,3,H,W] contiguous");
   const int B = img.size(0), H = img.size(2), W = img.size(3), cout = out.size(1);
@@ -268,17 +305,20 @@ void conv_stem(const Tensor& img, const Tensor& weight, const c10::optional<Tens
 int64_t instnorm_workspace_bytes(int64_t B, int64_t C) { return pfk_instnorm_workspace_bytes((int)B, (int)C); }
 
 void instnorm_stats(const Tensor& x, int64_t B, int64_t HW, double eps, Tensor mean, Tensor rstd, Tensor workspace) {
+  OpScope scope(x);
   check_pm(x, "x"); check_dev_f32(mean, "mean"); check_dev_f32(rstd, "rstd");
   const int C = x.size(1);
   TORCH_CHECK(x.size(0) == B * HW, "instnorm_stats: rows");
   TORCH_CHECK(mean.is_contiguous() && rstd.is_contiguous() && mean.numel() == B * C && rstd.numel() == B * C, "instnorm_stats: mean/rstd [B*C]");
-  TORCH_CHECK(workspace.is_cuda() && workspace.is_contiguous(), "instnorm_stats: workspace");
+  check_dev(workspace, "workspace");
+  TORCH_CHECK(workspace.is_contiguous(), "instnorm_stats: workspace");
   check_ok(pfk_instnorm_stats_f32(fptr(x), x.stride(0), (int)B, (int)HW, C, (float)eps, fptr(mean), fptr(rstd),
                                   workspace.data_ptr(), (long long)workspace.nbytes(), cur_stream()), "instnorm_stats");
 }
 
 void norm_apply(const Tensor& x, const Tensor& mean, const Tensor& rstd, const c10::optional<Tensor>& residual, Tensor out,
                 int64_t B, int64_t HW, bool relu, bool relu_after_residual) {
+  OpScope scope(x);
   check_pm(x, "x"); check_pm(out, "out"); check_dev_f32(mean, "mean"); check_dev_f32(rstd, "rstd");
   const int C = x.size(1);
   TORCH_CHECK(x.size(0) == B * HW && out.size(0) == B * HW && out.size(1) == C, "norm_apply: shapes");
@@ -294,6 +334,7 @@ void norm_apply(const Tensor& x, const Tensor& mean, const Tensor& rstd, const c
 }
 
 void forward_interpolate(const Tensor& flow, Tensor out) {
+  OpScope scope(flow);
   check_dev_f32(flow, "flow"); check_dev_f32(out, "out");
   TORCH_CHECK(flow.dim() == 4 && flow.size(1) == 2 && flow.is_contiguous() && out.is_contiguous() && out.sizes() == flow.sizes(),
               "forward_interpolate: flow/out [B,2,H,W] contiguous");
@@ -303,6 +344,7 @@ void forward_interpolate(const Tensor& flow, Tensor out) {
 // weight gradient in the packed [cout, ktot] layout; dy [M, cout] (cout % 4 == 0)
 void conv_wgrad(at::TensorList srcs, const Tensor& dy, int64_t B, int64_t H, int64_t W, int64_t kh, int64_t kw, Tensor out,
                 bool with_bias) {
+  OpScope scope(dy);
   TORCH_CHECK(srcs.size() >= 1 && srcs.size() <= 3, "conv_wgrad: 1..3 sources");
   check_pm(dy, "dy"); check_dev_f32(out, "out");
   pfk_conv_desc d{};
@@ -325,18 +367,21 @@ void conv_wgrad(at::TensorList srcs, const Tensor& dy, int64_t B, int64_t H, int
 }
 
 void gru_gates_zr(const Tensor& a_zr, const Tensor& h, Tensor z, Tensor r, Tensor rh) {
+  OpScope scope(h);
   check_pm(h, "h"); check_dev_f32(a_zr, "a_zr");
   const int64_t M = h.size(0); const int C = h.size(1);
   TORCH_CHECK(a_zr.is_contiguous() && a_zr.size(0) == M && a_zr.size(1) == 2 * C && z.is_contiguous() && r.is_contiguous() && rh.is_contiguous());
   check_ok(pfk_gru_gates_zr_f32(fptr(a_zr), fptr(h), h.stride(0), fptr(z), fptr(r), fptr(rh), M, C, cur_stream()), "gru_gates_zr");
 }
 void gru_gates_q(const Tensor& a_q, const Tensor& z, const Tensor& h, Tensor q, Tensor h_new) {
+  OpScope scope(h);
   check_pm(h, "h");
   const int64_t M = h.size(0); const int C = h.size(1);
   TORCH_CHECK(a_q.is_contiguous() && a_q.size(0) == M && a_q.size(1) == C && z.is_contiguous() && q.is_contiguous() && h_new.is_contiguous());
   check_ok(pfk_gru_gates_q_f32(fptr(a_q), fptr(z), fptr(h), h.stride(0), fptr(q), fptr(h_new), M, C, cur_stream()), "gru_gates_q");
 }
 void gru_backward_q(const Tensor& dh_new, const Tensor& z, const Tensor& q, const Tensor& h, Tensor da_q, Tensor da_zr, Tensor dh) {
+  OpScope scope(h);
   check_pm(h, "h"); check_pm(dh_new, "dh_new");
   const int64_t M = h.size(0); const int C = h.size(1);
   TORCH_CHECK(z.is_contiguous() && q.is_contiguous() && da_q.is_contiguous() && da_zr.is_contiguous() && dh.is_contiguous() &&
@@ -345,6 +390,7 @@ void gru_backward_q(const Tensor& dh_new, const Tensor& z, const Tensor& q, cons
                                   fptr(dh), M, C, cur_stream()), "gru_backward_q");
 }
 void gru_backward_zr(const Tensor& d_rh, const Tensor& h, const Tensor& r, Tensor da_zr, Tensor dh) {
+  OpScope scope(h);
   check_pm(h, "h");
   const int64_t M = h.size(0); const int C = h.size(1);
   TORCH_CHECK(d_rh.is_contiguous() && r.is_contiguous() && da_zr.is_contiguous() && dh.is_contiguous() && da_zr.size(1) == 2 * C);
@@ -353,6 +399,7 @@ void gru_backward_zr(const Tensor& d_rh, const Tensor& h, const Tensor& r, Tenso
 
 int64_t abi_version() { return pfk_abi_version(); }
 int64_t conv_workspace_bytes() { return pfk_conv_workspace_bytes(); }
+int64_t conv_workspace_fault_offset() { return pfk_conv_workspace_fault_offset(); }
 void debug_set_tile(int64_t cfg) { pfk_debug_set_tile((int)cfg); }
 
 }  // namespace
@@ -378,6 +425,7 @@ TORCH_LIBRARY(pfk, m) {
         "int epilogue, bool relu, float scale, Tensor(a!)? out, Tensor(b!)? h, Tensor(c!)? aux_z, Tensor(d!)? aux_rh, "
         "Tensor(e!)? workspace=None, Tensor? residual=None, int stride=1, bool relu_after_residual=False) -> ()");
   m.def("conv_workspace_bytes() -> int", &conv_workspace_bytes);
+  m.def("conv_workspace_fault_offset() -> int", &conv_workspace_fault_offset);
   m.def("conv_cin2(Tensor inp, Tensor weight, Tensor? bias, Tensor(a!) out, int B, int H, int W, int k, bool relu) -> ()");
   m.def("flow_delta(Tensor inp, Tensor weight, Tensor? bias, Tensor coords0, Tensor(a!) coords1, Tensor(b!)? delta_out, "
         "Tensor(c!)? flow_out) -> ()");

@@ -7,11 +7,20 @@
 
 What gets replaced:
 * seam B1 — every model family binds ``get_corr_block`` by name into its own model module at import
-  (`from .corr import get_corr_block`, raft.py:10, gma.py, sea_raft.py, ccmr.py, ms_raft_plus.py), so the
+  (`from .corr import get_corr_block`, raft.py:10, gma.py:11, sea_raft.py:10, ccmr.py:10, ms_raft_plus.py:12), so the
   patch target is the *model module's* global, not `corr.py`;
 * seam B3 — ``model.update_block`` is wrapped by `PfkUpdateBlock`, which keeps the original sub-modules
   (state_dict keys, checkpoints and optimizers are untouched) and only overrides ``forward``;
 * seam B4 — ``model.fnet`` / ``model.cnet`` (`BasicEncoder`) are wrapped by `PfkEncoder` the same way.
+
+Dispatch is by *implementation identity*, never by class name alone: about two dozen ptlflow families call their block
+``BasicUpdateBlock`` with different layers and ``forward`` signatures (sea_raft/update.py:39-54 is a ConvNeXt stack that
+returns one tensor; ccmr/update.py:152 takes six arguments).  A block is wrapped only when
+  (1) its class comes from a module whose source was checked to be the RAFT/GMA implementation (`_UPDATE_BLOCKS`,
+      `_ENCODERS` below — extendable with `register_update_block` / `register_encoder`), AND
+  (2) its ``state_dict`` names and shapes are exactly those of the `UpdateSpec` / `BasicEncoder` the kernels implement.
+Everything else is left untouched and keeps running the reference's own code; the B1 hook (which only depends on the
+`get_corr_block` contract the five families share) is still installed for it.
 
 Nothing in ptlflow is edited or copied; `restore(model)` undoes the patch.
 """
@@ -19,7 +28,7 @@ from __future__ import annotations
 
 import importlib
 import sys
-from typing import Optional
+from typing import Callable, Dict, Optional, Tuple
 
 import torch
 
@@ -29,34 +38,131 @@ from .update import PfkUpdateBlock, UpdateSpec, basic_spec, gma_spec, small_spec
 
 _ORIG = "_pfk_original_get_corr_block"
 
-# class name of model.update_block -> spec factory (raft/update.py:115-142)
-_SPECS = {
-    "BasicUpdateBlock": lambda m: basic_spec(getattr(m, "corr_levels", 4), getattr(m, "corr_radius", 4)),
-    "GMAUpdateBlock": lambda m: gma_spec(getattr(m, "corr_levels", 4), getattr(m, "corr_radius", 4)),
-    "SmallUpdateBlock": lambda m: small_spec(getattr(m, "corr_levels", 4), getattr(m, "corr_radius", 3)),
+# (module of the class, class name) -> spec factory(corr_channels); raft/update.py:115-142, gma/update.py:127-160
+_UPDATE_BLOCKS: Dict[Tuple[str, str], Callable[[int], UpdateSpec]] = {
+    ("ptlflow.models.raft.update", "BasicUpdateBlock"): lambda cc: _with_corr_channels(basic_spec(), cc),
+    ("ptlflow.models.raft.update", "SmallUpdateBlock"): lambda cc: _with_corr_channels(small_spec(), cc),
+    ("ptlflow.models.gma.update", "GMAUpdateBlock"): lambda cc: _with_corr_channels(gma_spec(), cc),
 }
-# families whose CorrBlock pyramid is not the avg-pool one
+# (module, class) of the BasicEncoder implementations that are raft/extractor.py:122-194 verbatim
+_ENCODERS = {
+    ("ptlflow.models.raft.extractor", "BasicEncoder"),
+    ("ptlflow.models.gma.extractor", "BasicEncoder"),
+}
+# families whose CorrBlock pyramid is not the avg-pool one (sea_raft/corr.py:71-84)
 _PYRAMID = {"ptlflow.models.sea_raft.sea_raft": "bilinear_f2"}
+
+
+def _with_corr_channels(spec: UpdateSpec, corr_channels: int) -> UpdateSpec:
+    from dataclasses import replace
+    return replace(spec, corr_channels=corr_channels)
+
+
+def register_update_block(module: str, cls: str, factory: Callable[[int], UpdateSpec]) -> None:
+    """Declare another family's update block to be one of the three implementations above (shape check still applies)."""
+    _UPDATE_BLOCKS[(module, cls)] = factory
+
+
+def register_encoder(module: str, cls: str = "BasicEncoder") -> None:
+    _ENCODERS.add((module, cls))
+
+
+def match_update_block(block: torch.nn.Module) -> Optional[UpdateSpec]:
+    """The `UpdateSpec` this block implements, or None when it is not (provably) one of ours."""
+    from .synth import update_block_shapes
+    factory = _UPDATE_BLOCKS.get((type(block).__module__, type(block).__name__))
+    if factory is None:
+        return None
+    sd = {k: tuple(v.shape) for k, v in block.state_dict().items()}
+    w = sd.get("encoder.convc1.weight")
+    if w is None or len(w) != 4:
+        return None
+    spec = factory(int(w[1]))
+    want = update_block_shapes(spec)
+    # GMA registers its unused relative-position tables nowhere under update_block; any extra or missing key is a mismatch
+    return spec if sd == want else None
+
+
+def _basic_encoder_shapes(out_dim: int, norm_fn: str) -> Dict[str, tuple]:
+    """state_dict names/shapes of BasicEncoder (raft/extractor.py:122-170) for norm_fn in {instance, batch, none}."""
+    sh: Dict[str, tuple] = {}
+
+    def conv(name, co, ci, k):
+        sh[name + ".weight"] = (co, ci, k, k)
+        sh[name + ".bias"] = (co,)
+
+    def norm(name, c):
+        if norm_fn == "batch":
+            sh[name + ".weight"] = (c,)
+            sh[name + ".bias"] = (c,)
+            sh[name + ".running_mean"] = (c,)
+            sh[name + ".running_var"] = (c,)
+            sh[name + ".num_batches_tracked"] = ()
+
+    conv("conv1", 64, 3, 7)
+    norm("norm1", 64)
+    cin = 64
+    for i, (dim, stride) in enumerate(((64, 1), (96, 2), (128, 2)), start=1):
+        for j, (ci, s) in enumerate(((cin, stride), (dim, 1))):
+            p = f"layer{i}.{j}"
+            conv(p + ".conv1", dim, ci, 3)
+            conv(p + ".conv2", dim, dim, 3)
+            norm(p + ".norm1", dim)
+            norm(p + ".norm2", dim)
+            if s != 1:
+                norm(p + ".norm3", dim)
+                conv(p + ".downsample.0", dim, ci, 1)
+                norm(p + ".downsample.1", dim)
+        cin = dim
+    conv("conv2", out_dim, 128, 1)
+    return sh
+
+
+def match_encoder(enc: torch.nn.Module) -> bool:
+    if (type(enc).__module__, type(enc).__name__) not in _ENCODERS:
+        return False
+    norm_fn = getattr(enc, "norm_fn", None)
+    if norm_fn not in ("instance", "batch", "none") or getattr(enc, "dropout", None) is not None:
+        return False
+    sd = {k: tuple(v.shape) for k, v in enc.state_dict().items()}
+    out = sd.get("conv2.weight")
+    return out is not None and sd == _basic_encoder_shapes(out[0], norm_fn)
+
+
+def _supported_envelope(fmap1: torch.Tensor, fmap2: torch.Tensor, num_levels: int, radius: int) -> bool:
+    """What `CorrBlock` (K1-K3) was built for; anything else stays on the reference implementation."""
+    if fmap1.dim() != 4 or fmap2.dim() != 4 or fmap1.shape[0] != fmap2.shape[0] or fmap1.shape[1] != fmap2.shape[1]:
+        return False
+    B, D, h, w = fmap1.shape
+    h2, w2 = fmap2.shape[-2:]
+    if not (1 <= radius <= 4 and 1 <= num_levels <= 8 and D % 32 == 0):
+        return False
+    if fmap1.dtype not in (torch.float32, torch.float16, torch.bfloat16):
+        return False
+    # kernels address one batch element's feature matrix / one source with 32-bit byte offsets
+    return max(h * w, h2 * w2) * D * 4 < 2 ** 31 - 1 and B * h * w * num_levels * (2 * radius + 1) ** 2 * 4 < 2 ** 31 - 1
 
 
 def _make_corr_hook(module_name: str, original):
     pyramid = _PYRAMID.get(module_name, "avgpool")
 
     def get_corr_block(fmap1, fmap2, num_levels: int = 4, radius: int = 4, alternate_corr: bool = False, **kw):
-        # GPU fp32 inference goes to the kernels; anything else (CPU tensors, training graphs that need
-        # gradients to the feature maps, alternate_corr) stays on the reference's own implementation.
-        if (fmap1.is_cuda and not alternate_corr and not (torch.is_grad_enabled() and fmap1.requires_grad)):
+        # GPU tensors inside the kernels' envelope go to libpfk (inference and — with gradients flowing to the feature maps
+        # through `pfk_corr_lookup_bwd_f32` / `pfk_corr_volume_bwd_f32` — training); CPU tensors, alternate_corr, other
+        # shapes stay on the reference's own implementation.
+        if fmap1.is_cuda and not alternate_corr and not kw and _supported_envelope(fmap1, fmap2, num_levels, radius):
             return _pfk_get_corr_block(fmap1, fmap2, num_levels=num_levels, radius=radius, pyramid=pyramid)
         return original(fmap1=fmap1, fmap2=fmap2, num_levels=num_levels, radius=radius, alternate_corr=alternate_corr, **kw)
 
+    get_corr_block.pyramid = pyramid
     return get_corr_block
 
 
 def accelerate(model: torch.nn.Module, corr: bool = True, update_block: bool = True,
                conv_precision: str = "fp32", encoders: bool = True) -> torch.nn.Module:
-    """Patch seams B1/B3 of a ptlflow model instance in place and return it.
+    """Patch seams B1/B3/B4 of a ptlflow model instance in place and return it.
 
-    ``conv_precision``: "fp32" (default, the parity path) or a split-bf16 mode of the update block's convolutions
+    ``conv_precision``: "fp32" (default, the parity path) or a split-bf16 mode of the convolutions
     ("bf16x6", "bf16x3", "bf16"), see ``UpdateEngine``."""
     load_native()
     mod_name = type(model).__module__
@@ -66,17 +172,15 @@ def accelerate(model: torch.nn.Module, corr: bool = True, update_block: bool = T
         setattr(mod, _ORIG, mod.get_corr_block)
         mod.get_corr_block = _make_corr_hook(mod_name, getattr(mod, _ORIG))
     if update_block and hasattr(model, "update_block") and not isinstance(model.update_block, PfkUpdateBlock):
-        ub = model.update_block
-        factory = _SPECS.get(type(ub).__name__)
-        if factory is not None:
-            spec: UpdateSpec = factory(model)
-            model.update_block = PfkUpdateBlock(ub, spec, conv_precision)
+        spec = match_update_block(model.update_block)
+        if spec is not None:
+            model.update_block = PfkUpdateBlock(model.update_block, spec, conv_precision)
     if encoders:
-        # seam B4: the BasicEncoder feature / context networks (raft, gma, ... : `self.fnet`, `self.cnet`)
+        # seam B4: the BasicEncoder feature / context networks (raft, gma: `self.fnet`, `self.cnet`)
         from .encoder import PfkEncoder
         for attr in ("fnet", "cnet"):
             enc = getattr(model, attr, None)
-            if enc is not None and type(enc).__name__ == "BasicEncoder" and getattr(enc, "norm_fn", None) in ("instance", "batch", "none"):
+            if enc is not None and not isinstance(enc, PfkEncoder) and match_encoder(enc):
                 setattr(model, attr, PfkEncoder(enc, conv_precision))
     return model
 

@@ -183,7 +183,9 @@ class RAFT(nn.Module):
         if self._engine is None or self._engine.device != device:
             self._engine = UpdateEngine(params, self.spec, device, self.conv_precision)
         elif v != self._versions:
+            # re-packing allocates new weight tensors: every captured graph still points at the old (freed) ones
             self._engine.pack(params)
+            self._graphs.clear()
         self._versions = v
         return self._engine
 
@@ -239,7 +241,9 @@ class RAFT(nn.Module):
         eng = self.engine(x.device)
         eng.bind(B, h, w)
         graphable = self.use_graph and self.spec.has_mask and not self.spec.aggregate and not self.alternate_corr
-        st = self._graphs.get((B, h, w, x.device)) if graphable else None
+        # everything the recorded launch sequence depends on besides the buffers' addresses
+        gkey = (B, h, w, x.device, self.iters, self.upsample_every_iter, self.corr_levels, self.corr_radius)
+        st = self._graphs.get(gkey) if graphable else None
         if st is not None and (st["engine"] is not eng or st["hx_ptr"] != eng.hx.data_ptr()):
             st = None      # a new engine, or its buffers were re-bound for another shape in between: the recorded addresses are stale
         if st is None:
@@ -276,7 +280,7 @@ class RAFT(nn.Module):
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
                     self._iterate(corr_fn, eng, coords0, coords1, flow_up)
-                self._graphs[(B, h, w, x.device)] = {"graph": graph, "corr": corr_fn, "coords0": coords0, "coords1": coords1,
+                self._graphs[gkey] = {"graph": graph, "corr": corr_fn, "coords0": coords0, "coords1": coords1,
                                                      "flow_up": flow_up, "engine": eng, "hx_ptr": eng.hx.data_ptr()}
         out_up = self.unpad(flow_up, pads)
         flow_small = coords1 - coords0

@@ -195,6 +195,13 @@ class UpdateEngine:
         self.workspace = torch.zeros(self.ops.conv_workspace_bytes(), device=dev, dtype=torch.uint8)
         self._shape = (B, H, W)
 
+    def faults(self) -> int:
+        """Stream-K fix-ups that timed out since the workspace was created (pfk_conv_workspace_fault_offset): 0 means every
+        convolution result so far is complete.  Reads one word back from the device (synchronises the stream); affected
+        tiles are NaN in any case, so this is for telling *why* an output went NaN."""
+        off = self.ops.conv_workspace_fault_offset()
+        return int(self.workspace[off: off + 4].view(torch.int32).item())
+
     # views into hx
     @property
     def h_view(self):
@@ -357,7 +364,8 @@ class PfkUpdateBlock(torch.nn.Module):
         self.spec = spec
         self._engine: Optional[UpdateEngine] = None
         self._versions = None
-        self._inp_key = None
+        self._inp_ref, self._inp_version = None, -1      # strong references: the address cannot be recycled while cached
+        self._attn_ref, self._attn_version = None, -1
 
     def _param_versions(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
@@ -393,13 +401,17 @@ class PfkUpdateBlock(torch.nn.Module):
         B, _, H, W = net.shape
         eng.bind(B, H, W)
         ops = eng.ops
-        # state in: skip copies when the tensor already *is* our buffer (second iteration onwards)
-        if net.data_ptr() != eng.hx.data_ptr():
+        # state in.  `net` that already *is* our buffer (the view handed back by the previous call) marks the second and later
+        # iterations of one forward: nothing to copy.  Anything else starts a new forward: `net`, `inp` (and GMA's attention)
+        # are (re)loaded unconditionally — the reference builds them as fresh tensors per forward (raft.py:158-160) and the
+        # caching allocator hands the next forward the same addresses, so neither data_ptr nor _version can tell two
+        # forwards apart.  Within a forward the loop passes the same `inp` object every iteration: identity + _version.
+        new_forward = net.data_ptr() != eng.hx.data_ptr()
+        if new_forward:
             ops.nchw_to_pm(net.float().contiguous(), eng.h_view)
-        key = (inp.data_ptr(), inp._version, tuple(inp.shape))
-        if key != self._inp_key:
+        if new_forward or inp is not self._inp_ref or inp._version != self._inp_version:
             ops.nchw_to_pm(inp.float().contiguous(), eng.inp_view)
-            self._inp_key = key
+            self._inp_ref, self._inp_version = inp, inp._version
         # corr: a channels-last view of a [M, C] buffer (what ptlflow_amd.CorrBlock returns) is used as is
         cpm = corr.permute(0, 2, 3, 1)
         if corr.dtype == torch.float32 and cpm.is_contiguous():
@@ -409,10 +421,11 @@ class PfkUpdateBlock(torch.nn.Module):
             ops.nchw_to_pm(corr.float().contiguous(), corr_pm)
         ops.nchw_to_pm(flow.float().contiguous(), eng.flow_view)
         if eng.spec.aggregate:
-            akey = (attention.data_ptr(), attention._version, tuple(attention.shape))
-            if akey != getattr(self, "_attn_key", None) or eng.attn is None:
+            if attention is None:
+                raise RuntimeError("GMAUpdateBlock.forward needs the attention map (gma/update.py:148)")
+            if new_forward or eng.attn is None or attention is not self._attn_ref or attention._version != self._attn_version:
                 eng.set_attention(attention)
-                self._attn_key = akey
+                self._attn_ref, self._attn_version = attention, attention._version
         eng.motion_and_gru(corr_pm)
         eng._scratch_c1.zero_()
         eng.heads(eng._scratch_c0, eng._scratch_c1, eng._delta, want_mask=True, write_flow=False)

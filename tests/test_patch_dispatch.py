@@ -1,0 +1,132 @@
+"""`patch.accelerate` on LIVE reference models of every family north_star names (CPU, build container only).
+
+The seam must wrap exactly the blocks the kernels implement — raft / raft_small / gma — and leave foreign blocks that merely
+share a class name alone (sea_raft/update.py:39-54: a ConvNeXt stack returning one tensor; ccmr/update.py:110-168 and
+ms_raft_plus/update.py: six-argument forward with an XCiT aggregator), while still installing the `get_corr_block` hook
+(seam B1) those families share."""
+import sys
+
+import pytest
+import torch
+
+from oracle import raft_oracle as O
+from oracle import ref_loader
+
+pytestmark = [pytest.mark.reference,
+              pytest.mark.skipif(not ref_loader.reference_available(), reason="needs /root/reference")]
+
+
+def _native():
+    try:
+        import ptlflow_amd
+        ptlflow_amd.load_native()
+    except Exception as e:  # libs not built in this checkout
+        pytest.skip(f"native libs unavailable: {e}")
+
+
+def _build(fam, cls, **kw):
+    torch.manual_seed(7)
+    m = ref_loader.ref_module(f"ptlflow.models.{fam}.{fam}")
+    return getattr(m, cls)(**kw).eval(), m
+
+
+@pytest.mark.parametrize("fam,cls,kw", [("raft", "RAFT", {}), ("raft", "RAFTSmall", {}), ("gma", "GMA", {})])
+def test_own_families_are_wrapped(fam, cls, kw):
+    _native()
+    from ptlflow_amd import patch
+    from ptlflow_amd.encoder import PfkEncoder
+    from ptlflow_amd.update import PfkUpdateBlock
+    model, mod = _build(fam, cls, **kw)
+    keys = set(model.state_dict())
+    orig = mod.get_corr_block
+    patch.accelerate(model)
+    try:
+        assert isinstance(model.update_block, PfkUpdateBlock)
+        assert model.update_block.spec.corr_channels == model.corr_levels * (2 * model.corr_radius + 1) ** 2
+        basic = cls != "RAFTSmall"     # raft_small's bottleneck SmallEncoder is not the BasicEncoder the kernels implement
+        assert isinstance(model.fnet, PfkEncoder) == basic and isinstance(model.cnet, PfkEncoder) == basic
+        assert mod.get_corr_block is not orig and mod.get_corr_block.pyramid == "avgpool"
+        assert set(model.state_dict()) == keys
+    finally:
+        patch.restore(model)
+    assert mod.get_corr_block is orig and not isinstance(model.update_block, PfkUpdateBlock)
+
+
+@pytest.mark.parametrize("fam,cls,kw,pyramid", [("sea_raft", "SEARAFT", {"block_dims": [64, 128, 256]}, "bilinear_f2"),
+                                                ("ccmr", "CCMR", {}, "avgpool"),
+                                                ("ms_raft_plus", "MSRAFTPlus", {}, "avgpool")])
+def test_foreign_blocks_are_left_alone(fam, cls, kw, pyramid):
+    """Same class name `BasicUpdateBlock`, different implementation: must not be wrapped; seam B1 is still installed."""
+    _native()
+    from ptlflow_amd import patch
+    from ptlflow_amd.encoder import PfkEncoder
+    from ptlflow_amd.update import PfkUpdateBlock
+    model, mod = _build(fam, cls, **kw)
+    assert type(model.update_block).__name__ == "BasicUpdateBlock"
+    ub, fnet, cnet = model.update_block, getattr(model, "fnet", None), getattr(model, "cnet", None)
+    orig = mod.get_corr_block
+    patch.accelerate(model)
+    try:
+        assert model.update_block is ub and not isinstance(model.update_block, PfkUpdateBlock)
+        assert getattr(model, "fnet", None) is fnet and getattr(model, "cnet", None) is cnet
+        assert not isinstance(fnet, PfkEncoder) and not isinstance(cnet, PfkEncoder)
+        assert mod.get_corr_block is not orig and mod.get_corr_block.pyramid == pyramid
+        # CPU tensors: the hook hands the call to the family's own CorrBlock
+        cb = mod.get_corr_block(fmap1=torch.randn(1, 32, 16, 16), fmap2=torch.randn(1, 32, 16, 16), num_levels=2, radius=3)
+        assert type(cb).__module__ == f"ptlflow.models.{fam}.corr"
+    finally:
+        patch.restore(model)
+    assert mod.get_corr_block is orig
+
+
+def test_sea_raft_cpu_forward_unchanged_by_patch():
+    """accelerate() on SEA-RAFT must not break the model: CPU forward before == after (everything stays on the reference)."""
+    _native()
+    from ptlflow_amd import patch
+    model, _ = _build("sea_raft", "SEARAFT", block_dims=[64, 128, 256], iters=2)
+    x = O.smooth_pair(1, 128, 192, seed=3)
+    with torch.no_grad():
+        before = model({"images": x.clone()})["flows"]
+        patch.accelerate(model)
+        try:
+            after = model({"images": x.clone()})["flows"]
+        finally:
+            patch.restore(model)
+    assert torch.equal(before, after)
+
+
+def test_shape_mismatch_is_not_wrapped():
+    """Right module and class, other widths (a `BasicUpdateBlock(hidden_dim=96)`): parameter shapes decide."""
+    _native()
+    from ptlflow_amd import patch
+    upd = ref_loader.ref_module("ptlflow.models.raft.update")
+    assert patch.match_update_block(upd.BasicUpdateBlock(4, 4)) is not None
+    assert patch.match_update_block(upd.BasicUpdateBlock(2, 3)).corr_channels == 98
+    assert patch.match_update_block(upd.SmallUpdateBlock(4, 3)) is not None
+    assert patch.match_update_block(upd.SmallUpdateBlock(4, 3, hidden_dim=64)) is None
+
+    class BasicUpdateBlock(torch.nn.Module):      # a stranger with the famous name
+        def __init__(self):
+            super().__init__()
+            self.encoder = torch.nn.Conv2d(4, 4, 1)
+
+    assert patch.match_update_block(BasicUpdateBlock()) is None
+    ext = ref_loader.ref_module("ptlflow.models.raft.extractor")
+    assert patch.match_encoder(ext.BasicEncoder(output_dim=256, norm_fn="instance"))
+    assert patch.match_encoder(ext.BasicEncoder(output_dim=256, norm_fn="batch"))
+    assert not patch.match_encoder(ext.BasicEncoder(output_dim=256, norm_fn="group"))       # GroupNorm: no kernel
+    assert not patch.match_encoder(ext.BasicEncoder(output_dim=256, norm_fn="batch", dropout=0.5))
+    assert not patch.match_encoder(ext.SmallEncoder(output_dim=128, norm_fn="instance"))
+
+
+def test_hook_envelope():
+    from ptlflow_amd.patch import _supported_envelope
+    f = torch.empty(1, 256, 55, 128)
+    assert _supported_envelope(f, f, 4, 4)
+    assert not _supported_envelope(f, f, 4, 5)            # radius > 4: reference
+    assert not _supported_envelope(f, f, 9, 4)            # more than 8 levels
+    g = torch.empty(1, 100, 8, 8)
+    assert not _supported_envelope(g, g, 4, 4)            # feature dim not a multiple of 32
+    assert not _supported_envelope(f, torch.empty(1, 128, 55, 128), 4, 4)
+    big = torch.empty(1, 256, 1, 1).expand(1, 256, 1500, 1500)
+    assert not _supported_envelope(big, big, 4, 4)        # > 2 GiB feature matrix: 32-bit offsets
