@@ -75,6 +75,7 @@ def parse():
                     help="arithmetic of the update block's convolutions for the timed run: fp32 MFMA (default, the headline) "
                          "or split-bf16 MFMA (include/pfk.h, pfk_conv2d_bf16s)")
     ap.add_argument("--no-split-modes", action="store_true", help="skip the extra split-bf16 legs (`split_bf16` in the output)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the model_benchmark-protocol, gma, bf16 and training legs")
     ap.add_argument("--cpu-forwards", type=int, default=3)
     ap.add_argument("--cpu-budget-s", type=float, default=30.0, help="stop timing CPU forwards after this many seconds")
     return ap.parse_args()
@@ -95,6 +96,79 @@ def instrumented_forward(model, inputs):
     finally:
         eng.profile = None
     return stats
+
+
+def timed(fn, warmup: int, steps: int) -> float:
+    """Mean seconds per call of `fn` over `steps` calls after `warmup` untimed ones (device-synchronised on both sides)."""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def protocol_leg(model, dev, H, W):
+    """The reference's own benchmarking protocol (model_benchmark.py:421-466, utils/timer.py:81-96): batch 1, `torch.rand`
+    images in [0, 1], one warm-up forward, then >= 10 forwards each bracketed by a device synchronisation; the MEDIAN wall
+    time is what `model_benchmark-all.csv` publishes."""
+    g = torch.Generator().manual_seed(1234)
+    one = {"images": torch.rand(1, 2, 3, H, W, generator=g).to(dev)}
+    model(one)
+    torch.cuda.synchronize()
+    times = []
+    for _ in range(10):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        model(one)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    med = 0.5 * (times[4] + times[5])
+    return {"value": 1.0 / med, "unit": "frame-pairs/s", "ms_median": 1e3 * med, "ms_min": 1e3 * times[0], "ms_max": 1e3 * times[-1],
+            "protocol": "model_benchmark.py: batch 1, torch.rand input, 1 warm-up + 10 synchronised forwards, median"}
+
+
+def train_leg(dev, batch=10, H=368, W=496, iters=12, steps=4, warmup=2):
+    """BASELINE config 5 on one GPU: a full training step of RAFT on a FlyingChairs-shaped batch (raft-train1-chairs.yaml:
+    batch 10 per rank, 368x496 crops, 12 iterations, gamma 0.8, AdamW lr 4e-4 wd 1e-4, gradient clipping at 1.0):
+    train-mode forward -> sequence loss -> backward -> clip -> optimizer step, all inside the timed region."""
+    from ptlflow_amd.raft import RAFT
+    from ptlflow_amd.train import sequence_loss
+    model = RAFT(iters=iters).load_synthetic(1234).to(dev).train()
+    opt = torch.optim.AdamW(model.parameters(), lr=4e-4, weight_decay=1e-4, eps=1e-8)
+    g = torch.Generator().manual_seed(99)
+    inputs = {"images": torch.rand(batch, 2, 3, H, W, generator=g).to(dev)}
+    gt = (torch.rand(batch, 2, H, W, generator=g) * 20 - 10).to(dev)
+    valid = torch.ones(batch, 1, H, W, device=dev)
+    last = {}
+
+    def step():
+        out = model(inputs)
+        loss = sequence_loss(out["flow_preds"], gt, valid, 0.8, 400.0)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        opt.step()
+        last["loss"] = loss
+
+    sec = timed(step, warmup, steps)
+
+    # share of the step still spent in the torch / MIOpen encoders (forward + backward of fnet on both frames and cnet)
+    def enc_only():
+        x, _ = model.preprocess(inputs["images"])
+        f1, f2 = model.fnet([x[:, 0].contiguous(), x[:, 1].contiguous()])
+        c = model.cnet(x[:, 0].contiguous())
+        (f1.square().mean() + f2.square().mean() + c.square().mean()).backward()
+        opt.zero_grad(set_to_none=True)
+
+    enc = timed(enc_only, 1, 3)
+    return {"value": batch / sec, "unit": "samples/s", "ms_per_step": 1e3 * sec, "loss": float(last["loss"]),
+            "encoders_fwd_bwd_ms": 1e3 * enc, "encoder_share": enc / sec,
+            "config": f"raft train step, batch {batch}, {H}x{W}, {iters} iterations, fp32, sequence loss + backward + clip 1.0 + AdamW; "
+                      "correlation / lookup / update block / upsampling forward+backward on libpfk, encoders on torch autograd"}
 
 
 def main():
@@ -291,6 +365,33 @@ def main():
             result["skip_dead_upsample"] = {"value": args.batch * 1e3 / ms, "unit": "frame-pairs/s", "ms_per_step": ms,
                                             "identical_output": bool(torch.equal(o3["flows"], out["flows"]))}
             del m3, o3
+        default_cfg = args.model == "raft" and (args.height, args.width, args.iters) == (436, 1024, 32) and args.conv_precision == "fp32"
+        if world == 1 and default_cfg and not args.no_extra_legs:
+            del out
+            torch.cuda.empty_cache()
+            # (a) like-for-like with the reference's published protocol (batch 1, rand, median of 10)
+            result["model_benchmark_protocol"] = protocol_leg(model, dev, args.height, args.width)
+            del model
+            torch.cuda.empty_cache()
+            # (b) BASELINE config 3: gma on the shared CorrBlock / GRU path (fp32), and bf16 operands for raft and gma
+            legs = {}
+            for name, ctor, b in (("gma_fp32", lambda: GMA(iters=32), 4), ("raft_bf16", lambda: RAFT(iters=32, conv_precision="bf16"), 8),
+                                  ("gma_bf16", lambda: GMA(iters=32, conv_precision="bf16"), 4)):
+                try:
+                    m = ctor().load_synthetic(1234).eval().to(dev)
+                    xin = {"images": smooth_pair(b, args.height, args.width, seed=1234).to(dev)}
+                    sec = timed(lambda: m(xin), 2, 5)
+                    legs[name] = {"value": b / sec, "unit": "frame-pairs/s", "ms_per_step": 1e3 * sec, "batch": b}
+                    del m, xin
+                    torch.cuda.empty_cache()
+                except Exception as e:  # a leg must never take the headline line down with it
+                    legs[name] = {"error": repr(e)[:300]}
+            result["config3"] = legs
+            # (c) BASELINE config 5: the training step
+            try:
+                result["train"] = train_leg(dev)
+            except Exception as e:
+                result["train"] = {"error": repr(e)[:300]}
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()

@@ -29,6 +29,9 @@
  *                         ptlflow/models/raft/raft.py:174,178 (flow = coords1-coords0; coords1 += d)
  *   pfk_convex_upsample_f32  ptlflow/models/raft/raft.py:112-123 RAFT.upsample_flow
  *   pfk_altcorr_forward_f32  ptlflow/utils/external/alt_cuda_corr/correlation_kernel.cu:258-285 (alt_cuda_corr.forward)
+ *   pfk_corr_lookup_bwd_f32 / pfk_corr_volume_bwd_f32 / pfk_convex_upsample_bwd_f32
+ *                         what torch.autograd runs for corr.py:29-64 and raft.py:112-123 in a training step (train.py;
+ *                         gradients reach fmap1 / fmap2 only, `coords` is detached at raft.py:171)
  * The native plug-in precedent in the reference is alt_cuda_corr
  * (ptlflow/utils/external/alt_cuda_corr/correlation.cpp:23-54: pybind forward/backward on raw
  * contiguous CUDA tensors); this header is the same kind of boundary, minus torch.
@@ -53,7 +56,7 @@ enum pfk_status {
 };
 
 #define PFK_MAX_LEVELS 8
-#define PFK_ABI_VERSION 2
+#define PFK_ABI_VERSION 3
 
 int pfk_abi_version(void);
 const char* pfk_status_string(int status);
@@ -91,6 +94,48 @@ typedef struct {
   int out_ld;      /* >= num_levels*(2r+1)^2, multiple of 4 */
 } pfk_lookup_desc;
 int pfk_corr_lookup_f32(const pfk_lookup_desc* d, pfk_stream_t stream);
+
+/* ---- backward of K3 (training): scatter d(out) through the forward's four bilinear weights --------------------
+ * grad_out [B*N][grad_out_ld] (the layout of pfk_corr_lookup_f32's `out`); grad_levels[l] is the gradient of the level-l
+ * volume, one [lvl_h][lvl_w] map per source pixel at row stride lvl_ld[l] floats (>= lvl_h*lvl_w; a stride padded to a
+ * multiple of 4 makes the buffer a legal operand of pfk_corr_volume_bwd_f32).  ACCUMULATES (+=): the caller zeroes the
+ * buffers once per training step and every recurrent iteration's lookup adds into them.  Deterministic (no atomics).
+ * Taps that fell outside the map in the forward (zero padding) receive nothing. */
+typedef struct {
+  float* grad_levels[PFK_MAX_LEVELS];
+  int lvl_h[PFK_MAX_LEVELS];
+  int lvl_w[PFK_MAX_LEVELS];
+  long long lvl_ld[PFK_MAX_LEVELS];
+  int num_levels;
+  int radius;      /* 1..4 */
+  int B, h, w;
+  const float* coords;    /* [B][2][h][w], the coordinates the forward was called with */
+  const float* grad_out;
+  int grad_out_ld;
+} pfk_lookup_bwd_desc;
+int pfk_corr_lookup_bwd_f32(const pfk_lookup_bwd_desc* d, pfk_stream_t stream);
+
+/* ---- backward of K1 for one batch element and one pyramid level (training) -----------------------------------
+ * The level-l volume is C = scale * F1 . F2_l^T with F2_l the (avg-pooled / bilinearly halved) target feature map, so
+ *   df1[i][d]  = (accumulate_df1 ? df1[i][d] : 0) + scale * sum_j dC[i][j] * f2[j][d]         i < N1   (fp32 MFMA GEMM)
+ *   df2[j][d]  =                                       scale * sum_i dC[i][j] * f1[i][d]         j < ldc  (transposed product)
+ * dC [N1][ldc]: ldc % 4 == 0, columns [N2, ldc) zero.  f1 [N1][ld1] pixel-major.  f2_cm: F2_l CHANNEL-major [D][ld2cm],
+ * ld2cm == round_up(ldc, 32), columns >= N2 zero (pfk_pm_to_cm_f32 into a zeroed buffer).  df1 [N1][df1_ld];
+ * df2 [ldc][round_up(D, 32)] pixel-major (rows >= N2 and columns >= D come out zero).
+ * workspace: pfk_corr_volume_bwd_workspace_bytes(N1, ldc, D) bytes, 16-byte aligned (may be NULL when that is 0). */
+long long pfk_corr_volume_bwd_workspace_bytes(int N1, int ldc, int D);
+int pfk_corr_volume_bwd_f32(const float* dC, int ldc, int N1, int N2, const float* f1, int ld1, const float* f2_cm, int ld2cm,
+                            int D, float scale, float* df1, int df1_ld, int accumulate_df1, float* df2, void* workspace,
+                            long long workspace_bytes, pfk_stream_t stream);
+
+/* ---- backward of the convex upsampling (raft/raft.py:112-123) -------------------------------------------------
+ * flow: NCHW [B][2][H][W] (flow_ld == 0) or pixel-major rows flow[p*flow_ld + 0..1]; mask pixel-major [M][mask_ld] as in
+ * pfk_convex_upsample_f32; grad_out [B][2][8H][8W] -> grad_mask pixel-major [M][grad_mask_ld] (576 channels written),
+ * grad_flow [B][2][H][W].  workspace: pfk_convex_upsample_bwd_workspace_bytes(B, H, W).  Deterministic. */
+long long pfk_convex_upsample_bwd_workspace_bytes(int B, int H, int W);
+int pfk_convex_upsample_bwd_f32(const float* flow, int flow_ld, const float* mask, int mask_ld, const float* grad_out,
+                                float* grad_mask, int grad_mask_ld, float* grad_flow, void* workspace, long long workspace_bytes,
+                                int B, int H, int W, pfk_stream_t stream);
 
 /* ---- K4-K6: "same"-padded convolution (stride 1, or s for the encoders) as an implicit GEMM on fp32 MFMA ----
  * out[p][co] = epilogue( bias[co] + sum_{s, ky, kx, c} src[s][p + (ky-kh/2)*W + (kx-kw/2)][c]

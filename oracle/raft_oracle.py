@@ -366,9 +366,14 @@ def sub(P: Params, prefix: str) -> Params:
 # --------------------------------------------------------------------------------------
 # encoders (adjacent to the path, inside the timed forward)  raft/extractor.py:6-267
 # --------------------------------------------------------------------------------------
+_BN_TRAIN = False   # set by raft_forward_train: nn.BatchNorm2d in model.train() normalises with the batch's statistics
+
+
 def _norm(P: Params, name: str, x: Tensor, kind: str) -> Tensor:
     if kind == "instance":  # nn.InstanceNorm2d defaults: no affine, no running stats
         return F.instance_norm(x, eps=1e-5)
+    if kind == "batch" and _BN_TRAIN:   # train mode: batch statistics (running buffers are a side effect, not an input)
+        return F.batch_norm(x, None, None, P[name + ".weight"], P[name + ".bias"], training=True, eps=1e-5)
     if kind == "batch":  # eval mode: running statistics
         return F.batch_norm(
             x, P[name + ".running_mean"], P[name + ".running_var"],
@@ -559,6 +564,55 @@ def gma_forward(P: Params, images: Tensor, iters: int = 32, corr_levels: int = 4
         coords1 = coords1 + delta
         flow_up = unpad(convex_upsample(coords1 - coords0, up_mask), pads)
     return {"flows": flow_up[:, None], "flow_small": coords1 - coords0}
+
+
+def sequence_loss(flow_preds: Sequence[Tensor], flow_gt: Tensor, valid: Tensor, gamma: float = 0.8,
+                  max_flow: float = 400.0) -> Tensor:
+    """SequenceLoss.forward (raft/raft.py:31-45); flow_gt [B,2,H,W], valid [B,1,H,W]."""
+    n = len(flow_preds)
+    mag = torch.sum(flow_gt**2, dim=1, keepdim=True).sqrt()
+    keep = (valid >= 0.5) & (mag < max_flow)
+    loss = 0.0
+    for i in range(n):
+        loss = loss + gamma ** (n - i - 1) * (keep * (flow_preds[i] - flow_gt).abs()).mean()
+    return loss
+
+
+def raft_forward_train(P: Params, images: Tensor, iters: int = 12, small: bool = False, corr_levels: int = 4,
+                       corr_radius: Optional[int] = None) -> List[Tensor]:
+    """RAFT.forward in TRAINING mode (raft.py:125-193, `self.training` branch): differentiable w.r.t. every tensor of
+    ``P`` (pass float64 leaves with requires_grad for a float64-autograd gradient oracle); returns ``flow_preds``.
+    `coords1` is detached at the top of every iteration (raft.py:171); BatchNorm (cnet) uses batch statistics."""
+    global _BN_TRAIN
+    if corr_radius is None:
+        corr_radius = 3 if small else 4
+    hdim, cdim = (96, 64) if small else (128, 128)
+    x, pads = preprocess(images)
+    image1, image2 = x[:, 0], x[:, 1]
+    B = image1.shape[0]
+    _BN_TRAIN = True
+    try:
+        fm = encoder(sub(P, "fnet"), torch.cat([image1, image2], 0), "instance", small)
+        cnet = encoder(sub(P, "cnet"), image1, "none" if small else "batch", small)
+    finally:
+        _BN_TRAIN = False
+    pyramid = correlation_pyramid(fm[:B], fm[B:], corr_levels)
+    net, inp = torch.split(cnet, [hdim, cdim], dim=1)
+    net, inp = torch.tanh(net), torch.relu(inp)
+    h, w = image1.shape[-2] // 8, image1.shape[-1] // 8
+    coords0 = coords_grid(B, h, w, x.dtype)
+    coords1 = coords_grid(B, h, w, x.dtype)
+    U = sub(P, "update_block")
+    step = small_update_block if small else basic_update_block
+    preds = []
+    for _ in range(iters):
+        coords1 = coords1.detach()
+        corr = lookup(pyramid, coords1, corr_radius)
+        net, up_mask, delta = step(U, net, inp, corr, coords1 - coords0)
+        coords1 = coords1 + delta
+        flow_up = upflow8(coords1 - coords0) if up_mask is None else convex_upsample(coords1 - coords0, up_mask)
+        preds.append(unpad(flow_up, pads))
+    return preds
 
 
 def epe(a: Tensor, b: Tensor) -> Tuple[float, float]:

@@ -37,6 +37,7 @@ HIP_SOURCES = [
     ("pfk_altcorr.hip", []),
     ("pfk_encoder.hip", []),
     ("pfk_wgrad.hip", []),
+    ("pfk_bwd.hip", ["-ffp-contract=off"]),   # same coordinate arithmetic as pfk_corr.hip (pfk_lookup.h)
 ]
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
              f"-I{INCLUDE}", f"-I{CSRC}", "-Wall", "-Wno-unused-function"]
@@ -56,7 +57,7 @@ def _run(cmd) -> None:
 
 def build_libpfk(force: bool = False) -> Path:
     OBJ.mkdir(exist_ok=True)
-    headers = [INCLUDE / "pfk.h", CSRC / "pfk_common.h", CSRC / "pfk_gemm.h"]
+    headers = [INCLUDE / "pfk.h", CSRC / "pfk_common.h", CSRC / "pfk_gemm.h", CSRC / "pfk_lookup.h"]
     objs = []
     for src, extra in HIP_SOURCES:
         s = CSRC / src

@@ -42,9 +42,52 @@ def to_pixel_major(x: torch.Tensor) -> torch.Tensor:
     return out.view(B, H * W, C)
 
 
+class _PyramidToken(torch.autograd.Function):
+    """Builds the pyramid (no graph inside) and returns a 1-element token every lookup of this block depends on.  Autograd
+    therefore runs this node's backward after ALL lookup backwards of the step — which only scatter into the block's level
+    gradient buffers — and turns those buffers into the two feature-map gradients with two GEMMs per level."""
+
+    @staticmethod
+    def forward(ctx, fmap1, fmap2, block):
+        block._build(fmap1.detach(), fmap2.detach())
+        block._zero_grad_levels()
+        ctx.block = block
+        ctx.save_for_backward(fmap1, fmap2)
+        return fmap1.new_zeros(1, dtype=torch.float32)
+
+    @staticmethod
+    def backward(ctx, _g):
+        fmap1, fmap2 = ctx.saved_tensors
+        d1, d2 = ctx.block._volume_backward(fmap1, fmap2)
+        return d1, d2, None
+
+
+class _LookupFn(torch.autograd.Function):
+    """One pyramid lookup -> pixel-major [B*h*w, C]; backward adds d(out) into the block's level-gradient buffers through the
+    forward's bilinear weights (`pfk_corr_lookup_bwd_f32`).  `coords` is detached by every caller (raft.py:171)."""
+
+    @staticmethod
+    def forward(ctx, token, coords, block):
+        out = torch.empty(block.B * block.h * block.w, block.channels, device=coords.device, dtype=torch.float32)
+        c = coords.detach().float().contiguous()
+        _ops().corr_lookup(block.corr_pyramid, c, block.radius, out)
+        ctx.block, ctx.coords = block, c
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        b = ctx.block
+        g = g.float()
+        if g.dim() != 2 or g.stride(1) != 1:
+            g = g.reshape(-1, b.channels).contiguous()
+        _ops().corr_lookup_bwd(b.grad_levels, b._lvl_h, b._lvl_w, ctx.coords, b.radius, g)
+        return torch.zeros(1, device=g.device, dtype=torch.float32), None, None
+
+
 class CorrBlock:
-    """All-pairs correlation pyramid + radius-r lookup on the GPU (inference path; ``coords`` is
-    detached by every caller — raft.py:171 — so no coordinate gradient exists)."""
+    """All-pairs correlation pyramid + radius-r lookup on the GPU.  ``coords`` is detached by every caller (raft.py:171), so
+    no coordinate gradient exists; when a feature map requires grad (training) the block records an autograd graph whose
+    backward runs on libpfk too (`_PyramidToken` / `_LookupFn`) and delivers the gradients of ``fmap1`` / ``fmap2``."""
 
     def __init__(self, fmap1: torch.Tensor, fmap2: torch.Tensor, num_levels: int = 4, radius: int = 4,
                  pyramid: str = "avgpool"):
@@ -63,11 +106,21 @@ class CorrBlock:
         self._out: Optional[torch.Tensor] = None
         self.corr_pyramid: List[torch.Tensor] = []
         self._shape = None
-        self.update(fmap1, fmap2)
+        self.grad_levels: List[torch.Tensor] = []
+        self._token: Optional[torch.Tensor] = None
+        if torch.is_grad_enabled() and (fmap1.requires_grad or fmap2.requires_grad):
+            self._token = _PyramidToken.apply(fmap1, fmap2, self)     # calls _build
+        else:
+            self.update(fmap1, fmap2)
 
     def update(self, fmap1: torch.Tensor, fmap2: torch.Tensor) -> "CorrBlock":
-        """(Re)build the pyramid for a new frame pair.  Feature maps of the same shape as last time are written into the
-        SAME level tensors (same addresses), which is what lets the iteration loop live in a captured hipGraph."""
+        """(Re)build the pyramid for a new frame pair (inference).  Feature maps of the same shape as last time are written
+        into the SAME level tensors (same addresses), which is what lets the iteration loop live in a captured hipGraph."""
+        self._token = None
+        with torch.no_grad():
+            return self._build(fmap1, fmap2)
+
+    def _build(self, fmap1: torch.Tensor, fmap2: torch.Tensor) -> "CorrBlock":
         ops = _ops()
         self.out_dtype = fmap1.dtype
         B, D, h, w = fmap1.shape
@@ -102,8 +155,72 @@ class CorrBlock:
                 ops.corr_volume(f1, f2, scale, self.corr_pyramid[l].view(B, N, h2 * w2))
         return self
 
+    # ------------------------------------------------------------------ training (autograd) side
+    def _zero_grad_levels(self) -> None:
+        """Gradient buffers of the pyramid levels: one [h_l][w_l] map per source pixel at a row stride padded to a multiple
+        of 4 floats (so a buffer is directly the A operand / dY operand of the two backward GEMMs); zeroed once per step."""
+        M = self.B * self.h * self.w
+        sizes = [(int(p.shape[1]), int(p.shape[2])) for p in self.corr_pyramid]
+        if len(self.grad_levels) != len(sizes) or any(g.shape[0] != M or g.shape[1] != (hl * wl + 3) // 4 * 4
+                                                      for g, (hl, wl) in zip(self.grad_levels, sizes)):
+            dev = self.corr_pyramid[0].device
+            self.grad_levels = [torch.zeros(M, max(4, (hl * wl + 3) // 4 * 4), device=dev, dtype=torch.float32) for hl, wl in sizes]
+        else:
+            for g in self.grad_levels:
+                g.zero_()
+        self._lvl_h, self._lvl_w = [s[0] for s in sizes], [s[1] for s in sizes]
+
+    def _f2_levels(self, f2: torch.Tensor) -> List[torch.Tensor]:
+        """The per-level target feature maps the volume levels are correlations with (raft/corr.py:25-27: pooling the volume's
+        target dims == correlating with the pooled map; sea_raft/corr.py:81-83: bilinear halving)."""
+        out = [f2]
+        for _ in range(1, self.num_levels):
+            prev = out[-1]
+            if self.pyramid_mode == "avgpool":
+                out.append(F.avg_pool2d(prev, 2, stride=2))
+            else:
+                out.append(F.interpolate(prev, scale_factor=0.5, mode="bilinear", align_corners=False))
+        return out
+
+    def _volume_backward(self, fmap1: torch.Tensor, fmap2: torch.Tensor):
+        """grad_levels -> (d fmap1, d fmap2): per level  dF1 += s dC_l F2_l  (MFMA GEMM) and  dF2_l = s dC_l^T F1  (the
+        transposed product on the weight-gradient kernel); the chain F2 -> F2_l (tiny feature-map pooling) by torch autograd."""
+        ops = _ops()
+        B, D, h, w = fmap1.shape
+        N = h * w
+        scale = 1.0 / math.sqrt(D)
+        f1 = to_pixel_major(fmap1.detach()).contiguous()
+        df1 = torch.empty(B, N, D, device=f1.device, dtype=torch.float32)
+        leaf = fmap2.detach().float().requires_grad_(True)
+        with torch.enable_grad():
+            f2_levels = self._f2_levels(leaf)
+        G = []
+        first = True
+        for l, f2l in enumerate(f2_levels):
+            h2, w2 = f2l.shape[-2:]
+            N2 = h2 * w2
+            if N2 == 0 or l >= len(self.grad_levels):
+                G.append(torch.zeros_like(f2l))
+                continue
+            ldc = self.grad_levels[l].shape[1]
+            ld2cm = (ldc + 31) // 32 * 32
+            f2cm = torch.zeros(B, D, ld2cm, device=f1.device, dtype=torch.float32)
+            ops.pm_to_cm(to_pixel_major(f2l.detach()).reshape(B * N2, D), f2cm)
+            df2 = torch.empty(B, ldc, (D + 31) // 32 * 32, device=f1.device, dtype=torch.float32)
+            ops.corr_volume_bwd(self.grad_levels[l].view(B, N, ldc), N2, f1, f2cm, scale, df1, not first, df2)
+            first = False
+            G.append(df2[:, :N2, :D].permute(0, 2, 1).reshape(B, D, h2, w2))
+        d2 = G[0]
+        if len(f2_levels) > 1:
+            d2 = d2 + torch.autograd.grad(f2_levels[1:], leaf, G[1:])[0]
+        d1 = df1.view(B, h, w, D).permute(0, 3, 1, 2)
+        return d1.to(fmap1.dtype), d2.to(fmap2.dtype)
+
     def lookup_pm(self, coords: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Lookup into a pixel-major ``[B*h*w, C]`` buffer (allocated once and reused unless given)."""
+        """Lookup into a pixel-major ``[B*h*w, C]`` buffer (allocated once and reused unless given).  In a training graph
+        every call returns a fresh tensor that autograd keeps for the backward."""
+        if self._token is not None and torch.is_grad_enabled():
+            return _LookupFn.apply(self._token, coords, self)
         if out is None:
             if self._out is None:
                 self._out = torch.empty(self.B * self.h * self.w, self.channels, device=coords.device,

@@ -7,6 +7,7 @@
 // (SURVEY.md finding 3).  The only fused operations are the three explicit fmaf() of the
 // bilinear accumulation, which reproduce torch's CPU grid_sample bit for bit.
 #include "pfk_common.h"
+#include "pfk_lookup.h"
 
 namespace {
 
@@ -22,8 +23,6 @@ namespace {
 // lane+64 from LDS with its own per-tap floor()/weights.  Algorithmic traffic: (2r+2)^2 reads +
 // (2r+1)^2 writes per pixel per level (20.4 MB / iteration at 55x128, L=4, r=4).
 // ------------------------------------------------------------------------------------------
-constexpr int PATCH = 12;
-constexpr int PATCH_LD = 13;
 
 struct LookupArgs {
   const float* lv[PFK_MAX_LEVELS];
@@ -35,28 +34,12 @@ struct LookupArgs {
   int out_ld;
 };
 
-// pixel -> normalised -> pixel, every step rounded (see file header).
-__device__ __forceinline__ float roundtrip(float p, float size_m1, float half_span) {
-  float g = 2.0f * p;
-  g = g / size_m1;       // correctly rounded IEEE division (hipcc default for fp32)
-  g = g - 1.0f;
-  float ix = g + 1.0f;
-  return ix * half_span;
-}
-
-__device__ __forceinline__ int safe_base(float v) {
-  // integer-valued float -> int; anything non-finite or absurd maps far outside every map so the
-  // patch is staged as zeros (and the weights carry the NaN, as in the reference).
-  return (fabsf(v) < 1.0e9f) ? (int)v : -(1 << 30);
-}
-
 // PIX consecutive source pixels per workgroup: the kernel is a chain of dependent latencies (coords -> patch
 // loads -> LDS -> outputs), so each wave keeps PIX independent patches in flight instead of one — 4x fewer,
 // 4x fatter workgroups, one resident round on the chip at 55x128.
 // Every wave works on its own LDS region (its level's patches and tap tables), so the only synchronisation needed between
 // staging and sampling is within the wave: LDS operations of a wave complete in order, `s_waitcnt lgkmcnt(0)` (also a
 // compiler barrier) is enough — no workgroup barrier couples the four levels' very different amounts of work.
-__device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 constexpr int PIX = 4;
 

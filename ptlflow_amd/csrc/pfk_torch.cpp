@@ -260,6 +260,75 @@ std::vector<Tensor> altcorr_backward(const Tensor& fmap1, const Tensor& fmap2, c
   return {g1, g2, gc};
 }
 
+// backward of corr_lookup: accumulates into grad_levels[l] ([B*N, ld_l] buffers holding one [h_l][w_l] map per row)
+void corr_lookup_bwd(at::TensorList grad_levels, at::IntArrayRef lvl_h, at::IntArrayRef lvl_w, const Tensor& coords,
+                     int64_t radius, const Tensor& grad_out) {
+  OpScope scope(coords);
+  check_dev_f32(coords, "coords"); check_pm(grad_out, "grad_out");
+  TORCH_CHECK(coords.dim() == 4 && coords.size(1) == 2 && coords.is_contiguous(), "corr_lookup_bwd: coords [B,2,h,w] contiguous");
+  TORCH_CHECK(grad_levels.size() >= 1 && grad_levels.size() <= PFK_MAX_LEVELS && lvl_h.size() == grad_levels.size() &&
+              lvl_w.size() == grad_levels.size(), "corr_lookup_bwd: 1..8 levels with their map sizes");
+  pfk_lookup_bwd_desc d{};
+  d.B = coords.size(0); d.h = coords.size(2); d.w = coords.size(3);
+  const int64_t M = (int64_t)d.B * d.h * d.w;
+  for (size_t l = 0; l < grad_levels.size(); ++l) {
+    const Tensor& v = grad_levels[l];
+    check_pm(v, "grad_level");
+    TORCH_CHECK(v.size(0) == M && v.size(1) >= lvl_h[l] * lvl_w[l], "corr_lookup_bwd: grad level must be [B*N, >= h_l*w_l]");
+    d.grad_levels[l] = fptr(v); d.lvl_h[l] = lvl_h[l]; d.lvl_w[l] = lvl_w[l]; d.lvl_ld[l] = v.stride(0);
+  }
+  d.num_levels = grad_levels.size(); d.radius = radius;
+  d.coords = fptr(coords); d.grad_out = fptr(grad_out); d.grad_out_ld = grad_out.stride(0);
+  const int n = 2 * radius + 1;
+  TORCH_CHECK(grad_out.size(0) == M && grad_out.size(1) >= d.num_levels * n * n, "corr_lookup_bwd: grad_out shape");
+  check_ok(pfk_corr_lookup_bwd_f32(&d, cur_stream()), "corr_lookup_bwd");
+}
+
+// backward of corr_volume for one pyramid level, all batch elements: dC [B,N1,ldc] (columns >= N2 zero), f1 [B,N1,D],
+// f2cm [B,D,ld2cm] channel-major zero-padded -> df1 [B,N1,D] (+= when accumulate), df2 [B,ldc,Dpad]
+void corr_volume_bwd(const Tensor& dC, int64_t N2, const Tensor& f1, const Tensor& f2cm, double scale, Tensor df1, bool accumulate,
+                     Tensor df2) {
+  OpScope scope(dC);
+  check_dev_f32(dC, "dC"); check_dev_f32(f1, "f1"); check_dev_f32(f2cm, "f2cm"); check_dev_f32(df1, "df1"); check_dev_f32(df2, "df2");
+  TORCH_CHECK(dC.dim() == 3 && f1.dim() == 3 && f2cm.dim() == 3 && df1.dim() == 3 && df2.dim() == 3, "corr_volume_bwd: 3-D tensors");
+  TORCH_CHECK(dC.is_contiguous() && f1.is_contiguous() && f2cm.is_contiguous() && df1.is_contiguous() && df2.is_contiguous(),
+              "corr_volume_bwd: contiguous tensors");
+  const int B = dC.size(0), N1 = dC.size(1), ldc = dC.size(2), D = f1.size(2), ld2cm = f2cm.size(2);
+  TORCH_CHECK(f1.size(0) == B && f1.size(1) == N1 && f2cm.size(0) == B && f2cm.size(1) == D && df1.sizes() == f1.sizes() &&
+              df2.size(0) == B && df2.size(1) == ldc && df2.size(2) == (D + 31) / 32 * 32, "corr_volume_bwd: shape mismatch");
+  const long long need = pfk_corr_volume_bwd_workspace_bytes(N1, ldc, D);
+  Tensor ws;
+  void* wsp = nullptr;
+  if (need > 0) { ws = at::empty({(int64_t)need}, dC.options().dtype(at::kByte)); wsp = ws.data_ptr(); }
+  for (int b = 0; b < B; ++b)
+    check_ok(pfk_corr_volume_bwd_f32(fptr(dC) + (int64_t)b * N1 * ldc, ldc, N1, (int)N2, fptr(f1) + (int64_t)b * N1 * D, D,
+                                     fptr(f2cm) + (int64_t)b * D * ld2cm, ld2cm, D, (float)scale, fptr(df1) + (int64_t)b * N1 * D, D,
+                                     accumulate, fptr(df2) + (int64_t)b * ldc * df2.size(2), wsp, need, cur_stream()),
+             "corr_volume_bwd");
+}
+
+// backward of convex_upsample(_pm): flow NCHW [B,2,H,W] or pixel-major [M, >=2]
+void convex_upsample_bwd(const Tensor& flow, const Tensor& mask, const Tensor& grad_out, Tensor grad_mask, Tensor grad_flow) {
+  OpScope scope(mask);
+  check_dev_f32(flow, "flow"); check_pm(mask, "mask"); check_dev_f32(grad_out, "grad_out"); check_pm(grad_mask, "grad_mask");
+  check_dev_f32(grad_flow, "grad_flow");
+  TORCH_CHECK(grad_out.dim() == 4 && grad_out.size(1) == 2 && grad_out.is_contiguous() && grad_out.size(2) % 8 == 0 &&
+              grad_out.size(3) % 8 == 0, "convex_upsample_bwd: grad_out [B,2,8H,8W] contiguous");
+  const int B = grad_out.size(0), H = grad_out.size(2) / 8, W = grad_out.size(3) / 8;
+  const int64_t M = (int64_t)B * H * W;
+  int flow_ld = 0;
+  if (flow.dim() == 2) { check_pm(flow, "flow"); TORCH_CHECK(flow.size(0) == M && flow.size(1) >= 2); flow_ld = flow.stride(0); }
+  else TORCH_CHECK(flow.dim() == 4 && flow.is_contiguous() && flow.size(0) == B && flow.size(1) == 2 && flow.size(2) == H && flow.size(3) == W,
+                   "convex_upsample_bwd: flow [B,2,H,W] contiguous or pixel-major [M,2+]");
+  TORCH_CHECK(mask.size(0) == M && mask.size(1) == 576 && grad_mask.size(0) == M && grad_mask.size(1) == 576, "convex_upsample_bwd: mask shapes");
+  TORCH_CHECK(grad_flow.is_contiguous() && grad_flow.numel() == M * 2, "convex_upsample_bwd: grad_flow [B,2,H,W]");
+  const long long need = pfk_convex_upsample_bwd_workspace_bytes(B, H, W);
+  Tensor ws = at::empty({(int64_t)need}, mask.options().dtype(at::kByte));
+  check_ok(pfk_convex_upsample_bwd_f32(fptr(flow), flow_ld, fptr(mask), mask.stride(0), fptr(grad_out), fptr(grad_mask),
+                                       grad_mask.stride(0), fptr(grad_flow), ws.data_ptr(), need, B, H, W, cur_stream()),
+           "convex_upsample_bwd");
+}
+
 void nchw_to_pm(const Tensor& in, Tensor out) {
   OpScope scope(in);
   check_dev_f32(in, "in"); check_pm(out, "out");
@@ -434,6 +503,9 @@ TORCH_LIBRARY(pfk, m) {
   m.def("convex_upsample_pm(Tensor flow_pm, Tensor mask, Tensor(a!) out) -> ()");
   m.def("altcorr_forward(Tensor fmap1, Tensor fmap2, Tensor coords, int radius) -> Tensor");
   m.def("altcorr_backward(Tensor fmap1, Tensor fmap2, Tensor coords, Tensor corr_grad, int radius) -> Tensor[]");
+  m.def("corr_lookup_bwd(Tensor(a!)[] grad_levels, int[] lvl_h, int[] lvl_w, Tensor coords, int radius, Tensor grad_out) -> ()");
+  m.def("corr_volume_bwd(Tensor dC, int N2, Tensor f1, Tensor f2cm, float scale, Tensor(a!) df1, bool accumulate, Tensor(b!) df2) -> ()");
+  m.def("convex_upsample_bwd(Tensor flow, Tensor mask, Tensor grad_out, Tensor(a!) grad_mask, Tensor(b!) grad_flow) -> ()");
   m.def("nchw_to_pm(Tensor inp, Tensor(a!) out) -> ()");
   m.def("pm_to_nchw(Tensor inp, Tensor(a!) out) -> ()");
   m.def("pm_to_cm(Tensor inp, Tensor(a!) out) -> ()");
@@ -451,6 +523,9 @@ TORCH_LIBRARY_IMPL(pfk, CUDA, m) {
   m.impl("convex_upsample_pm", &convex_upsample_pm);
   m.impl("altcorr_forward", &altcorr_forward);
   m.impl("altcorr_backward", &altcorr_backward);
+  m.impl("corr_lookup_bwd", &corr_lookup_bwd);
+  m.impl("corr_volume_bwd", &corr_volume_bwd);
+  m.impl("convex_upsample_bwd", &convex_upsample_bwd);
   m.impl("nchw_to_pm", &nchw_to_pm);
   m.impl("pm_to_nchw", &pm_to_nchw);
   m.impl("pm_to_cm", &pm_to_cm);

@@ -222,10 +222,59 @@ class RAFT(nn.Module):
         return x[..., pads[2]: ht - pads[3], pads[0]: wd - pads[1]]
 
     # -- forward -----------------------------------------------------------------------------------
-    @torch.no_grad()
     def forward(self, inputs: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         if self.training:
-            raise RuntimeError("ptlflow_amd.RAFT is the inference mirror; training goes through ptlflow + patch.accelerate")
+            return self._forward_train(inputs)
+        with torch.no_grad():
+            return self._forward_eval(inputs)
+
+    def _forward_train(self, inputs: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """RAFT.forward in training mode (raft.py:125-193): same loop, every iteration's upsampled flow kept in
+        ``flow_preds`` for the sequence loss (raft.py:20-45; `ptlflow_amd.train.sequence_loss`).  The correlation volume,
+        pyramid and lookups (forward and backward), the whole update block (forward, dgrad, wgrad) and the convex upsampling
+        (forward and backward) run on libpfk through autograd nodes (ptlflow_amd/corr.py, ptlflow_amd/train.py); the two
+        encoders are the torch modules (BatchNorm of `cnet` in batch-statistics mode, as `model.train()` implies)."""
+        from .train import convex_upsample, update_block_train_pm
+        load_native()
+        if self.spec.aggregate:
+            raise RuntimeError("training mode of the GMA mirror is not implemented (the aggregate branch has no backward kernels)")
+        images = inputs["images"]
+        if not images.is_cuda:
+            raise RuntimeError("ptlflow_amd.RAFT needs GPU inputs (no CPU fallback)")
+        x, pads = self.preprocess(images.float())
+        image1, image2 = x[:, 0].contiguous(), x[:, 1].contiguous()
+        B = image1.shape[0]
+        fmap1, fmap2 = self.fnet([image1, image2])
+        corr_fn = CorrBlock(fmap1.float(), fmap2.float(), num_levels=self.corr_levels, radius=self.corr_radius)
+        cnet = self.cnet(image1)
+        net, inp = torch.split(cnet, [self.hidden_dim, self.context_dim], dim=1)
+        net, inp = torch.tanh(net), torch.relu(inp)
+        h, w = image1.shape[-2] // 8, image1.shape[-1] // 8
+        M = B * h * w
+        ys, xs = torch.meshgrid(torch.arange(h, device=x.device, dtype=torch.float32),
+                                torch.arange(w, device=x.device, dtype=torch.float32), indexing="ij")
+        coords0 = torch.stack([xs, ys], 0)[None].repeat(B, 1, 1, 1).contiguous()
+        coords1 = coords0.clone()
+        P = dict(self.update_block.named_parameters())
+        cache: dict = {}
+        hpm = net.permute(0, 2, 3, 1).reshape(M, self.hidden_dim)
+        ipm = inp.permute(0, 2, 3, 1).reshape(M, self.context_dim)
+        preds = []
+        for _ in range(self.iters):
+            coords1 = coords1.detach()
+            corr_pm = corr_fn.lookup_pm(coords1)
+            fpm = (coords1 - coords0).permute(0, 2, 3, 1).reshape(M, 2)
+            hpm, mask_pm, delta_pm = update_block_train_pm(P, self.spec, hpm, ipm, corr_pm, fpm, B, h, w, cache)
+            coords1 = coords1 + delta_pm.view(B, h, w, 2).permute(0, 3, 1, 2)
+            flow = coords1 - coords0
+            if mask_pm is not None:
+                flow_up = convex_upsample(flow, mask_pm)
+            else:
+                flow_up = 8 * F.interpolate(flow, size=(8 * h, 8 * w), mode="bilinear", align_corners=True)
+            preds.append(self.unpad(flow_up, pads))
+        return {"flows": preds[-1][:, None], "flow_preds": preds}
+
+    def _forward_eval(self, inputs: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         load_native()
         ops = torch.ops.pfk
         images = inputs["images"]

@@ -267,12 +267,11 @@ def _pad4(x: torch.Tensor) -> torch.Tensor:
     return x if c % 4 == 0 else F.pad(x, (0, round_up(c, 4) - c))
 
 
-def update_block_train(P: Dict[str, torch.Tensor], spec, net, inp, corr, flow, cache: Optional[dict] = None):
+def update_block_train_pm(P: Dict[str, torch.Tensor], spec, h, i, c, f, B: int, H: int, W: int, cache: Optional[dict] = None):
     """BasicUpdateBlock.forward / SmallUpdateBlock.forward (update.py:144-153 / :122-128) with every convolution on
-    ``conv_pm``.  ``P``: the block's named parameters; ``cache``: a dict that keeps the packed weights between the recurrent
-    calls of one training step.  NCHW in, NCHW out: ``(net, mask | None, delta_flow)``."""
-    B, _, H, W = net.shape
-    h, i, c, f = _pm(net), _pm(inp), _pm(corr), _pm(flow)
+    ``conv_pm``, on pixel-major tensors: ``h`` [M, Ch], ``i`` [M, Ci], ``c`` [M, corr channels], ``f`` [M, 2] ->
+    ``(h', mask [M, 576] | None, delta [M, 2])``.  ``P``: the block's named parameters; ``cache``: a dict that keeps the packed
+    weights between the recurrent calls of one training step."""
 
     def conv(srcs, name, relu=False, real=None):
         w = P[name + ".weight"]
@@ -300,5 +299,59 @@ def update_block_train(P: Dict[str, torch.Tensor], spec, net, inp, corr, flow, c
     mask = None
     if spec.has_mask:
         mask = 0.25 * conv([conv([h], "mask.0", True)], "mask.2")
-        mask = _nchw(mask, B, H, W)
-    return _nchw(h, B, H, W), mask, _nchw(delta, B, H, W)
+    return h, mask, delta
+
+
+def update_block_train(P: Dict[str, torch.Tensor], spec, net, inp, corr, flow, cache: Optional[dict] = None):
+    """NCHW face of `update_block_train_pm` (what `PfkUpdateBlock` calls from the reference's loop):
+    NCHW in, NCHW out: ``(net, mask | None, delta_flow)``."""
+    B, _, H, W = net.shape
+    h, mask, delta = update_block_train_pm(P, spec, _pm(net), _pm(inp), _pm(corr), _pm(flow), B, H, W, cache)
+    return _nchw(h, B, H, W), (None if mask is None else _nchw(mask, B, H, W)), _nchw(delta, B, H, W)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# Convex upsampling (raft/raft.py:112-123) and the sequence loss (raft/raft.py:20-45) for the training step
+# --------------------------------------------------------------------------------------------------------------------
+class _ConvexUpsample(torch.autograd.Function):
+    """flow [B,2,H,W] (NCHW), mask pixel-major [B*H*W, 576] (already x0.25) -> [B,2,8H,8W]; forward and both gradients on
+    libpfk (`pfk_convex_upsample_f32`, `pfk_convex_upsample_bwd_f32`)."""
+
+    @staticmethod
+    def forward(ctx, flow, mask):
+        flow = flow.float().contiguous()
+        mask = mask.float()
+        if mask.stride(1) != 1:
+            mask = mask.contiguous()
+        B, _, H, W = flow.shape
+        out = torch.empty(B, 2, 8 * H, 8 * W, device=flow.device, dtype=torch.float32)
+        torch.ops.pfk.convex_upsample(flow, mask, out)
+        ctx.save_for_backward(flow, mask)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        flow, mask = ctx.saved_tensors
+        gmask = torch.empty(mask.shape[0], 576, device=mask.device, dtype=torch.float32)
+        gflow = torch.empty_like(flow)
+        torch.ops.pfk.convex_upsample_bwd(flow, mask, g.float().contiguous(), gmask, gflow)
+        return gflow, gmask
+
+
+def convex_upsample(flow: torch.Tensor, mask_pm: torch.Tensor) -> torch.Tensor:
+    load_native()
+    return _ConvexUpsample.apply(flow, mask_pm)
+
+
+def sequence_loss(flow_preds: Sequence[torch.Tensor], flow_gt: torch.Tensor, valid: torch.Tensor, gamma: float = 0.8,
+                  max_flow: float = 400.0) -> torch.Tensor:
+    """SequenceLoss.forward (raft/raft.py:31-45): gamma-weighted L1 over the prediction sequence; pixels that are invalid
+    or whose ground-truth displacement is >= max_flow are excluded by zeroing (the mean still runs over all pixels, as in
+    the reference).  ``flow_gt`` [B,2,H,W], ``valid`` [B,1,H,W]."""
+    n = len(flow_preds)
+    mag = torch.sum(flow_gt ** 2, dim=1, keepdim=True).sqrt()
+    keep = (valid >= 0.5) & (mag < max_flow)
+    loss = 0.0
+    for k, pred in enumerate(flow_preds):
+        loss = loss + gamma ** (n - k - 1) * (keep * (pred - flow_gt).abs()).mean()
+    return loss
