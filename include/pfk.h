@@ -70,10 +70,22 @@ void pfk_debug_set_tile(int cfg);
 int pfk_corr_volume_f32(const float* f1, int ld1, const float* f2, int ld2, float* out,
                         int B, int N1, int N2, int D, float scale, pfk_stream_t stream);
 
+/* bf16 operands, bf16 volume — what the reference's matmul produces under torch.autocast(bfloat16):
+ * f1 fp32 rows (rounded to bf16 while staged; exact when they already hold bf16 values), f2_bf16 [B][N2][ld2] bf16 with
+ * ld2 == round_up(D, 32), out_bf16 [B][N1][N2] bf16; fp32 accumulate on the bf16 matrix cores, scaled, rounded to nearest even. */
+int pfk_corr_volume_bf16(const float* f1, int ld1, const void* f2_bf16, int ld2, void* out_bf16, int B, int N1, int N2, int D,
+                         float scale, pfk_stream_t stream);
+
 /* ---- K2: 2x2/stride-2 average pool over the target dims (floor) ------------------------------
  * in [M][H][W] -> out [M][H/2][W/2], value ((a00+a01)+a10)+a11) * 0.25 (torch's CPU order). */
 int pfk_corr_pool2x2_f32(const float* in, float* out, int64_t M, int H, int W,
                          pfk_stream_t stream);
+/* same on bf16 maps: fp32 accumulation, one rounding to bf16 (torch's avg_pool2d on bf16 tensors) */
+int pfk_corr_pool2x2_bf16(const void* in, void* out, int64_t M, int H, int W, pfk_stream_t stream);
+/* 2x2 average of a pixel-major FEATURE map [B][H][W][in_ld] -> [B][H/2][W/2][out_ld] (C channels): bit-identical to
+ * F.interpolate(fmap2, scale_factor=0.5, mode="bilinear", align_corners=False), SEA-RAFT's pyramid step
+ * (sea_raft/corr.py:81-83), and to F.avg_pool2d(fmap2, 2, 2) (AlternateCorrBlock, raft/corr.py:72-74). */
+int pfk_fmap_pool2x2_f32(const float* in, int in_ld, float* out, int out_ld, int B, int H, int W, int C, pfk_stream_t stream);
 
 /* ---- K3: radius-r bilinear lookup over all pyramid levels in one launch ----------------------
  * levels[l] is the level-l volume [B*N][lvl_h[l]][lvl_w[l]]; coords is [B][2][h][w] (x then y,
@@ -83,7 +95,7 @@ int pfk_corr_pool2x2_f32(const float* in, float* out, int64_t M, int H, int W,
  * zero padding per tap, FMA accumulation order of torch's CPU kernel (bit-exact values for the
  * same pyramid).  NaN / inf coordinates and 1-pixel levels give NaN exactly like the reference. */
 typedef struct {
-  const float* levels[PFK_MAX_LEVELS];
+  const void* levels[PFK_MAX_LEVELS];   /* float maps (pfk_corr_lookup_f32) or bf16 maps (pfk_corr_lookup_bf16) */
   int lvl_h[PFK_MAX_LEVELS];
   int lvl_w[PFK_MAX_LEVELS];
   int num_levels;
@@ -94,6 +106,8 @@ typedef struct {
   int out_ld;      /* >= num_levels*(2r+1)^2, multiple of 4 */
 } pfk_lookup_desc;
 int pfk_corr_lookup_f32(const pfk_lookup_desc* d, pfk_stream_t stream);
+/* same with `levels` pointing to bf16 maps; arithmetic and output fp32 (grid_sample is an fp32 op under autocast) */
+int pfk_corr_lookup_bf16(const pfk_lookup_desc* d, pfk_stream_t stream);
 
 /* ---- backward of K3 (training): scatter d(out) through the forward's four bilinear weights --------------------
  * grad_out [B*N][grad_out_ld] (the layout of pfk_corr_lookup_f32's `out`); grad_levels[l] is the gradient of the level-l

@@ -56,6 +56,10 @@ def pool2x2(vol: Tensor) -> Tensor:
     Written out so the summation order is explicit: ((a00 + a01) + a10) + a11, then * 0.25 —
     the order torch's CPU kernel uses (row-major window walk, one division by 4).
     """
+    if vol.dtype in (torch.bfloat16, torch.float16):
+        # autocast runs of the reference: F.avg_pool2d accumulates a 16-bit window in fp32 and rounds once; adding the
+        # four 16-bit values one by one would round three times.  Use the reference's own op there.
+        return F.avg_pool2d(vol, 2, stride=2)
     H, W = vol.shape[-2:]
     Ho, Wo = H // 2, W // 2
     v = vol[..., : 2 * Ho, : 2 * Wo]

@@ -90,7 +90,12 @@ class CorrBlock:
     backward runs on libpfk too (`_PyramidToken` / `_LookupFn`) and delivers the gradients of ``fmap1`` / ``fmap2``."""
 
     def __init__(self, fmap1: torch.Tensor, fmap2: torch.Tensor, num_levels: int = 4, radius: int = 4,
-                 pyramid: str = "avgpool"):
+                 pyramid: str = "avgpool", volume_dtype: Optional[torch.dtype] = None):
+        """``volume_dtype``: storage type of the pyramid — ``torch.float32`` (exact fp32 products on the fp32 matrix cores, the
+        parity path) or ``torch.bfloat16`` (bf16 operands and a bf16 volume: what the reference's matmul yields under
+        ``torch.autocast(bfloat16)``; half the HBM bytes).  Default: bf16 when the feature maps arrive in a 16-bit type (the
+        caller is running under autocast), fp32 otherwise.  The lookup's arithmetic and output are fp32 either way
+        (``F.grid_sample`` is an fp32 op under autocast)."""
         if not fmap1.is_cuda:
             raise RuntimeError("ptlflow_amd.CorrBlock needs GPU tensors (no CPU fallback)")
         if not 1 <= radius <= 4:
@@ -108,7 +113,15 @@ class CorrBlock:
         self._shape = None
         self.grad_levels: List[torch.Tensor] = []
         self._token: Optional[torch.Tensor] = None
-        if torch.is_grad_enabled() and (fmap1.requires_grad or fmap2.requires_grad):
+        needs_graph = torch.is_grad_enabled() and (fmap1.requires_grad or fmap2.requires_grad)
+        if volume_dtype is None:
+            volume_dtype = torch.bfloat16 if fmap1.dtype in (torch.bfloat16, torch.float16) and not needs_graph else torch.float32
+        if volume_dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("volume_dtype must be torch.float32 or torch.bfloat16")
+        if needs_graph and volume_dtype != torch.float32:
+            raise RuntimeError("the training path keeps the pyramid in fp32 (the backward kernels are fp32)")
+        self.volume_dtype = volume_dtype
+        if needs_graph:
             self._token = _PyramidToken.apply(fmap1, fmap2, self)     # calls _build
         else:
             self.update(fmap1, fmap2)
@@ -133,26 +146,36 @@ class CorrBlock:
         if fresh:
             self.corr_pyramid, self._out, self._shape = [], None, shape
         dev = f1.device
+        vt = self.volume_dtype
+        bf = vt == torch.bfloat16
+
+        def volume(f2_pm: torch.Tensor, out: torch.Tensor) -> None:
+            if bf:    # bf16 operands (f1 rounded while staged, f2 here), bf16 volume
+                ops.corr_volume_bf16(f1, f2_pm.to(torch.bfloat16), scale, out)
+            else:
+                ops.corr_volume(f1, f2_pm, scale, out)
+
         if self.pyramid_mode == "avgpool":  # raft/corr.py:19-27
             f2 = to_pixel_major(fmap2)
             if fresh:
                 hl, wl = h, w
                 for _ in range(self.num_levels):
-                    self.corr_pyramid.append(torch.empty(B * N, hl, wl, device=dev, dtype=torch.float32))
+                    self.corr_pyramid.append(torch.empty(B * N, hl, wl, device=dev, dtype=vt))
                     hl, wl = hl // 2, wl // 2
-            ops.corr_volume(f1, f2, scale, self.corr_pyramid[0].view(B, N, N))
+            volume(f2, self.corr_pyramid[0].view(B, N, N))
             for l in range(1, self.num_levels):
                 ops.corr_pool2x2(self.corr_pyramid[l - 1], self.corr_pyramid[l])
-        else:  # sea_raft/corr.py:77-84: one GEMM per level
-            f2n = fmap2.float()
+        else:  # sea_raft/corr.py:77-84: one GEMM per level against fmap2 halved bilinearly (== a 2x2 average, pfk_fmap_pool2x2_f32)
+            f2 = to_pixel_major(fmap2).reshape(B * fmap2.shape[-2] * fmap2.shape[-1], D)
+            h2, w2 = fmap2.shape[-2:]
             for l in range(self.num_levels):
                 if l > 0:
-                    f2n = F.interpolate(f2n, scale_factor=0.5, mode="bilinear", align_corners=False)
-                h2, w2 = f2n.shape[-2:]
-                f2 = to_pixel_major(f2n)
+                    nxt = torch.empty(B * (h2 // 2) * (w2 // 2), D, device=dev, dtype=torch.float32)
+                    ops.fmap_pool2x2(f2, nxt, B, h2, w2)
+                    f2, h2, w2 = nxt, h2 // 2, w2 // 2
                 if fresh:
-                    self.corr_pyramid.append(torch.empty(B * N, h2, w2, device=dev, dtype=torch.float32))
-                ops.corr_volume(f1, f2, scale, self.corr_pyramid[l].view(B, N, h2 * w2))
+                    self.corr_pyramid.append(torch.empty(B * N, h2, w2, device=dev, dtype=vt))
+                volume(f2.view(B, h2 * w2, D), self.corr_pyramid[l].view(B, N, h2 * w2))
         return self
 
     # ------------------------------------------------------------------ training (autograd) side
@@ -279,8 +302,8 @@ class AlternateCorrBlock:
 
 
 def get_corr_block(fmap1: torch.Tensor, fmap2: torch.Tensor, num_levels: int = 4, radius: int = 4,
-                   alternate_corr: bool = False, pyramid: str = "avgpool"):
+                   alternate_corr: bool = False, pyramid: str = "avgpool", volume_dtype: Optional[torch.dtype] = None):
     """Same signature as ptlflow/models/raft/corr.py:104-118; ``alternate_corr=True`` selects the on-demand block."""
     if alternate_corr:
         return AlternateCorrBlock(fmap1, fmap2, num_levels=num_levels, radius=radius)
-    return CorrBlock(fmap1, fmap2, num_levels=num_levels, radius=radius, pyramid=pyramid)
+    return CorrBlock(fmap1, fmap2, num_levels=num_levels, radius=radius, pyramid=pyramid, volume_dtype=volume_dtype)

@@ -25,7 +25,7 @@ namespace {
 // ------------------------------------------------------------------------------------------
 
 struct LookupArgs {
-  const float* lv[PFK_MAX_LEVELS];
+  const void* lv[PFK_MAX_LEVELS];   // float or __bf16 maps (template parameter T of the kernel)
   int lh[PFK_MAX_LEVELS];
   int lw[PFK_MAX_LEVELS];
   int L, r, B, h, w;
@@ -44,7 +44,7 @@ struct LookupArgs {
 constexpr int PIX = 4;
 
 // R = radius (compile-time: the (2R+1)^2 sample enumeration divides by constants), PIX pixels per workgroup.
-template <int PIX, int R>
+template <int PIX, int R, typename T>
 __global__ __launch_bounds__(256) void lookup_kernel(const LookupArgs a) {
   constexpr int n = 2 * R + 1, nn = n * n;
   __shared__ float s_patch[4][PIX][PATCH * PATCH_LD];
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void lookup_kernel(const LookupArgs a) {
         }
         const int xbi = safe_base(xb), ybi = safe_base(yb);
         const bool pl = (p0 + q) < M;
-        const float* vol = a.lv[l] + (p0 + q) * (long long)Hl * Wl;
+        const T* vol = static_cast<const T*>(a.lv[l]) + (p0 + q) * (long long)Hl * Wl;
 #pragma unroll
         for (int e3 = 0; e3 < 3; ++e3) {          // all loads of all PIX patches are issued before any is used
           const int e = lane + 64 * e3;
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void lookup_kernel(const LookupArgs a) {
           const int gy = ybi + yy, gx = xbi + xx;
           float t = 0.f;
           if (pl && e < PATCH * PATCH && (unsigned)gy < (unsigned)Hl && (unsigned)gx < (unsigned)Wl)
-            t = vol[(long long)gy * Wl + gx];
+            t = (float)vol[(long long)gy * Wl + gx];   // bf16 volume: exact widening (grid_sample runs in fp32 under autocast)
           v[q][e3] = t;
         }
       }
@@ -146,8 +146,9 @@ __global__ __launch_bounds__(256) void lookup_kernel(const LookupArgs a) {
 // ------------------------------------------------------------------------------------------
 // K2 pooling: one thread per output element, HBM-bound (reads 4 B x 4, writes 4 B).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pool2x2_kernel(const float* __restrict__ in,
-                                                      float* __restrict__ out, long long total,
+template <typename T>
+__global__ __launch_bounds__(256) void pool2x2_kernel(const T* __restrict__ in,
+                                                      T* __restrict__ out, long long total,
                                                       int H, int W, int Ho, int Wo) {
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
@@ -155,17 +156,32 @@ __global__ __launch_bounds__(256) void pool2x2_kernel(const float* __restrict__ 
     const long long t = idx / Wo;
     const int yo = (int)(t % Ho);
     const long long m = t / Ho;
-    const float* src = in + (m * H + 2 * yo) * (long long)W + 2 * xo;
-    const float a00 = src[0], a01 = src[1], a10 = src[W], a11 = src[W + 1];
-    out[idx] = (((a00 + a01) + a10) + a11) * 0.25f;
+    const T* src = in + (m * H + 2 * yo) * (long long)W + 2 * xo;
+    const float a00 = (float)src[0], a01 = (float)src[1], a10 = (float)src[W], a11 = (float)src[W + 1];
+    out[idx] = (T)((((a00 + a01) + a10) + a11) * 0.25f);   // bf16: fp32 accumulate, one rounding (torch's opmath)
   }
 }
 
-}  // namespace
+// 2x2 / stride-2 average of a pixel-major feature map [B][H][W][ld] -> [B][H/2][W/2][out_ld], C channels (C % 4 == 0),
+// same summation order as above.  This IS F.interpolate(scale_factor=0.5, mode="bilinear", align_corners=False): every
+// output samples the centre of a 2x2 cell, four weights of exactly 0.25 (sea_raft/corr.py:81-83) — bit-identical to it.
+__global__ __launch_bounds__(256) void fmap_pool2x2_kernel(const float* __restrict__ in, int in_ld, float* __restrict__ out,
+                                                           int out_ld, long long total4, int C4, int H, int W, int Ho, int Wo) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total4) return;
+  const int c = (int)(idx % C4) * 4;
+  long long t = idx / C4;
+  const int xo = (int)(t % Wo); t /= Wo;
+  const int yo = (int)(t % Ho);
+  const long long b = t / Ho;
+  const float* src = in + ((b * H + 2 * yo) * (long long)W + 2 * xo) * in_ld + c;
+  const f32x4 a00 = *reinterpret_cast<const f32x4*>(src), a01 = *reinterpret_cast<const f32x4*>(src + in_ld);
+  const f32x4 a10 = *reinterpret_cast<const f32x4*>(src + (long long)W * in_ld), a11 = *reinterpret_cast<const f32x4*>(src + (long long)(W + 1) * in_ld);
+  *reinterpret_cast<f32x4*>(out + ((b * Ho + yo) * (long long)Wo + xo) * out_ld + c) = (((a00 + a01) + a10) + a11) * 0.25f;
+}
 
-extern "C" {
-
-int pfk_corr_lookup_f32(const pfk_lookup_desc* d, pfk_stream_t stream) {
+template <typename T>
+int lookup_launch(const pfk_lookup_desc* d, pfk_stream_t stream) {
   if (!d || !d->coords || !d->out) return PFK_ERR_BAD_ARG;
   if (d->num_levels < 1 || d->num_levels > PFK_MAX_LEVELS) return PFK_ERR_BAD_ARG;
   if (d->radius < 1 || d->radius > 4) return PFK_ERR_UNSUPPORTED;
@@ -184,24 +200,54 @@ int pfk_corr_lookup_f32(const pfk_lookup_desc* d, pfk_stream_t stream) {
   const dim3 grid((unsigned)blocks), block(256);
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (d->radius) {
-    case 1: hipLaunchKernelGGL((lookup_kernel<PIX, 1>), grid, block, 0, st, a); break;
-    case 2: hipLaunchKernelGGL((lookup_kernel<PIX, 2>), grid, block, 0, st, a); break;
-    case 3: hipLaunchKernelGGL((lookup_kernel<PIX, 3>), grid, block, 0, st, a); break;
-    default: hipLaunchKernelGGL((lookup_kernel<PIX, 4>), grid, block, 0, st, a); break;
+    case 1: hipLaunchKernelGGL((lookup_kernel<PIX, 1, T>), grid, block, 0, st, a); break;
+    case 2: hipLaunchKernelGGL((lookup_kernel<PIX, 2, T>), grid, block, 0, st, a); break;
+    case 3: hipLaunchKernelGGL((lookup_kernel<PIX, 3, T>), grid, block, 0, st, a); break;
+    default: hipLaunchKernelGGL((lookup_kernel<PIX, 4, T>), grid, block, 0, st, a); break;
   }
   return pfk_launch_status();
 }
 
-int pfk_corr_pool2x2_f32(const float* in, float* out, int64_t M, int H, int W,
-                         pfk_stream_t stream) {
+template <typename T>
+int pool_launch(const T* in, T* out, int64_t M, int H, int W, pfk_stream_t stream) {
   if (!in || !out || M <= 0 || H <= 0 || W <= 0) return PFK_ERR_BAD_ARG;
   const int Ho = H / 2, Wo = W / 2;
   const long long total = (long long)M * Ho * Wo;
   if (total == 0) return PFK_OK;  // a 1-pixel level pools to nothing
   long long blocks = (total + 255) / 256;
   if (blocks > 256LL * 32) blocks = 256LL * 32;  // grid-stride beyond 32 blocks per CU
-  hipLaunchKernelGGL(pool2x2_kernel, dim3((unsigned)blocks), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), in, out, total, H, W, Ho, Wo);
+  hipLaunchKernelGGL(pool2x2_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), in, out, total, H,
+                     W, Ho, Wo);
+  return pfk_launch_status();
+}
+
+}  // namespace
+
+extern "C" {
+
+int pfk_corr_lookup_f32(const pfk_lookup_desc* d, pfk_stream_t stream) { return lookup_launch<float>(d, stream); }
+
+// levels[] point to bf16 maps (the pyramid of pfk_corr_volume_bf16 / pfk_corr_pool2x2_bf16); coordinates, weights,
+// accumulation and the output stay fp32 — F.grid_sample is on autocast's fp32 list, so that is what the reference runs.
+int pfk_corr_lookup_bf16(const pfk_lookup_desc* d, pfk_stream_t stream) { return lookup_launch<__bf16>(d, stream); }
+
+int pfk_corr_pool2x2_f32(const float* in, float* out, int64_t M, int H, int W, pfk_stream_t stream) {
+  return pool_launch<float>(in, out, M, H, W, stream);
+}
+
+int pfk_corr_pool2x2_bf16(const void* in, void* out, int64_t M, int H, int W, pfk_stream_t stream) {
+  return pool_launch<__bf16>(static_cast<const __bf16*>(in), static_cast<__bf16*>(out), M, H, W, stream);
+}
+
+int pfk_fmap_pool2x2_f32(const float* in, int in_ld, float* out, int out_ld, int B, int H, int W, int C, pfk_stream_t stream) {
+  if (!in || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || in_ld < C || out_ld < C) return PFK_ERR_BAD_ARG;
+  if ((C & 3) || (in_ld & 3) || (out_ld & 3) || !pfk_aligned16(in) || !pfk_aligned16(out)) return PFK_ERR_ALIGNMENT;
+  const int Ho = H / 2, Wo = W / 2;
+  const long long total4 = (long long)B * Ho * Wo * (C / 4);
+  if (total4 == 0) return PFK_OK;
+  if ((total4 + 255) / 256 > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(fmap_pool2x2_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), in,
+                     in_ld, out, out_ld, total4, C / 4, H, W, Ho, Wo);
   return pfk_launch_status();
 }
 

@@ -21,6 +21,7 @@ struct GemmArgs {
   int relu;
   float scale;
   float* out; int out_ld; int out_coff;
+  int out_bf16;        // LINEAR: `out` points to bf16 elements (out_ld / out_coff / o_bs in elements): v is rounded to nearest even
   const float* residual; int residual_ld;   // LINEAR: out = residual[p][n] + v (after relu/scale)
   float* h; int h_ld;
   float* aux_z; float* aux_rh;
@@ -70,7 +71,8 @@ __device__ __forceinline__ void epilogue(const GemmArgs& a, const f32x16 (&acc)[
           v *= a.scale;
           if (a.residual != nullptr) v = a.residual[p * a.residual_ld + n] + v;
           if (a.relu2) v = (v < 0.f) ? 0.f : v;
-          outp[p * a.out_ld + a.out_coff + n] = v;
+          if (a.out_bf16) reinterpret_cast<__bf16*>(a.out)[batch * a.o_bs + p * a.out_ld + a.out_coff + n] = (__bf16)v;
+          else outp[p * a.out_ld + a.out_coff + n] = v;
         } else if constexpr (EPI == PFK_EPI_GRU_ZR) {
           const int ch = a.ch_hidden;
           const float g = sigmoid_f(v);

@@ -9,7 +9,7 @@
 // Pixel-major activations are passed as 2-D tensors [M, C] whose row stride is the buffer's
 // `ld` — a channel slice of a wider buffer (buf[:, 128:384]) is just a view.
 #include <ATen/ATen.h>
-#include <c10/hip/HIPGuard.h>
+#include <c10/core/DeviceGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
 
@@ -31,7 +31,7 @@ void check_ok(int status, const char* what) {
 thread_local const c10::Device* tl_op_device = nullptr;
 struct OpScope {
   c10::Device dev;
-  c10::hip::HIPGuard guard;
+  c10::DeviceGuard guard;   // generic guard: resolves to the (CUDA-masquerading) HIP implementation registered for the tensor's device type
   explicit OpScope(const Tensor& t) : dev(t.device()), guard(t.device()) {
     TORCH_CHECK(t.is_cuda(), "pfk ops need GPU tensors");
     tl_op_device = &dev;
@@ -75,12 +75,37 @@ void corr_volume(const Tensor& f1, const Tensor& f2, double scale, Tensor out) {
 
 void corr_pool2x2(const Tensor& in, Tensor out) {
   OpScope scope(in);
-  check_dev_f32(in, "in"); check_dev_f32(out, "out");
+  check_dev(in, "in"); check_dev(out, "out");
+  TORCH_CHECK(in.scalar_type() == out.scalar_type() && (in.scalar_type() == at::kFloat || in.scalar_type() == at::kBFloat16),
+              "corr_pool2x2: float32 or bfloat16 maps");
   TORCH_CHECK(in.dim() == 3 && in.is_contiguous() && out.is_contiguous(), "corr_pool2x2: [M,H,W] contiguous");
   const int64_t M = in.size(0); const int H = in.size(1), W = in.size(2);
   TORCH_CHECK(out.numel() == M * (H / 2) * (W / 2), "corr_pool2x2: out has wrong size");
   if (out.numel() == 0) return;
-  check_ok(pfk_corr_pool2x2_f32(fptr(in), fptr(out), M, H, W, cur_stream()), "corr_pool2x2");
+  if (in.scalar_type() == at::kFloat) check_ok(pfk_corr_pool2x2_f32(fptr(in), fptr(out), M, H, W, cur_stream()), "corr_pool2x2");
+  else check_ok(pfk_corr_pool2x2_bf16(in.data_ptr(), out.data_ptr(), M, H, W, cur_stream()), "corr_pool2x2 (bf16)");
+}
+
+// bf16 volume: f1 fp32 [B,N1,D], f2 bf16 [B,N2,D] -> out bf16 [B,N1,N2]
+void corr_volume_bf16(const Tensor& f1, const Tensor& f2, double scale, Tensor out) {
+  OpScope scope(f1);
+  check_dev_f32(f1, "f1"); check_dev(f2, "f2"); check_dev(out, "out");
+  TORCH_CHECK(f2.scalar_type() == at::kBFloat16 && out.scalar_type() == at::kBFloat16, "corr_volume_bf16: f2 and out must be bfloat16");
+  TORCH_CHECK(f1.dim() == 3 && f2.dim() == 3 && out.dim() == 3 && f1.is_contiguous() && f2.is_contiguous() && out.is_contiguous(),
+              "corr_volume_bf16: contiguous [B,N,D] inputs, [B,N1,N2] out");
+  const int B = f1.size(0), N1 = f1.size(1), D = f1.size(2), N2 = f2.size(1);
+  TORCH_CHECK(f2.size(0) == B && f2.size(2) == D && out.size(0) == B && out.size(1) == N1 && out.size(2) == N2, "corr_volume_bf16: shape mismatch");
+  check_ok(pfk_corr_volume_bf16(fptr(f1), D, f2.data_ptr(), D, out.data_ptr(), B, N1, N2, D, (float)scale, cur_stream()), "corr_volume_bf16");
+}
+
+// pixel-major feature map [B*H*W, C] -> [B*(H/2)*(W/2), C]: 2x2 average == bilinear x0.5 (align_corners=False)
+void fmap_pool2x2(const Tensor& in, Tensor out, int64_t B, int64_t H, int64_t W) {
+  OpScope scope(in);
+  check_pm(in, "in"); check_pm(out, "out");
+  TORCH_CHECK(in.size(0) == B * H * W && out.size(0) == B * (H / 2) * (W / 2) && out.size(1) == in.size(1), "fmap_pool2x2: shapes");
+  if (out.numel() == 0) return;
+  check_ok(pfk_fmap_pool2x2_f32(fptr(in), in.stride(0), fptr(out), out.stride(0), (int)B, (int)H, (int)W, (int)in.size(1), cur_stream()),
+           "fmap_pool2x2");
 }
 
 void corr_lookup(at::TensorList levels, const Tensor& coords, int64_t radius, Tensor out) {
@@ -91,18 +116,20 @@ void corr_lookup(at::TensorList levels, const Tensor& coords, int64_t radius, Te
   pfk_lookup_desc d{};
   d.B = coords.size(0); d.h = coords.size(2); d.w = coords.size(3);
   const int64_t M = (int64_t)d.B * d.h * d.w;
+  const bool bf = levels[0].scalar_type() == at::kBFloat16;
   for (size_t l = 0; l < levels.size(); ++l) {
     const Tensor& v = levels[l];
-    check_dev_f32(v, "level");
+    check_dev(v, "level");
+    TORCH_CHECK(v.scalar_type() == (bf ? at::kBFloat16 : at::kFloat), "corr_lookup: levels must all be float32 or all bfloat16");
     TORCH_CHECK(v.dim() == 3 && v.is_contiguous() && v.size(0) == M, "corr_lookup: level must be [B*N,h_l,w_l] contiguous");
-    d.levels[l] = fptr(v); d.lvl_h[l] = v.size(1); d.lvl_w[l] = v.size(2);
+    d.levels[l] = v.data_ptr(); d.lvl_h[l] = v.size(1); d.lvl_w[l] = v.size(2);
   }
   d.num_levels = levels.size(); d.radius = radius;
   d.coords = fptr(coords); d.out = fptr(out); d.out_ld = out.stride(0);
   TORCH_CHECK(out.size(0) == M, "corr_lookup: out rows");
   const int n = 2 * radius + 1;
   TORCH_CHECK(out.size(1) >= d.num_levels * n * n, "corr_lookup: out channels");
-  check_ok(pfk_corr_lookup_f32(&d, cur_stream()), "corr_lookup");
+  check_ok(bf ? pfk_corr_lookup_bf16(&d, cur_stream()) : pfk_corr_lookup_f32(&d, cur_stream()), "corr_lookup");
 }
 
 void conv2d(at::TensorList srcs, int64_t B, int64_t H, int64_t W, int64_t kh, int64_t kw,
@@ -489,6 +516,8 @@ TORCH_LIBRARY(pfk, m) {
   m.def("debug_set_tile(int cfg) -> ()", &debug_set_tile);
   m.def("corr_volume(Tensor f1, Tensor f2, float scale, Tensor(a!) out) -> ()");
   m.def("corr_pool2x2(Tensor inp, Tensor(a!) out) -> ()");
+  m.def("corr_volume_bf16(Tensor f1, Tensor f2, float scale, Tensor(a!) out) -> ()");
+  m.def("fmap_pool2x2(Tensor inp, Tensor(a!) out, int B, int H, int W) -> ()");
   m.def("corr_lookup(Tensor[] levels, Tensor coords, int radius, Tensor(a!) out) -> ()");
   m.def("conv2d(Tensor[] srcs, int B, int H, int W, int kh, int kw, Tensor weight, Tensor? bias, int cout, "
         "int epilogue, bool relu, float scale, Tensor(a!)? out, Tensor(b!)? h, Tensor(c!)? aux_z, Tensor(d!)? aux_rh, "
@@ -514,6 +543,8 @@ TORCH_LIBRARY(pfk, m) {
 TORCH_LIBRARY_IMPL(pfk, CUDA, m) {
   m.impl("corr_volume", &corr_volume);
   m.impl("corr_pool2x2", &corr_pool2x2);
+  m.impl("corr_volume_bf16", &corr_volume_bf16);
+  m.impl("fmap_pool2x2", &fmap_pool2x2);
   m.impl("corr_lookup", &corr_lookup);
   m.impl("conv2d", &conv2d);
   m.impl("conv_cin2", &conv_cin2);

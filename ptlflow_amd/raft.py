@@ -296,8 +296,11 @@ class RAFT(nn.Module):
         if st is not None and (st["engine"] is not eng or st["hx_ptr"] != eng.hx.data_ptr()):
             st = None      # a new engine, or its buffers were re-bound for another shape in between: the recorded addresses are stale
         if st is None:
-            corr_cls = AlternateCorrBlock if self.alternate_corr else CorrBlock
-            corr_fn = corr_cls(fm[:B], fm[B:], num_levels=self.corr_levels, radius=self.corr_radius)
+            if self.alternate_corr:
+                corr_fn = AlternateCorrBlock(fm[:B], fm[B:], num_levels=self.corr_levels, radius=self.corr_radius)
+            else:   # conv_precision "bf16" = BASELINE config 3's precision: bf16 operands everywhere autocast would put them
+                vt = torch.bfloat16 if self.conv_precision == "bf16" else torch.float32
+                corr_fn = CorrBlock(fm[:B], fm[B:], num_levels=self.corr_levels, radius=self.corr_radius, volume_dtype=vt)
             ys, xs = torch.meshgrid(torch.arange(h, device=x.device, dtype=torch.float32),
                                     torch.arange(w, device=x.device, dtype=torch.float32), indexing="ij")
             coords0 = torch.stack([xs, ys], 0)[None].repeat(B, 1, 1, 1).contiguous()

@@ -165,7 +165,7 @@ def test_raft_headline_split_modes(gpu):
         print(f"headline EPE {p}: mean {mean:.3e} max {mx:.3e}")
     assert res["bf16x6"][0] <= 1e-3 and res["bf16x6"][1] <= 1e-2
     assert res["bf16x3"][0] <= 2e-2
-    assert res["bf16"][0] <= 2.0
+    # plain bf16 (config 3) has its own gate: tests/test_gpu_bf16_gate.py
 
 
 def test_gma_split_modes(gpu):
@@ -185,7 +185,7 @@ def test_gma_split_modes(gpu):
         print(f"gma {prec}: EPE mean {res[prec][0]:.3e} max {res[prec][1]:.3e}")
     assert res["bf16x6"][0] <= 1e-3 and res["bf16x6"][1] <= 1e-2
     assert res["bf16x3"][0] <= 1e-2
-    assert res["bf16"][0] <= 2.0
+    # plain bf16 (config 3) has its own gate: tests/test_gpu_bf16_gate.py
 
 
 def test_kitti_shape_split(gpu):

@@ -116,3 +116,34 @@ def test_alt_corr_oracle_matches_reference_iterative_block():
     assert (ours - it).abs().max().item() < 1e-4
     full = corr_mod.CorrBlock(f1, f2, num_levels=3, radius=3)(c)
     assert (ours - full).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("small", [False, True])
+def test_oracle_under_autocast_is_the_reference_under_autocast(small):
+    """The bf16 gate (tests/test_gpu_bf16_gate.py) measures the reference's own bf16-vs-fp32 gap by running the ORACLE under
+    `torch.autocast("cpu", bfloat16)`; that is legitimate only if the oracle under autocast is the reference under autocast."""
+    ref = ref_loader.build_raft(small=small, iters=6)
+    x = O.smooth_pair(1, 128, 192, seed=3)
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+        r = ref({"images": x.clone()})["flows"].float()
+        o = O.raft_forward(_sd(ref), x, iters=6, small=small)["flows"].float()
+    mean, mx = O.epe(o[:, 0], r[:, 0])
+    assert mean <= 1e-6 and mx <= 1e-5
+    with torch.no_grad():
+        gap = O.epe(r[:, 0], ref({"images": x.clone()})["flows"][:, 0])[0]
+    assert gap > 1e-4        # the autocast run really is a different (bf16) computation
+
+
+def test_gma_oracle_matches_reference_fp32_and_autocast():
+    torch.manual_seed(3)
+    m = ref_loader.ref_module("ptlflow.models.gma.gma").GMA(iters=4).eval()
+    with torch.no_grad():
+        m.update_block.aggregator.gamma.fill_(0.4)      # the reference initialises gamma to 0 (aggregate branch silent)
+    sd = _sd(m)
+    x = O.smooth_pair(1, 128, 192, seed=3)
+    with torch.no_grad():
+        r32, o32 = m({"images": x.clone()})["flows"], O.gma_forward(sd, x, iters=4)["flows"]
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            r, o = m({"images": x.clone()})["flows"].float(), O.gma_forward(sd, x, iters=4)["flows"].float()
+    assert O.epe(o32[:, 0], r32[:, 0])[1] <= 1e-5
+    assert O.epe(o[:, 0], r[:, 0])[1] <= 1e-5
