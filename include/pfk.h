@@ -324,6 +324,10 @@ int pfk_norm_apply_f32(const float* x, int x_ld, const float* mean, const float*
                        int residual_ld, float* out, int out_ld, int B, int HW, int C, int relu,
                        int relu_after_residual, pfk_stream_t stream);
 
+/* In-place softmax over each row of x [rows][ld] (cols entries used) — GMA's attention map (gma/gma_utils.py:75-76:
+ * `sim.softmax(dim=-1)`, once per forward; the similarity itself is pfk_corr_volume_f32 of the q / k maps). */
+int pfk_softmax_rows_f32(float* x, long long rows, int cols, long long ld, pfk_stream_t stream);
+
 /* NCHW [B][C][H][W] -> pixel-major [B*H*W][ld] (+ channel offset) and back. */
 int pfk_nchw_to_pm_f32(const float* in, float* out, int out_ld, int out_coff, int B, int C,
                        int H, int W, pfk_stream_t stream);

@@ -29,6 +29,7 @@ struct GemmArgs {
   long long M;
   long long a_bs, b_bs, o_bs;  // per-blockIdx.y strides (batched correlation), floats
   int tiles_n;
+  int supertile;           // > 0: walk the tile grid in supertile x supertile blocks (see tile_of) instead of row-major
   float* sk_ws;            // stream-K: one 64x64 fp32 partial per block
   unsigned* sk_flags;      // stream-K: one ready flag per block (zeroed before every launch)
   int sk_steps;            // K-steps per tile (host-computed)
@@ -37,6 +38,30 @@ struct GemmArgs {
   long long wbf_plane_bytes;
   int dbg;                 // split-bf16 timing ablations (results are garbage): 1 no global loads, 2 no split + LDS stores, 4 no fragment reads + MFMAs
 };
+
+// Tile id -> (tile_m, tile_n).  Row-major by default (tile_n fastest: the column tiles of one row panel run together and share
+// the A panel through L2).  With a supertile edge S the grid is walked in S x S blocks of tiles: a big square-ish GEMM whose
+// B operand does not fit an XCD's 4 MB L2 (the correlation volume: B = all of fmap2, 7.2 MB) otherwise streams B from HBM once
+// per row of tiles; inside a supertile both panels (S*BM and S*BN rows) are L2-resident, which cuts operand traffic ~S/2-fold.
+// Ragged edges: the last band / last column block are narrower; every earlier one is full, so offsets stay closed-form.
+__device__ __forceinline__ void tile_of(int bid, int tiles_m, int tiles_n, int S, int& tile_m, int& tile_n) {
+  if (S <= 0) { tile_n = bid % tiles_n; tile_m = bid / tiles_n; return; }
+  const int per_band = S * tiles_n;
+  int band = bid / per_band;
+  const int full_bands = tiles_m / S;
+  if (band > full_bands) band = full_bands;
+  const int m_base = band * S;
+  const int hb = (tiles_m - m_base) < S ? (tiles_m - m_base) : S;
+  const int local = bid - band * per_band;
+  int col = local / (hb * S);
+  const int full_cols = tiles_n / S;
+  if (col > full_cols) col = full_cols;
+  const int n_base = col * S;
+  const int wb = (tiles_n - n_base) < S ? (tiles_n - n_base) : S;
+  const int l2 = local - col * hb * S;
+  tile_m = m_base + l2 / wb;
+  tile_n = n_base + l2 - (l2 / wb) * wb;
+}
 
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 

@@ -283,8 +283,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs a) {
   const int wn0 = (wid % WAVES_N) * WN;
 
   const int bid = pfk_xcd_remap(blockIdx.x, gridDim.x);
-  const int tile_n = bid % a.tiles_n;
-  const int tile_m = bid / a.tiles_n;
+  int tile_m, tile_n;
+  tile_of(bid, (int)gridDim.x / a.tiles_n, a.tiles_n, a.supertile, tile_m, tile_n);
   const long long m0 = (long long)tile_m * BM;
   const int n0 = tile_n * BN;
   const long long batch = blockIdx.y;
@@ -426,8 +426,8 @@ __global__ __launch_bounds__(256 * GROUPS) void conv_gemm_v3_kernel(const GemmAr
   const int wn0 = (wid % WAVES_N) * WN;
 
   const int bid = pfk_xcd_remap(blockIdx.x, gridDim.x);
-  const int tile_n = bid % a.tiles_n;
-  const int tile_m = bid / a.tiles_n;
+  int tile_m, tile_n;
+  tile_of(bid, (int)gridDim.x / a.tiles_n, a.tiles_n, a.supertile, tile_m, tile_n);
   const long long m0 = (long long)tile_m * BM;
   const int n0 = tile_n * BN;
   const long long batch = blockIdx.y;
@@ -687,6 +687,8 @@ int launch_cfg(const GemmArgs& a, int epi, int batches, hipStream_t st) {
   const long long nblk = tiles_m * g.tiles_n;
   if (nblk <= 0 || nblk > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
   dim3 grid((unsigned)nblk, (unsigned)batches);
+  // both operand panels much larger than an XCD's L2: walk the grid in 16 x 16 supertiles (tile_of)
+  g.supertile = (tiles_m >= 32 && g.tiles_n >= 32) ? 16 : 0;
   switch (epi) {
     case PFK_EPI_LINEAR: return launch_one<BM, BN, WM, WN, PFK_EPI_LINEAR, VARIANT>(g, grid, st);
     case PFK_EPI_GRU_ZR: return launch_one<BM, BN, WM, WN, PFK_EPI_GRU_ZR, VARIANT>(g, grid, st);

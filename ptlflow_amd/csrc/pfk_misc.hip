@@ -326,6 +326,31 @@ __global__ __launch_bounds__(256) void forward_interp_kernel(const float* __rest
   }
 }
 
+// In-place softmax over the rows of a [rows][ld] matrix (cols used): GMA's attention map, gma_utils.py:75-76
+// (`sim.softmax(dim=-1)` over N = h*w target pixels, once per forward).  One 256-thread block per row, three passes over the
+// row (max, sum of exp, normalise); the row (28 KB at 55x128) stays in L2 between passes.  expf / division as torch's kernel.
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ x, long long ld, int cols) {
+  __shared__ float red[4];
+  float* row = x + (long long)blockIdx.x * ld;
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+  float m = -INFINITY;
+  for (int c = t; c < cols; c += 256) m = fmaxf(m, row[c]);
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) m = fmaxf(m, __shfl_xor(m, s, 64));
+  if (lane == 0) red[wid] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float sum = 0.f;
+  for (int c = t; c < cols; c += 256) sum += expf(row[c] - m);
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) sum += __shfl_xor(sum, s, 64);
+  if (lane == 0) red[wid] = sum;
+  __syncthreads();
+  sum = (red[0] + red[1]) + (red[2] + red[3]);
+  for (int c = t; c < cols; c += 256) row[c] = expf(row[c] - m) / sum;
+}
+
 }  // namespace
 
 extern "C" {
@@ -440,6 +465,12 @@ int pfk_pm_to_cm_f32(const float* in, int in_ld, float* out, int out_ld, int B, 
   dim3 grid((N + 31) / 32, (C + 31) / 32, B);
   hipLaunchKernelGGL(pm_to_nchw_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), in,
                      in_ld, 0, out, C, N, out_ld);
+  return pfk_launch_status();
+}
+
+int pfk_softmax_rows_f32(float* x, long long rows, int cols, long long ld, pfk_stream_t stream) {
+  if (!x || rows <= 0 || cols <= 0 || ld < cols || rows > 0x7fffffffLL) return PFK_ERR_BAD_ARG;
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, static_cast<hipStream_t>(stream), x, ld, cols);
   return pfk_launch_status();
 }
 

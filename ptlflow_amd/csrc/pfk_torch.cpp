@@ -429,6 +429,14 @@ void norm_apply(const Tensor& x, const Tensor& mean, const Tensor& rstd, const c
                               relu, relu_after_residual, cur_stream()), "norm_apply");
 }
 
+void softmax_rows(Tensor x) {
+  OpScope scope(x);
+  check_dev_f32(x, "x");
+  TORCH_CHECK(x.dim() >= 2 && x.is_contiguous(), "softmax_rows: contiguous [..., rows, cols]");
+  const int64_t cols = x.size(-1), rows = x.numel() / cols;
+  check_ok(pfk_softmax_rows_f32(fptr(x), rows, (int)cols, cols, cur_stream()), "softmax_rows");
+}
+
 void forward_interpolate(const Tensor& flow, Tensor out) {
   OpScope scope(flow);
   check_dev_f32(flow, "flow"); check_dev_f32(out, "out");
@@ -508,6 +516,7 @@ TORCH_LIBRARY(pfk, m) {
   m.def("gru_backward_zr(Tensor d_rh, Tensor h, Tensor r, Tensor(a!) da_zr, Tensor(b!) dh) -> ()");
   m.def("conv_wgrad(Tensor[] srcs, Tensor dy, int B, int H, int W, int kh, int kw, Tensor(a!) out, bool with_bias=False) -> ()");
   m.def("forward_interpolate(Tensor flow, Tensor(a!) out) -> ()");
+  m.def("softmax_rows(Tensor(a!) x) -> ()");
   m.def("instnorm_workspace_bytes(int B, int C) -> int", &instnorm_workspace_bytes);
   m.def("conv_stem(Tensor img, Tensor weight, Tensor? bias, Tensor(a!) out, bool relu) -> ()");
   m.def("instnorm_stats(Tensor x, int B, int HW, float eps, Tensor(a!) mean, Tensor(b!) rstd, Tensor(c!) workspace) -> ()");
@@ -567,6 +576,7 @@ TORCH_LIBRARY_IMPL(pfk, CUDA, m) {
   m.impl("gru_backward_zr", &gru_backward_zr);
   m.impl("conv_wgrad", &conv_wgrad);
   m.impl("forward_interpolate", &forward_interpolate);
+  m.impl("softmax_rows", &softmax_rows);
   m.impl("instnorm_stats", &instnorm_stats);
   m.impl("norm_apply", &norm_apply);
 }

@@ -1,8 +1,9 @@
-"""BasicEncoder (the feature / context networks) on libpfk kernels — SURVEY.md §8 f3.
+"""BasicEncoder / SmallEncoder (the feature / context networks) on libpfk kernels — SURVEY.md §8 f3.
 
 Reference: ptlflow/models/raft/extractor.py:122-194 (``BasicEncoder``: 7x7/2 stem, three pairs of ``ResidualBlock``s at
 1/2, 1/4, 1/8 resolution, 1x1 output conv; ``norm_fn`` = ``instance`` for fnet, ``batch`` for cnet; gma/ and the other
-RAFT descendants reuse it).  Activations stay pixel-major ``[B*H*W, C]`` between kernels:
+RAFT descendants reuse it) and :197-267 (``SmallEncoder`` of raft_small: the same skeleton at widths 32/64/96 with
+``BottleneckBlock``s — 1x1 -> 3x3 (stride) -> 1x1, :62-119).  Activations stay pixel-major ``[B*H*W, C]`` between kernels:
 
 * stem                     -> ``pfk_conv_stem_f32`` (reads the NCHW image)
 * 3x3 / 1x1, stride 1 / 2  -> ``pfk_conv2d_f32`` or ``pfk_conv2d_bf16s`` (implicit GEMM; bias, relu, residual add and the
@@ -26,6 +27,9 @@ from .update import CONV_PRECISIONS, EPI_LINEAR
 # (name, cin, cout, stride) of the six residual blocks, extractor.py:150-153
 _BLOCKS = (("layer1.0", 64, 64, 1), ("layer1.1", 64, 64, 1), ("layer2.0", 64, 96, 2), ("layer2.1", 96, 96, 1),
            ("layer3.0", 96, 128, 2), ("layer3.1", 128, 128, 1))
+# the six bottleneck blocks of SmallEncoder, extractor.py:216-219
+_SMALL_BLOCKS = (("layer1.0", 32, 32, 1), ("layer1.1", 32, 32, 1), ("layer2.0", 32, 64, 2), ("layer2.1", 64, 64, 1),
+                 ("layer3.0", 64, 96, 2), ("layer3.1", 96, 96, 1))
 EPS = 1e-5
 
 
@@ -34,8 +38,11 @@ def _out(n: int, s: int) -> int:
 
 
 class EncoderEngine:
-    def __init__(self, params: Dict[str, torch.Tensor], norm: str, device: torch.device, conv_precision: str = "fp32"):
+    def __init__(self, params: Dict[str, torch.Tensor], norm: str, device: torch.device, conv_precision: str = "fp32",
+                 small: bool = False):
         load_native()
+        self.small = small
+        self.blocks = _SMALL_BLOCKS if small else _BLOCKS
         if norm not in ("instance", "batch", "none"):
             raise ValueError(norm)
         if conv_precision not in CONV_PRECISIONS:
@@ -73,8 +80,9 @@ class EncoderEngine:
         assert w.shape[1:] == (3, 7, 7), "stem must be Conv2d(3, C, 7, stride=2, padding=3)"
         W["stem.w"] = w.permute(2, 3, 1, 0).reshape(49, 3, w.shape[0]).contiguous()
         W["stem.b"] = b
-        for name, cin, cout, stride in _BLOCKS:
-            for conv, nrm in (("conv1", "norm1"), ("conv2", "norm2")):
+        convs = (("conv1", "norm1"), ("conv2", "norm2"), ("conv3", "norm3")) if self.small else (("conv1", "norm1"), ("conv2", "norm2"))
+        for name, cin, cout, stride in self.blocks:
+            for conv, nrm in convs:
                 w, b = self._fold(P, f"{name}.{conv}", f"{name}.{nrm}")
                 W[f"{name}.{conv}.w"], W[f"{name}.{conv}.b"] = self._pk(w), b
             if stride != 1:
@@ -106,7 +114,26 @@ class EncoderEngine:
         self.ops.norm_apply(x, mean, rstd, residual, x, B, HW, relu, relu2)
         return x
 
+    def _bottleneck(self, x, B, H, W, name, cout, stride):
+        """BottleneckBlock.forward (extractor.py:110-119): relu(norm(1x1)) -> relu(norm(3x3, stride)) -> relu(norm(1x1)); relu(x + y)."""
+        Ho, Wo = _out(H, stride), _out(W, stride)
+        mid = cout // 4
+        if self.norm == "instance":
+            y = self._inorm(self._conv(x, B, H, W, 1, f"{name}.conv1", mid), B, H * W, relu=True)
+            y = self._inorm(self._conv(y, B, H, W, 3, f"{name}.conv2", mid, stride), B, Ho * Wo, relu=True)
+            y = self._conv(y, B, Ho, Wo, 1, f"{name}.conv3", cout)
+            if stride != 1:
+                x = self._inorm(self._conv(x, B, H, W, 1, f"{name}.ds", cout, stride), B, Ho * Wo, relu=False)
+            return self._inorm(y, B, Ho * Wo, relu=True, residual=x, relu2=True)
+        y = self._conv(x, B, H, W, 1, f"{name}.conv1", mid, relu=True)
+        y = self._conv(y, B, H, W, 3, f"{name}.conv2", mid, stride, relu=True)
+        if stride != 1:
+            x = self._conv(x, B, H, W, 1, f"{name}.ds", cout, stride)
+        return self._conv(y, B, Ho, Wo, 1, f"{name}.conv3", cout, relu=True, residual=x, relu2=True)
+
     def _block(self, x, B, H, W, name, cout, stride):
+        if self.small:
+            return self._bottleneck(x, B, H, W, name, cout, stride)
         Ho, Wo = _out(H, stride), _out(W, stride)
         if self.norm == "instance":
             y = self._inorm(self._conv(x, B, H, W, 3, f"{name}.conv1", cout, stride), B, Ho * Wo, relu=True)
@@ -129,7 +156,7 @@ class EncoderEngine:
         B, _, H, W = img.shape
         H1, W1 = _out(H, 2), _out(W, 2)
         # the convolution kernels address a source with 32-bit byte offsets: keep every activation matrix under 2 GiB
-        per_image = H1 * W1 * 128 * 4
+        per_image = H1 * W1 * 128 * 4   # widest activation row: 128 floats (32 at half resolution for the small encoder; same bound)
         max_b = max(1, self.max_matrix_bytes // per_image)
         if B > max_b:
             return torch.cat([self(img[i:i + max_b]) for i in range(0, B, max_b)], 0)
@@ -138,7 +165,7 @@ class EncoderEngine:
         if self.norm == "instance":
             x = self._inorm(x, B, H1 * W1, relu=True)
         h, w = H1, W1
-        for name, _cin, cout, stride in _BLOCKS:
+        for name, _cin, cout, stride in self.blocks:
             x = self._block(x, B, h, w, name, cout, stride)
             h, w = _out(h, stride), _out(w, stride)
         y = self._conv(x, B, h, w, 1, "out", self.out_dim)
@@ -152,8 +179,9 @@ class PfkEncoder(torch.nn.Module):
     optimizers are untouched.  GPU inference goes to ``EncoderEngine``; training mode, gradient graphs, CPU tensors and
     GroupNorm stay on the reference's own code."""
 
-    def __init__(self, ref: torch.nn.Module, conv_precision: str = "fp32"):
+    def __init__(self, ref: torch.nn.Module, conv_precision: str = "fp32", small: bool = False):
         super().__init__()
+        self.small = small
         for name, child in ref.named_children():
             self.add_module(name, child)
         self._ref = [ref]   # in a list: not registered twice in the module tree
@@ -167,7 +195,7 @@ class PfkEncoder(torch.nn.Module):
         ref = self._ref[0]
         v = tuple((t.data_ptr(), t._version) for t in list(ref.parameters()) + list(ref.buffers()))
         if self._engine is None or self._engine.device != device or v != self._versions:
-            self._engine = EncoderEngine(ref.state_dict(), self.norm_fn, device, self.conv_precision)
+            self._engine = EncoderEngine(ref.state_dict(), self.norm_fn, device, self.conv_precision, self.small)
             self._versions = v
         return self._engine
 

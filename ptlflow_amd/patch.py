@@ -47,6 +47,7 @@ _UPDATE_BLOCKS: Dict[Tuple[str, str], Callable[[int], UpdateSpec]] = {
 # (module, class) of the BasicEncoder implementations that are raft/extractor.py:122-194 verbatim
 _ENCODERS = {
     ("ptlflow.models.raft.extractor", "BasicEncoder"),
+    ("ptlflow.models.raft.extractor", "SmallEncoder"),     # raft_small: bottleneck blocks, extractor.py:197-267
     ("ptlflow.models.gma.extractor", "BasicEncoder"),
 }
 # families whose CorrBlock pyramid is not the avg-pool one (sea_raft/corr.py:71-84)
@@ -83,8 +84,9 @@ def match_update_block(block: torch.nn.Module) -> Optional[UpdateSpec]:
     return spec if sd == want else None
 
 
-def _basic_encoder_shapes(out_dim: int, norm_fn: str) -> Dict[str, tuple]:
-    """state_dict names/shapes of BasicEncoder (raft/extractor.py:122-170) for norm_fn in {instance, batch, none}."""
+def _basic_encoder_shapes(out_dim: int, norm_fn: str, small: bool = False) -> Dict[str, tuple]:
+    """state_dict names/shapes of BasicEncoder (raft/extractor.py:122-170) / SmallEncoder (:197-236) for norm_fn in
+    {instance, batch, none}."""
     sh: Dict[str, tuple] = {}
 
     def conv(name, co, ci, k):
@@ -99,22 +101,33 @@ def _basic_encoder_shapes(out_dim: int, norm_fn: str) -> Dict[str, tuple]:
             sh[name + ".running_var"] = (c,)
             sh[name + ".num_batches_tracked"] = ()
 
-    conv("conv1", 64, 3, 7)
-    norm("norm1", 64)
-    cin = 64
-    for i, (dim, stride) in enumerate(((64, 1), (96, 2), (128, 2)), start=1):
+    dims = (32, 32, 64, 96) if small else (64, 64, 96, 128)
+    conv("conv1", dims[0], 3, 7)
+    norm("norm1", dims[0])
+    cin = dims[0]
+    for i, (dim, stride) in enumerate(zip(dims[1:], (1, 2, 2)), start=1):
         for j, (ci, s) in enumerate(((cin, stride), (dim, 1))):
             p = f"layer{i}.{j}"
-            conv(p + ".conv1", dim, ci, 3)
-            conv(p + ".conv2", dim, dim, 3)
-            norm(p + ".norm1", dim)
-            norm(p + ".norm2", dim)
-            if s != 1:
+            if small:    # BottleneckBlock: 1x1 -> 3x3 -> 1x1 at a quarter of the width, norm4 on the downsample path
+                conv(p + ".conv1", dim // 4, ci, 1)
+                conv(p + ".conv2", dim // 4, dim // 4, 3)
+                conv(p + ".conv3", dim, dim // 4, 1)
+                norm(p + ".norm1", dim // 4)
+                norm(p + ".norm2", dim // 4)
                 norm(p + ".norm3", dim)
+                extra = ".norm4"
+            else:
+                conv(p + ".conv1", dim, ci, 3)
+                conv(p + ".conv2", dim, dim, 3)
+                norm(p + ".norm1", dim)
+                norm(p + ".norm2", dim)
+                extra = ".norm3"
+            if s != 1:
+                norm(p + extra, dim)
                 conv(p + ".downsample.0", dim, ci, 1)
                 norm(p + ".downsample.1", dim)
         cin = dim
-    conv("conv2", out_dim, 128, 1)
+    conv("conv2", out_dim, dims[3], 1)
     return sh
 
 
@@ -126,7 +139,7 @@ def match_encoder(enc: torch.nn.Module) -> bool:
         return False
     sd = {k: tuple(v.shape) for k, v in enc.state_dict().items()}
     out = sd.get("conv2.weight")
-    return out is not None and sd == _basic_encoder_shapes(out[0], norm_fn)
+    return out is not None and sd == _basic_encoder_shapes(out[0], norm_fn, type(enc).__name__ == "SmallEncoder")
 
 
 def _supported_envelope(fmap1: torch.Tensor, fmap2: torch.Tensor, num_levels: int, radius: int) -> bool:
@@ -181,7 +194,7 @@ def accelerate(model: torch.nn.Module, corr: bool = True, update_block: bool = T
         for attr in ("fnet", "cnet"):
             enc = getattr(model, attr, None)
             if enc is not None and not isinstance(enc, PfkEncoder) and match_encoder(enc):
-                setattr(model, attr, PfkEncoder(enc, conv_precision))
+                setattr(model, attr, PfkEncoder(enc, conv_precision, small=type(enc).__name__ == "SmallEncoder"))
     return model
 
 

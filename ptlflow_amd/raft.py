@@ -134,9 +134,9 @@ class RAFT(nn.Module):
         # True: never materialise the N x N volume, compute the lookup windows on demand (raft.py `alternate_corr`,
         # raft/corr.py:67-101) — the memory / time trade for high resolutions
         self.alternate_corr = alternate_corr
-        # True: fnet / cnet run on libpfk kernels (ptlflow_amd/encoder.py; BasicEncoder only — raft_small's bottleneck
-        # encoder stays on torch); False: the torch modules
-        self.native_encoders = native_encoders and not small
+        # True: fnet / cnet run on libpfk kernels (ptlflow_amd/encoder.py: BasicEncoder, and raft_small's bottleneck
+        # SmallEncoder); False: the torch modules
+        self.native_encoders = native_encoders
         self._enc = None
         self._enc_versions = None
         # "fp32" (default: fp32 matrix cores, the parity path) | "bf16x6" | "bf16x3" | "bf16": split-bf16 operands
@@ -196,8 +196,8 @@ class RAFT(nn.Module):
         from .encoder import EncoderEngine
         v = tuple((p.data_ptr(), p._version) for m in (self.fnet, self.cnet) for p in list(m.parameters()) + list(m.buffers()))
         if self._enc is None or self._enc[0].device != device or v != self._enc_versions:
-            self._enc = (EncoderEngine(self.fnet.state_dict(), "instance", device, self.conv_precision),
-                         EncoderEngine(self.cnet.state_dict(), "batch", device, self.conv_precision))
+            self._enc = (EncoderEngine(self.fnet.state_dict(), "instance", device, self.conv_precision, self.small),
+                         EncoderEngine(self.cnet.state_dict(), "none" if self.small else "batch", device, self.conv_precision, self.small))
             self._enc_versions = v
         return self._enc
 
@@ -410,4 +410,33 @@ class GMA(RAFT):
         return gma_spec(corr_levels, corr_radius)
 
     def _after_context(self, eng: UpdateEngine, inp: torch.Tensor) -> None:
-        eng.set_attention(self.att(inp))
+        eng.set_attention(self._attention(inp))
+
+    def _attention(self, inp: torch.Tensor) -> torch.Tensor:
+        """Attention.forward, content-only, one head (gma_utils.py:50-78) on libpfk: `to_qk` as two 1x1 convolutions on the
+        MFMA conv kernel (q and k land in their own pixel-major matrices), the N x N similarity as K1 (`pfk_corr_volume_f32`
+        with scale = dim_head^-0.5: the same all-pairs inner product as the correlation volume), and an in-place row softmax."""
+        from .packing import pack_conv_weight
+        ops = torch.ops.pfk
+        B, C, h, w = inp.shape
+        N = h * w
+        att = self.att
+        if att.heads != 1 or C % 32:
+            return att(inp)
+        wv = att.to_qk.weight
+        key = (wv.data_ptr(), wv._version, wv.device)
+        if getattr(self, "_qk_key", None) != key:
+            wq, wk = wv.detach().float().chunk(2, dim=0)
+            self._qk_w = (pack_conv_weight(wq.contiguous(), [(0, C, C)]), pack_conv_weight(wk.contiguous(), [(0, C, C)]))
+            self._qk_key = key
+        x = inp.float().permute(0, 2, 3, 1)
+        x = x.reshape(B * N, C) if x.is_contiguous() else x.contiguous().view(B * N, C)
+        d = wv.shape[0] // 2
+        q = torch.empty(B * N, d, device=inp.device, dtype=torch.float32)
+        k = torch.empty(B * N, d, device=inp.device, dtype=torch.float32)
+        for wt, dst in zip(self._qk_w, (q, k)):
+            ops.conv2d([x], B, h, w, 1, 1, wt, None, d, 0, False, 1.0, dst, None, None, None, None)
+        attn = torch.empty(B, N, N, device=inp.device, dtype=torch.float32)
+        ops.corr_volume(q.view(B, N, d), k.view(B, N, d), float(att.scale), attn)
+        ops.softmax_rows(attn)
+        return attn.view(B, 1, N, N)

@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Time the correlation path's kernels on the north-star shape (55x128 grid, D=256, L=4, r=4; GPU box): K1 fp32 (tile walk:
+row-major vs 16x16 supertiles), K1 bf16, K2, K3 on fp32 / bf16 pyramids, lookup backward, volume backward."""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ptlflow_amd
+ptlflow_amd.load_native()
+ops = torch.ops.pfk
+dev = torch.device("cuda")
+torch.manual_seed(0)
+
+
+def timeit(fn, n=20, warm=3):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return 1e3 * e0.elapsed_time(e1) / n   # us
+
+
+h, w, D, L, r = 55, 128, 256, 4, 4
+N = h * w
+for B in (1, 8):
+    f1 = torch.randn(B, N, D, device=dev); f2 = torch.randn(B, N, D, device=dev)
+    vol = torch.empty(B, N, N, device=dev)
+    flop = 2.0 * B * N * N * D
+    us = timeit(lambda: ops.corr_volume(f1, f2, 1 / 16.0, vol))
+    print(f"K1 fp32 B={B}: {us:.1f} us  {flop/us/1e6:.1f} TFLOP/s ({100*flop/us/1e6/157.3:.1f}% of 157.3)  write {4*B*N*N/us/1e6:.2f} TB/s")
+    ref = vol.clone()
+    f2b = f2.to(torch.bfloat16)
+    volb = torch.empty(B, N, N, device=dev, dtype=torch.bfloat16)
+    us = timeit(lambda: ops.corr_volume_bf16(f1, f2b, 1 / 16.0, volb))
+    err = (volb.float() - ref).abs().max().item()
+    print(f"K1 bf16 B={B}: {us:.1f} us  write {2*B*N*N/us/1e6:.2f} TB/s ({100*2*B*N*N/us/1e6/8:.1f}% of 8 TB/s)  {flop/us/1e6:.0f} TFLOP/s  max|bf16-fp32| {err:.3e}")
+    for dt, name in ((torch.float32, "fp32"), (torch.bfloat16, "bf16")):
+        lv, hh, ww = [], h, w
+        for l in range(L):
+            lv.append(torch.empty(B * N, hh, ww, device=dev, dtype=dt)); hh //= 2; ww //= 2
+        lv[0].copy_((ref if dt == torch.float32 else volb).view(B * N, h, w))
+        def pools():
+            for l in range(1, L):
+                ops.corr_pool2x2(lv[l - 1], lv[l])
+        us = timeit(pools)
+        el = 4 if dt == torch.float32 else 2
+        byt = sum(v.numel() for v in lv[:-1]) * el + sum(v.numel() for v in lv[1:]) * el
+        print(f"K2 {name} B={B}: {us:.1f} us  {byt/us/1e6:.2f} TB/s")
+        ys, xs = torch.meshgrid(torch.arange(h, device=dev, dtype=torch.float32), torch.arange(w, device=dev, dtype=torch.float32), indexing="ij")
+        coords = (torch.stack([xs, ys], 0)[None] + torch.randn(B, 2, h, w, device=dev) * 6).contiguous()
+        out = torch.empty(B * N, 324, device=dev)
+        us = timeit(lambda: ops.corr_lookup(lv, coords, r, out), n=50)
+        alg = B * (N * L * (100 * el + 81 * 4) + 8 * N)
+        print(f"K3 {name} B={B}: {us:.1f} us  algorithmic {alg/1e6:.1f} MB -> {alg/us/1e6:.2f} TB/s ({100*alg/us/1e6/8:.1f}% of 8 TB/s)")
+    # backward pieces (training shapes are smaller; here the same shape for comparability)
+    if B == 1:
+        sizes = [(int(v.shape[1]), int(v.shape[2])) for v in lv]
+        bufs = [torch.zeros(B * N, (a * b + 3) // 4 * 4, device=dev) for a, b in sizes]
+        g = torch.randn(B * N, 324, device=dev)
+        us = timeit(lambda: ops.corr_lookup_bwd(bufs, [s[0] for s in sizes], [s[1] for s in sizes], coords, r, g), n=50)
+        print(f"K3 backward B={B}: {us:.1f} us")

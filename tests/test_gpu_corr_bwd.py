@@ -57,7 +57,7 @@ def test_lookup_backward_kernel(gpu, B, h, w, L, r):
         assert bool((buf[:, a * b:] == 0).all())          # the pad columns stay zero (they are GEMM operands)
 
 
-@pytest.mark.parametrize("mode,B,D,h,w,L,r", [("avgpool", 2, 64, 12, 18, 4, 4), ("avgpool", 1, 256, 23, 31, 4, 4),
+@pytest.mark.parametrize("mode,B,D,h,w,L,r", [("avgpool", 2, 64, 16, 24, 4, 4), ("avgpool", 1, 256, 23, 31, 4, 4),
                                               ("bilinear_f2", 1, 64, 16, 24, 4, 4), ("avgpool", 1, 32, 13, 11, 2, 3)])
 def test_corr_block_autograd(gpu, mode, B, D, h, w, L, r):
     """`CorrBlock` under autograd: three lookups at different coordinates, gradients of fmap1 / fmap2 vs float64 autograd

@@ -91,10 +91,10 @@ def test_instance_norm(gpu, B, H, W, C):
     close(unpm(xp, B, H, W), ref2, rtol=1e-5, atol=1e-5)
 
 
-def _encoder_params(kind, out_dim, seed):
+def _encoder_params(kind, out_dim, seed, small=False):
     from ptlflow_amd.raft import Encoder
     from ptlflow_amd.synth import synth_state_dict
-    enc = Encoder(out_dim, kind, False)
+    enc = Encoder(out_dim, kind, small)
     own = enc.state_dict()
     shapes = {"fnet." + k: tuple(v.shape) for k, v in own.items()}      # "fnet." prefix: the encoder init statistics
     return {k[len("fnet."):]: v for k, v in synth_state_dict(shapes, seed).items()}
@@ -114,6 +114,20 @@ def test_basic_encoder(gpu, kind, B, H, W, precision, tol):
     assert tuple(out.shape) == tuple(ref.shape)
     scale = float(ref.abs().max())
     close(out, ref, rtol=tol, atol=tol * scale)
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 2e-4), ("bf16x6", 2e-4)])
+@pytest.mark.parametrize("kind,out_dim,B,H,W", [("instance", 128, 2, 64, 96), ("none", 160, 1, 72, 136), ("batch", 128, 1, 136, 72)])
+def test_small_encoder(gpu, kind, out_dim, B, H, W, precision, tol):
+    """Whole SmallEncoder of raft_small (extractor.py:197-267: bottleneck blocks 1x1 -> 3x3(stride) -> 1x1 at widths 8 / 16 / 24,
+    instance norm for fnet, no norm for cnet) vs the oracle."""
+    from ptlflow_amd.encoder import EncoderEngine
+    P = _encoder_params(kind, out_dim, seed=12, small=True)
+    x = (O.smooth_pair(B, H, W, seed=5)[:, 0] - 0.5) * 2.0
+    ref = O.encoder(P, x, kind, small=True)
+    out = EncoderEngine(P, kind, gpu, precision, small=True)(x.cuda())
+    assert tuple(out.shape) == tuple(ref.shape)
+    close(out, ref, rtol=tol, atol=tol * float(ref.abs().max()))
 
 
 def test_encoder_batch_chunking(gpu):

@@ -20,12 +20,25 @@ def _run(gpu, small, B, H, W, iters, tol):
     gt = torch.randn(B, 2, H, W, generator=g) * 4
     valid = (torch.rand(B, 1, H, W, generator=g) > 0.1).float()
     gt[0, :, :8, :8] = 500.0                       # beyond max_flow: excluded by the loss
-    # float64 oracle
+    # float64 oracle (and the same graph in float32 on the CPU: how much of a gradient's error is fp32 conditioning —
+    # instance-norm'd encoder weights have scale-invariant, heavily cancelling gradients — rather than the kernels)
     names = [n for n, _ in model.named_parameters()]
-    P = {k: (v.double().requires_grad_(True) if k in names else (v.double() if v.is_floating_point() else v)) for k, v in sd.items()}
-    preds = O.raft_forward_train(P, x.double(), iters=iters, small=small)
-    loss_ref = O.sequence_loss(preds, gt.double(), valid.double())
-    grads = dict(zip(names, torch.autograd.grad(loss_ref, [P[n] for n in names], allow_unused=True)))
+    # the reference registers a strided block's norm under two names (`norm3` / `norm4` and `downsample.1`, extractor.py:40-49);
+    # the oracle reads `downsample.1`, torch's named_parameters() reports the first name
+    dup = ".norm4." if small else ".norm3."     # BottleneckBlock has a real norm3; its downsample norm is norm4
+    alias = {n: n.replace(dup, ".downsample.1.") for n in names}
+    alias = {n: (a if a in sd else n) for n, a in alias.items()}
+
+    def oracle_grads(dtype):
+        leaves = {a: sd[a].to(dtype).requires_grad_(True) for a in set(alias.values())}
+        P = {k: leaves.get(k, v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}
+        preds = O.raft_forward_train(P, x.to(dtype), iters=iters, small=small)
+        loss = O.sequence_loss(preds, gt.to(dtype), valid.to(dtype))
+        keys = sorted(leaves)
+        return loss, dict(zip(keys, torch.autograd.grad(loss, [leaves[k] for k in keys], allow_unused=True)))
+
+    loss_ref, g64 = oracle_grads(torch.float64)
+    _, g32 = oracle_grads(torch.float32)
     # libpfk
     model = model.to(gpu).train()
     out = model({"images": x.to(gpu)})
@@ -33,10 +46,10 @@ def _run(gpu, small, B, H, W, iters, tol):
     loss = sequence_loss(out["flow_preds"], gt.to(gpu), valid.to(gpu))
     loss.backward()
     assert abs(loss.item() - loss_ref.item()) <= 1e-4 * abs(loss_ref.item())
-    scale_all = max(float(v.abs().max()) for v in grads.values() if v is not None)
-    worst = []
+    scale_all = max(float(v.abs().max()) for v in g64.values() if v is not None)
+    rows = []
     for n, p in model.named_parameters():
-        ref = grads[n]
+        ref = g64[alias[n]]
         if ref is None:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
             continue
@@ -44,10 +57,15 @@ def _run(gpu, small, B, H, W, iters, tol):
         # scale: the tensor's own, floored for tensors whose true gradient is (numerically) zero, e.g. a conv bias in front
         # of an instance / batch norm
         scale = max(float(ref.abs().max()), 1e-4 * scale_all)
-        err = float((p.grad.double().cpu() - ref).abs().max())
-        worst.append((err / scale, n))
-    worst.sort(reverse=True)
-    assert worst[0][0] <= tol, "gradient mismatch (err/scale, name): " + ", ".join(f"{e:.2e} {n}" for e, n in worst[:6])
+        err = float((p.grad.double().cpu() - ref).abs().max()) / scale
+        err_cpu32 = float((g32[alias[n]].double() - ref).abs().max()) / scale
+        rows.append((err / max(tol, 3.0 * err_cpu32), err, err_cpu32, n))
+    rows.sort(reverse=True)
+    print("worst gradients (err/allowed, err/scale, fp32-CPU-autograd err/scale, name):")
+    for r in rows[:8]:
+        print("   %.2f  %.2e  %.2e  %s" % r)
+    # gate: 5e-4 of the tensor's scale, or 3x what fp32 autograd of the reference's own ops loses on that tensor
+    assert rows[0][0] <= 1.0, "gradient mismatch: " + ", ".join(f"{r[1]:.2e} (cpu32 {r[2]:.2e}) {r[3]}" for r in rows[:6])
 
 
 def test_train_step_raft(gpu):

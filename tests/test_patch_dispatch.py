@@ -43,8 +43,8 @@ def test_own_families_are_wrapped(fam, cls, kw):
     try:
         assert isinstance(model.update_block, PfkUpdateBlock)
         assert model.update_block.spec.corr_channels == model.corr_levels * (2 * model.corr_radius + 1) ** 2
-        basic = cls != "RAFTSmall"     # raft_small's bottleneck SmallEncoder is not the BasicEncoder the kernels implement
-        assert isinstance(model.fnet, PfkEncoder) == basic and isinstance(model.cnet, PfkEncoder) == basic
+        assert isinstance(model.fnet, PfkEncoder) and isinstance(model.cnet, PfkEncoder)
+        assert model.fnet.small == (cls == "RAFTSmall")      # raft_small: the bottleneck SmallEncoder path of EncoderEngine
         assert mod.get_corr_block is not orig and mod.get_corr_block.pyramid == "avgpool"
         assert set(model.state_dict()) == keys
     finally:
@@ -116,7 +116,9 @@ def test_shape_mismatch_is_not_wrapped():
     assert patch.match_encoder(ext.BasicEncoder(output_dim=256, norm_fn="batch"))
     assert not patch.match_encoder(ext.BasicEncoder(output_dim=256, norm_fn="group"))       # GroupNorm: no kernel
     assert not patch.match_encoder(ext.BasicEncoder(output_dim=256, norm_fn="batch", dropout=0.5))
-    assert not patch.match_encoder(ext.SmallEncoder(output_dim=128, norm_fn="instance"))
+    assert patch.match_encoder(ext.SmallEncoder(output_dim=128, norm_fn="instance"))
+    assert patch.match_encoder(ext.SmallEncoder(output_dim=160, norm_fn="none"))
+    assert not patch.match_encoder(ext.SmallEncoder(output_dim=128, norm_fn="group"))
 
 
 def test_hook_envelope():
