@@ -156,19 +156,28 @@ def train_leg(dev, batch=10, H=368, W=496, iters=12, steps=4, warmup=2):
 
     sec = timed(step, warmup, steps)
 
-    # share of the step still spent in the torch / MIOpen encoders (forward + backward of fnet on both frames and cnet)
+    # share of the step spent in the two encoders (forward + backward of fnet on both frames and cnet), on the path the model
+    # really uses: libpfk autograd nodes (ptlflow_amd/train_encoder.py) — or torch / MIOpen with native_encoders=False
+    from ptlflow_amd.train_encoder import encoder_train
+
     def enc_only():
         x, _ = model.preprocess(inputs["images"])
-        f1, f2 = model.fnet([x[:, 0].contiguous(), x[:, 1].contiguous()])
-        c = model.cnet(x[:, 0].contiguous())
-        (f1.square().mean() + f2.square().mean() + c.square().mean()).backward()
+        i1, i2 = x[:, 0].contiguous(), x[:, 1].contiguous()
+        if model.native_encoders:
+            f, c = encoder_train(model.fnet, torch.cat([i1, i2], 0)), encoder_train(model.cnet, i1)
+            (f.square().mean() + c.square().mean()).backward()
+        else:
+            f1, f2 = model.fnet([i1, i2])
+            c = model.cnet(i1)
+            (f1.square().mean() + f2.square().mean() + c.square().mean()).backward()
         opt.zero_grad(set_to_none=True)
 
     enc = timed(enc_only, 1, 3)
     return {"value": batch / sec, "unit": "samples/s", "ms_per_step": 1e3 * sec, "loss": float(last["loss"]),
             "encoders_fwd_bwd_ms": 1e3 * enc, "encoder_share": enc / sec,
+            "encoders_on": "libpfk" if model.native_encoders else "torch/MIOpen",
             "config": f"raft train step, batch {batch}, {H}x{W}, {iters} iterations, fp32, sequence loss + backward + clip 1.0 + AdamW; "
-                      "correlation / lookup / update block / upsampling forward+backward on libpfk, encoders on torch autograd"}
+                      "encoders, correlation / lookup, update block and upsampling forward+backward on libpfk autograd nodes"}
 
 
 def main():
@@ -212,23 +221,16 @@ def main():
     images_cpu = smooth_pair(args.batch, args.height, args.width, seed=1234 + rank)
     inputs = {"images": images_cpu.to(dev)}
 
-    for _ in range(args.warmup):
-        out = model(inputs)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = model(inputs)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # warm-up, barrier + device sync, EXACTLY `steps` timed steps, barrier + sync, max over ranks: ptlflow_amd/shard.py
+    # (the same function the world_size-2 gloo test drives on CPU)
+    from ptlflow_amd.shard import timed_steps
+    state = {}
+
+    def one_step():
+        state["out"] = model(inputs)
+
+    elapsed = timed_steps(one_step, args.steps, args.warmup, torch.cuda.synchronize)
+    out = state["out"]
 
     pairs = args.batch * args.steps * world
     result = {

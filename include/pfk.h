@@ -328,6 +328,23 @@ int pfk_norm_apply_f32(const float* x, int x_ld, const float* mean, const float*
  * `sim.softmax(dim=-1)`, once per forward; the similarity itself is pfk_corr_volume_f32 of the q / k maps). */
 int pfk_softmax_rows_f32(float* x, long long rows, int cols, long long ld, pfk_stream_t stream);
 
+/* ---- encoder backward (training, BASELINE config 5) ---------------------------------------------------------------
+ * Backward of y = relu?((x - mean) * rstd) with per-(image, channel) statistics (pfk_instnorm_stats_f32): instance norm,
+ * and batch norm in training mode when called with B = 1 and HW = all pixels of the batch (torch.autograd of
+ * nn.InstanceNorm2d / nn.BatchNorm2d + relu in raft/extractor.py:51-59, 172-181):
+ *   g = dy * (y > 0);  sum_g[b*C+c] = sum_p g;  sum_gxhat[b*C+c] = sum_p g * x_hat;  dx = rstd * (g - sum_g/HW - x_hat * sum_gxhat/HW)
+ * sum_g / sum_gxhat may be NULL (kept in the workspace); for an affine batch norm they are d(beta) / d(gamma) when dy is the
+ * gradient w.r.t. the un-affine'd output.  workspace: pfk_norm_bwd_workspace_bytes(B, C).  Deterministic. */
+long long pfk_norm_bwd_workspace_bytes(int B, int C);
+int pfk_norm_bwd_f32(const float* x, int x_ld, const float* dy, int dy_ld, const float* mean, const float* rstd, float* dx,
+                     int dx_ld, float* sum_g, float* sum_gxhat, int B, int HW, int C, int relu, void* workspace,
+                     long long workspace_bytes, pfk_stream_t stream);
+/* Weight / bias gradient of the stem (pfk_conv_stem_f32): dy pixel-major [B*Ho*Wo][dy_ld] -> dw [49][3][cout] (the packed
+ * layout of the forward's weight), db [cout] (may be NULL).  cout <= 64.  workspace: pfk_conv_stem_wgrad_workspace_bytes(). */
+long long pfk_conv_stem_wgrad_workspace_bytes(void);
+int pfk_conv_stem_wgrad_f32(const float* img, const float* dy, int dy_ld, float* dw, float* db, int B, int H, int W, int cout,
+                            void* workspace, long long workspace_bytes, pfk_stream_t stream);
+
 /* NCHW [B][C][H][W] -> pixel-major [B*H*W][ld] (+ channel offset) and back. */
 int pfk_nchw_to_pm_f32(const float* in, float* out, int out_ld, int out_coff, int B, int C,
                        int H, int W, pfk_stream_t stream);

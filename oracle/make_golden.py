@@ -175,6 +175,40 @@ def golden_warm_start():
     torch.save(out, os.path.join(OUT, "warm_start.pt"))
 
 
+def golden_sea_raft_model():
+    """The correlation path of the REAL SEA-RAFT model in one forward (sea_raft/sea_raft.py:209-224): the two 1/8-resolution
+    feature maps its `get_corr_block` call receives (D = 256, ResNet-FPN features of a seeded random-init model on a smooth
+    frame pair) and, per refinement iteration, the coordinates handed to `corr_fn` and what it returned.  The weights are not
+    needed to replay this: the fixture is self-contained."""
+    mod = ref_loader.ref_module("ptlflow.models.sea_raft.sea_raft")
+    torch.manual_seed(1234)
+    model = mod.SEARAFT(block_dims=[64, 128, 256], iters=4).eval()
+    rec = {"calls": []}
+    orig = mod.get_corr_block
+
+    def spy(fmap1, fmap2, radius, num_levels, alternate_corr=False):
+        cb = orig(fmap1=fmap1, fmap2=fmap2, radius=radius, num_levels=num_levels, alternate_corr=alternate_corr)
+        rec.update(fmap1=fmap1.detach().clone(), fmap2=fmap2.detach().clone(), radius=radius, levels=num_levels,
+                   pyramid_shapes=[tuple(p.shape) for p in cb.corr_pyramid])
+
+        def call(coords):
+            out = cb(coords)
+            rec["calls"].append({"coords": coords.detach().clone(), "out": out.detach().clone()})
+            return out
+
+        return call
+
+    mod.get_corr_block = spy
+    try:
+        x = O.smooth_pair(1, 128, 192, seed=47)
+        with torch.no_grad():
+            model({"images": x})
+    finally:
+        mod.get_corr_block = orig
+    assert len(rec["calls"]) == 4 and rec["fmap1"].shape == (1, 256, 16, 24)
+    torch.save(rec, os.path.join(OUT, "sea_raft_model.pt"))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(4)
@@ -183,6 +217,7 @@ def main():
     golden_forward()
     golden_gma()
     golden_warm_start()
+    golden_sea_raft_model()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
 

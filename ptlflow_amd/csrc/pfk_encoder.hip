@@ -162,6 +162,176 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict
   *reinterpret_cast<f32x4*>(out + p * out_ld + c4) = v;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Backward of  y = relu?((x - mean) * rstd)  with per-(image, channel) statistics over HW pixels (instance norm; batch norm
+// in training mode is the same thing with the whole batch as ONE "image", B = 1, HW = all pixels):
+//     g   = dy * (y > 0)                      (relu mask, from x_hat = (x - mean) * rstd)
+//     s1  = sum_p g,   s2 = sum_p g * x_hat   (per (image, channel); also d(beta), d(gamma) of an affine batch norm)
+//     dx  = rstd * (g - s1 / HW - x_hat * s2 / HW)
+// Partial sums per (image, chunk) reduced in a fixed order (deterministic), then one elementwise pass.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void norm_bwd_partial_kernel(const float* __restrict__ x, int x_ld, const float* __restrict__ dy,
+                                                               int dy_ld, const float* __restrict__ mean,
+                                                               const float* __restrict__ rstd, int C, int HW, int relu,
+                                                               float* __restrict__ part1, float* __restrict__ part2) {
+  __shared__ f32x4 red1[256], red2[256];
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int tpr = C >> 2, rpi = 256 / tpr;
+  const int t = threadIdx.x;
+  const int c4 = (t % tpr) * 4, rr = t / tpr;
+  const bool active = rr < rpi;
+  const int rows = (HW + IN_CHUNKS - 1) / IN_CHUNKS;
+  const int r0 = chunk * rows, r1 = min(HW, r0 + rows);
+  f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f};
+  if (active) {
+    const f32x4 m = *reinterpret_cast<const f32x4*>(mean + (long long)b * C + c4);
+    const f32x4 rs = *reinterpret_cast<const f32x4*>(rstd + (long long)b * C + c4);
+    const float* xb = x + (long long)b * HW * x_ld + c4;
+    const float* gb = dy + (long long)b * HW * dy_ld + c4;
+    for (int r = r0 + rr; r < r1; r += rpi) {
+      const f32x4 xh = (*reinterpret_cast<const f32x4*>(xb + (long long)r * x_ld) - m) * rs;
+      f32x4 g = *reinterpret_cast<const f32x4*>(gb + (long long)r * dy_ld);
+      if (relu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] = xh[e] > 0.f ? g[e] : 0.f;
+      }
+      a1 += g;
+      a2 += g * xh;
+    }
+  }
+  red1[t] = a1; red2[t] = a2;
+  __syncthreads();
+  if (t < tpr) {
+    f32x4 s1 = red1[t], s2 = red2[t];
+    for (int k = 1; k < rpi; ++k) { s1 += red1[t + k * tpr]; s2 += red2[t + k * tpr]; }
+    *reinterpret_cast<f32x4*>(part1 + ((long long)b * IN_CHUNKS + chunk) * C + c4) = s1;
+    *reinterpret_cast<f32x4*>(part2 + ((long long)b * IN_CHUNKS + chunk) * C + c4) = s2;
+  }
+}
+
+__global__ void norm_bwd_finalize_kernel(const float* __restrict__ part1, const float* __restrict__ part2, int C,
+                                         float* __restrict__ s1, float* __restrict__ s2, int total) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;   // b*C + c
+  if (i >= total) return;
+  const int b = i / C, c = i - b * C;
+  float a = 0.f, q = 0.f;
+  for (int k = 0; k < IN_CHUNKS; ++k) {
+    a += part1[((long long)b * IN_CHUNKS + k) * C + c];
+    q += part2[((long long)b * IN_CHUNKS + k) * C + c];
+  }
+  s1[i] = a; s2[i] = q;
+}
+
+__global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __restrict__ x, int x_ld, const float* __restrict__ dy,
+                                                             int dy_ld, const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd, const float* __restrict__ s1,
+                                                             const float* __restrict__ s2, float* __restrict__ dx, int dx_ld,
+                                                             long long M, int HW, int C, int relu) {
+  const int tpr = C >> 2;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long p = idx / tpr;
+  if (p >= M) return;
+  const int c4 = (int)(idx - p * tpr) * 4;
+  const long long sidx = (p / HW) * C + c4;
+  const f32x4 m = *reinterpret_cast<const f32x4*>(mean + sidx), rs = *reinterpret_cast<const f32x4*>(rstd + sidx);
+  const f32x4 a = *reinterpret_cast<const f32x4*>(s1 + sidx), q = *reinterpret_cast<const f32x4*>(s2 + sidx);
+  const f32x4 xh = (*reinterpret_cast<const f32x4*>(x + p * x_ld + c4) - m) * rs;
+  f32x4 g = *reinterpret_cast<const f32x4*>(dy + p * dy_ld + c4);
+  if (relu) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) g[e] = xh[e] > 0.f ? g[e] : 0.f;
+  }
+  const float inv = 1.0f / (float)HW;
+  *reinterpret_cast<f32x4*>(dx + p * dx_ld + c4) = rs * (g - a * inv - xh * (q * inv));
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Weight (and bias) gradient of the stem: dW[ky][kx][ci][c] = sum_p dY[p][c] * img[ci][2yo + ky - 3][2xo + kx - 3].
+// Same tiling as the forward kernel (32 consecutive output pixels of one output row per tile, thread = channel x 8 pixels,
+// the 3 x 7 x 69 input patch staged in LDS), but PERSISTENT: a block walks tiles bid, bid + G, ... and keeps its 147 (+1 bias)
+// accumulators per thread in registers; at the end the four pixel-group waves are summed through LDS and the block's
+// partial goes to part[block][148][64]; a second kernel adds the partials in block order (deterministic).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int STEM_NW = 3 * STEM_K * STEM_K;   // 147
+
+__global__ __launch_bounds__(256) void conv_stem_wgrad_kernel(const float* __restrict__ img, const float* __restrict__ dy,
+                                                              int dy_ld, float* __restrict__ part, int H, int W, int Ho, int Wo,
+                                                              int tiles_per_row, long long tiles, int cout) {
+  __shared__ float sp[3][STEM_K][STEM_PW + 3];
+  __shared__ float sred[4][64];
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const bool cok = lane < cout;
+  float acc[STEM_NW + 1];
+#pragma unroll
+  for (int i = 0; i <= STEM_NW; ++i) acc[i] = 0.f;
+  for (long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int orow = (int)(tile / tiles_per_row);
+    const int xo0 = (int)(tile - (long long)orow * tiles_per_row) * STEM_TP;
+    const int yo = orow % Ho, b = orow / Ho;
+    const int iy0 = 2 * yo - STEM_R, ix0 = 2 * xo0 - STEM_R;
+    const float* src = img + (long long)b * 3 * H * W;
+    __syncthreads();   // the previous tile's patch is no longer read
+    for (int e = threadIdx.x; e < 3 * STEM_K * STEM_PW; e += 256) {
+      const int ci = e / (STEM_K * STEM_PW);
+      const int r = e - ci * (STEM_K * STEM_PW);
+      const int ky = r / STEM_PW, xx = r - ky * STEM_PW;
+      const int gy = iy0 + ky, gx = ix0 + xx;
+      float v = 0.f;
+      if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) v = src[((long long)ci * H + gy) * W + gx];
+      sp[ci][ky][xx] = v;
+    }
+    float d[STEM_NP];
+#pragma unroll
+    for (int p = 0; p < STEM_NP; ++p) {
+      const int xo = xo0 + g * STEM_NP + p;
+      d[p] = (cok && xo < Wo) ? dy[((long long)orow * Wo + xo) * dy_ld + lane] : 0.f;
+      acc[STEM_NW] += d[p];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ky = 0; ky < STEM_K; ++ky)
+#pragma unroll
+      for (int ci = 0; ci < 3; ++ci) {
+        float v[2 * STEM_NP + STEM_K - 2];
+#pragma unroll
+        for (int j = 0; j < 2 * STEM_NP + STEM_K - 2; ++j) v[j] = sp[ci][ky][2 * STEM_NP * g + j];
+#pragma unroll
+        for (int kx = 0; kx < STEM_K; ++kx) {
+          float t = acc[(ky * STEM_K + kx) * 3 + ci];
+#pragma unroll
+          for (int p = 0; p < STEM_NP; ++p) t = fmaf(d[p], v[2 * p + kx], t);
+          acc[(ky * STEM_K + kx) * 3 + ci] = t;
+        }
+      }
+  }
+  // sum the four pixel-group waves (fixed order) and write this block's partial: part[block][148][64]
+  float* mine = part + (long long)blockIdx.x * (STEM_NW + 1) * 64;
+#pragma unroll 1
+  for (int i = 0; i <= STEM_NW; ++i) {
+    float v = 0.f;
+    // acc[i] with a run-time i would spill the array: select it with a compile-time unrolled scan instead
+#pragma unroll
+    for (int k = 0; k <= STEM_NW; ++k) v = (k == i) ? acc[k] : v;
+    __syncthreads();
+    sred[g][lane] = v;
+    __syncthreads();
+    if (g == 0) mine[i * 64 + lane] = (sred[0][lane] + sred[1][lane]) + (sred[2][lane] + sred[3][lane]);
+  }
+}
+
+__global__ __launch_bounds__(256) void conv_stem_wgrad_reduce_kernel(const float* __restrict__ part, int nblocks, int cout,
+                                                                     float* __restrict__ dw, float* __restrict__ db) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;   // (k, c) over 148 x 64
+  if (i >= (STEM_NW + 1) * 64) return;
+  const int k = i >> 6, c = i & 63;
+  if (c >= cout) return;
+  float s = 0.f;
+  for (int b = 0; b < nblocks; ++b) s += part[(long long)b * (STEM_NW + 1) * 64 + i];
+  if (k < STEM_NW) dw[k * cout + c] = s;
+  else if (db != nullptr) db[c] = s;
+}
+
 }  // namespace
 
 extern "C" {
@@ -196,6 +366,56 @@ int pfk_instnorm_stats_f32(const float* x, int ld, int B, int HW, int C, float e
   const int total = B * C;
   hipLaunchKernelGGL(instnorm_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, st, sums, sq, C, HW, eps, mean,
                      rstd, total);
+  return pfk_launch_status();
+}
+
+
+long long pfk_norm_bwd_workspace_bytes(int B, int C) { return ((long long)B * IN_CHUNKS * C * 2 + (long long)B * C * 2) * (long long)sizeof(float); }
+
+int pfk_norm_bwd_f32(const float* x, int x_ld, const float* dy, int dy_ld, const float* mean, const float* rstd, float* dx,
+                     int dx_ld, float* sum_g, float* sum_gxhat, int B, int HW, int C, int relu, void* workspace,
+                     long long workspace_bytes, pfk_stream_t stream) {
+  if (!x || !dy || !mean || !rstd || !dx || !workspace || B <= 0 || HW <= 0 || C <= 0) return PFK_ERR_BAD_ARG;
+  if (x_ld < C || dy_ld < C || dx_ld < C) return PFK_ERR_BAD_ARG;
+  if ((C & 3) || (x_ld & 3) || (dy_ld & 3) || (dx_ld & 3) || C > 1024 || !pfk_aligned16(x) || !pfk_aligned16(dy) ||
+      !pfk_aligned16(dx) || !pfk_aligned16(mean) || !pfk_aligned16(rstd) || !pfk_aligned16(workspace))
+    return PFK_ERR_ALIGNMENT;
+  if (workspace_bytes < pfk_norm_bwd_workspace_bytes(B, C)) return PFK_ERR_BAD_ARG;
+  float* p1 = static_cast<float*>(workspace);
+  float* p2 = p1 + (size_t)B * IN_CHUNKS * C;
+  float* s1 = sum_g ? sum_g : p2 + (size_t)B * IN_CHUNKS * C;
+  float* s2 = sum_gxhat ? sum_gxhat : p2 + (size_t)B * IN_CHUNKS * C + (size_t)B * C;
+  if (!pfk_aligned16(s1) || !pfk_aligned16(s2)) return PFK_ERR_ALIGNMENT;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(norm_bwd_partial_kernel, dim3(IN_CHUNKS, (unsigned)B), dim3(256), 0, st, x, x_ld, dy, dy_ld, mean, rstd, C, HW,
+                     relu, p1, p2);
+  const int total = B * C;
+  hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, st, p1, p2, C, s1, s2, total);
+  const long long M = (long long)B * HW;
+  const long long blocks = (M * (C >> 2) + 255) / 256;
+  if (blocks > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, x_ld, dy, dy_ld, mean, rstd, s1, s2, dx,
+                     dx_ld, M, HW, C, relu);
+  return pfk_launch_status();
+}
+
+constexpr int STEM_WG_BLOCKS = 512;
+long long pfk_conv_stem_wgrad_workspace_bytes(void) { return (long long)STEM_WG_BLOCKS * (STEM_NW + 1) * 64 * (long long)sizeof(float); }
+
+int pfk_conv_stem_wgrad_f32(const float* img, const float* dy, int dy_ld, float* dw, float* db, int B, int H, int W, int cout,
+                            void* workspace, long long workspace_bytes, pfk_stream_t stream) {
+  if (!img || !dy || !dw || !workspace || B <= 0 || H <= 0 || W <= 0 || cout <= 0 || dy_ld < cout) return PFK_ERR_BAD_ARG;
+  if (cout > 64) return PFK_ERR_UNSUPPORTED;
+  if (workspace_bytes < pfk_conv_stem_wgrad_workspace_bytes()) return PFK_ERR_BAD_ARG;
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const int tpr = (Wo + STEM_TP - 1) / STEM_TP;
+  const long long tiles = (long long)B * Ho * tpr;
+  const int nblocks = (int)(tiles < STEM_WG_BLOCKS ? tiles : STEM_WG_BLOCKS);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float* part = static_cast<float*>(workspace);
+  hipLaunchKernelGGL(conv_stem_wgrad_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, img, dy, dy_ld, part, H, W, Ho, Wo, tpr,
+                     tiles, cout);
+  hipLaunchKernelGGL(conv_stem_wgrad_reduce_kernel, dim3(((STEM_NW + 1) * 64 + 255) / 256), dim3(256), 0, st, part, nblocks, cout, dw, db);
   return pfk_launch_status();
 }
 

@@ -429,6 +429,38 @@ void norm_apply(const Tensor& x, const Tensor& mean, const Tensor& rstd, const c
                               relu, relu_after_residual, cur_stream()), "norm_apply");
 }
 
+int64_t norm_bwd_workspace_bytes(int64_t B, int64_t C) { return pfk_norm_bwd_workspace_bytes((int)B, (int)C); }
+
+// backward of relu?((x - mean) * rstd): dx, and the two per-(image, channel) sums (d beta / d gamma of an affine batch norm)
+void norm_bwd(const Tensor& x, const Tensor& dy, const Tensor& mean, const Tensor& rstd, Tensor dx, Tensor sum_g, Tensor sum_gxhat,
+              int64_t B, int64_t HW, bool relu) {
+  OpScope scope(x);
+  check_pm(x, "x"); check_pm(dy, "dy"); check_pm(dx, "dx"); check_dev_f32(mean, "mean"); check_dev_f32(rstd, "rstd");
+  check_dev_f32(sum_g, "sum_g"); check_dev_f32(sum_gxhat, "sum_gxhat");
+  const int C = x.size(1);
+  TORCH_CHECK(x.size(0) == B * HW && dy.size(0) == B * HW && dx.size(0) == B * HW && dy.size(1) == C && dx.size(1) == C, "norm_bwd: shapes");
+  TORCH_CHECK(mean.numel() == B * C && rstd.numel() == B * C && sum_g.numel() == B * C && sum_gxhat.numel() == B * C &&
+              mean.is_contiguous() && rstd.is_contiguous() && sum_g.is_contiguous() && sum_gxhat.is_contiguous(), "norm_bwd: [B*C] statistics");
+  const long long need = pfk_norm_bwd_workspace_bytes((int)B, C);
+  Tensor ws = at::empty({(int64_t)need}, x.options().dtype(at::kByte));
+  check_ok(pfk_norm_bwd_f32(fptr(x), x.stride(0), fptr(dy), dy.stride(0), fptr(mean), fptr(rstd), fptr(dx), dx.stride(0), fptr(sum_g),
+                            fptr(sum_gxhat), (int)B, (int)HW, C, relu, ws.data_ptr(), need, cur_stream()), "norm_bwd");
+}
+
+// stem weight / bias gradient: img [B,3,H,W], dy pixel-major [B*Ho*Wo, cout] -> dw [49,3,cout], db [cout]
+void conv_stem_wgrad(const Tensor& img, const Tensor& dy, Tensor dw, Tensor db) {
+  OpScope scope(img);
+  check_dev_f32(img, "img"); check_pm(dy, "dy"); check_dev_f32(dw, "dw"); check_dev_f32(db, "db");
+  TORCH_CHECK(img.dim() == 4 && img.size(1) == 3 && img.is_contiguous(), "conv_stem_wgrad: img [B,3,H,W] contiguous");
+  const int B = img.size(0), H = img.size(2), W = img.size(3), cout = dy.size(1);
+  TORCH_CHECK(dy.size(0) == (int64_t)B * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1), "conv_stem_wgrad: dy rows");
+  TORCH_CHECK(dw.is_contiguous() && dw.numel() == 49 * 3 * cout && db.is_contiguous() && db.numel() == cout, "conv_stem_wgrad: dw [49,3,cout], db [cout]");
+  const long long need = pfk_conv_stem_wgrad_workspace_bytes();
+  Tensor ws = at::empty({(int64_t)need}, img.options().dtype(at::kByte));
+  check_ok(pfk_conv_stem_wgrad_f32(fptr(img), fptr(dy), dy.stride(0), fptr(dw), fptr(db), B, H, W, cout, ws.data_ptr(), need, cur_stream()),
+           "conv_stem_wgrad");
+}
+
 void softmax_rows(Tensor x) {
   OpScope scope(x);
   check_dev_f32(x, "x");
@@ -517,6 +549,8 @@ TORCH_LIBRARY(pfk, m) {
   m.def("conv_wgrad(Tensor[] srcs, Tensor dy, int B, int H, int W, int kh, int kw, Tensor(a!) out, bool with_bias=False) -> ()");
   m.def("forward_interpolate(Tensor flow, Tensor(a!) out) -> ()");
   m.def("softmax_rows(Tensor(a!) x) -> ()");
+  m.def("norm_bwd(Tensor x, Tensor dy, Tensor mean, Tensor rstd, Tensor(a!) dx, Tensor(b!) sum_g, Tensor(c!) sum_gxhat, int B, int HW, bool relu) -> ()");
+  m.def("conv_stem_wgrad(Tensor img, Tensor dy, Tensor(a!) dw, Tensor(b!) db) -> ()");
   m.def("instnorm_workspace_bytes(int B, int C) -> int", &instnorm_workspace_bytes);
   m.def("conv_stem(Tensor img, Tensor weight, Tensor? bias, Tensor(a!) out, bool relu) -> ()");
   m.def("instnorm_stats(Tensor x, int B, int HW, float eps, Tensor(a!) mean, Tensor(b!) rstd, Tensor(c!) workspace) -> ()");
@@ -577,6 +611,8 @@ TORCH_LIBRARY_IMPL(pfk, CUDA, m) {
   m.impl("conv_wgrad", &conv_wgrad);
   m.impl("forward_interpolate", &forward_interpolate);
   m.impl("softmax_rows", &softmax_rows);
+  m.impl("norm_bwd", &norm_bwd);
+  m.impl("conv_stem_wgrad", &conv_stem_wgrad);
   m.impl("instnorm_stats", &instnorm_stats);
   m.impl("norm_apply", &norm_apply);
 }

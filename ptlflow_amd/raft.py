@@ -232,9 +232,11 @@ class RAFT(nn.Module):
         """RAFT.forward in training mode (raft.py:125-193): same loop, every iteration's upsampled flow kept in
         ``flow_preds`` for the sequence loss (raft.py:20-45; `ptlflow_amd.train.sequence_loss`).  The correlation volume,
         pyramid and lookups (forward and backward), the whole update block (forward, dgrad, wgrad) and the convex upsampling
-        (forward and backward) run on libpfk through autograd nodes (ptlflow_amd/corr.py, ptlflow_amd/train.py); the two
-        encoders are the torch modules (BatchNorm of `cnet` in batch-statistics mode, as `model.train()` implies)."""
+        (forward and backward) and both encoders (ptlflow_amd/train_encoder.py; BatchNorm of `cnet` with batch statistics, as
+        `model.train()` implies) run on libpfk through autograd nodes (ptlflow_amd/corr.py, ptlflow_amd/train.py);
+        `native_encoders=False` keeps the encoders on the torch modules."""
         from .train import convex_upsample, update_block_train_pm
+        from .train_encoder import encoder_train
         load_native()
         if self.spec.aggregate:
             raise RuntimeError("training mode of the GMA mirror is not implemented (the aggregate branch has no backward kernels)")
@@ -244,9 +246,14 @@ class RAFT(nn.Module):
         x, pads = self.preprocess(images.float())
         image1, image2 = x[:, 0].contiguous(), x[:, 1].contiguous()
         B = image1.shape[0]
-        fmap1, fmap2 = self.fnet([image1, image2])
+        if self.native_encoders:      # forward, data and weight gradients of both encoders on libpfk (ptlflow_amd/train_encoder.py)
+            fm = encoder_train(self.fnet, torch.cat([image1, image2], 0))
+            fmap1, fmap2 = fm[:B], fm[B:]
+            cnet = encoder_train(self.cnet, image1)
+        else:                         # the torch modules (MIOpen convolutions / norms under torch.autograd)
+            fmap1, fmap2 = self.fnet([image1, image2])
+            cnet = self.cnet(image1)
         corr_fn = CorrBlock(fmap1.float(), fmap2.float(), num_levels=self.corr_levels, radius=self.corr_radius)
-        cnet = self.cnet(image1)
         net, inp = torch.split(cnet, [self.hidden_dim, self.context_dim], dim=1)
         net, inp = torch.tanh(net), torch.relu(inp)
         h, w = image1.shape[-2] // 8, image1.shape[-1] // 8

@@ -59,3 +59,38 @@ def run_sharded(forward: Callable[[torch.Tensor], torch.Tensor], images: torch.T
             dist.broadcast(buf, src=r)
         parts.append(buf)
     return torch.cat(parts, 0)
+
+
+def timed_steps(step: Callable[[], object], steps: int, warmup: int, sync: Callable[[], None] = lambda: None):
+    """bench.py's timing protocol, one place for 1 and N ranks: `warmup` untimed steps, then EXACTLY `steps` timed steps
+    bracketed by (device sync, barrier, device sync) on both sides; the elapsed time is the MAX over ranks (all-reduce),
+    so `units / elapsed` is the whole job's throughput.  `sync` is the device synchronisation (torch.cuda.synchronize on
+    GPUs, a no-op on CPU); any initialised process group works (RCCL on GPUs, gloo on CPU).  Returns seconds."""
+    import time
+    grouped = dist.is_available() and dist.is_initialized()
+    for _ in range(warmup):
+        step()
+    sync()
+    if grouped:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    if grouped:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if grouped:
+        backend = dist.get_backend()
+        dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def job_throughput(units_per_rank_per_step: int, steps: int, elapsed: float) -> float:
+    """Whole-job units/s under weak scaling: every rank processed `units_per_rank_per_step` per step."""
+    world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+    return units_per_rank_per_step * steps * world / elapsed

@@ -61,10 +61,14 @@ def test_bf16_pyramid_and_lookup(gpu):
     pyr = O.correlation_pyramid(f1.bfloat16(), f2.bfloat16(), 4)
     cb = CorrBlock(f1.to(gpu), f2.to(gpu), 4, 4, volume_dtype=torch.bfloat16)
     assert all(p.dtype == torch.bfloat16 for p in cb.corr_pyramid)
-    for a, b in zip(cb.corr_pyramid, pyr):
-        a32, b32 = a.float().cpu().reshape(b.shape), b.float()
-        # fp32-accumulated, once-rounded (GPU) vs bf16 matmul then bf16 division (oracle): at most one bf16 ulp apart
-        assert ((a32 - b32).abs() <= 2.0 ** -7 * b32.abs().clamp_min(2.0 ** -6)).all()
+    import torch.nn.functional as F
+    a32, b32 = cb.corr_pyramid[0].float().cpu().reshape(pyr[0].shape), pyr[0].float()
+    # level 0: fp32-accumulated, once-rounded (GPU) vs bf16 matmul then bf16 division (oracle): at most one bf16 ulp apart
+    assert ((a32 - b32).abs() <= 2.0 ** -7 * b32.abs().clamp_min(2.0 ** -6)).all()
+    assert ((a32 - b32) != 0).float().mean().item() < 1e-2          # ... and that only on rounding ties of the accumulation order
+    # levels 1..: the kernel's pool of ITS OWN previous level is what torch's bf16 avg_pool2d gives (fp32 window sum, one rounding)
+    for prev, cur in zip(cb.corr_pyramid[:-1], cb.corr_pyramid[1:]):
+        assert torch.equal(F.avg_pool2d(prev.cpu().unsqueeze(1), 2, stride=2).squeeze(1), cur.cpu())
     c = O.coords_grid(B, h, w) + torch.rand(B, 2, h, w, generator=g) * 8 - 4
     got = cb(c.to(gpu)).cpu()
     ref = O.lookup([p.float().cpu() for p in cb.corr_pyramid], c, 4)      # same pyramid, oracle lookup

@@ -77,6 +77,38 @@ def test_sea_raft_pyramid_mode(gpu):
     assert (cb(c.cuda()).cpu() - ref).abs().max().item() < 5e-5
 
 
+def test_sea_raft_pyramid_north_star_shape(gpu):
+    """SEA-RAFT's pyramid at the north-star shape (55x128 grid, D = 256): per-level volume against `fmap2` halved by the
+    HIP 2x2 feature-map average (== bilinear x0.5), lookups vs the oracle (sea_raft/corr.py:71-117)."""
+    from ptlflow_amd.corr import CorrBlock
+    g = torch.Generator().manual_seed(14)
+    f1, f2 = torch.randn(1, 256, 55, 128, generator=g), torch.randn(1, 256, 55, 128, generator=g)
+    pyr = O.sea_correlation_pyramid(f1, f2, 4)
+    cb = CorrBlock(f1.cuda(), f2.cuda(), 4, 4, pyramid="bilinear_f2")
+    assert [tuple(p.shape[1:]) for p in cb.corr_pyramid] == [(55, 128), (27, 64), (13, 32), (6, 16)]
+    for a, b in zip(cb.corr_pyramid, pyr):
+        assert (a.cpu().reshape(b.shape) - b).abs().max().item() < 3e-5
+    c = O.coords_grid(1, 55, 128) + torch.rand(1, 2, 55, 128, generator=g) * 10 - 5
+    ref = O.lookup(pyr, c, 4)
+    assert (cb(c.cuda()).cpu() - ref).abs().max().item() < 1e-4
+    # the lookup of the kernel's OWN pyramid is bit-exact
+    assert torch.equal(cb(c.cuda()).cpu(), O.lookup([p.cpu().unsqueeze(1) for p in cb.corr_pyramid], c, 4))
+
+
+def test_sea_raft_model_golden(gpu):
+    """Seam B1 as the real SEA-RAFT model uses it (tests/golden/sea_raft_model.pt: the feature maps of its `get_corr_block`
+    call and every iteration's coords -> lookup, recorded from the live reference): `CorrBlock(pyramid="bilinear_f2")`."""
+    import os
+    from ptlflow_amd.corr import get_corr_block
+    gold = torch.load(os.path.join(os.path.dirname(__file__), "golden", "sea_raft_model.pt"))
+    corr_fn = get_corr_block(gold["fmap1"].cuda(), gold["fmap2"].cuda(), num_levels=gold["levels"], radius=gold["radius"],
+                             pyramid="bilinear_f2")
+    for call in gold["calls"]:
+        got = corr_fn(call["coords"].cuda()).cpu()
+        assert got.shape == call["out"].shape
+        assert (got - call["out"]).abs().max().item() < 2e-4 * max(1.0, call["out"].abs().max().item())
+
+
 @pytest.mark.parametrize("B,H1,W1,H2,W2,C,r", [(1, 16, 24, 16, 24, 256, 4), (2, 11, 13, 5, 6, 128, 3), (1, 9, 10, 9, 10, 36, 4)])
 def test_alt_cuda_corr_abi(gpu, B, H1, W1, H2, W2, C, r):
     """Seam B2: the module importable as `alt_cuda_corr` (correlation.cpp:23-37 contract) vs the oracle."""

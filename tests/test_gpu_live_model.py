@@ -39,7 +39,9 @@ def _run_case(model, gpu, H, W, gate=1e-3):
     for g, r in zip(got, ref):
         mean, mx = O.epe(g[:, 0], r[:, 0])
         assert mean <= gate, f"EPE vs the unpatched CPU forward: mean {mean:.3e} max {mx:.3e}"
-    assert torch.equal(again, got[0])
+    # pair 1 again after pair 2: nothing of pair 2 may survive.  Bit-identical when every op of the forward is ours; GMA's
+    # stand-in attention runs torch's matmul + softmax on the GPU, whose first call may pick another kernel: allow its rounding.
+    assert O.epe(again[:, 0], got[0][:, 0])[1] <= 1e-5
     # the two pairs really differ (otherwise the test could not see a stale-context bug)
     assert O.epe(ref[0][:, 0], ref[1][:, 0])[0] > 0.05
 

@@ -74,3 +74,61 @@ def test_train_step_raft(gpu):
 
 def test_train_step_raft_small(gpu):
     _run(gpu, True, 1, 184, 248, 3, 5e-4)
+
+
+@pytest.mark.parametrize("kind,small,B,H,W", [("instance", False, 2, 96, 136), ("batch", False, 2, 96, 136), ("instance", True, 1, 104, 72),
+                                              ("none", True, 2, 64, 96)])
+def test_encoder_train_gradients(gpu, kind, small, B, H, W):
+    """`encoder_train` (stem, strided / plain convolutions, instance norm or training-mode batch norm, residual blocks — forward,
+    data and weight gradients on libpfk) vs float64 autograd through the oracle's encoder; running statistics updated as
+    nn.BatchNorm2d does."""
+    from ptlflow_amd.raft import Encoder
+    from ptlflow_amd.synth import synth_state_dict
+    from ptlflow_amd.train_encoder import encoder_train
+    out_dim = 128 if small else 256
+    enc = Encoder(out_dim, kind, small)
+    sd = synth_state_dict({"fnet." + k: tuple(v.shape) for k, v in enc.state_dict().items()}, 31)
+    enc.load_state_dict({k[len("fnet."):]: v for k, v in sd.items()})
+    x = (O.smooth_pair(B, H, W, seed=8)[:, 0] - 0.5) * 2.0
+    g = torch.Generator().manual_seed(2)
+    names = [n for n, _ in enc.named_parameters()]
+    dup = ".norm4." if small else ".norm3."
+    alias = {n: (n.replace(dup, ".downsample.1.") if n.replace(dup, ".downsample.1.") in enc.state_dict() else n) for n in names}
+    P64 = {k: (v.double() if v.is_floating_point() else v) for k, v in enc.state_dict().items()}
+    leaves = {a: P64[a].clone().requires_grad_(True) for a in set(alias.values())}
+    P64.update(leaves)
+    O._BN_TRAIN = True
+    try:
+        ref = O.encoder(P64, x.double(), kind, small)
+    finally:
+        O._BN_TRAIN = False
+    go = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    keys = sorted(leaves)
+    gref = dict(zip(keys, torch.autograd.grad((ref * go).sum(), [leaves[k] for k in keys], allow_unused=True)))
+    rm0 = {k: v.clone() for k, v in enc.state_dict().items() if "running_" in k}
+    enc = enc.to(gpu).train()
+    out = encoder_train(enc, x.to(gpu))
+    assert tuple(out.shape) == tuple(ref.shape)
+    scale = float(ref.abs().max())
+    assert float((out.detach().double().cpu() - ref.detach()).abs().max()) <= 2e-4 * scale
+    (out * go.float().to(gpu)).sum().backward()
+    rows = []
+    smax = max(float(v.abs().max()) for v in gref.values() if v is not None)
+    for n, p in enc.named_parameters():
+        r = gref[alias[n]]
+        if r is None:
+            continue
+        s = max(float(r.abs().max()), 1e-4 * smax)
+        rows.append((float((p.grad.double().cpu() - r).abs().max()) / s, n))
+    rows.sort(reverse=True)
+    print("encoder_train worst gradient errors:", ", ".join(f"{e:.1e} {n}" for e, n in rows[:4]))
+    assert rows[0][0] <= 5e-4, rows[:5]
+    if kind == "batch":   # running statistics: momentum 0.1, unbiased variance (nn.BatchNorm2d)
+        tm = Encoder(out_dim, kind, small)
+        tm.load_state_dict({k[len("fnet."):]: v for k, v in sd.items()})
+        tm.train()(x)
+        for k, v in tm.state_dict().items():
+            if "running_" in k:
+                got = enc.state_dict()[k].cpu()
+                assert float((got - v).abs().max()) <= 1e-4 * max(1.0, float(v.abs().max())), k
+                assert not torch.equal(got, rm0[k])
