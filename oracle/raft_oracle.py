@@ -361,6 +361,16 @@ def gma_update_block(P: Params, net, inp, corr, flow, attn):
     return net, mask_head(P, net), flow_head(P, net)
 
 
+def ccmr_update_block(P: Params, net, inp, corr, flow, aggregator, global_context):
+    """CCMR's BasicUpdateBlock.forward (ccmr/update.py:152-168): RAFT's motion encoder, the scale's aggregator module
+    (`aggregator(global_context, motion_features)`, an XCiT block in the reference) -> SepConvGRU over
+    cat([inp, motion_features, aggregated]) -> flow head, 0.25 * mask head."""
+    mf = motion_encoder(P, flow, corr)
+    mfg = aggregator(global_context, mf)
+    net = sepconv_gru(P, net, torch.cat([inp, mf, mfg], dim=1))
+    return net, mask_head(P, net), flow_head(P, net)
+
+
 def sub(P: Params, prefix: str) -> Params:
     """View of a state_dict under ``prefix.`` with the prefix stripped."""
     k = prefix + "."

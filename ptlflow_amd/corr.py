@@ -108,6 +108,9 @@ class CorrBlock:
             raise ValueError(f"unknown pyramid mode {pyramid!r}")
         n = 2 * radius + 1
         self.channels = num_levels * n * n
+        # row stride of the pixel-major lookup buffer: the convolution that consumes it wants a multiple of 4 floats
+        # (L = 2 levels of radius 4 give 162 channels: ccmr / ms_raft_plus); the pad columns stay zero
+        self.cpad = (self.channels + 3) // 4 * 4
         self._out: Optional[torch.Tensor] = None
         self.corr_pyramid: List[torch.Tensor] = []
         self._shape = None
@@ -246,8 +249,7 @@ class CorrBlock:
             return _LookupFn.apply(self._token, coords, self)
         if out is None:
             if self._out is None:
-                self._out = torch.empty(self.B * self.h * self.w, self.channels, device=coords.device,
-                                        dtype=torch.float32)
+                self._out = torch.zeros(self.B * self.h * self.w, self.cpad, device=coords.device, dtype=torch.float32)
             out = self._out
         c = coords
         if c.dtype != torch.float32 or not c.is_contiguous():
@@ -257,9 +259,11 @@ class CorrBlock:
 
     def __call__(self, coords: torch.Tensor) -> torch.Tensor:
         out = self.lookup_pm(coords)
-        res = out.view(self.B, self.h, self.w, self.channels).permute(0, 3, 1, 2)
+        res = out.view(self.B, self.h, self.w, out.shape[1])[..., : self.channels].permute(0, 3, 1, 2)
         if self.out_dtype != torch.float32:
             res = res.to(self.out_dtype)
+        elif out.shape[1] != self.channels:
+            res._pfk_padded_pm = out     # PfkUpdateBlock takes the zero-padded pixel-major buffer behind this view as is
         return res
 
 

@@ -34,7 +34,7 @@ import torch
 
 from . import load_native
 from .corr import get_corr_block as _pfk_get_corr_block
-from .update import PfkUpdateBlock, UpdateSpec, basic_spec, gma_spec, small_spec
+from .update import PfkUpdateBlock, UpdateSpec, basic_spec, ccmr_spec, gma_spec, ms_raft_plus_spec, small_spec
 
 _ORIG = "_pfk_original_get_corr_block"
 
@@ -43,7 +43,13 @@ _UPDATE_BLOCKS: Dict[Tuple[str, str], Callable[[int], UpdateSpec]] = {
     ("ptlflow.models.raft.update", "BasicUpdateBlock"): lambda cc: _with_corr_channels(basic_spec(), cc),
     ("ptlflow.models.raft.update", "SmallUpdateBlock"): lambda cc: _with_corr_channels(small_spec(), cc),
     ("ptlflow.models.gma.update", "GMAUpdateBlock"): lambda cc: _with_corr_channels(gma_spec(), cc),
+    # ccmr/update.py:110-168: RAFT's encoder / SepConvGRU(512) / heads around an XCiT aggregator that stays the reference's module
+    ("ptlflow.models.ccmr.update", "BasicUpdateBlock"): lambda cc: ccmr_spec(cc),
+    # ms_raft_plus/update.py:119-153 (stack_coords=False): RAFT's block with a x2 mask head
+    ("ptlflow.models.ms_raft_plus.update", "BasicUpdateBlock"): lambda cc: ms_raft_plus_spec(cc),
 }
+# parameters of a matched block that belong to a sub-module the wrapper keeps calling as is (not part of the shape check)
+_FOREIGN_PREFIX = {("ptlflow.models.ccmr.update", "BasicUpdateBlock"): "aggregator."}
 # (module, class) of the BasicEncoder implementations that are raft/extractor.py:122-194 verbatim
 _ENCODERS = {
     ("ptlflow.models.raft.extractor", "BasicEncoder"),
@@ -74,11 +80,16 @@ def match_update_block(block: torch.nn.Module) -> Optional[UpdateSpec]:
     factory = _UPDATE_BLOCKS.get((type(block).__module__, type(block).__name__))
     if factory is None:
         return None
-    sd = {k: tuple(v.shape) for k, v in block.state_dict().items()}
+    foreign = _FOREIGN_PREFIX.get((type(block).__module__, type(block).__name__))
+    sd = {k: tuple(v.shape) for k, v in block.state_dict().items() if not (foreign and k.startswith(foreign))}
     w = sd.get("encoder.convc1.weight")
     if w is None or len(w) != 4:
         return None
     spec = factory(int(w[1]))
+    mk = sd.get("mask.2.weight")
+    if mk is not None and spec.has_mask and mk[0] != spec.mask_channels and len(mk) == 4:
+        from dataclasses import replace
+        spec = replace(spec, mask_channels=int(mk[0]))      # 9 * scale^2: the upsampling factor is the model's choice
     want = update_block_shapes(spec)
     # GMA registers its unused relative-position tables nowhere under update_block; any extra or missing key is a mismatch
     return spec if sd == want else None

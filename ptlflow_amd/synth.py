@@ -70,7 +70,7 @@ def update_block_shapes(spec) -> Dict[str, tuple]:
     conv("encoder.convf2", s.f2, s.f1, 3, 3)
     conv("encoder.conv", s.enc_out, (s.c2 if s.c2 else s.c1) + s.f2, 3, 3)
     cin = s.hidden + s.x_channels
-    if getattr(s, "aggregate", False):
+    if getattr(s, "aggregate", False) and not getattr(s, "external_aggregate", False):
         sh["aggregator.to_v.weight"] = (s.motion_channels, s.motion_channels, 1, 1)
         sh["aggregator.gamma"] = (1,)
     for kh, kw, sfx in s.gru_passes:
@@ -80,7 +80,7 @@ def update_block_shapes(spec) -> Dict[str, tuple]:
     conv("flow_head.conv2", 2, s.fh_hidden, 3, 3)
     if s.has_mask:
         conv("mask.0", 256, s.hidden, 3, 3)
-        conv("mask.2", 576, 256, 1, 1)
+        conv("mask.2", getattr(s, "mask_channels", 576), 256, 1, 1)
     return sh
 
 

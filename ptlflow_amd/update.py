@@ -50,6 +50,9 @@ class UpdateSpec:
     fh_hidden: int
     has_mask: bool
     aggregate: bool = False   # GMA: + attention-aggregated motion features (gma/update.py:148-152)
+    mask_channels: int = 576  # mask head's output: 9 * scale^2 (raft / gma: scale 8; ccmr / ms_raft_plus: scale 2 -> 36)
+    external_aggregate: bool = False   # CCMR: the second motion-feature slot is filled by the caller's own module
+                                       # (an XCiT block per scale, ccmr/update.py:135-168), not by GMA's attn @ v
 
     @property
     def motion_channels(self) -> int:     # encoder out | flow
@@ -74,6 +77,19 @@ def gma_spec(corr_levels: int = 4, corr_radius: int = 4) -> UpdateSpec:
     """GMAUpdateBlock (gma/update.py:127-160): BasicUpdateBlock + Aggregate, SepConvGRU input 128+128+128."""
     return UpdateSpec(128, 128, corr_levels * (2 * corr_radius + 1) ** 2, 256, 192, 128, 64, 126,
                       ((1, 5, "1"), (5, 1, "2")), 256, True, True)
+
+
+def ccmr_spec(corr_channels: int, mask_channels: int = 36) -> UpdateSpec:
+    """CCMR's BasicUpdateBlock (ccmr/update.py:110-168): RAFT's motion encoder, SepConvGRU with input 128 + 128 + 128 (inp |
+    motion features | globally aggregated motion features from an XCiT block), FlowHead, mask head for x2 convex upsampling."""
+    return UpdateSpec(128, 128, corr_channels, 256, 192, 128, 64, 126, ((1, 5, "1"), (5, 1, "2")), 256, True, True,
+                      mask_channels, True)
+
+
+def ms_raft_plus_spec(corr_channels: int, mask_channels: int = 36) -> UpdateSpec:
+    """MS-RAFT+'s BasicUpdateBlock with stack_coords=False (ms_raft_plus/update.py:119-153): RAFT's block with a x2 mask head."""
+    return UpdateSpec(128, 128, corr_channels, 256, 192, 128, 64, 126, ((1, 5, "1"), (5, 1, "2")), 256, True, False,
+                      mask_channels)
 
 
 def small_spec(corr_levels: int = 4, corr_radius: int = 3) -> UpdateSpec:
@@ -154,12 +170,12 @@ class UpdateEngine:
         if s.has_mask:
             w["fm.w"] = pk(torch.cat([g("flow_head.conv1.weight"), g("mask.0.weight")], 0), seg1(Ch))
             w["fm.b"] = torch.cat([g("flow_head.conv1.bias"), g("mask.0.bias")]).contiguous()
-            w["mk.w"] = pk(g("mask.2.weight"), seg1(s.fh_hidden))
+            w["mk.w"] = pk(g("mask.2.weight"), seg1(256))
             w["mk.b"] = g("mask.2.bias").contiguous()
         else:
             w["fm.w"] = pk(g("flow_head.conv1.weight"), seg1(Ch))
             w["fm.b"] = g("flow_head.conv1.bias").contiguous()
-        if s.aggregate:
+        if s.aggregate and not s.external_aggregate:
             w["tv.w"] = pk(g("aggregator.to_v.weight"), seg1(s.motion_channels))
             w["tv.b"] = None
             self.gamma = float(P["aggregator.gamma"].detach().float().cpu().item())   # one host read per (re)pack
@@ -182,11 +198,11 @@ class UpdateEngine:
         self.zbuf = z(s.hidden)
         self.rh = z(s.hidden)
         self.fm = z(s.fh_hidden * (2 if s.has_mask else 1))
-        self.mask = z(576) if s.has_mask else None
+        self.mask = z(s.mask_channels) if s.has_mask else None
         self._scratch_c0 = torch.zeros(B, 2, H, W, device=dev, dtype=torch.float32)
         self._scratch_c1 = torch.zeros(B, 2, H, W, device=dev, dtype=torch.float32)
         self._delta = torch.zeros(B, 2, H, W, device=dev, dtype=torch.float32)
-        if s.aggregate:
+        if s.aggregate and not s.external_aggregate:
             N = H * W
             self.vbuf = z(s.motion_channels)
             self.vT = torch.zeros(B, s.motion_channels, round_up(N, 32), device=dev, dtype=torch.float32)
@@ -290,8 +306,8 @@ class UpdateEngine:
             # algorithmic HBM bytes: every input channel read once, every output written once, the weight once (fp32)
             self.bytes[key] = 4.0 * (B * H * W * (self._real_cin[key] + cout) + cout * kh * kw * self._real_cin[key])
 
-    def motion_and_gru(self, corr_pm: torch.Tensor) -> None:
-        """update.py:104-112 (encoder) + :58-73 / :24-32 (GRU); `flow` must already be in hx."""
+    def motion(self, corr_pm: torch.Tensor) -> None:
+        """BasicMotionEncoder / SmallMotionEncoder (update.py:104-112 / :85-91) into its hx slice; `flow` must already be in hx."""
         s = self.spec
         B, H, W = self._shape
         if s.c2:
@@ -305,14 +321,40 @@ class UpdateEngine:
         self._conv([self.flo1], 3, 3, "f2", s.f2, out=self.corflo[:, cor_c: cor_c + s.f2])
         o = s.hidden + s.context
         self._conv([self.corflo], 3, 3, "cv", s.enc_out, out=self.hx[:, o: o + s.enc_out])
-        if s.aggregate:
-            if self.attn is None:
-                raise RuntimeError("GMA update block needs set_attention() before the first iteration")
-            self._aggregate()
+
+    @property
+    def motion_view(self):
+        """encoder out | flow: the reference's `motion_features` (update.py:112), a slice of hx"""
+        s = self.spec
+        o = s.hidden + s.context
+        return self.hx[:, o: o + s.motion_channels]
+
+    @property
+    def aggregate_view(self):
+        """the second motion-feature slot (GMA: fmap + gamma * attn @ v; CCMR: the caller's XCiT output)"""
+        s = self.spec
+        o = s.hidden + s.context + s.motion_channels
+        return self.hx[:, o: o + s.motion_channels]
+
+    def gru(self) -> None:
+        """SepConvGRU / ConvGRU passes (update.py:58-73 / :24-32) over hx = [h | x], h updated in place."""
+        s = self.spec
         Ch = s.hidden
         for kh, kw, sfx in s.gru_passes:
             self._conv([self.hx], kh, kw, "zr" + sfx, 2 * Ch, epi=EPI_GRU_ZR, h=self.h_view, z=self.zbuf, rh=self.rh)
             self._conv([self.rh, self.x_view], kh, kw, "q" + sfx, Ch, epi=EPI_GRU_Q, h=self.h_view, z=self.zbuf)
+
+    def motion_and_gru(self, corr_pm: torch.Tensor) -> None:
+        """update.py:104-112 (encoder) + :58-73 / :24-32 (GRU); `flow` must already be in hx."""
+        s = self.spec
+        self.motion(corr_pm)
+        if s.aggregate:
+            if s.external_aggregate:
+                raise RuntimeError("this block's aggregate slot is filled by the caller: use motion(), aggregate_view, gru()")
+            if self.attn is None:
+                raise RuntimeError("GMA update block needs set_attention() before the first iteration")
+            self._aggregate()
+        self.gru()
 
     def heads(self, coords0: torch.Tensor, coords1: torch.Tensor, delta_out: Optional[torch.Tensor],
               want_mask: bool = True, write_flow: bool = True) -> None:
@@ -323,7 +365,7 @@ class UpdateEngine:
         self.ops.flow_delta(self.fm[:, : s.fh_hidden], self.w["fh2.w"], self.w["fh2.b"], coords0, coords1, delta_out,
                             self.flow_view if write_flow else None)
         if s.has_mask and want_mask:
-            self._conv([self.fm[:, s.fh_hidden:]], 1, 1, "mk", 576, relu=False, scale=0.25, out=self.mask)
+            self._conv([self.fm[:, s.fh_hidden:]], 1, 1, "mk", s.mask_channels, relu=False, scale=0.25, out=self.mask)
 
     def step(self, corr_pm: torch.Tensor, coords0: torch.Tensor, coords1: torch.Tensor, want_mask: bool = True) -> None:
         """One full RAFT iteration body after the lookup; updates hx (net, flow) and coords1 in place."""
@@ -341,7 +383,7 @@ class UpdateEngine:
 
     def mask_nchw(self) -> torch.Tensor:
         B, H, W = self._shape
-        return self.mask.view(B, H, W, 576).permute(0, 3, 1, 2)
+        return self.mask.view(B, H, W, self.spec.mask_channels).permute(0, 3, 1, 2)
 
 
 class PfkUpdateBlock(torch.nn.Module):
@@ -380,21 +422,35 @@ class PfkUpdateBlock(torch.nn.Module):
             self._versions = v
         return self._engine
 
-    def forward(self, net, inp, corr, flow, attention=None):
-        extra = () if attention is None else (attention,)
+    def forward(self, net, inp, corr, flow, *extra, **kw):
+        """raft: (net, inp, corr, flow); gma: + attention (gma/update.py:148); ccmr: + global_context, level_index
+        (ccmr/update.py:152); ms_raft_plus: + coords_x, coords_y, only None supported (stack_coords=False)."""
+        s = self.spec
+        if s.external_aggregate:
+            names = ("global_context", "level_index")
+        elif s.aggregate:
+            names = ("attention",)
+        else:
+            names = ("coords_x", "coords_y")
+        args = dict(zip(names, extra))
+        args.update(kw)
+        if not s.aggregate and any(v is not None for v in args.values()):
+            return self._ref[0](net, inp, corr, flow, *extra, **kw)     # a variant the kernels do not implement
+        attention = args.get("attention")
         if torch.is_grad_enabled() and (net.requires_grad or any(p.requires_grad for p in self.parameters())):
             # training graph (SURVEY §8 f4): every convolution forward / dgrad / wgrad on the MFMA kernel through the
             # differentiable composition of ptlflow_amd/train.py; GMA's aggregate branch, CPU tensors and split-bf16
             # modes keep the reference module's own autograd
-            if self.native_backward and net.is_cuda and not self.spec.aggregate and self.conv_precision == "fp32":
+            if (self.native_backward and net.is_cuda and not self.spec.aggregate and self.conv_precision == "fp32"
+                    and self.spec.mask_channels == 576):
                 from .train import update_block_train
                 h, mask, delta = update_block_train(dict(self.named_parameters()), self.spec, net, inp, corr, flow, self._train_cache)
                 return h.to(net.dtype), (None if mask is None else mask.to(net.dtype)), delta.to(net.dtype)
-            return self._ref[0](net, inp, corr, flow, *extra)
+            return self._ref[0](net, inp, corr, flow, *extra, **kw)
         with torch.no_grad():
-            return self._forward_kernels(net, inp, corr, flow, attention)
+            return self._forward_kernels(net, inp, corr, flow, attention, args.get("global_context"), args.get("level_index", 0))
 
-    def _forward_kernels(self, net, inp, corr, flow, attention=None):
+    def _forward_kernels(self, net, inp, corr, flow, attention=None, global_context=None, level_index=0):
         if not net.is_cuda:
             raise RuntimeError("PfkUpdateBlock needs GPU tensors (no CPU fallback)")
         eng = self._get_engine(net.device)
@@ -414,19 +470,32 @@ class PfkUpdateBlock(torch.nn.Module):
             self._inp_ref, self._inp_version = inp, inp._version
         # corr: a channels-last view of a [M, C] buffer (what ptlflow_amd.CorrBlock returns) is used as is
         cpm = corr.permute(0, 2, 3, 1)
-        if corr.dtype == torch.float32 and cpm.is_contiguous():
-            corr_pm = cpm.reshape(B * H * W, corr.shape[1])
+        C = corr.shape[1]
+        padded = getattr(corr, "_pfk_padded_pm", None)
+        if padded is not None and padded.shape[0] == B * H * W:
+            corr_pm = padded                                   # [M, round_up(C, 4)], pad columns zero (CorrBlock's own buffer)
+        elif corr.dtype == torch.float32 and cpm.is_contiguous() and C % 4 == 0:
+            corr_pm = cpm.reshape(B * H * W, C)
         else:
-            corr_pm = torch.empty(B * H * W, corr.shape[1], device=net.device, dtype=torch.float32)
-            ops.nchw_to_pm(corr.float().contiguous(), corr_pm)
+            corr_pm = torch.zeros(B * H * W, round_up(C, 4), device=net.device, dtype=torch.float32)
+            ops.nchw_to_pm(corr.float().contiguous(), corr_pm[:, :C])
         ops.nchw_to_pm(flow.float().contiguous(), eng.flow_view)
-        if eng.spec.aggregate:
-            if attention is None:
-                raise RuntimeError("GMAUpdateBlock.forward needs the attention map (gma/update.py:148)")
-            if new_forward or eng.attn is None or attention is not self._attn_ref or attention._version != self._attn_version:
-                eng.set_attention(attention)
-                self._attn_ref, self._attn_version = attention, attention._version
-        eng.motion_and_gru(corr_pm)
+        if eng.spec.external_aggregate:
+            # CCMR (ccmr/update.py:152-163): motion encoder on the kernels, the scale's XCiT block — the reference's own module,
+            # torch — on the NCHW view of the motion features, its output into the aggregate slot of hx, then GRU + heads
+            eng.motion(corr_pm)
+            mf = eng.motion_view.unflatten(0, (B, H, W)).permute(0, 3, 1, 2)
+            mfg = self._ref[0].aggregator[level_index](global_context, mf)
+            ops.nchw_to_pm(mfg.float().contiguous(), eng.aggregate_view)
+            eng.gru()
+        else:
+            if eng.spec.aggregate:
+                if attention is None:
+                    raise RuntimeError("GMAUpdateBlock.forward needs the attention map (gma/update.py:148)")
+                if new_forward or eng.attn is None or attention is not self._attn_ref or attention._version != self._attn_version:
+                    eng.set_attention(attention)
+                    self._attn_ref, self._attn_version = attention, attention._version
+            eng.motion_and_gru(corr_pm)
         eng._scratch_c1.zero_()
         eng.heads(eng._scratch_c0, eng._scratch_c1, eng._delta, want_mask=True, write_flow=False)
         mask = eng.mask_nchw() if eng.spec.has_mask else None

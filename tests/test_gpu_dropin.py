@@ -193,3 +193,85 @@ def test_alt_cuda_corr_backward(gpu):
     assert (g1.cpu() - f1.grad).abs().max().item() < 1e-4 * max(1.0, f1.grad.abs().max().item())
     assert (g2.cpu() - f2.grad).abs().max().item() < 1e-4 * max(1.0, f2.grad.abs().max().item())
     assert tuple(gc.shape) == tuple(coords.shape) and float(gc.abs().max()) == 0.0
+
+
+def test_ms_raft_plus_update_block(gpu):
+    """MS-RAFT+'s update block (ms_raft_plus/update.py:119-153, stack_coords=False): RAFT's block on a 2-level lookup
+    (162 correlation channels: not a multiple of 4) with a x2 mask head (36 channels), fed by `get_corr_block` as the model does."""
+    from ptlflow_amd.corr import get_corr_block
+    from ptlflow_amd.raft import _param_tree
+    from ptlflow_amd.synth import synth_state_dict, update_block_shapes
+    from ptlflow_amd.update import PfkUpdateBlock, ms_raft_plus_spec
+    spec = ms_raft_plus_spec(162)
+    holder = _param_tree(update_block_shapes(spec))
+    P = synth_state_dict({k: tuple(v.shape) for k, v in holder.state_dict().items()}, seed=23)
+    holder.load_state_dict(P)
+    ub = PfkUpdateBlock(holder, spec).cuda().eval()
+    g = torch.Generator().manual_seed(7)
+    B, D, h, w = 2, 64, 14, 18
+    f1, f2 = torch.randn(B, D, h, w, generator=g), torch.randn(B, D, h, w, generator=g)
+    net = torch.tanh(torch.randn(B, 128, h, w, generator=g))
+    inp = torch.relu(torch.randn(B, 128, h, w, generator=g))
+    pyr = O.correlation_pyramid(f1, f2, 2)
+    c0 = O.coords_grid(B, h, w)
+    c1, n_ref = c0.clone(), net
+    for _ in range(3):
+        n_ref, m_ref, d = O.basic_update_block(P, n_ref, inp, O.lookup(pyr, c1, 4), c1 - c0)
+        c1 = c1 + d
+    with torch.no_grad():
+        corr_fn = get_corr_block(fmap1=f1.cuda(), fmap2=f2.cuda(), radius=4, num_levels=2, alternate_corr=False)
+        g0 = c0.cuda()
+        g1, n, i = g0.clone(), net.cuda(), inp.cuda()
+        for _ in range(3):
+            corr = corr_fn(g1)
+            assert tuple(corr.shape) == (B, 162, h, w)
+            n, up_mask, delta = ub(n, i, corr, g1 - g0, None, None)        # coords_x / coords_y: unused when stack_coords=False
+            g1 = g1 + delta
+    assert (g1.cpu() - c1).abs().max().item() < 2e-4
+    assert tuple(up_mask.shape) == (B, 36, h, w) and (up_mask.cpu() - m_ref).abs().max().item() < 2e-4
+    assert (n.cpu() - n_ref).abs().max().item() < 2e-4
+
+
+def test_ccmr_update_block_hybrid(gpu):
+    """CCMR's update block (ccmr/update.py:110-168): motion encoder, SepConvGRU(512) and heads on the kernels around the
+    block's OWN aggregator module (an XCiT per scale in the reference; any `aggregator[level](global_context, motion)` here),
+    called at two scales one after the other as the coarse-to-fine loop does (ccmr.py:180-213)."""
+    from ptlflow_amd.raft import _param_tree
+    from ptlflow_amd.synth import synth_state_dict, update_block_shapes
+    from ptlflow_amd.update import PfkUpdateBlock, ccmr_spec
+
+    class Agg(torch.nn.Module):          # stands in for XCiT(embed_dim=128, separate=True): (context, motion) -> 128 channels
+        def __init__(self):
+            super().__init__()
+            self.mix = torch.nn.Conv2d(256, 128, 1)
+
+        def forward(self, ctx, mf):
+            return torch.tanh(self.mix(torch.cat([ctx, mf], 1)))
+
+    spec = ccmr_spec(162)
+    holder = _param_tree(update_block_shapes(spec))
+    P = synth_state_dict({k: tuple(v.shape) for k, v in holder.state_dict().items()}, seed=29)
+    holder.load_state_dict(P)
+    torch.manual_seed(3)
+    holder.add_module("aggregator", torch.nn.ModuleList([Agg(), Agg()]))
+    cpu_aggs = [a for a in holder.aggregator]
+    import copy
+    cpu_aggs = copy.deepcopy(cpu_aggs)
+    ub = PfkUpdateBlock(holder, spec).cuda().eval()
+    assert any(k.startswith("aggregator.") for k in ub.state_dict())       # the foreign sub-module stays registered
+    g = torch.Generator().manual_seed(8)
+    with torch.no_grad():
+        for level, (h, w) in enumerate(((9, 12), (18, 24))):
+            B = 1
+            net = torch.tanh(torch.randn(B, 128, h, w, generator=g))
+            inp = torch.relu(torch.randn(B, 128, h, w, generator=g))
+            ctx = torch.randn(B, 128, h, w, generator=g)
+            n_ref, n = net, net.cuda()
+            for it in range(2):
+                corr = torch.randn(B, 162, h, w, generator=g)
+                flow = torch.randn(B, 2, h, w, generator=g) * 2
+                n_ref, m_ref, d_ref = O.ccmr_update_block(P, n_ref, inp, corr, flow, cpu_aggs[level], ctx)
+                n, m, d = ub(n, inp.cuda(), corr.cuda(), flow.cuda(), ctx.cuda(), level_index=level)
+                for a, b in ((n, n_ref), (m, m_ref), (d, d_ref)):
+                    assert (a.cpu() - b).abs().max().item() < 2e-4
+            assert tuple(m.shape) == (B, 36, h, w)

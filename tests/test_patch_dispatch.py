@@ -52,9 +52,32 @@ def test_own_families_are_wrapped(fam, cls, kw):
     assert mod.get_corr_block is orig and not isinstance(model.update_block, PfkUpdateBlock)
 
 
-@pytest.mark.parametrize("fam,cls,kw,pyramid", [("sea_raft", "SEARAFT", {"block_dims": [64, 128, 256]}, "bilinear_f2"),
-                                                ("ccmr", "CCMR", {}, "avgpool"),
-                                                ("ms_raft_plus", "MSRAFTPlus", {}, "avgpool")])
+@pytest.mark.parametrize("fam,cls", [("ccmr", "CCMR"), ("ms_raft_plus", "MSRAFTPlus")])
+def test_multiscale_families_get_their_own_spec(fam, cls):
+    """ccmr / ms_raft_plus: `BasicUpdateBlock` again, but RAFT's layers around an XCiT aggregator (ccmr) or with a x2 mask head
+    (both): wrapped with the spec derived from THEIR parameter shapes; their multi-scale encoders stay the reference's."""
+    _native()
+    from ptlflow_amd import patch
+    from ptlflow_amd.encoder import PfkEncoder
+    from ptlflow_amd.update import PfkUpdateBlock
+    model, mod = _build(fam, cls)
+    keys = set(model.state_dict())
+    fnet, cnet = model.fnet, model.cnet
+    patch.accelerate(model)
+    try:
+        ub = model.update_block
+        assert isinstance(ub, PfkUpdateBlock)
+        assert ub.spec.mask_channels == 36 and ub.spec.corr_channels == 162 and ub.spec.hidden == 128
+        assert ub.spec.external_aggregate == (fam == "ccmr") and ub.spec.aggregate == (fam == "ccmr")
+        assert model.fnet is fnet and model.cnet is cnet and not isinstance(fnet, PfkEncoder)
+        assert set(model.state_dict()) == keys
+        assert mod.get_corr_block.pyramid == "avgpool"
+    finally:
+        patch.restore(model)
+    assert not isinstance(model.update_block, PfkUpdateBlock)
+
+
+@pytest.mark.parametrize("fam,cls,kw,pyramid", [("sea_raft", "SEARAFT", {"block_dims": [64, 128, 256]}, "bilinear_f2")])
 def test_foreign_blocks_are_left_alone(fam, cls, kw, pyramid):
     """Same class name `BasicUpdateBlock`, different implementation: must not be wrapped; seam B1 is still installed."""
     _native()
