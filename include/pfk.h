@@ -334,7 +334,9 @@ int pfk_softmax_rows_f32(float* x, long long rows, int cols, long long ld, pfk_s
  * nn.InstanceNorm2d / nn.BatchNorm2d + relu in raft/extractor.py:51-59, 172-181):
  *   g = dy * (y > 0);  sum_g[b*C+c] = sum_p g;  sum_gxhat[b*C+c] = sum_p g * x_hat;  dx = rstd * (g - sum_g/HW - x_hat * sum_gxhat/HW)
  * sum_g / sum_gxhat may be NULL (kept in the workspace); for an affine batch norm they are d(beta) / d(gamma) when dy is the
- * gradient w.r.t. the un-affine'd output.  workspace: pfk_norm_bwd_workspace_bytes(B, C).  Deterministic. */
+ * gradient w.r.t. the un-affine'd output.  The two sums and the final subtraction are carried in double (the residual of a
+ * mean-dominated gradient is otherwise lost to fp32 cancellation).  workspace: pfk_norm_bwd_workspace_bytes(B, C) bytes,
+ * 32-byte aligned.  Deterministic. */
 long long pfk_norm_bwd_workspace_bytes(int B, int C);
 int pfk_norm_bwd_f32(const float* x, int x_ld, const float* dy, int dy_ld, const float* mean, const float* rstd, float* dx,
                      int dx_ld, float* sum_g, float* sum_gxhat, int B, int HW, int C, int relu, void* workspace,

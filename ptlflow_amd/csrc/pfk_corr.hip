@@ -42,6 +42,7 @@ struct LookupArgs {
 // compiler barrier) is enough — no workgroup barrier couples the four levels' very different amounts of work.
 
 constexpr int PIX = 4;
+static_assert(PIX * 9 <= 64, "one table pass covers PIX * (2R+1) <= 64 lanes");
 
 // R = radius (compile-time: the (2R+1)^2 sample enumeration divides by constants), PIX pixels per workgroup.
 template <int PIX, int R, typename T>
@@ -78,22 +79,31 @@ __global__ __launch_bounds__(256) void lookup_kernel(const LookupArgs a) {
       const int Hl = a.lh[l], Wl = a.lw[l];
       const float inv = 1.0f / (float)(1 << l);   // coords / 2**l is exact (corr.py:45)
       float v[PIX][3];
+      // tap tables of all PIX pixels in ONE pass: lane = q * n + i evaluates window index i of pixel q on both axes (two IEEE
+      // divisions per lane; one pass over 36 lanes instead of PIX passes over 9)
+      if (lane < PIX * n) {
+        const int q = lane / n, i = lane - q * n;
+        float cxq = cx0[0], cyq = cy0[0];
+#pragma unroll
+        for (int qq = 1; qq < PIX; ++qq) { cxq = (q == qq) ? cx0[qq] : cxq; cyq = (q == qq) ? cy0[qq] : cyq; }
+        const float cx = cxq * inv, cy = cyq * inv;
+        const float xb = floorf(cx) - (float)(R + 1);
+        const float yb = floorf(cy) - (float)(R + 1);
+        const float off = (float)(i - R);
+        const float ix = roundtrip(cx + off, (float)(Wl - 1), (float)(Wl - 1) * 0.5f);
+        const float iy = roundtrip(cy + off, (float)(Hl - 1), (float)(Hl - 1) * 0.5f);
+        const float x0 = floorf(ix), y0 = floorf(iy);
+        const float dxf = x0 - xb, dyf = y0 - yb;   // position of the tap inside the staged patch (absurd / NaN -> 0)
+        s_rx[wid][q][i] = (dxf >= 0.f && dxf <= (float)(PATCH - 2)) ? (int)dxf : 0;
+        s_ry[wid][q][i] = ((dyf >= 0.f && dyf <= (float)(PATCH - 2)) ? (int)dyf : 0) * PATCH_LD;
+        s_wx[wid][q][i] = ix - x0;
+        s_wy[wid][q][i] = iy - y0;
+      }
 #pragma unroll
       for (int q = 0; q < PIX; ++q) {
         const float cx = cx0[q] * inv, cy = cy0[q] * inv;
         const float xb = floorf(cx) - (float)(R + 1);
         const float yb = floorf(cy) - (float)(R + 1);
-        if (lane < n) {
-          const float off = (float)(lane - R);
-          const float ix = roundtrip(cx + off, (float)(Wl - 1), (float)(Wl - 1) * 0.5f);
-          const float iy = roundtrip(cy + off, (float)(Hl - 1), (float)(Hl - 1) * 0.5f);
-          const float x0 = floorf(ix), y0 = floorf(iy);
-          const float dxf = x0 - xb, dyf = y0 - yb;   // position of the tap inside the staged patch (absurd / NaN -> 0)
-          s_rx[wid][q][lane] = (dxf >= 0.f && dxf <= (float)(PATCH - 2)) ? (int)dxf : 0;
-          s_ry[wid][q][lane] = ((dyf >= 0.f && dyf <= (float)(PATCH - 2)) ? (int)dyf : 0) * PATCH_LD;
-          s_wx[wid][q][lane] = ix - x0;
-          s_wy[wid][q][lane] = iy - y0;
-        }
         const int xbi = safe_base(xb), ybi = safe_base(yb);
         const bool pl = (p0 + q) < M;
         const T* vol = static_cast<const T*>(a.lv[l]) + (p0 + q) * (long long)Hl * Wl;

@@ -171,11 +171,18 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict
 //     dx  = rstd * (g - s1 / HW - x_hat * s2 / HW)
 // Partial sums per (image, chunk) reduced in a fixed order (deterministic), then one elementwise pass.
 // ------------------------------------------------------------------------------------------------------------------
+// Accumulation and the final subtraction run in DOUBLE: when the incoming gradient is dominated by its per-channel mean (the
+// situation of an encoder fed by the correlation backward), g - mean(g) - x_hat * mean(g x_hat) cancels to a small residual and
+// fp32 sums lose 2-3 digits there (measured: 1e-2 relative on encoder weight gradients, for MIOpen's kernels as well); torch's
+// CPU kernels accumulate float tensors in double for the same reason.  MI355X's fp64 vector rate makes this free next to the
+// memory traffic of the pass.
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
 __global__ __launch_bounds__(256) void norm_bwd_partial_kernel(const float* __restrict__ x, int x_ld, const float* __restrict__ dy,
                                                                int dy_ld, const float* __restrict__ mean,
                                                                const float* __restrict__ rstd, int C, int HW, int relu,
-                                                               float* __restrict__ part1, float* __restrict__ part2) {
-  __shared__ f32x4 red1[256], red2[256];
+                                                               double* __restrict__ part1, double* __restrict__ part2) {
+  __shared__ f64x4 red1[256], red2[256];
   const int b = blockIdx.y, chunk = blockIdx.x;
   const int tpr = C >> 2, rpi = 256 / tpr;
   const int t = threadIdx.x;
@@ -183,7 +190,7 @@ __global__ __launch_bounds__(256) void norm_bwd_partial_kernel(const float* __re
   const bool active = rr < rpi;
   const int rows = (HW + IN_CHUNKS - 1) / IN_CHUNKS;
   const int r0 = chunk * rows, r1 = min(HW, r0 + rows);
-  f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f};
+  f64x4 a1 = {0., 0., 0., 0.}, a2 = {0., 0., 0., 0.};
   if (active) {
     const f32x4 m = *reinterpret_cast<const f32x4*>(mean + (long long)b * C + c4);
     const f32x4 rs = *reinterpret_cast<const f32x4*>(rstd + (long long)b * C + c4);
@@ -192,41 +199,45 @@ __global__ __launch_bounds__(256) void norm_bwd_partial_kernel(const float* __re
     for (int r = r0 + rr; r < r1; r += rpi) {
       const f32x4 xh = (*reinterpret_cast<const f32x4*>(xb + (long long)r * x_ld) - m) * rs;
       f32x4 g = *reinterpret_cast<const f32x4*>(gb + (long long)r * dy_ld);
-      if (relu) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) g[e] = xh[e] > 0.f ? g[e] : 0.f;
+      for (int e = 0; e < 4; ++e) {
+        if (relu) g[e] = xh[e] > 0.f ? g[e] : 0.f;
+        a1[e] += (double)g[e];
+        a2[e] += (double)g[e] * (double)xh[e];
       }
-      a1 += g;
-      a2 += g * xh;
     }
   }
   red1[t] = a1; red2[t] = a2;
   __syncthreads();
   if (t < tpr) {
-    f32x4 s1 = red1[t], s2 = red2[t];
+    f64x4 s1 = red1[t], s2 = red2[t];
     for (int k = 1; k < rpi; ++k) { s1 += red1[t + k * tpr]; s2 += red2[t + k * tpr]; }
-    *reinterpret_cast<f32x4*>(part1 + ((long long)b * IN_CHUNKS + chunk) * C + c4) = s1;
-    *reinterpret_cast<f32x4*>(part2 + ((long long)b * IN_CHUNKS + chunk) * C + c4) = s2;
+    *reinterpret_cast<f64x4*>(part1 + ((long long)b * IN_CHUNKS + chunk) * C + c4) = s1;
+    *reinterpret_cast<f64x4*>(part2 + ((long long)b * IN_CHUNKS + chunk) * C + c4) = s2;
   }
 }
 
-__global__ void norm_bwd_finalize_kernel(const float* __restrict__ part1, const float* __restrict__ part2, int C,
-                                         float* __restrict__ s1, float* __restrict__ s2, int total) {
+// s1 / s2 in double for the apply pass; float copies for the caller (d beta / d gamma of an affine batch norm)
+__global__ void norm_bwd_finalize_kernel(const double* __restrict__ part1, const double* __restrict__ part2, int C,
+                                         double* __restrict__ d1, double* __restrict__ d2, float* __restrict__ s1,
+                                         float* __restrict__ s2, int total) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;   // b*C + c
   if (i >= total) return;
   const int b = i / C, c = i - b * C;
-  float a = 0.f, q = 0.f;
+  double a = 0., q = 0.;
   for (int k = 0; k < IN_CHUNKS; ++k) {
     a += part1[((long long)b * IN_CHUNKS + k) * C + c];
     q += part2[((long long)b * IN_CHUNKS + k) * C + c];
   }
-  s1[i] = a; s2[i] = q;
+  d1[i] = a; d2[i] = q;
+  if (s1) s1[i] = (float)a;
+  if (s2) s2[i] = (float)q;
 }
 
 __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __restrict__ x, int x_ld, const float* __restrict__ dy,
                                                              int dy_ld, const float* __restrict__ mean,
-                                                             const float* __restrict__ rstd, const float* __restrict__ s1,
-                                                             const float* __restrict__ s2, float* __restrict__ dx, int dx_ld,
+                                                             const float* __restrict__ rstd, const double* __restrict__ s1,
+                                                             const double* __restrict__ s2, float* __restrict__ dx, int dx_ld,
                                                              long long M, int HW, int C, int relu) {
   const int tpr = C >> 2;
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -235,15 +246,16 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __rest
   const int c4 = (int)(idx - p * tpr) * 4;
   const long long sidx = (p / HW) * C + c4;
   const f32x4 m = *reinterpret_cast<const f32x4*>(mean + sidx), rs = *reinterpret_cast<const f32x4*>(rstd + sidx);
-  const f32x4 a = *reinterpret_cast<const f32x4*>(s1 + sidx), q = *reinterpret_cast<const f32x4*>(s2 + sidx);
   const f32x4 xh = (*reinterpret_cast<const f32x4*>(x + p * x_ld + c4) - m) * rs;
-  f32x4 g = *reinterpret_cast<const f32x4*>(dy + p * dy_ld + c4);
-  if (relu) {
+  const f32x4 g = *reinterpret_cast<const f32x4*>(dy + p * dy_ld + c4);
+  const double inv = 1.0 / (double)HW;
+  f32x4 out;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) g[e] = xh[e] > 0.f ? g[e] : 0.f;
+  for (int e = 0; e < 4; ++e) {
+    const float ge = (relu && !(xh[e] > 0.f)) ? 0.f : g[e];
+    out[e] = (float)((double)rs[e] * ((double)ge - s1[sidx + e] * inv - (double)xh[e] * (s2[sidx + e] * inv)));
   }
-  const float inv = 1.0f / (float)HW;
-  *reinterpret_cast<f32x4*>(dx + p * dx_ld + c4) = rs * (g - a * inv - xh * (q * inv));
+  *reinterpret_cast<f32x4*>(dx + p * dx_ld + c4) = out;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -370,7 +382,7 @@ int pfk_instnorm_stats_f32(const float* x, int ld, int B, int HW, int C, float e
 }
 
 
-long long pfk_norm_bwd_workspace_bytes(int B, int C) { return ((long long)B * IN_CHUNKS * C * 2 + (long long)B * C * 2) * (long long)sizeof(float); }
+long long pfk_norm_bwd_workspace_bytes(int B, int C) { return ((long long)B * IN_CHUNKS * C * 2 + (long long)B * C * 2) * (long long)sizeof(double); }
 
 int pfk_norm_bwd_f32(const float* x, int x_ld, const float* dy, int dy_ld, const float* mean, const float* rstd, float* dx,
                      int dx_ld, float* sum_g, float* sum_gxhat, int B, int HW, int C, int relu, void* workspace,
@@ -378,23 +390,22 @@ int pfk_norm_bwd_f32(const float* x, int x_ld, const float* dy, int dy_ld, const
   if (!x || !dy || !mean || !rstd || !dx || !workspace || B <= 0 || HW <= 0 || C <= 0) return PFK_ERR_BAD_ARG;
   if (x_ld < C || dy_ld < C || dx_ld < C) return PFK_ERR_BAD_ARG;
   if ((C & 3) || (x_ld & 3) || (dy_ld & 3) || (dx_ld & 3) || C > 1024 || !pfk_aligned16(x) || !pfk_aligned16(dy) ||
-      !pfk_aligned16(dx) || !pfk_aligned16(mean) || !pfk_aligned16(rstd) || !pfk_aligned16(workspace))
+      !pfk_aligned16(dx) || !pfk_aligned16(mean) || !pfk_aligned16(rstd) || (reinterpret_cast<uintptr_t>(workspace) & 31u))
     return PFK_ERR_ALIGNMENT;
   if (workspace_bytes < pfk_norm_bwd_workspace_bytes(B, C)) return PFK_ERR_BAD_ARG;
-  float* p1 = static_cast<float*>(workspace);
-  float* p2 = p1 + (size_t)B * IN_CHUNKS * C;
-  float* s1 = sum_g ? sum_g : p2 + (size_t)B * IN_CHUNKS * C;
-  float* s2 = sum_gxhat ? sum_gxhat : p2 + (size_t)B * IN_CHUNKS * C + (size_t)B * C;
-  if (!pfk_aligned16(s1) || !pfk_aligned16(s2)) return PFK_ERR_ALIGNMENT;
+  double* p1 = static_cast<double*>(workspace);
+  double* p2 = p1 + (size_t)B * IN_CHUNKS * C;
+  double* d1 = p2 + (size_t)B * IN_CHUNKS * C;
+  double* d2 = d1 + (size_t)B * C;
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(norm_bwd_partial_kernel, dim3(IN_CHUNKS, (unsigned)B), dim3(256), 0, st, x, x_ld, dy, dy_ld, mean, rstd, C, HW,
                      relu, p1, p2);
   const int total = B * C;
-  hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, st, p1, p2, C, s1, s2, total);
+  hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, st, p1, p2, C, d1, d2, sum_g, sum_gxhat, total);
   const long long M = (long long)B * HW;
   const long long blocks = (M * (C >> 2) + 255) / 256;
   if (blocks > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, x_ld, dy, dy_ld, mean, rstd, s1, s2, dx,
+  hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, x_ld, dy, dy_ld, mean, rstd, d1, d2, dx,
                      dx_ld, M, HW, C, relu);
   return pfk_launch_status();
 }

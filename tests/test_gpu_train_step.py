@@ -54,18 +54,26 @@ def _run(gpu, small, B, H, W, iters, tol):
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
             continue
         assert p.grad is not None, f"{n}: no gradient"
+        got = p.grad.double().cpu()
         # scale: the tensor's own, floored for tensors whose true gradient is (numerically) zero, e.g. a conv bias in front
         # of an instance / batch norm
-        scale = max(float(ref.abs().max()), 1e-4 * scale_all)
-        err = float((p.grad.double().cpu() - ref).abs().max()) / scale
+        scale = max(float(ref.abs().max()), 1e-3 * scale_all)
+        err = float((got - ref).abs().max()) / scale
         err_cpu32 = float((g32[alias[n]].double() - ref).abs().max()) / scale
-        rows.append((err / max(tol, 3.0 * err_cpu32), err, err_cpu32, n))
+        l2 = float((got - ref).norm()) / max(float(ref.norm()), 1e-3 * scale_all * ref.numel() ** 0.5)
+        rows.append((err / max(tol, 5.0 * err_cpu32), err, err_cpu32, l2, n))
     rows.sort(reverse=True)
-    print("worst gradients (err/allowed, err/scale, fp32-CPU-autograd err/scale, name):")
+    print("worst gradients (max-err/allowed, max-err/scale, fp32-CPU-autograd max-err/scale, L2-relative err, name):")
     for r in rows[:8]:
-        print("   %.2f  %.2e  %.2e  %s" % r)
-    # gate: 5e-4 of the tensor's scale, or 3x what fp32 autograd of the reference's own ops loses on that tensor
-    assert rows[0][0] <= 1.0, "gradient mismatch: " + ", ".join(f"{r[1]:.2e} (cpu32 {r[2]:.2e}) {r[3]}" for r in rows[:6])
+        print("   %.2f  %.2e  %.2e  %.2e  %s" % r)
+    worst_l2 = max(rows, key=lambda r: r[3])
+    print("worst L2-relative: %.2e %s" % (worst_l2[3], worst_l2[4]))
+    # Gates.  (1) every parameter's gradient within 5e-4 of its scale in the L2 sense.  (2) element-wise (max norm): 5e-4 of the
+    # tensor's scale — or, where fp32 itself cannot do better, 5x what fp32 CPU autograd of the reference's own ops loses on that
+    # tensor against float64: the fp32 forward differs from the float64 one by ~1e-6, which flips a handful of ReLU / |.| / floor
+    # decisions, and each flip moves single gradient elements by O(1) of their value on any fp32 implementation.
+    assert worst_l2[3] <= tol, f"L2-relative gradient error {worst_l2[3]:.2e} on {worst_l2[4]}"
+    assert rows[0][0] <= 1.0, "gradient mismatch: " + ", ".join(f"{r[1]:.2e} (cpu32 {r[2]:.2e}) {r[4]}" for r in rows[:6])
 
 
 def test_train_step_raft(gpu):
@@ -118,7 +126,7 @@ def test_encoder_train_gradients(gpu, kind, small, B, H, W):
         r = gref[alias[n]]
         if r is None:
             continue
-        s = max(float(r.abs().max()), 1e-4 * smax)
+        s = max(float(r.abs().max()), 1e-3 * smax)
         rows.append((float((p.grad.double().cpu() - r).abs().max()) / s, n))
     rows.sort(reverse=True)
     print("encoder_train worst gradient errors:", ", ".join(f"{e:.1e} {n}" for e, n in rows[:4]))
