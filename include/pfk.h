@@ -71,9 +71,9 @@ int pfk_corr_volume_f32(const float* f1, int ld1, const float* f2, int ld2, floa
                         int B, int N1, int N2, int D, float scale, pfk_stream_t stream);
 
 /* bf16 operands, bf16 volume — what the reference's matmul produces under torch.autocast(bfloat16):
- * f1 fp32 rows (rounded to bf16 while staged; exact when they already hold bf16 values), f2_bf16 [B][N2][ld2] bf16 with
- * ld2 == round_up(D, 32), out_bf16 [B][N1][N2] bf16; fp32 accumulate on the bf16 matrix cores, scaled, rounded to nearest even. */
-int pfk_corr_volume_bf16(const float* f1, int ld1, const void* f2_bf16, int ld2, void* out_bf16, int B, int N1, int N2, int D,
+ * f1_bf16 [B][N1][ld1], f2_bf16 [B][N2][ld2] bf16 rows (ld % 8 == 0, D % 8 == 0), out_bf16 [B][N1][N2] bf16; fp32 accumulate
+ * on the bf16 matrix cores, scaled, rounded to nearest even.  HBM-write-bound (2 B per volume element). */
+int pfk_corr_volume_bf16(const void* f1_bf16, int ld1, const void* f2_bf16, int ld2, void* out_bf16, int B, int N1, int N2, int D,
                          float scale, pfk_stream_t stream);
 
 /* ---- K2: 2x2/stride-2 average pool over the target dims (floor) ------------------------------

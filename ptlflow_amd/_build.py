@@ -37,6 +37,7 @@ HIP_SOURCES = [
     ("pfk_altcorr.hip", []),
     ("pfk_encoder.hip", []),
     ("pfk_wgrad.hip", []),
+    ("pfk_corr_bf16.hip", []),
     ("pfk_bwd.hip", ["-ffp-contract=off"]),   # same coordinate arithmetic as pfk_corr.hip (pfk_lookup.h)
 ]
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",

@@ -152,9 +152,11 @@ class CorrBlock:
         vt = self.volume_dtype
         bf = vt == torch.bfloat16
 
+        f1b = f1.to(torch.bfloat16) if bf else None    # exact when the maps already hold bf16 values (an autocast encoder)
+
         def volume(f2_pm: torch.Tensor, out: torch.Tensor) -> None:
-            if bf:    # bf16 operands (f1 rounded while staged, f2 here), bf16 volume
-                ops.corr_volume_bf16(f1, f2_pm.to(torch.bfloat16), scale, out)
+            if bf:    # bf16 operands, fp32 accumulate, bf16 volume
+                ops.corr_volume_bf16(f1b, f2_pm.to(torch.bfloat16), scale, out)
             else:
                 ops.corr_volume(f1, f2_pm, scale, out)
 

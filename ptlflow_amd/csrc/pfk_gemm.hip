@@ -871,32 +871,4 @@ int pfk_corr_volume_f32(const float* f1, int ld1, const float* f2, int ld2, floa
   return launch(a, PFK_EPI_LINEAR, B, static_cast<hipStream_t>(stream));
 }
 
-// K1 with bf16 operands and a bf16 volume (what the reference computes under torch.autocast(bfloat16): matmul of bf16 feature
-// maps, bf16 result): the split-bf16 kernel with one plane — f1 is rounded to bf16 while it is staged,
-// f2 arrives as bf16 rows (it plays the pre-split "weight"), fp32 accumulate, scale, round to nearest even, 2-byte stores.
-// HBM-write-bound by design (2 B per volume element; 106 MB per 55x128 pair).
-int pfk_corr_volume_bf16(const float* f1, int ld1, const void* f2_bf16, int ld2, void* out_bf16, int B, int N1, int N2, int D,
-                         float scale, pfk_stream_t stream) {
-  if (!f1 || !f2_bf16 || !out_bf16 || B <= 0 || N1 <= 0 || N2 <= 0 || D <= 0) return PFK_ERR_BAD_ARG;
-  if (ld1 < D || ld2 < D) return PFK_ERR_BAD_ARG;
-  if (!pfk_aligned16(f1) || !pfk_aligned16(f2_bf16) || (ld1 & 3) || (D & 3)) return PFK_ERR_ALIGNMENT;
-  if (ld2 != round_up32(D)) return PFK_ERR_UNSUPPORTED;   // f2 rows are read as packed weight rows
-  if ((long long)N1 * ld1 * 4 >= 0x7fffffffLL || (long long)N2 * ld2 * 2 >= 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
-  for (int b = 0; b < B; ++b) {
-    GemmArgs a{};
-    a.src0 = f1 + (long long)b * N1 * ld1; a.ld0 = ld1; a.ch0 = D; a.nsrc = 1;
-    a.H = 1; a.W = N1; a.Ho = 1; a.Wo = N1; a.stride = 1; a.kh = 1; a.kw = 1;
-    a.wbf = static_cast<const char*>(f2_bf16) + (long long)b * N2 * ld2 * 2;
-    a.wbf_plane_bytes = (long long)N2 * ld2 * 2;
-    a.bias = nullptr; a.b_rows = N2; a.ktot = ld2; a.sk_steps = ld2 / 32;
-    a.relu = 0; a.scale = scale;
-    a.out = reinterpret_cast<float*>(static_cast<char*>(out_bf16) + (long long)b * N1 * N2 * 2);
-    a.out_ld = N2; a.out_coff = 0; a.out_bf16 = 1;
-    a.M = N1;
-    const int rc = launch_bf(a, PFK_EPI_LINEAR, 1, static_cast<hipStream_t>(stream));
-    if (rc != PFK_OK) return rc;
-  }
-  return PFK_OK;
-}
-
 }  // extern "C"

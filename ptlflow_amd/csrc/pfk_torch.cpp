@@ -86,16 +86,17 @@ void corr_pool2x2(const Tensor& in, Tensor out) {
   else check_ok(pfk_corr_pool2x2_bf16(in.data_ptr(), out.data_ptr(), M, H, W, cur_stream()), "corr_pool2x2 (bf16)");
 }
 
-// bf16 volume: f1 fp32 [B,N1,D], f2 bf16 [B,N2,D] -> out bf16 [B,N1,N2]
+// bf16 volume: f1, f2 bf16 [B,N,D] -> out bf16 [B,N1,N2]
 void corr_volume_bf16(const Tensor& f1, const Tensor& f2, double scale, Tensor out) {
   OpScope scope(f1);
-  check_dev_f32(f1, "f1"); check_dev(f2, "f2"); check_dev(out, "out");
-  TORCH_CHECK(f2.scalar_type() == at::kBFloat16 && out.scalar_type() == at::kBFloat16, "corr_volume_bf16: f2 and out must be bfloat16");
+  check_dev(f1, "f1"); check_dev(f2, "f2"); check_dev(out, "out");
+  TORCH_CHECK(f1.scalar_type() == at::kBFloat16 && f2.scalar_type() == at::kBFloat16 && out.scalar_type() == at::kBFloat16,
+              "corr_volume_bf16: f1, f2 and out must be bfloat16");
   TORCH_CHECK(f1.dim() == 3 && f2.dim() == 3 && out.dim() == 3 && f1.is_contiguous() && f2.is_contiguous() && out.is_contiguous(),
               "corr_volume_bf16: contiguous [B,N,D] inputs, [B,N1,N2] out");
   const int B = f1.size(0), N1 = f1.size(1), D = f1.size(2), N2 = f2.size(1);
   TORCH_CHECK(f2.size(0) == B && f2.size(2) == D && out.size(0) == B && out.size(1) == N1 && out.size(2) == N2, "corr_volume_bf16: shape mismatch");
-  check_ok(pfk_corr_volume_bf16(fptr(f1), D, f2.data_ptr(), D, out.data_ptr(), B, N1, N2, D, (float)scale, cur_stream()), "corr_volume_bf16");
+  check_ok(pfk_corr_volume_bf16(f1.data_ptr(), D, f2.data_ptr(), D, out.data_ptr(), B, N1, N2, D, (float)scale, cur_stream()), "corr_volume_bf16");
 }
 
 // pixel-major feature map [B*H*W, C] -> [B*(H/2)*(W/2), C]: 2x2 average == bilinear x0.5 (align_corners=False)

@@ -33,7 +33,9 @@ for B in (1, 8):
     ref = vol.clone()
     f2b = f2.to(torch.bfloat16)
     volb = torch.empty(B, N, N, device=dev, dtype=torch.bfloat16)
-    us = timeit(lambda: ops.corr_volume_bf16(f1, f2b, 1 / 16.0, volb))
+    f1b = f1.to(torch.bfloat16)
+    us = timeit(lambda: ops.corr_volume_bf16(f1b, f2b, 1 / 16.0, volb))
+    ref = torch.bmm(f1b.float(), f2b.float().transpose(1, 2)) / 16 if B == 1 else ref
     err = (volb.float() - ref).abs().max().item()
     print(f"K1 bf16 B={B}: {us:.1f} us  write {2*B*N*N/us/1e6:.2f} TB/s ({100*2*B*N*N/us/1e6/8:.1f}% of 8 TB/s)  {flop/us/1e6:.0f} TFLOP/s  max|bf16-fp32| {err:.3e}")
     for dt, name in ((torch.float32, "fp32"), (torch.bfloat16, "bf16")):

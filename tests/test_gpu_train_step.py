@@ -60,19 +60,20 @@ def _run(gpu, small, B, H, W, iters, tol):
         scale = max(float(ref.abs().max()), 1e-3 * scale_all)
         err = float((got - ref).abs().max()) / scale
         err_cpu32 = float((g32[alias[n]].double() - ref).abs().max()) / scale
-        l2 = float((got - ref).norm()) / max(float(ref.norm()), 1e-3 * scale_all * ref.numel() ** 0.5)
-        rows.append((err / max(tol, 5.0 * err_cpu32), err, err_cpu32, l2, n))
+        den = max(float(ref.norm()), 1e-3 * scale_all * ref.numel() ** 0.5)
+        l2 = float((got - ref).norm()) / den
+        l2_cpu32 = float((g32[alias[n]].double() - ref).norm()) / den
+        rows.append((err / max(tol, 5.0 * err_cpu32), err, err_cpu32, l2 / max(tol, 5.0 * l2_cpu32), n, l2, l2_cpu32))
     rows.sort(reverse=True)
     print("worst gradients (max-err/allowed, max-err/scale, fp32-CPU-autograd max-err/scale, L2-relative err, name):")
     for r in rows[:8]:
-        print("   %.2f  %.2e  %.2e  %.2e  %s" % r)
+        print("   %.2f  %.2e  %.2e  %.2f  %s  (L2 %.2e, fp32-CPU L2 %.2e)" % r)
     worst_l2 = max(rows, key=lambda r: r[3])
-    print("worst L2-relative: %.2e %s" % (worst_l2[3], worst_l2[4]))
-    # Gates.  (1) every parameter's gradient within 5e-4 of its scale in the L2 sense.  (2) element-wise (max norm): 5e-4 of the
-    # tensor's scale — or, where fp32 itself cannot do better, 5x what fp32 CPU autograd of the reference's own ops loses on that
-    # tensor against float64: the fp32 forward differs from the float64 one by ~1e-6, which flips a handful of ReLU / |.| / floor
+    print("worst L2 err/allowed: %.2f %s (L2 %.2e, fp32-CPU L2 %.2e)" % (worst_l2[3], worst_l2[4], worst_l2[5], worst_l2[6]))
+    # Gates, in the L2 sense and element-wise (max norm): within 5e-4 of the tensor's scale — or, where fp32 itself cannot do
+    # better, 5x what fp32 CPU autograd of the reference's own ops loses on that tensor against float64: the fp32 forward differs from the float64 one by ~1e-6, which flips a handful of ReLU / |.| / floor
     # decisions, and each flip moves single gradient elements by O(1) of their value on any fp32 implementation.
-    assert worst_l2[3] <= tol, f"L2-relative gradient error {worst_l2[3]:.2e} on {worst_l2[4]}"
+    assert worst_l2[3] <= 1.0, f"L2-relative gradient error {worst_l2[5]:.2e} (fp32 CPU autograd: {worst_l2[6]:.2e}) on {worst_l2[4]}"
     assert rows[0][0] <= 1.0, "gradient mismatch: " + ", ".join(f"{r[1]:.2e} (cpu32 {r[2]:.2e}) {r[4]}" for r in rows[:6])
 
 
@@ -140,3 +141,29 @@ def test_encoder_train_gradients(gpu, kind, small, B, H, W):
                 got = enc.state_dict()[k].cpu()
                 assert float((got - v).abs().max()) <= 1e-4 * max(1.0, float(v.abs().max())), k
                 assert not torch.equal(got, rm0[k])
+
+
+@pytest.mark.parametrize("G,HW,C,relu", [(1, 1872, 8, True), (2, 1872, 24, True), (2, 3264, 64, True), (4, 816, 96, False), (3, 209, 128, True),
+                                         (1, 6528, 64, True), (2, 3264, 96, True)])
+def test_norm_forward_backward_kernels(gpu, G, HW, C, relu):
+    """`_Norm` (pfk_instnorm_stats_f32 + pfk_norm_apply_f32 forward, pfk_norm_bwd_f32 backward) for G groups of HW pixels vs
+    float64 autograd of F.instance_norm (+ relu): several images, channel counts that leave idle threads in the reduction
+    (24, 96), odd pixel counts."""
+    import torch.nn.functional as F
+    from ptlflow_amd.train_encoder import _Norm
+    g = torch.Generator().manual_seed(G * 1000 + C)
+    x = torch.randn(G, C, HW, 1, generator=g, dtype=torch.float64) * 1.7 + 0.4
+    x.requires_grad_(True)
+    ref = F.instance_norm(x, eps=1e-5)
+    if relu:
+        ref = F.relu(ref)
+    go = torch.randn(ref.shape, generator=g, dtype=torch.float64) + 0.8          # a gradient with a sizeable mean component
+    ref.backward(go)
+    xp = x.detach().float().squeeze(-1).permute(0, 2, 1).reshape(G * HW, C).contiguous().to(gpu).requires_grad_(True)
+    out = _Norm.apply(xp, G, HW, relu)[0]
+    out.backward(go.float().squeeze(-1).permute(0, 2, 1).reshape(G * HW, C).contiguous().to(gpu))
+    want = ref.detach().squeeze(-1).permute(0, 2, 1).reshape(G * HW, C)
+    assert float((out.detach().double().cpu() - want).abs().max()) <= 2e-5
+    gw = x.grad.squeeze(-1).permute(0, 2, 1).reshape(G * HW, C)
+    err = float((xp.grad.double().cpu() - gw).abs().max()) / float(gw.abs().max())
+    assert err <= 2e-5, f"d x relative error {err:.2e}"
