@@ -312,8 +312,9 @@ int pfk_conv_stem_f32(const float* img, const float* weight, const float* bias, 
                       int H, int W, int cout, int relu, pfk_stream_t stream);
 
 /* InstanceNorm2d statistics (extractor.py:136-140; affine=False, biased variance, eps inside the sqrt) over
- * pixel-major x[B*HW][ld], channels [0, C): mean[b*C+c], rstd[b*C+c].  Deterministic two-pass reduction; needs
- * pfk_instnorm_workspace_bytes(B, C) of device scratch. */
+ * pixel-major x[B*HW][ld], channels [0, C): mean[b*C+c], rstd[b*C+c].  Deterministic two-pass reduction with double
+ * accumulators (results rounded to fp32); needs pfk_instnorm_workspace_bytes(B, C) bytes of 32-byte-aligned device scratch.
+ * Training-mode batch norm statistics are the same call with B = 1 and HW = every pixel of the batch. */
 long long pfk_instnorm_workspace_bytes(int B, int C);
 int pfk_instnorm_stats_f32(const float* x, int ld, int B, int HW, int C, float eps, float* mean, float* rstd,
                            void* workspace, long long workspace_bytes, pfk_stream_t stream);

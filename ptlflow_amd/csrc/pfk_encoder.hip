@@ -83,10 +83,16 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const float* __restrict_
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int IN_CHUNKS = 32;
 
+// Sums are carried in DOUBLE: a channel whose mean is large next to its spread (common after a biased convolution) loses the
+// low digits of (x - mean) when the mean itself carries fp32 accumulation error, and everything downstream of the norm —
+// the normalised activations, their relu masks and, in training, the weight gradients of the layers in front of it — inherits
+// that error (measured on BasicEncoder gradients: 9e-3 with fp32 sums, 1e-6 with double; MIOpen's fp32 kernels 9e-4).
+typedef double f64x4s __attribute__((ext_vector_type(4)));
+
 template <bool CENTERED>
 __global__ __launch_bounds__(256) void instnorm_partial_kernel(const float* __restrict__ x, int ld, int C, int HW,
-                                                               const float* __restrict__ sums, float* __restrict__ part) {
-  __shared__ f32x4 red[256];
+                                                               const double* __restrict__ sums, double* __restrict__ part) {
+  __shared__ f64x4s red[256];
   const int b = blockIdx.y, chunk = blockIdx.x;
   const int tpr = C >> 2;                   // threads per row
   const int rpi = 256 / tpr;                // rows per iteration
@@ -95,42 +101,45 @@ __global__ __launch_bounds__(256) void instnorm_partial_kernel(const float* __re
   const bool active = rr < rpi;
   const int rows = (HW + IN_CHUNKS - 1) / IN_CHUNKS;
   const int r0 = chunk * rows, r1 = min(HW, r0 + rows);
-  f32x4 mean = {0.f, 0.f, 0.f, 0.f};
+  f64x4s mean = {0., 0., 0., 0.};
   if (CENTERED && active) {
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < IN_CHUNKS; ++k) s += *reinterpret_cast<const f32x4*>(sums + ((long long)b * IN_CHUNKS + k) * C + c4);
-    mean = s / (float)HW;
+    f64x4s s = {0., 0., 0., 0.};
+    for (int k = 0; k < IN_CHUNKS; ++k) s += *reinterpret_cast<const f64x4s*>(sums + ((long long)b * IN_CHUNKS + k) * C + c4);
+    mean = s / (double)HW;
   }
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  f64x4s acc = {0., 0., 0., 0.};
   if (active) {
     const float* base = x + (long long)b * HW * ld + c4;
     for (int r = r0 + rr; r < r1; r += rpi) {
-      f32x4 v = *reinterpret_cast<const f32x4*>(base + (long long)r * ld);
-      if (CENTERED) { v -= mean; acc += v * v; }
-      else acc += v;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(base + (long long)r * ld);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const double d = (double)v[e] - mean[e];
+        acc[e] += CENTERED ? d * d : d;
+      }
     }
   }
   red[t] = acc;
   __syncthreads();
   if (t < tpr) {
-    f32x4 s = red[t];
+    f64x4s s = red[t];
     for (int k = 1; k < rpi; ++k) s += red[t + k * tpr];
-    *reinterpret_cast<f32x4*>(part + ((long long)b * IN_CHUNKS + chunk) * C + c4) = s;
+    *reinterpret_cast<f64x4s*>(part + ((long long)b * IN_CHUNKS + chunk) * C + c4) = s;
   }
 }
 
-__global__ void instnorm_finalize_kernel(const float* __restrict__ sums, const float* __restrict__ sq, int C, int HW,
+__global__ void instnorm_finalize_kernel(const double* __restrict__ sums, const double* __restrict__ sq, int C, int HW,
                                          float eps, float* __restrict__ mean, float* __restrict__ rstd, int total) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;   // b*C + c
   if (i >= total) return;
   const int b = i / C, c = i - b * C;
-  float s = 0.f, q = 0.f;
+  double s = 0., q = 0.;
   for (int k = 0; k < IN_CHUNKS; ++k) {
     s += sums[((long long)b * IN_CHUNKS + k) * C + c];
     q += sq[((long long)b * IN_CHUNKS + k) * C + c];
   }
-  mean[i] = s / (float)HW;
-  rstd[i] = 1.0f / sqrtf(q / (float)HW + eps);
+  mean[i] = (float)(s / (double)HW);
+  rstd[i] = (float)(1.0 / sqrt(q / (double)HW + (double)eps));
 }
 
 // y = (x - mean) * rstd ; relu? ; [y = residual + y ; relu?]   (float4 per thread)
@@ -360,7 +369,7 @@ int pfk_conv_stem_f32(const float* img, const float* weight, const float* bias, 
   return pfk_launch_status();
 }
 
-long long pfk_instnorm_workspace_bytes(int B, int C) { return (long long)B * IN_CHUNKS * C * 2 * (long long)sizeof(float); }
+long long pfk_instnorm_workspace_bytes(int B, int C) { return (long long)B * IN_CHUNKS * C * 2 * (long long)sizeof(double); }
 
 int pfk_instnorm_stats_f32(const float* x, int ld, int B, int HW, int C, float eps, float* mean, float* rstd,
                            void* workspace, long long workspace_bytes, pfk_stream_t stream) {
@@ -369,8 +378,9 @@ int pfk_instnorm_stats_f32(const float* x, int ld, int B, int HW, int C, float e
       !pfk_aligned16(rstd))
     return PFK_ERR_ALIGNMENT;
   if (workspace_bytes < pfk_instnorm_workspace_bytes(B, C)) return PFK_ERR_BAD_ARG;
-  float* sums = static_cast<float*>(workspace);
-  float* sq = sums + (size_t)B * IN_CHUNKS * C;
+  if (reinterpret_cast<uintptr_t>(workspace) & 31u) return PFK_ERR_ALIGNMENT;
+  double* sums = static_cast<double*>(workspace);
+  double* sq = sums + (size_t)B * IN_CHUNKS * C;
   hipStream_t st = static_cast<hipStream_t>(stream);
   dim3 grid(IN_CHUNKS, (unsigned)B);
   hipLaunchKernelGGL(instnorm_partial_kernel<false>, grid, dim3(256), 0, st, x, ld, C, HW, nullptr, sums);

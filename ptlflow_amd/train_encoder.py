@@ -26,6 +26,7 @@ from . import load_native
 from .train import ConvPacks, conv_pm, packs_for
 
 EPS = 1e-5
+_DEBUG_F64_STATS = False
 
 
 def _ws(nbytes: int, device) -> torch.Tensor:
@@ -74,9 +75,14 @@ class _Norm(torch.autograd.Function):
         if x.stride(1) != 1:
             x = x.contiguous()
         C = x.shape[1]
-        mean = torch.empty(G * C, device=x.device, dtype=torch.float32)
-        rstd = torch.empty(G * C, device=x.device, dtype=torch.float32)
-        ops.instnorm_stats(x, G, HW, EPS, mean, rstd, _ws(ops.instnorm_workspace_bytes(G, C), x.device))
+        if _DEBUG_F64_STATS:      # diagnostic only (scripts/enc_grad_check.py): statistics in float64 by torch
+            xd = x.double().view(G, HW, C)
+            mean = xd.mean(1).reshape(-1).float()
+            rstd = (1.0 / torch.sqrt(xd.var(1, unbiased=False) + EPS)).reshape(-1).float()
+        else:
+            mean = torch.empty(G * C, device=x.device, dtype=torch.float32)
+            rstd = torch.empty(G * C, device=x.device, dtype=torch.float32)
+            ops.instnorm_stats(x, G, HW, EPS, mean, rstd, _ws(ops.instnorm_workspace_bytes(G, C), x.device))
         out = torch.empty(x.shape[0], C, device=x.device, dtype=torch.float32)
         ops.norm_apply(x, mean, rstd, None, out, G, HW, relu, False)
         ctx.save_for_backward(x, mean, rstd)

@@ -115,6 +115,13 @@ def test_encoder_train_gradients(gpu, kind, small, B, H, W):
     keys = sorted(leaves)
     gref = dict(zip(keys, torch.autograd.grad((ref * go).sum(), [leaves[k] for k in keys], allow_unused=True)))
     rm0 = {k: v.clone() for k, v in enc.state_dict().items() if "running_" in k}
+    # the same graph in float32 on the CPU (torch's own kernels): what fp32 can deliver on this network — gradients behind a
+    # normalisation are heavily cancelling sums, and on random-weight encoders fp32 autograd itself is 1e-2 off on some tensors
+    cpu32 = Encoder(out_dim, kind, small)
+    cpu32.load_state_dict({k[len("fnet."):]: v for k, v in sd.items()})
+    cpu32.train()
+    (cpu32(x) * go.float()).sum().backward()
+    g32 = {n: p.grad.double() for n, p in cpu32.named_parameters()}
     enc = enc.to(gpu).train()
     out = encoder_train(enc, x.to(gpu))
     assert tuple(out.shape) == tuple(ref.shape)
@@ -128,10 +135,12 @@ def test_encoder_train_gradients(gpu, kind, small, B, H, W):
         if r is None:
             continue
         s = max(float(r.abs().max()), 1e-3 * smax)
-        rows.append((float((p.grad.double().cpu() - r).abs().max()) / s, n))
+        e_gpu = float((p.grad.double().cpu() - r).abs().max()) / s
+        e_cpu = float((g32[n] - r).abs().max()) / s
+        rows.append((e_gpu / max(5e-4, 5.0 * e_cpu), e_gpu, e_cpu, n))
     rows.sort(reverse=True)
-    print("encoder_train worst gradient errors:", ", ".join(f"{e:.1e} {n}" for e, n in rows[:4]))
-    assert rows[0][0] <= 5e-4, rows[:5]
+    print("encoder_train worst gradient errors (libpfk, fp32 CPU autograd):", ", ".join(f"{e:.1e} / {c:.1e} {n}" for _, e, c, n in rows[:4]))
+    assert rows[0][0] <= 1.0, rows[:5]
     if kind == "batch":   # running statistics: momentum 0.1, unbiased variance (nn.BatchNorm2d)
         tm = Encoder(out_dim, kind, small)
         tm.load_state_dict({k[len("fnet."):]: v for k, v in sd.items()})
