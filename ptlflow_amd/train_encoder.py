@@ -27,6 +27,7 @@ from .train import ConvPacks, conv_pm, packs_for
 
 EPS = 1e-5
 _DEBUG_F64_STATS = False
+_DEBUG_BN = ""
 
 
 def _ws(nbytes: int, device) -> torch.Tensor:
@@ -111,6 +112,17 @@ def _norm(kind: str, x: torch.Tensor, B: int, HW: int, bn: Optional[torch.nn.Mod
     if kind == "instance":
         return _Norm.apply(x, B, HW, relu)[0]
     # nn.BatchNorm2d in training mode: batch statistics, affine, running buffers updated with momentum (unbiased variance)
+    if _DEBUG_BN == "miopen":      # diagnostics only (scripts/enc_grad_check.py)
+        import torch.nn.functional as F
+        C = x.shape[1]
+        y = F.batch_norm(x.view(B, HW, C).permute(0, 2, 1).reshape(B, C, HW, 1), None, None, bn.weight, bn.bias, True, 0.1, EPS)
+        y = y.reshape(B, C, HW).permute(0, 2, 1).reshape(B * HW, C)
+        return torch.relu(y) if relu else y
+    if _DEBUG_BN == "torch":
+        m = x.mean(0, keepdim=True)
+        v = (x - m).square().mean(0, keepdim=True)
+        y = (x - m) * torch.rsqrt(v + EPS) * bn.weight + bn.bias
+        return torch.relu(y) if relu else y
     xh, mean, rstd = _Norm.apply(x, 1, B * HW, False)
     y = xh * bn.weight + bn.bias
     if bn.track_running_stats and bn.running_mean is not None:
