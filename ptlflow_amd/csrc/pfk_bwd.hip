@@ -48,20 +48,22 @@ __global__ __launch_bounds__(256) void lookup_bwd_kernel(const LookupBwdArgs a) 
 
   const int lane = threadIdx.x & 63;
   const int wid = threadIdx.x >> 6;
-  const long long M = (long long)a.B * a.h * a.w;
-  const long long p0 = (long long)blockIdx.x * PIX;
-  const int N = a.h * a.w;
+  const unsigned M = (unsigned)a.B * (unsigned)a.h * (unsigned)a.w;   // < 2^31 (checked by the host): 32-bit scalar arithmetic
+  const unsigned p0 = blockIdx.x * (unsigned)PIX;
+  const unsigned N = (unsigned)(a.h * a.w);
 
   float cx0[PIX], cy0[PIX];
+  {
+    unsigned b = p0 / N, pix = p0 - b * N;
 #pragma unroll
-  for (int q = 0; q < PIX; ++q) {
-    const long long p = p0 + q;
-    cx0[q] = 0.f; cy0[q] = 0.f;
-    if (p < M) {
-      const int b = (int)(p / N);
-      const int pix = (int)(p % N);
-      cx0[q] = a.coords[((long long)b * 2 + 0) * N + pix];
-      cy0[q] = a.coords[((long long)b * 2 + 1) * N + pix];
+    for (int q = 0; q < PIX; ++q) {
+      cx0[q] = 0.f; cy0[q] = 0.f;
+      if (p0 + q < M) {
+        const float* cb = a.coords + (size_t)b * 2 * N + pix;
+        cx0[q] = cb[0];
+        cy0[q] = cb[N];
+      }
+      if (++pix == N) { pix = 0; ++b; }
     }
   }
 
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(256) void lookup_bwd_kernel(const LookupBwdArgs a) 
       }
       for (int idx = lane; idx < PIX * nn; idx += 64) {
         const int q = idx / nn, k = idx - q * nn;
-        s_g[wid][q][k] = (p0 + q < M) ? a.gout[(p0 + q) * a.gout_ld + l * nn + k] : 0.f;
+        s_g[wid][q][k] = (p0 + q < M) ? a.gout[(size_t)(p0 + q) * (unsigned)a.gout_ld + l * nn + k] : 0.f;
       }
     }
     wave_lds_sync();
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(256) void lookup_bwd_kernel(const LookupBwdArgs a) 
         for (int qq = 1; qq < PIX; ++qq) if (q == qq) { xb_q = xbi[qq]; yb_q = ybi[qq]; }
         const int gy = yb_q + yy, gx = xb_q + xx;
         if (p0 + q < M && (unsigned)gy < (unsigned)Hl && (unsigned)gx < (unsigned)Wl) {
-          float* dst = a.gl[l] + (p0 + q) * a.lld[l] + (long long)gy * Wl + gx;
+          float* dst = a.gl[l] + (size_t)(p0 + q) * (size_t)a.lld[l] + (gy * Wl + gx);
           *dst += acc;
         }
       }
@@ -261,8 +263,8 @@ int pfk_corr_lookup_bwd_f32(const pfk_lookup_bwd_desc* d, pfk_stream_t stream) {
   }
   a.L = d->num_levels; a.r = d->radius; a.B = d->B; a.h = d->h; a.w = d->w;
   a.coords = d->coords; a.gout = d->grad_out; a.gout_ld = d->grad_out_ld;
+  if ((long long)d->B * d->h * d->w >= 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
   const long long blocks = ((long long)d->B * d->h * d->w + BPIX - 1) / BPIX;
-  if (blocks > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
   const dim3 grid((unsigned)blocks), block(256);
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (d->radius) {

@@ -54,20 +54,24 @@ __global__ __launch_bounds__(256) void lookup_kernel(const LookupArgs a) {
 
   const int lane = threadIdx.x & 63;
   const int wid = threadIdx.x >> 6;
-  const long long M = (long long)a.B * a.h * a.w;
-  const long long p0 = (long long)blockIdx.x * PIX;
-  const int N = a.h * a.w;
+  // 32-bit pixel arithmetic (the host guarantees B*h*w < 2^31): the block index is wave-uniform, so everything derived from
+  // it lives on the CU's single scalar unit — 64-bit divisions and multiplications there were the kernel's bottleneck
+  const unsigned M = (unsigned)a.B * (unsigned)a.h * (unsigned)a.w;
+  const unsigned p0 = blockIdx.x * (unsigned)PIX;
+  const unsigned N = (unsigned)(a.h * a.w);
 
   float cx0[PIX], cy0[PIX];
+  {
+    unsigned b = p0 / N, pix = p0 - b * N;      // one division per block; the other pixels step from it
 #pragma unroll
-  for (int q = 0; q < PIX; ++q) {
-    const long long p = p0 + q;
-    cx0[q] = 0.f; cy0[q] = 0.f;
-    if (p < M) {
-      const int b = (int)(p / N);
-      const int pix = (int)(p % N);
-      cx0[q] = a.coords[((long long)b * 2 + 0) * N + pix];
-      cy0[q] = a.coords[((long long)b * 2 + 1) * N + pix];
+    for (int q = 0; q < PIX; ++q) {
+      cx0[q] = 0.f; cy0[q] = 0.f;
+      if (p0 + q < M) {
+        const float* cb = a.coords + (size_t)b * 2 * N + pix;
+        cx0[q] = cb[0];
+        cy0[q] = cb[N];
+      }
+      if (++pix == N) { pix = 0; ++b; }
     }
   }
 
@@ -78,6 +82,7 @@ __global__ __launch_bounds__(256) void lookup_kernel(const LookupArgs a) {
     if (active) {
       const int Hl = a.lh[l], Wl = a.lw[l];
       const float inv = 1.0f / (float)(1 << l);   // coords / 2**l is exact (corr.py:45)
+      const T* vol0 = static_cast<const T*>(a.lv[l]) + (size_t)p0 * (unsigned)(Hl * Wl);   // one 32x32->64 multiply per level
       float v[PIX][3];
       // tap tables of all PIX pixels in ONE pass: lane = q * n + i evaluates window index i of pixel q on both axes (two IEEE
       // divisions per lane; one pass over 36 lanes instead of PIX passes over 9)
@@ -106,7 +111,7 @@ __global__ __launch_bounds__(256) void lookup_kernel(const LookupArgs a) {
         const float yb = floorf(cy) - (float)(R + 1);
         const int xbi = safe_base(xb), ybi = safe_base(yb);
         const bool pl = (p0 + q) < M;
-        const T* vol = static_cast<const T*>(a.lv[l]) + (p0 + q) * (long long)Hl * Wl;
+        const T* vol = vol0 + (size_t)q * (unsigned)(Hl * Wl);
 #pragma unroll
         for (int e3 = 0; e3 < 3; ++e3) {          // all loads of all PIX patches are issued before any is used
           const int e = lane + 64 * e3;
@@ -114,7 +119,7 @@ __global__ __launch_bounds__(256) void lookup_kernel(const LookupArgs a) {
           const int gy = ybi + yy, gx = xbi + xx;
           float t = 0.f;
           if (pl && e < PATCH * PATCH && (unsigned)gy < (unsigned)Hl && (unsigned)gx < (unsigned)Wl)
-            t = (float)vol[(long long)gy * Wl + gx];   // bf16 volume: exact widening (grid_sample runs in fp32 under autocast)
+            t = (float)vol[gy * Wl + gx];   // 32-bit offset inside one map; bf16 volume: exact widening (grid_sample is fp32 under autocast)
           v[q][e3] = t;
         }
       }
@@ -133,6 +138,7 @@ __global__ __launch_bounds__(256) void lookup_kernel(const LookupArgs a) {
     if (active) {
       // the PIX * (2R+1)^2 samples of this level as one flat list over the lanes (324 = 5.06 wave-iterations at R = 4
       // instead of 4 x 2 with 47 idle lanes in every second one)
+      float* outl = a.out + (size_t)p0 * (unsigned)a.out_ld + l * nn;
       for (int idx = lane; idx < PIX * nn; idx += 64) {
         const int q = idx / nn, k = idx - q * nn;
         if (p0 + q >= M) continue;
@@ -146,7 +152,7 @@ __global__ __launch_bounds__(256) void lookup_kernel(const LookupArgs a) {
         t = fmaf(ne, w_ne, t);
         t = fmaf(sw, w_sw, t);
         t = fmaf(se, w_se, t);
-        a.out[(p0 + q) * a.out_ld + l * nn + k] = t;
+        outl[q * a.out_ld + k] = t;
       }
     }
     wave_lds_sync();   // the next round restages this wave's region
@@ -205,8 +211,8 @@ int lookup_launch(const pfk_lookup_desc* d, pfk_stream_t stream) {
   }
   a.L = d->num_levels; a.r = d->radius; a.B = d->B; a.h = d->h; a.w = d->w;
   a.coords = d->coords; a.out = d->out; a.out_ld = d->out_ld;
+  if ((long long)d->B * d->h * d->w >= 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;   // the kernel's pixel arithmetic is 32-bit
   const long long blocks = ((long long)d->B * d->h * d->w + PIX - 1) / PIX;
-  if (blocks > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
   const dim3 grid((unsigned)blocks), block(256);
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (d->radius) {

@@ -81,7 +81,10 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const float* __restrict_
 // partials in a fixed order; finalize: mean, rstd = 1/sqrt(var_biased + eps)  (F.instance_norm, extractor.py:136-140).
 // A thread owns 4 consecutive channels (float4) and every (256 / (C/4))-th row of the chunk.
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int IN_CHUNKS = 32;
+constexpr int IN_CHUNKS_MAX = 256;   // partial-sum slots per image in the workspace
+// chunks per image: enough blocks to fill the chip at small batches (the partial kernels are latency-bound per block), 32 once
+// the batch alone provides them
+static inline int in_chunks(int B) { int c = 1024 / (B > 0 ? B : 1); return c < 32 ? 32 : (c > IN_CHUNKS_MAX ? IN_CHUNKS_MAX : c); }
 
 // Sums are carried in DOUBLE: a channel whose mean is large next to its spread (common after a biased convolution) loses the
 // low digits of (x - mean) when the mean itself carries fp32 accumulation error, and everything downstream of the norm —
@@ -99,18 +102,33 @@ __global__ __launch_bounds__(256) void instnorm_partial_kernel(const float* __re
   const int t = threadIdx.x;
   const int c4 = (t % tpr) * 4, rr = t / tpr;
   const bool active = rr < rpi;
-  const int rows = (HW + IN_CHUNKS - 1) / IN_CHUNKS;
+  const int nch = (int)gridDim.x;
+  const int rows = (HW + nch - 1) / nch;
   const int r0 = chunk * rows, r1 = min(HW, r0 + rows);
   f64x4s mean = {0., 0., 0., 0.};
   if (CENTERED && active) {
     f64x4s s = {0., 0., 0., 0.};
-    for (int k = 0; k < IN_CHUNKS; ++k) s += *reinterpret_cast<const f64x4s*>(sums + ((long long)b * IN_CHUNKS + k) * C + c4);
+    for (int k = 0; k < nch; ++k) s += *reinterpret_cast<const f64x4s*>(sums + ((long long)b * nch + k) * C + c4);
     mean = s / (double)HW;
   }
   f64x4s acc = {0., 0., 0., 0.};
   if (active) {
     const float* base = x + (long long)b * HW * ld + c4;
-    for (int r = r0 + rr; r < r1; r += rpi) {
+    // two independent accumulator sets: the fp64 add / fma chain of one set would otherwise serialise the loop (a chunk has
+    // only a few hundred rows per thread and, at batch 1, the grid is far from filling the chip)
+    f64x4s acc1 = {0., 0., 0., 0.};
+    int r = r0 + rr;
+    for (; r + rpi < r1; r += 2 * rpi) {
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(base + (long long)r * ld);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(base + (long long)(r + rpi) * ld);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const double d0 = (double)v0[e] - mean[e], d1 = (double)v1[e] - mean[e];
+        acc[e] += CENTERED ? d0 * d0 : d0;
+        acc1[e] += CENTERED ? d1 * d1 : d1;
+      }
+    }
+    if (r < r1) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(base + (long long)r * ld);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -118,25 +136,26 @@ __global__ __launch_bounds__(256) void instnorm_partial_kernel(const float* __re
         acc[e] += CENTERED ? d * d : d;
       }
     }
+    acc += acc1;
   }
   red[t] = acc;
   __syncthreads();
   if (t < tpr) {
     f64x4s s = red[t];
     for (int k = 1; k < rpi; ++k) s += red[t + k * tpr];
-    *reinterpret_cast<f64x4s*>(part + ((long long)b * IN_CHUNKS + chunk) * C + c4) = s;
+    *reinterpret_cast<f64x4s*>(part + ((long long)b * nch + chunk) * C + c4) = s;
   }
 }
 
-__global__ void instnorm_finalize_kernel(const double* __restrict__ sums, const double* __restrict__ sq, int C, int HW,
+__global__ void instnorm_finalize_kernel(const double* __restrict__ sums, const double* __restrict__ sq, int nch, int C, int HW,
                                          float eps, float* __restrict__ mean, float* __restrict__ rstd, int total) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;   // b*C + c
   if (i >= total) return;
   const int b = i / C, c = i - b * C;
   double s = 0., q = 0.;
-  for (int k = 0; k < IN_CHUNKS; ++k) {
-    s += sums[((long long)b * IN_CHUNKS + k) * C + c];
-    q += sq[((long long)b * IN_CHUNKS + k) * C + c];
+  for (int k = 0; k < nch; ++k) {
+    s += sums[((long long)b * nch + k) * C + c];
+    q += sq[((long long)b * nch + k) * C + c];
   }
   mean[i] = (float)(s / (double)HW);
   rstd[i] = (float)(1.0 / sqrt(q / (double)HW + (double)eps));
@@ -197,7 +216,8 @@ __global__ __launch_bounds__(256) void norm_bwd_partial_kernel(const float* __re
   const int t = threadIdx.x;
   const int c4 = (t % tpr) * 4, rr = t / tpr;
   const bool active = rr < rpi;
-  const int rows = (HW + IN_CHUNKS - 1) / IN_CHUNKS;
+  const int nch = (int)gridDim.x;
+  const int rows = (HW + nch - 1) / nch;
   const int r0 = chunk * rows, r1 = min(HW, r0 + rows);
   f64x4 a1 = {0., 0., 0., 0.}, a2 = {0., 0., 0., 0.};
   if (active) {
@@ -221,22 +241,22 @@ __global__ __launch_bounds__(256) void norm_bwd_partial_kernel(const float* __re
   if (t < tpr) {
     f64x4 s1 = red1[t], s2 = red2[t];
     for (int k = 1; k < rpi; ++k) { s1 += red1[t + k * tpr]; s2 += red2[t + k * tpr]; }
-    *reinterpret_cast<f64x4*>(part1 + ((long long)b * IN_CHUNKS + chunk) * C + c4) = s1;
-    *reinterpret_cast<f64x4*>(part2 + ((long long)b * IN_CHUNKS + chunk) * C + c4) = s2;
+    *reinterpret_cast<f64x4*>(part1 + ((long long)b * nch + chunk) * C + c4) = s1;
+    *reinterpret_cast<f64x4*>(part2 + ((long long)b * nch + chunk) * C + c4) = s2;
   }
 }
 
 // s1 / s2 in double for the apply pass; float copies for the caller (d beta / d gamma of an affine batch norm)
-__global__ void norm_bwd_finalize_kernel(const double* __restrict__ part1, const double* __restrict__ part2, int C,
+__global__ void norm_bwd_finalize_kernel(const double* __restrict__ part1, const double* __restrict__ part2, int nch, int C,
                                          double* __restrict__ d1, double* __restrict__ d2, float* __restrict__ s1,
                                          float* __restrict__ s2, int total) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;   // b*C + c
   if (i >= total) return;
   const int b = i / C, c = i - b * C;
   double a = 0., q = 0.;
-  for (int k = 0; k < IN_CHUNKS; ++k) {
-    a += part1[((long long)b * IN_CHUNKS + k) * C + c];
-    q += part2[((long long)b * IN_CHUNKS + k) * C + c];
+  for (int k = 0; k < nch; ++k) {
+    a += part1[((long long)b * nch + k) * C + c];
+    q += part2[((long long)b * nch + k) * C + c];
   }
   d1[i] = a; d2[i] = q;
   if (s1) s1[i] = (float)a;
@@ -369,7 +389,7 @@ int pfk_conv_stem_f32(const float* img, const float* weight, const float* bias, 
   return pfk_launch_status();
 }
 
-long long pfk_instnorm_workspace_bytes(int B, int C) { return (long long)B * IN_CHUNKS * C * 2 * (long long)sizeof(double); }
+long long pfk_instnorm_workspace_bytes(int B, int C) { return (long long)B * in_chunks(B) * C * 2 * (long long)sizeof(double); }
 
 int pfk_instnorm_stats_f32(const float* x, int ld, int B, int HW, int C, float eps, float* mean, float* rstd,
                            void* workspace, long long workspace_bytes, pfk_stream_t stream) {
@@ -380,19 +400,20 @@ int pfk_instnorm_stats_f32(const float* x, int ld, int B, int HW, int C, float e
   if (workspace_bytes < pfk_instnorm_workspace_bytes(B, C)) return PFK_ERR_BAD_ARG;
   if (reinterpret_cast<uintptr_t>(workspace) & 31u) return PFK_ERR_ALIGNMENT;
   double* sums = static_cast<double*>(workspace);
-  double* sq = sums + (size_t)B * IN_CHUNKS * C;
+  const int nch = in_chunks(B);
+  double* sq = sums + (size_t)B * nch * C;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  dim3 grid(IN_CHUNKS, (unsigned)B);
+  dim3 grid((unsigned)nch, (unsigned)B);
   hipLaunchKernelGGL(instnorm_partial_kernel<false>, grid, dim3(256), 0, st, x, ld, C, HW, nullptr, sums);
   hipLaunchKernelGGL(instnorm_partial_kernel<true>, grid, dim3(256), 0, st, x, ld, C, HW, sums, sq);
   const int total = B * C;
-  hipLaunchKernelGGL(instnorm_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, st, sums, sq, C, HW, eps, mean,
+  hipLaunchKernelGGL(instnorm_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, st, sums, sq, nch, C, HW, eps, mean,
                      rstd, total);
   return pfk_launch_status();
 }
 
 
-long long pfk_norm_bwd_workspace_bytes(int B, int C) { return ((long long)B * IN_CHUNKS * C * 2 + (long long)B * C * 2) * (long long)sizeof(double); }
+long long pfk_norm_bwd_workspace_bytes(int B, int C) { return ((long long)B * in_chunks(B) * C * 2 + (long long)B * C * 2) * (long long)sizeof(double); }
 
 int pfk_norm_bwd_f32(const float* x, int x_ld, const float* dy, int dy_ld, const float* mean, const float* rstd, float* dx,
                      int dx_ld, float* sum_g, float* sum_gxhat, int B, int HW, int C, int relu, void* workspace,
@@ -404,14 +425,15 @@ int pfk_norm_bwd_f32(const float* x, int x_ld, const float* dy, int dy_ld, const
     return PFK_ERR_ALIGNMENT;
   if (workspace_bytes < pfk_norm_bwd_workspace_bytes(B, C)) return PFK_ERR_BAD_ARG;
   double* p1 = static_cast<double*>(workspace);
-  double* p2 = p1 + (size_t)B * IN_CHUNKS * C;
-  double* d1 = p2 + (size_t)B * IN_CHUNKS * C;
+  const int nch = in_chunks(B);
+  double* p2 = p1 + (size_t)B * nch * C;
+  double* d1 = p2 + (size_t)B * nch * C;
   double* d2 = d1 + (size_t)B * C;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(norm_bwd_partial_kernel, dim3(IN_CHUNKS, (unsigned)B), dim3(256), 0, st, x, x_ld, dy, dy_ld, mean, rstd, C, HW,
+  hipLaunchKernelGGL(norm_bwd_partial_kernel, dim3((unsigned)nch, (unsigned)B), dim3(256), 0, st, x, x_ld, dy, dy_ld, mean, rstd, C, HW,
                      relu, p1, p2);
   const int total = B * C;
-  hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, st, p1, p2, C, d1, d2, sum_g, sum_gxhat, total);
+  hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, st, p1, p2, nch, C, d1, d2, sum_g, sum_gxhat, total);
   const long long M = (long long)B * HW;
   const long long blocks = (M * (C >> 2) + 255) / 256;
   if (blocks > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
