@@ -62,6 +62,8 @@ int pfk_abi_version(void);
 const char* pfk_status_string(int status);
 /* tuning/debug knob: force the implicit-GEMM tile configuration (-1 = heuristic). Not thread-safe. */
 void pfk_debug_set_tile(int cfg);
+/* tuning knob of the pyramid lookup: source pixels per workgroup, 4 (default) or 8. Not thread-safe. */
+void pfk_debug_set_lookup_pix(int pix);
 
 /* ---- K1: all-pairs correlation --------------------------------------------------------------
  * out[b][i][j] = scale * sum_d f1[b][i][d] * f2[b][j][d]        (fp32 MFMA, exact fp32 products)

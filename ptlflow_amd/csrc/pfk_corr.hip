@@ -41,8 +41,7 @@ struct LookupArgs {
 // staging and sampling is within the wave: LDS operations of a wave complete in order, `s_waitcnt lgkmcnt(0)` (also a
 // compiler barrier) is enough — no workgroup barrier couples the four levels' very different amounts of work.
 
-constexpr int PIX = 4;
-static_assert(PIX * 9 <= 64, "one table pass covers PIX * (2R+1) <= 64 lanes");
+// (pixels per workgroup: template parameter PIX, 4 by default — lookup_launch)
 
 // R = radius (compile-time: the (2R+1)^2 sample enumeration divides by constants), PIX pixels per workgroup.
 template <int PIX, int R, typename T>
@@ -84,10 +83,10 @@ __global__ __launch_bounds__(256) void lookup_kernel(const LookupArgs a) {
       const float inv = 1.0f / (float)(1 << l);   // coords / 2**l is exact (corr.py:45)
       const T* vol0 = static_cast<const T*>(a.lv[l]) + (size_t)p0 * (unsigned)(Hl * Wl);   // one 32x32->64 multiply per level
       float v[PIX][3];
-      // tap tables of all PIX pixels in ONE pass: lane = q * n + i evaluates window index i of pixel q on both axes (two IEEE
-      // divisions per lane; one pass over 36 lanes instead of PIX passes over 9)
-      if (lane < PIX * n) {
-        const int q = lane / n, i = lane - q * n;
+      // tap tables of all PIX pixels in one pass (two for PIX = 8): entry e = q * n + i evaluates window index i of pixel q on
+      // both axes (two IEEE divisions per lane; one pass over 36 lanes instead of PIX passes over 9)
+      for (int e = lane; e < PIX * n; e += 64) {
+        const int q = e / n, i = e - q * n;
         float cxq = cx0[0], cyq = cy0[0];
 #pragma unroll
         for (int qq = 1; qq < PIX; ++qq) { cxq = (q == qq) ? cx0[qq] : cxq; cyq = (q == qq) ? cy0[qq] : cyq; }
@@ -196,6 +195,20 @@ __global__ __launch_bounds__(256) void fmap_pool2x2_kernel(const float* __restri
   *reinterpret_cast<f32x4*>(out + ((b * Ho + yo) * (long long)Wo + xo) * out_ld + c) = (((a00 + a01) + a10) + a11) * 0.25f;
 }
 
+int g_lookup_pix = 4;   // pixels per workgroup: 4 or 8 (pfk_debug_set_lookup_pix; tuning knob)
+
+template <int PX, typename T>
+int lookup_launch_pix(const LookupArgs& a, int radius, long long M, hipStream_t st) {
+  const dim3 grid((unsigned)((M + PX - 1) / PX)), block(256);
+  switch (radius) {
+    case 1: hipLaunchKernelGGL((lookup_kernel<PX, 1, T>), grid, block, 0, st, a); break;
+    case 2: hipLaunchKernelGGL((lookup_kernel<PX, 2, T>), grid, block, 0, st, a); break;
+    case 3: hipLaunchKernelGGL((lookup_kernel<PX, 3, T>), grid, block, 0, st, a); break;
+    default: hipLaunchKernelGGL((lookup_kernel<PX, 4, T>), grid, block, 0, st, a); break;
+  }
+  return pfk_launch_status();
+}
+
 template <typename T>
 int lookup_launch(const pfk_lookup_desc* d, pfk_stream_t stream) {
   if (!d || !d->coords || !d->out) return PFK_ERR_BAD_ARG;
@@ -211,17 +224,10 @@ int lookup_launch(const pfk_lookup_desc* d, pfk_stream_t stream) {
   }
   a.L = d->num_levels; a.r = d->radius; a.B = d->B; a.h = d->h; a.w = d->w;
   a.coords = d->coords; a.out = d->out; a.out_ld = d->out_ld;
-  if ((long long)d->B * d->h * d->w >= 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;   // the kernel's pixel arithmetic is 32-bit
-  const long long blocks = ((long long)d->B * d->h * d->w + PIX - 1) / PIX;
-  const dim3 grid((unsigned)blocks), block(256);
+  const long long M = (long long)d->B * d->h * d->w;
+  if (M >= 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;   // the kernel's pixel arithmetic is 32-bit
   hipStream_t st = static_cast<hipStream_t>(stream);
-  switch (d->radius) {
-    case 1: hipLaunchKernelGGL((lookup_kernel<PIX, 1, T>), grid, block, 0, st, a); break;
-    case 2: hipLaunchKernelGGL((lookup_kernel<PIX, 2, T>), grid, block, 0, st, a); break;
-    case 3: hipLaunchKernelGGL((lookup_kernel<PIX, 3, T>), grid, block, 0, st, a); break;
-    default: hipLaunchKernelGGL((lookup_kernel<PIX, 4, T>), grid, block, 0, st, a); break;
-  }
-  return pfk_launch_status();
+  return g_lookup_pix == 8 ? lookup_launch_pix<8, T>(a, d->radius, M, st) : lookup_launch_pix<4, T>(a, d->radius, M, st);
 }
 
 template <typename T>
@@ -240,6 +246,8 @@ int pool_launch(const T* in, T* out, int64_t M, int H, int W, pfk_stream_t strea
 }  // namespace
 
 extern "C" {
+
+void pfk_debug_set_lookup_pix(int pix) { g_lookup_pix = pix == 8 ? 8 : 4; }
 
 int pfk_corr_lookup_f32(const pfk_lookup_desc* d, pfk_stream_t stream) { return lookup_launch<float>(d, stream); }
 

@@ -77,8 +77,8 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const float* __restrict_
 
 // ------------------------------------------------------------------------------------------------------------------
 // Instance-norm statistics over pixel-major x[B*HW][ld], channels [0, C), C % 4 == 0.
-// Pass 1: per (image, chunk) partial sums; pass 2: partial sums of (x - mean)^2 with the mean re-derived from pass 1's
-// partials in a fixed order; finalize: mean, rstd = 1/sqrt(var_biased + eps)  (F.instance_norm, extractor.py:136-140).
+// Pass 1: per (image, chunk) partial sums, reduced over the chunks in a fixed order (chunk_reduce_kernel); pass 2: partial sums
+// of (x - mean)^2, reduced the same way; finish: mean, rstd = 1/sqrt(var_biased + eps)  (F.instance_norm, extractor.py:136-140).
 // A thread owns 4 consecutive channels (float4) and every (256 / (C/4))-th row of the chunk.
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int IN_CHUNKS_MAX = 256;   // partial-sum slots per image in the workspace
@@ -106,11 +106,7 @@ __global__ __launch_bounds__(256) void instnorm_partial_kernel(const float* __re
   const int rows = (HW + nch - 1) / nch;
   const int r0 = chunk * rows, r1 = min(HW, r0 + rows);
   f64x4s mean = {0., 0., 0., 0.};
-  if (CENTERED && active) {
-    f64x4s s = {0., 0., 0., 0.};
-    for (int k = 0; k < nch; ++k) s += *reinterpret_cast<const f64x4s*>(sums + ((long long)b * nch + k) * C + c4);
-    mean = s / (double)HW;
-  }
+  if (CENTERED && active) mean = *reinterpret_cast<const f64x4s*>(sums + (long long)b * C + c4) / (double)HW;   // sums: [B][C] totals
   f64x4s acc = {0., 0., 0., 0.};
   if (active) {
     const float* base = x + (long long)b * HW * ld + c4;
@@ -147,18 +143,31 @@ __global__ __launch_bounds__(256) void instnorm_partial_kernel(const float* __re
   }
 }
 
-__global__ void instnorm_finalize_kernel(const double* __restrict__ sums, const double* __restrict__ sq, int nch, int C, int HW,
-                                         float eps, float* __restrict__ mean, float* __restrict__ rstd, int total) {
+// part[b][k][c], k < nch  ->  tot[b][c] = sum_k, for NA arrays laid out one after the other (stride `astride` doubles in part,
+// B*C in tot).  One block per (64 channels, image): thread = (channel, one of four chunk slices); slices are combined through LDS
+// in a fixed order, so the result does not depend on the launch.  (A single thread per (b, c) walking all chunks is a chain of
+// nch dependent loads — 66 us at 256 chunks, more than the pass that produced them.)
+__global__ __launch_bounds__(256) void chunk_reduce_kernel(const double* __restrict__ part, long long astride, int NA, int nch, int C,
+                                                           double* __restrict__ tot, long long tstride) {
+  __shared__ double red[4][64];
+  const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+  for (int a = 0; a < NA; ++a) {
+    double s = 0.;
+    if (c < C)
+      for (int k = sl; k < nch; k += 4) s += part[a * astride + ((long long)b * nch + k) * C + c];
+    red[sl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (sl == 0 && c < C) tot[a * tstride + (long long)b * C + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    __syncthreads();
+  }
+}
+
+__global__ void instnorm_finish_kernel(const double* __restrict__ sum, const double* __restrict__ sq, int HW, float eps,
+                                       float* __restrict__ mean, float* __restrict__ rstd, int total) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;   // b*C + c
   if (i >= total) return;
-  const int b = i / C, c = i - b * C;
-  double s = 0., q = 0.;
-  for (int k = 0; k < nch; ++k) {
-    s += sums[((long long)b * nch + k) * C + c];
-    q += sq[((long long)b * nch + k) * C + c];
-  }
-  mean[i] = (float)(s / (double)HW);
-  rstd[i] = (float)(1.0 / sqrt(q / (double)HW + (double)eps));
+  mean[i] = (float)(sum[i] / (double)HW);
+  rstd[i] = (float)(1.0 / sqrt(sq[i] / (double)HW + (double)eps));
 }
 
 // y = (x - mean) * rstd ; relu? ; [y = residual + y ; relu?]   (float4 per thread)
@@ -246,21 +255,13 @@ __global__ __launch_bounds__(256) void norm_bwd_partial_kernel(const float* __re
   }
 }
 
-// s1 / s2 in double for the apply pass; float copies for the caller (d beta / d gamma of an affine batch norm)
-__global__ void norm_bwd_finalize_kernel(const double* __restrict__ part1, const double* __restrict__ part2, int nch, int C,
-                                         double* __restrict__ d1, double* __restrict__ d2, float* __restrict__ s1,
-                                         float* __restrict__ s2, int total) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;   // b*C + c
+// float copies of the reduced sums for the caller (d beta / d gamma of an affine batch norm)
+__global__ void norm_bwd_copy_kernel(const double* __restrict__ d1, const double* __restrict__ d2, float* __restrict__ s1,
+                                     float* __restrict__ s2, int total) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
-  const int b = i / C, c = i - b * C;
-  double a = 0., q = 0.;
-  for (int k = 0; k < nch; ++k) {
-    a += part1[((long long)b * nch + k) * C + c];
-    q += part2[((long long)b * nch + k) * C + c];
-  }
-  d1[i] = a; d2[i] = q;
-  if (s1) s1[i] = (float)a;
-  if (s2) s2[i] = (float)q;
+  if (s1) s1[i] = (float)d1[i];
+  if (s2) s2[i] = (float)d2[i];
 }
 
 __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __restrict__ x, int x_ld, const float* __restrict__ dy,
@@ -389,29 +390,29 @@ int pfk_conv_stem_f32(const float* img, const float* weight, const float* bias, 
   return pfk_launch_status();
 }
 
-long long pfk_instnorm_workspace_bytes(int B, int C) { return (long long)B * in_chunks(B) * C * 2 * (long long)sizeof(double); }
+long long pfk_instnorm_workspace_bytes(int B, int C) { return ((long long)B * in_chunks(B) * C + 2LL * B * C) * (long long)sizeof(double); }
 
 int pfk_instnorm_stats_f32(const float* x, int ld, int B, int HW, int C, float eps, float* mean, float* rstd,
                            void* workspace, long long workspace_bytes, pfk_stream_t stream) {
   if (!x || !mean || !rstd || !workspace || B <= 0 || HW <= 0 || C <= 0 || ld < C) return PFK_ERR_BAD_ARG;
-  if ((C & 3) || (ld & 3) || C > 1024 || !pfk_aligned16(x) || !pfk_aligned16(workspace) || !pfk_aligned16(mean) ||
-      !pfk_aligned16(rstd))
+  if ((C & 3) || (ld & 3) || C > 1024 || !pfk_aligned16(x) || !pfk_aligned16(mean) || !pfk_aligned16(rstd) ||
+      (reinterpret_cast<uintptr_t>(workspace) & 31u))
     return PFK_ERR_ALIGNMENT;
   if (workspace_bytes < pfk_instnorm_workspace_bytes(B, C)) return PFK_ERR_BAD_ARG;
-  if (reinterpret_cast<uintptr_t>(workspace) & 31u) return PFK_ERR_ALIGNMENT;
-  double* sums = static_cast<double*>(workspace);
   const int nch = in_chunks(B);
-  double* sq = sums + (size_t)B * nch * C;
+  double* part = static_cast<double*>(workspace);            // [B][nch][C], reused by both passes
+  double* sum = part + (size_t)B * nch * C;                  // [B][C]
+  double* sq = sum + (size_t)B * C;                          // [B][C]
   hipStream_t st = static_cast<hipStream_t>(stream);
-  dim3 grid((unsigned)nch, (unsigned)B);
-  hipLaunchKernelGGL(instnorm_partial_kernel<false>, grid, dim3(256), 0, st, x, ld, C, HW, nullptr, sums);
-  hipLaunchKernelGGL(instnorm_partial_kernel<true>, grid, dim3(256), 0, st, x, ld, C, HW, sums, sq);
+  const dim3 grid((unsigned)nch, (unsigned)B), rgrid((unsigned)((C + 63) / 64), (unsigned)B);
+  hipLaunchKernelGGL(instnorm_partial_kernel<false>, grid, dim3(256), 0, st, x, ld, C, HW, nullptr, part);
+  hipLaunchKernelGGL(chunk_reduce_kernel, rgrid, dim3(256), 0, st, part, 0LL, 1, nch, C, sum, 0LL);
+  hipLaunchKernelGGL(instnorm_partial_kernel<true>, grid, dim3(256), 0, st, x, ld, C, HW, sum, part);
+  hipLaunchKernelGGL(chunk_reduce_kernel, rgrid, dim3(256), 0, st, part, 0LL, 1, nch, C, sq, 0LL);
   const int total = B * C;
-  hipLaunchKernelGGL(instnorm_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, st, sums, sq, nch, C, HW, eps, mean,
-                     rstd, total);
+  hipLaunchKernelGGL(instnorm_finish_kernel, dim3((total + 255) / 256), dim3(256), 0, st, sum, sq, HW, eps, mean, rstd, total);
   return pfk_launch_status();
 }
-
 
 long long pfk_norm_bwd_workspace_bytes(int B, int C) { return ((long long)B * in_chunks(B) * C * 2 + (long long)B * C * 2) * (long long)sizeof(double); }
 
@@ -433,7 +434,11 @@ int pfk_norm_bwd_f32(const float* x, int x_ld, const float* dy, int dy_ld, const
   hipLaunchKernelGGL(norm_bwd_partial_kernel, dim3((unsigned)nch, (unsigned)B), dim3(256), 0, st, x, x_ld, dy, dy_ld, mean, rstd, C, HW,
                      relu, p1, p2);
   const int total = B * C;
-  hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, st, p1, p2, nch, C, d1, d2, sum_g, sum_gxhat, total);
+  // p1 and p2 are adjacent [B][nch][C] arrays, d1 and d2 adjacent [B][C] arrays: one reduction launch for both
+  hipLaunchKernelGGL(chunk_reduce_kernel, dim3((unsigned)((C + 63) / 64), (unsigned)B), dim3(256), 0, st, p1, (long long)B * nch * C, 2, nch, C,
+                     d1, (long long)B * C);
+  if (sum_g || sum_gxhat)
+    hipLaunchKernelGGL(norm_bwd_copy_kernel, dim3((total + 255) / 256), dim3(256), 0, st, d1, d2, sum_g, sum_gxhat, total);
   const long long M = (long long)B * HW;
   const long long blocks = (M * (C >> 2) + 255) / 256;
   if (blocks > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;

@@ -538,6 +538,7 @@ int64_t abi_version() { return pfk_abi_version(); }
 int64_t conv_workspace_bytes() { return pfk_conv_workspace_bytes(); }
 int64_t conv_workspace_fault_offset() { return pfk_conv_workspace_fault_offset(); }
 void debug_set_tile(int64_t cfg) { pfk_debug_set_tile((int)cfg); }
+void debug_set_lookup_pix(int64_t pix) { pfk_debug_set_lookup_pix((int)pix); }
 
 }  // namespace
 
@@ -558,6 +559,7 @@ TORCH_LIBRARY(pfk, m) {
   m.def("norm_apply(Tensor x, Tensor mean, Tensor rstd, Tensor? residual, Tensor(a!) out, int B, int HW, bool relu, "
         "bool relu_after_residual) -> ()");
   m.def("debug_set_tile(int cfg) -> ()", &debug_set_tile);
+  m.def("debug_set_lookup_pix(int pix) -> ()", &debug_set_lookup_pix);
   m.def("corr_volume(Tensor f1, Tensor f2, float scale, Tensor(a!) out) -> ()");
   m.def("corr_pool2x2(Tensor inp, Tensor(a!) out) -> ()");
   m.def("corr_volume_bf16(Tensor f1, Tensor f2, float scale, Tensor(a!) out) -> ()");

@@ -53,9 +53,13 @@ for B in (1, 8):
         ys, xs = torch.meshgrid(torch.arange(h, device=dev, dtype=torch.float32), torch.arange(w, device=dev, dtype=torch.float32), indexing="ij")
         coords = (torch.stack([xs, ys], 0)[None] + torch.randn(B, 2, h, w, device=dev) * 6).contiguous()
         out = torch.empty(B * N, 324, device=dev)
-        us = timeit(lambda: ops.corr_lookup(lv, coords, r, out), n=50)
         alg = B * (N * L * (100 * el + 81 * 4) + 8 * N)
-        print(f"K3 {name} B={B}: {us:.1f} us  algorithmic {alg/1e6:.1f} MB -> {alg/us/1e6:.2f} TB/s ({100*alg/us/1e6/8:.1f}% of 8 TB/s)")
+        for pix in (4, 8):
+            ops.debug_set_lookup_pix(pix)
+            us = timeit(lambda: ops.corr_lookup(lv, coords, r, out), n=50)
+            ck = float(out.double().sum())
+            print(f"K3 {name} B={B} pix={pix}: {us:.1f} us  algorithmic {alg/1e6:.1f} MB -> {alg/us/1e6:.2f} TB/s ({100*alg/us/1e6/8:.1f}% of 8 TB/s)  checksum {ck:.6e}")
+        ops.debug_set_lookup_pix(4)
     # backward pieces (training shapes are smaller; here the same shape for comparability)
     if B == 1:
         sizes = [(int(v.shape[1]), int(v.shape[2])) for v in lv]
