@@ -279,12 +279,19 @@ std::vector<Tensor> altcorr_backward(const Tensor& fmap1, const Tensor& fmap2, c
   TORCH_CHECK(fmap1.dim() == 4 && fmap2.dim() == 4 && coords.dim() == 5 && corr_grad.dim() == 5);
   const int B = fmap1.size(0), H1 = fmap1.size(1), W1 = fmap1.size(2), C = fmap1.size(3);
   const int H2 = fmap2.size(1), W2 = fmap2.size(2), N = coords.size(1);
-  TORCH_CHECK(N == 1, "altcorr_backward: one coordinate set per call (as AlternateCorrBlock uses it)");
   const int rd = 2 * radius + 1;
-  TORCH_CHECK(corr_grad.size(0) == B && corr_grad.size(2) == rd * rd && corr_grad.size(3) == H1 && corr_grad.size(4) == W1);
+  TORCH_CHECK(corr_grad.size(0) == B && corr_grad.size(1) == N && corr_grad.size(2) == rd * rd && corr_grad.size(3) == H1 &&
+              corr_grad.size(4) == W1, "altcorr_backward: corr_grad [B,N,(2r+1)^2,H1,W1]");
   Tensor g1 = at::empty_like(fmap1), g2 = at::empty_like(fmap2), gc = at::zeros_like(coords);
-  check_ok(pfk_altcorr_backward_f32(fptr(fmap1), fptr(fmap2), fptr(coords), fptr(corr_grad), fptr(g1), fptr(g2), B, H1, W1, H2,
-                                    W2, C, radius, cur_stream()), "altcorr_backward");
+  // correlation_kernel.cu:122-256 loops over the N coordinate sets inside the kernel; here one launch per set, summed
+  for (int n = 0; n < N; ++n) {
+    Tensor cn = N == 1 ? coords.view({B, H1, W1, 2}) : coords.select(1, n).contiguous();
+    Tensor gn = N == 1 ? corr_grad.view({B, rd * rd, H1, W1}) : corr_grad.select(1, n).contiguous();
+    Tensor t1 = n == 0 ? g1 : at::empty_like(fmap1), t2 = n == 0 ? g2 : at::empty_like(fmap2);
+    check_ok(pfk_altcorr_backward_f32(fptr(fmap1), fptr(fmap2), fptr(cn), fptr(gn), fptr(t1), fptr(t2), B, H1, W1, H2, W2, C, radius,
+                                      cur_stream()), "altcorr_backward");
+    if (n) { g1.add_(t1); g2.add_(t2); }
+  }
   return {g1, g2, gc};
 }
 

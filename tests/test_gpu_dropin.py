@@ -275,3 +275,31 @@ def test_ccmr_update_block_hybrid(gpu):
                 for a, b in ((n, n_ref), (m, m_ref), (d, d_ref)):
                     assert (a.cpu() - b).abs().max().item() < 2e-4
             assert tuple(m.shape) == (B, 36, h, w)
+
+
+def test_alt_cuda_corr_backward_multi_set_and_half_inputs(gpu):
+    """`alt_cuda_corr.backward` with N = 2 coordinate sets per call (correlation_kernel.cu:122-256 loops over N) and `forward` on
+    half-precision callers (the reference's callers up-cast, raft/corr.py:90-96; the module accepts them directly)."""
+    import ptlflow_amd.altcorr as altcorr
+    g = torch.Generator().manual_seed(10)
+    B, H1, W1, H2, W2, C, r, N = 1, 8, 10, 8, 10, 64, 2, 2
+    f1 = torch.randn(B, H1, W1, C, generator=g, requires_grad=True)
+    f2 = torch.randn(B, H2, W2, C, generator=g, requires_grad=True)
+    base = torch.stack(torch.meshgrid(torch.arange(H1, dtype=torch.float32), torch.arange(W1, dtype=torch.float32),
+                                      indexing="ij")[::-1], -1)[None, None].repeat(B, N, 1, 1, 1)
+    coords = base + torch.randn(B, N, H1, W1, 2, generator=g) * 2
+    outs = [O.alt_corr_forward(f1, f2, coords[:, n:n + 1], r) for n in range(N)]
+    out = torch.cat(outs, 1)
+    grad = torch.randn(out.shape, generator=g)
+    out.backward(grad)
+    g1, g2, gc = altcorr.backward(f1.detach().cuda(), f2.detach().cuda(), coords.cuda(), grad.cuda(), r)
+    assert (g1.cpu() - f1.grad).abs().max().item() < 1e-4 * max(1.0, f1.grad.abs().max().item())
+    assert (g2.cpu() - f2.grad).abs().max().item() < 1e-4 * max(1.0, f2.grad.abs().max().item())
+    assert tuple(gc.shape) == tuple(coords.shape) and float(gc.abs().max()) == 0.0
+    (fwd,) = altcorr.forward(f1.detach().cuda(), f2.detach().cuda(), coords.cuda(), r)
+    assert (fwd.cpu() - out.detach()).abs().max().item() < 2e-4 * max(1.0, out.abs().max().item())
+    (h,) = altcorr.forward(f1.detach().half().cuda(), f2.detach().half().cuda(), coords.half().cuda(), r)
+    assert h.dtype == torch.float16
+    ref16 = torch.cat([O.alt_corr_forward(f1.detach().half().float(), f2.detach().half().float(), coords.half().float()[:, n:n + 1], r)
+                       for n in range(N)], 1)
+    assert (h.float().cpu() - ref16).abs().max().item() < 2e-2 * max(1.0, ref16.abs().max().item())
