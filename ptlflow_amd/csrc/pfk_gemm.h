@@ -122,6 +122,119 @@ __device__ __forceinline__ void epilogue(const GemmArgs& a, const f32x16 (&acc)[
   }
 }
 
+
+// Epilogue through LDS: the MFMA accumulator layout gives a lane one column of 16 scattered rows, i.e. sixteen 4-byte stores per
+// 32x32 block, each wave instruction covering two 128-byte row segments.  Here a wave parks one 32x32 block at a time in a private
+// 4 KB LDS region ([32][32] floats; the ds_write_b32 of a half-wave covers 32 consecutive floats, the ds_read_b128 lane groups hit
+// 16 distinct 16-byte slots: conflict-free unpadded) and re-reads it row-wise: lane = (row l >> 3 of 8, four columns (l & 7) * 4),
+// so the fused arithmetic runs on float4 and every global access (bias, residual, h, z, out) is a 16-byte access of a 128-byte
+// row segment — four store instructions per block instead of sixteen, 8 rows x 128 B per instruction.  The accumulation order of
+// the arithmetic per element is unchanged (bit-identical results).  `lds` = block-shared scratch >= 16 KB that no wave reads
+// any more (callers sit behind their K loop's final barrier).
+template <int MT, int NT, int EPI>
+__device__ __forceinline__ void epilogue_lds(const GemmArgs& a, const f32x16 (&acc)[MT][NT], long long m_base, int n_base, int lane,
+                                             long long batch, float* lds, int wid) {
+  float* reg = lds + wid * 1024;                       // this wave's [32][32] block
+  const int col_l = lane & 31, row_l = (lane >> 5) * 4;
+  const int rrow = lane >> 3, c4 = (lane & 7) * 4;     // read side: 8 rows per pass, 4 columns per lane
+  float* outp = a.out + batch * a.o_bs;
+  // 16-byte accesses need the row stride / offsets to be multiples of 4 floats and the bases 16-byte aligned (pfk.h asks for it;
+  // the training path's fresh [M, cout] outputs with cout = 126 or 2 do not comply): wave-uniform fall-back to scalar accesses
+  const bool vout = (((a.out_ld | a.out_coff) & 3) == 0) && ((reinterpret_cast<uintptr_t>(outp) & 15u) == 0);
+  const bool vres = a.residual == nullptr || (((a.residual_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.residual) & 15u) == 0));
+  const bool vbias = a.bias == nullptr || (reinterpret_cast<uintptr_t>(a.bias) & 15u) == 0;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = n_base + nt * 32 + c4;
+    const bool full = n + 3 < a.b_rows;
+    f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias != nullptr) {
+      if (full && vbias) bias = *reinterpret_cast<const f32x4*>(a.bias + n);
+      else {
+        if (n + 0 < a.b_rows) bias[0] = a.bias[n + 0];
+        if (n + 1 < a.b_rows) bias[1] = a.bias[n + 1];
+        if (n + 2 < a.b_rows) bias[2] = a.bias[n + 2];
+        if (n + 3 < a.b_rows) bias[3] = a.bias[n + 3];
+      }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) reg[((r & 3) + 8 * (r >> 2) + row_l) * 32 + col_l] = acc[mt][nt][r];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private region: in-order LDS, no workgroup barrier needed
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const int row = pass * 8 + rrow;
+        f32x4 v = *reinterpret_cast<const f32x4*>(reg + row * 32 + c4);
+        const long long p = m_base + mt * 32 + row;
+        if (p >= a.M || n >= a.b_rows) continue;
+        v += bias;
+        if constexpr (EPI == PFK_EPI_LINEAR) {
+          if (a.relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (v[e] < 0.f) ? 0.f : v[e];   // NaN-propagating like torch.relu
+          }
+          v *= a.scale;
+          if (a.residual != nullptr) {
+            if (full && vres) v = *reinterpret_cast<const f32x4*>(a.residual + p * a.residual_ld + n) + v;
+            else {
+              const float* rp = a.residual + p * a.residual_ld + n;
+              if (n + 0 < a.b_rows) v[0] = rp[0] + v[0];
+              if (n + 1 < a.b_rows) v[1] = rp[1] + v[1];
+              if (n + 2 < a.b_rows) v[2] = rp[2] + v[2];
+              if (n + 3 < a.b_rows) v[3] = rp[3] + v[3];
+            }
+          }
+          if (a.relu2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (v[e] < 0.f) ? 0.f : v[e];
+          }
+          if (a.out_bf16) {
+            __bf16* ob = reinterpret_cast<__bf16*>(a.out) + batch * a.o_bs + p * a.out_ld + a.out_coff + n;
+            if (n + 0 < a.b_rows) ob[0] = (__bf16)v[0];
+            if (n + 1 < a.b_rows) ob[1] = (__bf16)v[1];
+            if (n + 2 < a.b_rows) ob[2] = (__bf16)v[2];
+            if (n + 3 < a.b_rows) ob[3] = (__bf16)v[3];
+          } else if (full && vout) {
+            *reinterpret_cast<f32x4*>(outp + p * a.out_ld + a.out_coff + n) = v;
+          } else {
+            float* op = outp + p * a.out_ld + a.out_coff + n;
+            if (n + 0 < a.b_rows) op[0] = v[0];
+            if (n + 1 < a.b_rows) op[1] = v[1];
+            if (n + 2 < a.b_rows) op[2] = v[2];
+            if (n + 3 < a.b_rows) op[3] = v[3];
+          }
+        } else if constexpr (EPI == PFK_EPI_GRU_ZR) {     // cout = 2 * ch, ch % 4 == 0: a float4 never straddles z | r
+          const int ch = a.ch_hidden;
+          f32x4 g;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) g[e] = sigmoid_f(v[e]);
+          if (n < ch) {
+            *reinterpret_cast<f32x4*>(a.aux_z + p * ch + n) = g;
+          } else {
+            const int c = n - ch;
+            const f32x4 hv = *reinterpret_cast<const f32x4*>(a.h + p * a.h_ld + c);
+            *reinterpret_cast<f32x4*>(a.aux_rh + p * ch + c) = g * hv;
+          }
+        } else {  // PFK_EPI_GRU_Q
+          const int ch = a.ch_hidden;
+          const f32x4 z = *reinterpret_cast<const f32x4*>(a.aux_z + p * ch + n);
+          const f32x4 hv = *reinterpret_cast<const f32x4*>(a.h + p * a.h_ld + n);
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float q = tanhf(v[e]);
+            // (1 - z) * h + z * q, each product rounded (no contraction), as update.py:64,71
+            o[e] = __fadd_rn(__fmul_rn(__fsub_rn(1.0f, z[e]), hv[e]), __fmul_rn(z[e], q));
+          }
+          *reinterpret_cast<f32x4*>(a.h + p * a.h_ld + n) = o;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads are done before the next block overwrites the region
+    }
+  }
+}
+
 template <int MT, int NT>
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[MT][NT]) {
 #pragma unroll

@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs a) {
     if (more) st.advance();
     __syncthreads();
   }
-  epilogue<MT, NT, EPI, 0, 16>(a, acc, m0 + wm0, n0 + wn0, lane, batch);
+  epilogue_lds<MT, NT, EPI>(a, acc, m0 + wm0, n0 + wn0, lane, batch, smem, wid);   // behind the loop's final barrier
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(256 * GROUPS) void conv_gemm_v3_kernel(const GemmAr
   }
 
   if constexpr (GROUPS == 1) {
-    epilogue<MT, NT, EPI, 0, 16>(a, acc, m0 + wm0, n0 + wn0, lane, batch);
+    epilogue_lds<MT, NT, EPI>(a, acc, m0 + wm0, n0 + wn0, lane, batch, smem, wid);   // behind the loop's final barrier
   } else {
     // exchange accumulator halves: group g finishes registers [8g, 8g+8).
     // red[group][wave][tile][reg8][lane]: lane-contiguous, conflict-free.  (All stage reads are
@@ -632,7 +632,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_sk_kernel(const GemmArgs a) 
           for (int r = 0; r < 16; ++r) acc[0][0][r] = __builtin_nanf("");
         }
       }
-      epilogue<MT, NT, EPI, 0, 16>(a, acc, m0 + wm0, n0 + wn0, lane, 0);
+      epilogue_lds<MT, NT, EPI>(a, acc, m0 + wm0, n0 + wn0, lane, 0, smem, wid);
     }
     hi = lo;
     __syncthreads();   // LDS stages are reused by the next segment

@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256, bf_blocks_per_cu(NS, BM, BN, SUB)) void conv_g
     ks.template run<1>(acc, st, stage1, stage0);
     __syncthreads();
   }
-  epilogue<MT, NT, EPI, 0, 16>(a, acc, m0 + wm0, n0 + wn0, lane, 0);
+  epilogue_lds<MT, NT, EPI>(a, acc, m0 + wm0, n0 + wn0, lane, 0, reinterpret_cast<float*>(smem_bf), wid);   // behind the loop's final barrier
 }
 
 template <int EPI, int NS, int BM, int BN, int SUB>
