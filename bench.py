@@ -5,11 +5,11 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-A *step* is one forward of `ptlflow_amd.RAFT` (encoders on MIOpen, correlation volume + pyramid +
-32 x {lookup, update block, coordinate update, convex upsample} on libpfk kernels) over one batch of
-synthetic 436x1024 frame pairs already resident in HBM.  One process per GPU, frame pairs are
-independent so ranks share nothing (no data-path collective; RCCL is used only for the barrier and the
-max-over-ranks of the elapsed time): weak scaling, `value` = all pairs of all ranks / max time.
+A *step* is one forward of `ptlflow_amd.RAFT` (both encoders, correlation volume + pyramid + 32 x {lookup, update block,
+coordinate update, convex upsample} — every kernel libpfk's, no MIOpen / rocBLAS call in the forward) over one batch of
+synthetic 436x1024 frame pairs already resident in HBM.  One process per GPU, frame pairs are independent so ranks share
+nothing (no data-path collective; RCCL is used only for the barrier and the max-over-ranks of the elapsed time): weak
+scaling, `value` = all pairs of all ranks / max time (ptlflow_amd.shard.timed_steps).
 
 Besides the driver's contract fields the JSON line carries
   roofline      dominant kernel (largest summed time among the MFMA conv launches), HIP events around every
@@ -17,6 +17,13 @@ Besides the driver's contract fields the JSON line carries
   cpu_baseline  the CPU oracle (`oracle/raft_oracle.raft_forward`, a port of the reference forward on torch
                 CPU) timed on this host's cores on the same input: a reported baseline, not a target
   epe_vs_cpu    end-point error of the GPU `flows` vs that CPU forward on the same input (gate: mean <= 1e-3)
+  batch1, model_benchmark_protocol   one pair per forward; the latter is the reference's own protocol
+                (model_benchmark.py:421-466: torch.rand input, 1 warm-up + 10 synchronised forwards, median)
+  split_bf16, skip_dead_upsample     the same forward with split-bf16 convolution products / without the reference's dead
+                per-iteration mask + upsample work (bit-identical output) — beside the headline, never as it
+  config3       BASELINE config 3: gma (fp32) and raft / gma with bf16 operands (bf16 convolutions, bf16 correlation volume)
+  train         BASELINE config 5 on one GPU: a full RAFT training step (batch 10, 368x496, 12 iterations; forward, sequence
+                loss, backward, clip, AdamW), every kernel libpfk's; samples/s
 """
 from __future__ import annotations
 
