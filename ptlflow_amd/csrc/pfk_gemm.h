@@ -21,6 +21,7 @@ struct GemmArgs {
   int relu;
   float scale;
   float* out; int out_ld; int out_coff;
+  int vec_flags;       // host-computed (gemm_vec_flags): bit 0 out, bit 1 residual, bit 2 bias may be accessed as aligned float4
   int out_bf16;        // LINEAR: `out` points to bf16 elements (out_ld / out_coff / o_bs in elements): v is rounded to nearest even
   const float* residual; int residual_ld;   // LINEAR: out = residual[p][n] + v (after relu/scale)
   float* h; int h_ld;
@@ -137,12 +138,15 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs& a, const f32x16 (&a
   float* reg = lds + wid * 1024;                       // this wave's [32][32] block
   const int col_l = lane & 31, row_l = (lane >> 5) * 4;
   const int rrow = lane >> 3, c4 = (lane & 7) * 4;     // read side: 8 rows per pass, 4 columns per lane
-  float* outp = a.out + batch * a.o_bs;
+  // explicit global address space: with the plain generic pointers hipcc emitted flat_store for the LINEAR branch
+  typedef __attribute__((address_space(1))) float gfloat;
+  typedef __attribute__((address_space(1))) f32x4 gf32x4;
+  typedef __attribute__((address_space(1))) __bf16 gbf16;
+  gfloat* outp = (gfloat*)(a.out + batch * a.o_bs);
   // 16-byte accesses need the row stride / offsets to be multiples of 4 floats and the bases 16-byte aligned (pfk.h asks for it;
   // the training path's fresh [M, cout] outputs with cout = 126 or 2 do not comply): wave-uniform fall-back to scalar accesses
-  const bool vout = (((a.out_ld | a.out_coff) & 3) == 0) && ((reinterpret_cast<uintptr_t>(outp) & 15u) == 0);
-  const bool vres = a.residual == nullptr || (((a.residual_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.residual) & 15u) == 0));
-  const bool vbias = a.bias == nullptr || (reinterpret_cast<uintptr_t>(a.bias) & 15u) == 0;
+  // (decided on the host: a pointer-to-integer cast here makes the compiler lose the global address space of every store below)
+  const bool vout = a.vec_flags & 1, vres = a.vec_flags & 2, vbias = a.vec_flags & 4;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int n = n_base + nt * 32 + c4;
@@ -190,15 +194,15 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs& a, const f32x16 (&a
             for (int e = 0; e < 4; ++e) v[e] = (v[e] < 0.f) ? 0.f : v[e];
           }
           if (a.out_bf16) {
-            __bf16* ob = reinterpret_cast<__bf16*>(a.out) + batch * a.o_bs + p * a.out_ld + a.out_coff + n;
+            gbf16* ob = (gbf16*)(reinterpret_cast<__bf16*>(a.out) + batch * a.o_bs + p * a.out_ld + a.out_coff + n);
             if (n + 0 < a.b_rows) ob[0] = (__bf16)v[0];
             if (n + 1 < a.b_rows) ob[1] = (__bf16)v[1];
             if (n + 2 < a.b_rows) ob[2] = (__bf16)v[2];
             if (n + 3 < a.b_rows) ob[3] = (__bf16)v[3];
           } else if (full && vout) {
-            *reinterpret_cast<f32x4*>(outp + p * a.out_ld + a.out_coff + n) = v;
+            *(gf32x4*)(outp + p * a.out_ld + a.out_coff + n) = v;
           } else {
-            float* op = outp + p * a.out_ld + a.out_coff + n;
+            gfloat* op = outp + p * a.out_ld + a.out_coff + n;
             if (n + 0 < a.b_rows) op[0] = v[0];
             if (n + 1 < a.b_rows) op[1] = v[1];
             if (n + 2 < a.b_rows) op[2] = v[2];
@@ -233,6 +237,16 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs& a, const f32x16 (&a
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads are done before the next block overwrites the region
     }
   }
+}
+
+// alignment facts the float4 epilogue needs, evaluated where pointers are still integers
+static inline int gemm_vec_flags(const GemmArgs& a) {
+  auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+  int f = 0;
+  if (a.out && al(a.out) && (((a.out_ld | a.out_coff) & 3) == 0) && ((a.o_bs & 3) == 0)) f |= 1;
+  if (!a.residual || (al(a.residual) && (a.residual_ld & 3) == 0)) f |= 2;
+  if (!a.bias || al(a.bias)) f |= 4;
+  return f;
 }
 
 template <int MT, int NT>

@@ -701,7 +701,9 @@ int g_force_tile = -1;  // debug/tuning knob, see pfk_debug_set_tile
 
 // Configurations: 0-3 = v1 (64x64, 64x128, 128x128, 128x64); 4-7 = v3 one group, same tiles;
 // 8 = v3 two groups 64x64 (in-block split-K); 9 = stream-K on 64x64 tiles (needs a workspace); 10 = cfg 4 on swizzled LDS.
-int launch(const GemmArgs& a, int epi, int batches, hipStream_t st) {
+int launch(const GemmArgs& a0, int epi, int batches, hipStream_t st) {
+  GemmArgs a = a0;
+  a.vec_flags = gemm_vec_flags(a);
   int cfg;
   if (g_force_tile >= 0) {
     cfg = g_force_tile;

@@ -411,6 +411,7 @@ int g_bf_cfg = 0;   // debug/tuning knob (pfk_debug_set_tile(100 + cfg)); 0 = he
 
 int launch_bf(const GemmArgs& a0, int epi, int nsplit, hipStream_t st) {
   GemmArgs a = a0;
+  a.vec_flags = gemm_vec_flags(a);
   int cfg = g_bf_cfg % 10;
   a.dbg = g_bf_cfg / 10;
   if (cfg == 0) {

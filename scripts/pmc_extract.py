@@ -1,27 +1,46 @@
 #!/usr/bin/env python3
-"""Per (kernel, grid) averages of rocprofv3 PMC passes (…_counter_collection.csv) -> profiles/pmc_traffic.json entries.
+"""rocprofv3 PMC passes (…_counter_collection.csv) of `python bench.py ...` -> per update-block convolution averages
+(profiles/pmc_traffic.json entries).
 
-    pmc_extract.py --fetch DIR --write DIR [--sq DIR] --batch 8 --out profiles/pmc_traffic.json
+    pmc_extract.py --fetch DIR --write DIR [--sq DIR] --batch 8 [--out profiles/pmc_traffic.json] [--tag ""]
 
-Conv launches of one forward share a few kernel instantiations; the update block's convolutions are told apart by
-(epilogue template argument, grid size): at M = B*7040 pixels and 64x64 tiles, tiles_n = ceil(cout / 64)."""
+The update block's convolutions share three kernel instantiations with the encoders, so launches are identified by their
+POSITION in the iteration: after every `lookup_kernel` dispatch the implicit-GEMM launches come in the fixed order
+c1, c2, f2, cv, zr1, q1, zr2, q2, fm, mk (ptlflow_amd/update.py: motion_and_gru + heads; conv_cin2 / flow_delta are other kernels)."""
 import argparse
 import csv
 import glob
 import json
 import os
-import re
 from collections import defaultdict
+
+SEQ = ["c1", "c2", "f2", "cv", "zr1", "q1", "zr2", "q2", "fm", "mk"]
 
 
 def load(d):
     f = sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True))[0]
+    rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Dispatch_Id"]))
     acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
-    for r in csv.DictReader(open(f)):
-        key = (r["Kernel_Name"], int(r["Grid_Size"]))
-        a = acc[key][r["Counter_Name"]]
-        a[0] += float(r["Counter_Value"])
-        a[1] += 1
+    idx, last = None, None
+    for r in rows:
+        name, did = r["Kernel_Name"], r["Dispatch_Id"]
+        if did != last:                       # several counters per dispatch: advance the position once per dispatch
+            last = did
+            if "lookup_kernel" in name:
+                idx = 0
+                cur = "lookup"
+            elif "conv_gemm" in name and idx is not None and idx < len(SEQ):
+                cur = SEQ[idx]
+                idx += 1
+            else:
+                cur = None
+        if cur:
+            a = acc[cur][r["Counter_Name"]]
+            a[0] += float(r["Counter_Value"])
+            a[1] += 1
+            a2 = acc[cur]["_dur_ns"]
+            a2[0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+            a2[1] += 1
     return {k: {c: v[0] / v[1] for c, v in cs.items()} for k, cs in acc.items()}
 
 
@@ -32,32 +51,31 @@ def main():
     ap.add_argument("--sq", default="")
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--out", default="")
+    ap.add_argument("--tag", default="")
     a = ap.parse_args()
     fetch, write = load(a.fetch), load(a.write)
     sq = load(a.sq) if a.sq else {}
-    tiles_m = (a.batch * 7040 + 63) // 64
-    want = {"fm": (0, 8), "c2": (0, 3), "cv": (0, 2), "zr": (1, 4), "q": (2, 2), "mk": (0, 9), "c1": (0, 4), "f2": (0, 1)}
     entries = {}
-    for key, (epi, tn) in want.items():
-        grid = tiles_m * tn * 256
-        for (name, g), c in fetch.items():
-            m = re.search(r"conv_gemm(?:_v3)?_kernel<64, 64, 32, 32, (\d)", name)
-            if not m or int(m.group(1)) != epi or g != grid:
-                continue
-            e = {"fetch_kb": round(c.get("FETCH_SIZE", 0.0)), "write_kb": round(write.get((name, g), {}).get("WRITE_SIZE", 0.0)), "kernel": name[:60]}
-            s = sq.get((name, g))
-            if s and s.get("SQ_BUSY_CYCLES"):
-                # SQ_VALU_MFMA_BUSY_CYCLES counts cycles, summed over SEs like SQ_BUSY_CYCLES; 4 SIMDs per CU share ... report the raw ratio
-                e["mfma_busy_over_grbm"] = round(s.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / max(s.get("GRBM_GUI_ACTIVE", 1.0), 1.0), 4)
-                e["sq_wait_any_frac"] = round(s.get("SQ_WAIT_ANY", 0.0) / max(s.get("SQ_WAVE_CYCLES", 1.0), 1.0), 3)
-            entries[f"{key}@b{a.batch}"] = e
-            break
+    for key in SEQ + ["lookup"]:
+        if key not in fetch:
+            continue
+        e = {"fetch_kb": round(fetch[key].get("FETCH_SIZE", 0.0)), "write_kb": round(write.get(key, {}).get("WRITE_SIZE", 0.0)),
+             "avg_us": round(fetch[key]["_dur_ns"] / 1e3, 1)}
+        s = sq.get(key)
+        if s and s.get("SQ_WAVE_CYCLES"):
+            e["sq_wait_any_frac"] = round(s.get("SQ_WAIT_ANY", 0.0) / s["SQ_WAVE_CYCLES"], 3)
+            e["sq_active_inst_frac"] = round(s.get("SQ_ACTIVE_INST_ANY", 0.0) / s["SQ_WAVE_CYCLES"], 3)
+            if s.get("SQ_BUSY_CYCLES"):
+                e["mfma_busy_per_sq_busy"] = round(s.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / s["SQ_BUSY_CYCLES"], 3)
+        entries[f"{key}{a.tag}@b{a.batch}"] = e
     print(json.dumps(entries, indent=1))
     if a.out:
         doc = json.load(open(a.out)) if os.path.exists(a.out) else {"entries": {}}
         doc.setdefault("entries", {}).update(entries)
-        doc["note_r02"] = ("round-2 entries re-measured after the LDS-transposed epilogue (scripts/gpu_final2.sh: separate --pmc passes "
-                           "of `python bench.py --steps 1 --warmup 1 ...`); FETCH_SIZE x2 is the gfx950 correction of MI355X_MICROARCH.md")
+        doc["note_r02"] = ("round-2 entries (keys zr1/zr2/q1/q2/lookup, and every key re-measured after the LDS-transposed epilogue): separate "
+                           "--pmc passes of `python bench.py --steps 1 --warmup 1 ...` (scripts/gpu_final2.sh), launches identified by their "
+                           "position after each lookup_kernel dispatch; FETCH_SIZE is as reported (KB): consumers apply the x2 gfx950 "
+                           "correction of MI355X_MICROARCH.md for 16-byte/lane coalesced reads")
         json.dump(doc, open(a.out, "w"), indent=1)
 
 
