@@ -171,7 +171,9 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs& a, const f32x16 (&a
         const int row = pass * 8 + rrow;
         f32x4 v = *reinterpret_cast<const f32x4*>(reg + row * 32 + c4);
         const long long p = m_base + mt * 32 + row;
-        if (p >= a.M || n >= a.b_rows) continue;
+        // (columns past cout are filtered per element below, not here: knowing `n < cout` the compiler hoists the scalar tail's first
+        // store above the vector / scalar branch and every float4 store is preceded by a redundant dword store: +25 % write traffic)
+        if (p >= a.M) continue;
         v += bias;
         if constexpr (EPI == PFK_EPI_LINEAR) {
           if (a.relu) {
@@ -209,6 +211,7 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs& a, const f32x16 (&a
             if (n + 3 < a.b_rows) op[3] = v[3];
           }
         } else if constexpr (EPI == PFK_EPI_GRU_ZR) {     // cout = 2 * ch, ch % 4 == 0: a float4 never straddles z | r
+          if (n >= a.b_rows) continue;
           const int ch = a.ch_hidden;
           f32x4 g;
 #pragma unroll
@@ -221,6 +224,7 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs& a, const f32x16 (&a
             *reinterpret_cast<f32x4*>(a.aux_rh + p * ch + c) = g * hv;
           }
         } else {  // PFK_EPI_GRU_Q
+          if (n >= a.b_rows) continue;
           const int ch = a.ch_hidden;
           const f32x4 z = *reinterpret_cast<const f32x4*>(a.aux_z + p * ch + n);
           const f32x4 hv = *reinterpret_cast<const f32x4*>(a.h + p * a.h_ld + n);

@@ -726,7 +726,9 @@ int launch(const GemmArgs& a0, int epi, int batches, hipStream_t st) {
     // immediate-offset fragment reads are a few % faster (cfg 4).
     // a handful of output tiles with a very long K (GEMM-shaped callers with a tall reduction): only stream-K fills the chip
     const bool sk_long = a.sk_ws != nullptr && batches == 1 && blocks64 <= 64 && a.sk_steps >= 128;
-    cfg = (sk || sk_long) ? 9 : (a.sk_steps < 16 ? 0 : (blocks64 >= 3 * 256 ? 10 : 4));
+    // (round 2, after the LDS epilogue: with >= 3 tiles per CU the swizzled 3-stage kernel also wins for short K — c1 111 -> 104 us,
+    //  mask conv2 163 -> 158 us at batch 8; below that the 2-stage kernel's cheaper prologue still does)
+    cfg = (sk || sk_long) ? 9 : (blocks64 >= 3 * 256 ? 10 : (a.sk_steps < 16 ? 0 : 4));
   }
   switch (cfg) {
     case 0: return launch_cfg<64, 64, 32, 32, 0>(a, epi, batches, st);
