@@ -64,6 +64,7 @@ const char* pfk_status_string(int status);
 void pfk_debug_set_tile(int cfg);
 /* tuning knob of the pyramid lookup: source pixels per workgroup, 4 (default) or 8. Not thread-safe. */
 void pfk_debug_set_lookup_pix(int pix);
+void pfk_debug_set_wgrad(int variant);      /* 0: 128x32-tile weight-gradient kernel, 1: 128x128 tiles (tuning knob) */
 
 /* ---- K1: all-pairs correlation --------------------------------------------------------------
  * out[b][i][j] = scale * sum_d f1[b][i][d] * f2[b][j][d]        (fp32 MFMA, exact fp32 products)
@@ -198,14 +199,16 @@ typedef struct {
                             INPUT dims, sources have B*H*W rows, out / h / aux / residual have B*Ho*Wo rows */
   int relu_after_residual; /* LINEAR only: relu once more after the residual add (ResidualBlock, raft/extractor.py:53-61) */
   void* workspace;       /* optional: >= pfk_conv_workspace_bytes() of device memory, 16-byte aligned, private to
-                            the stream; enables the stream-K schedule for small grids (deterministic).  NULL: tile grid */
+                            the stream, ZERO-FILLED by the caller once after allocation (the kernels leave its flag region
+                            zeroed); enables the stream-K schedule for small grids (deterministic).  NULL: tile grid */
   long long workspace_bytes;
 } pfk_conv_desc;
 
 long long pfk_conv_workspace_bytes(void);
 /* Byte offset, inside a conv workspace, of a 32-bit counter of stream-K fix-ups that timed out (a partner block's partial
  * tile never became visible within the bounded spin).  The caller zero-initialises the workspace once; the kernels only
- * ever increment the word, and the affected output tile is written as NaN.  0 = every result so far is complete. */
+ * ever increment the word, and the affected output tile is written as NaN.  0 = every result so far is complete; after a
+ * non-zero reading zero-fill the workspace again before the next launch (flags of the lost fix-up may be left set). */
 long long pfk_conv_workspace_fault_offset(void);
 int pfk_conv_ktot(const pfk_conv_desc* d);
 int pfk_conv2d_f32(const pfk_conv_desc* d, pfk_stream_t stream);
@@ -314,8 +317,8 @@ int pfk_conv_stem_f32(const float* img, const float* weight, const float* bias, 
                       int H, int W, int cout, int relu, pfk_stream_t stream);
 
 /* InstanceNorm2d statistics (extractor.py:136-140; affine=False, biased variance, eps inside the sqrt) over
- * pixel-major x[B*HW][ld], channels [0, C): mean[b*C+c], rstd[b*C+c].  Deterministic two-pass reduction with double
- * accumulators (results rounded to fp32); needs pfk_instnorm_workspace_bytes(B, C) bytes of 32-byte-aligned device scratch.
+ * pixel-major x[B*HW][ld], channels [0, C): mean[b*C+c], rstd[b*C+c].  One pass over x, deterministic chunked reduction of sum(x) and
+ * sum(x*x) in double (var = E[x^2] - mean^2 evaluated in double; results rounded to fp32); needs pfk_instnorm_workspace_bytes(B, C) bytes of 32-byte-aligned device scratch.
  * Training-mode batch norm statistics are the same call with B = 1 and HW = every pixel of the batch. */
 long long pfk_instnorm_workspace_bytes(int B, int C);
 int pfk_instnorm_stats_f32(const float* x, int ld, int B, int HW, int C, float eps, float* mean, float* rstd,

@@ -77,9 +77,10 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const float* __restrict_
 
 // ------------------------------------------------------------------------------------------------------------------
 // Instance-norm statistics over pixel-major x[B*HW][ld], channels [0, C), C % 4 == 0.
-// Pass 1: per (image, chunk) partial sums, reduced over the chunks in a fixed order (chunk_reduce_kernel); pass 2: partial sums
-// of (x - mean)^2, reduced the same way; finish: mean, rstd = 1/sqrt(var_biased + eps)  (F.instance_norm, extractor.py:136-140).
-// A thread owns 4 consecutive channels (float4) and every (256 / (C/4))-th row of the chunk.
+// ONE pass over x: per (image, chunk) partial sums of x and of x*x, both carried in double (an fp32 square is exact in double), reduced
+// over the chunks in a fixed order (chunk_reduce_kernel); finish: mean, var_biased = E[x^2] - mean^2 (in double: the cancellation
+// costs mean^2/var * 2^-53, nothing next to the fp32 rounding of the results), rstd = 1/sqrt(var + eps)  (F.instance_norm,
+// extractor.py:136-140).  A thread owns 4 consecutive channels (float4) and every (256 / (C/4))-th row of the chunk.
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int IN_CHUNKS_MAX = 256;   // partial-sum slots per image in the workspace
 // chunks per image: enough blocks to fill the chip at small batches (the partial kernels are latency-bound per block), 32 once
@@ -87,15 +88,15 @@ constexpr int IN_CHUNKS_MAX = 256;   // partial-sum slots per image in the works
 static inline int in_chunks(int B) { int c = 1024 / (B > 0 ? B : 1); return c < 32 ? 32 : (c > IN_CHUNKS_MAX ? IN_CHUNKS_MAX : c); }
 
 // Sums are carried in DOUBLE: a channel whose mean is large next to its spread (common after a biased convolution) loses the
-// low digits of (x - mean) when the mean itself carries fp32 accumulation error, and everything downstream of the norm —
+// low digits of the variance when the sums carry fp32 accumulation error, and everything downstream of the norm —
 // the normalised activations, their relu masks and, in training, the weight gradients of the layers in front of it — inherits
 // that error (measured on BasicEncoder gradients: 9e-3 with fp32 sums, 1e-6 with double; MIOpen's fp32 kernels 9e-4).
 typedef double f64x4s __attribute__((ext_vector_type(4)));
 
-template <bool CENTERED>
+// part: two arrays [B][nch][C] one after the other (sum, then sum of squares; `astride` doubles apart)
 __global__ __launch_bounds__(256) void instnorm_partial_kernel(const float* __restrict__ x, int ld, int C, int HW,
-                                                               const double* __restrict__ sums, double* __restrict__ part) {
-  __shared__ f64x4s red[256];
+                                                               double* __restrict__ part, long long astride) {
+  __shared__ f64x4s red[2][256];
   const int b = blockIdx.y, chunk = blockIdx.x;
   const int tpr = C >> 2;                   // threads per row
   const int rpi = 256 / tpr;                // rows per iteration
@@ -105,59 +106,69 @@ __global__ __launch_bounds__(256) void instnorm_partial_kernel(const float* __re
   const int nch = (int)gridDim.x;
   const int rows = (HW + nch - 1) / nch;
   const int r0 = chunk * rows, r1 = min(HW, r0 + rows);
-  f64x4s mean = {0., 0., 0., 0.};
-  if (CENTERED && active) mean = *reinterpret_cast<const f64x4s*>(sums + (long long)b * C + c4) / (double)HW;   // sums: [B][C] totals
-  f64x4s acc = {0., 0., 0., 0.};
+  f64x4s s0 = {0., 0., 0., 0.}, q0 = {0., 0., 0., 0.};
   if (active) {
     const float* base = x + (long long)b * HW * ld + c4;
     // two independent accumulator sets: the fp64 add / fma chain of one set would otherwise serialise the loop (a chunk has
     // only a few hundred rows per thread and, at batch 1, the grid is far from filling the chip)
-    f64x4s acc1 = {0., 0., 0., 0.};
+    f64x4s s1 = {0., 0., 0., 0.}, q1 = {0., 0., 0., 0.};
     int r = r0 + rr;
     for (; r + rpi < r1; r += 2 * rpi) {
       const f32x4 v0 = *reinterpret_cast<const f32x4*>(base + (long long)r * ld);
       const f32x4 v1 = *reinterpret_cast<const f32x4*>(base + (long long)(r + rpi) * ld);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const double d0 = (double)v0[e] - mean[e], d1 = (double)v1[e] - mean[e];
-        acc[e] += CENTERED ? d0 * d0 : d0;
-        acc1[e] += CENTERED ? d1 * d1 : d1;
+        const double d0 = (double)v0[e], d1 = (double)v1[e];
+        s0[e] += d0; q0[e] = fma(d0, d0, q0[e]);
+        s1[e] += d1; q1[e] = fma(d1, d1, q1[e]);
       }
     }
     if (r < r1) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(base + (long long)r * ld);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const double d = (double)v[e] - mean[e];
-        acc[e] += CENTERED ? d * d : d;
+        const double d = (double)v[e];
+        s0[e] += d; q0[e] = fma(d, d, q0[e]);
       }
     }
-    acc += acc1;
+    s0 += s1; q0 += q1;
   }
-  red[t] = acc;
+  red[0][t] = s0;
+  red[1][t] = q0;
   __syncthreads();
-  if (t < tpr) {
-    f64x4s s = red[t];
-    for (int k = 1; k < rpi; ++k) s += red[t + k * tpr];
-    *reinterpret_cast<f64x4s*>(part + ((long long)b * nch + chunk) * C + c4) = s;
+  for (int u = t; u < 2 * tpr; u += 256) {   // [0, tpr): sums; [tpr, 2 tpr): sums of squares
+    const int which = u >= tpr, tt = u - which * tpr;
+    f64x4s s = red[which][tt];
+    for (int k = 1; k < rpi; ++k) s += red[which][tt + k * tpr];
+    *reinterpret_cast<f64x4s*>(part + which * astride + ((long long)b * nch + chunk) * C + tt * 4) = s;
   }
 }
 
 // part[b][k][c], k < nch  ->  tot[b][c] = sum_k, for NA arrays laid out one after the other (stride `astride` doubles in part,
-// B*C in tot).  One block per (64 channels, image): thread = (channel, one of four chunk slices); slices are combined through LDS
-// in a fixed order, so the result does not depend on the launch.  (A single thread per (b, c) walking all chunks is a chain of
-// nch dependent loads — 66 us at 256 chunks, more than the pass that produced them.)
-__global__ __launch_bounds__(256) void chunk_reduce_kernel(const double* __restrict__ part, long long astride, int NA, int nch, int C,
-                                                           double* __restrict__ tot, long long tstride) {
-  __shared__ double red[4][64];
-  const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+// `tstride` in tot).  One block of 1024 threads per (64 channels, image): thread = (channel, one of sixteen chunk slices), two
+// accumulators each; slices are combined through LDS in a fixed order, so the result does not depend on the launch.  (A single
+// thread per (b, c) walking all chunks is a chain of nch dependent adds — 66 us at 256 chunks, more than the pass that produced
+// them; four slices: 17 us.)
+__global__ __launch_bounds__(1024) void chunk_reduce_kernel(const double* __restrict__ part, long long astride, int NA, int nch, int C,
+                                                            double* __restrict__ tot, long long tstride) {
+  __shared__ double red[16][64];
+  const int cl = threadIdx.x & 63, b = blockIdx.y, c = blockIdx.x * 64 + cl, sl = threadIdx.x >> 6;
   for (int a = 0; a < NA; ++a) {
-    double s = 0.;
-    if (c < C)
-      for (int k = sl; k < nch; k += 4) s += part[a * astride + ((long long)b * nch + k) * C + c];
-    red[sl][threadIdx.x & 63] = s;
+    double s0 = 0., s1 = 0.;
+    if (c < C) {
+      const double* p = part + a * astride + (long long)b * nch * C + c;
+      int k = sl;
+      for (; k + 16 < nch; k += 32) { s0 += p[(long long)k * C]; s1 += p[(long long)(k + 16) * C]; }
+      if (k < nch) s0 += p[(long long)k * C];
+    }
+    red[sl][cl] = s0 + s1;
     __syncthreads();
-    if (sl == 0 && c < C) tot[a * tstride + (long long)b * C + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (sl == 0 && c < C) {
+      double s = 0.;
+#pragma unroll
+      for (int k = 0; k < 16; k += 4) s += (red[k][cl] + red[k + 1][cl]) + (red[k + 2][cl] + red[k + 3][cl]);
+      tot[a * tstride + (long long)b * C + c] = s;
+    }
     __syncthreads();
   }
 }
@@ -166,8 +177,11 @@ __global__ void instnorm_finish_kernel(const double* __restrict__ sum, const dou
                                        float* __restrict__ mean, float* __restrict__ rstd, int total) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;   // b*C + c
   if (i >= total) return;
-  mean[i] = (float)(sum[i] / (double)HW);
-  rstd[i] = (float)(1.0 / sqrt(sq[i] / (double)HW + (double)eps));
+  const double m = sum[i] / (double)HW;
+  double var = sq[i] / (double)HW - m * m;
+  var = var > 0. ? var : 0.;
+  mean[i] = (float)m;
+  rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
 // y = (x - mean) * rstd ; relu? ; [y = residual + y ; relu?]   (float4 per thread)
@@ -390,7 +404,7 @@ int pfk_conv_stem_f32(const float* img, const float* weight, const float* bias, 
   return pfk_launch_status();
 }
 
-long long pfk_instnorm_workspace_bytes(int B, int C) { return ((long long)B * in_chunks(B) * C + 2LL * B * C) * (long long)sizeof(double); }
+long long pfk_instnorm_workspace_bytes(int B, int C) { return (2LL * B * in_chunks(B) * C + 2LL * B * C) * (long long)sizeof(double); }
 
 int pfk_instnorm_stats_f32(const float* x, int ld, int B, int HW, int C, float eps, float* mean, float* rstd,
                            void* workspace, long long workspace_bytes, pfk_stream_t stream) {
@@ -400,15 +414,14 @@ int pfk_instnorm_stats_f32(const float* x, int ld, int B, int HW, int C, float e
     return PFK_ERR_ALIGNMENT;
   if (workspace_bytes < pfk_instnorm_workspace_bytes(B, C)) return PFK_ERR_BAD_ARG;
   const int nch = in_chunks(B);
-  double* part = static_cast<double*>(workspace);            // [B][nch][C], reused by both passes
-  double* sum = part + (size_t)B * nch * C;                  // [B][C]
+  double* part = static_cast<double*>(workspace);            // 2 x [B][nch][C]: sums, sums of squares
+  const long long astride = (long long)B * nch * C;
+  double* sum = part + 2 * astride;                          // [B][C]
   double* sq = sum + (size_t)B * C;                          // [B][C]
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 grid((unsigned)nch, (unsigned)B), rgrid((unsigned)((C + 63) / 64), (unsigned)B);
-  hipLaunchKernelGGL(instnorm_partial_kernel<false>, grid, dim3(256), 0, st, x, ld, C, HW, nullptr, part);
-  hipLaunchKernelGGL(chunk_reduce_kernel, rgrid, dim3(256), 0, st, part, 0LL, 1, nch, C, sum, 0LL);
-  hipLaunchKernelGGL(instnorm_partial_kernel<true>, grid, dim3(256), 0, st, x, ld, C, HW, sum, part);
-  hipLaunchKernelGGL(chunk_reduce_kernel, rgrid, dim3(256), 0, st, part, 0LL, 1, nch, C, sq, 0LL);
+  hipLaunchKernelGGL(instnorm_partial_kernel, grid, dim3(256), 0, st, x, ld, C, HW, part, astride);
+  hipLaunchKernelGGL(chunk_reduce_kernel, rgrid, dim3(1024), 0, st, part, astride, 2, nch, C, sum, (long long)B * C);
   const int total = B * C;
   hipLaunchKernelGGL(instnorm_finish_kernel, dim3((total + 255) / 256), dim3(256), 0, st, sum, sq, HW, eps, mean, rstd, total);
   return pfk_launch_status();
@@ -435,7 +448,7 @@ int pfk_norm_bwd_f32(const float* x, int x_ld, const float* dy, int dy_ld, const
                      relu, p1, p2);
   const int total = B * C;
   // p1 and p2 are adjacent [B][nch][C] arrays, d1 and d2 adjacent [B][C] arrays: one reduction launch for both
-  hipLaunchKernelGGL(chunk_reduce_kernel, dim3((unsigned)((C + 63) / 64), (unsigned)B), dim3(256), 0, st, p1, (long long)B * nch * C, 2, nch, C,
+  hipLaunchKernelGGL(chunk_reduce_kernel, dim3((unsigned)((C + 63) / 64), (unsigned)B), dim3(1024), 0, st, p1, (long long)B * nch * C, 2, nch, C,
                      d1, (long long)B * C);
   if (sum_g || sum_gxhat)
     hipLaunchKernelGGL(norm_bwd_copy_kernel, dim3((total + 255) / 256), dim3(256), 0, st, d1, d2, sum_g, sum_gxhat, total);

@@ -32,9 +32,10 @@ struct GemmArgs {
   int tiles_n;
   int supertile;           // > 0: walk the tile grid in supertile x supertile blocks (see tile_of) instead of row-major
   float* sk_ws;            // stream-K: one 64x64 fp32 partial per block
-  unsigned* sk_flags;      // stream-K: one ready flag per block (zeroed before every launch)
+  unsigned* sk_flags;      // stream-K: one ready flag per block (all zero between launches)
   int sk_steps;            // K-steps per tile (host-computed)
   long long sk_tiles;      // output tiles
+  int sk_groups;           // stream-K: 1, or 8 = one contiguous tile range per XCD (blockIdx.x % 8), stream-K inside each
   const void* wbf;         // split-bf16 path: weight planes [nsplit][cout][ktot] bf16, same k order as `weight`
   long long wbf_plane_bytes;
   int dbg;                 // split-bf16 timing ablations (results are garbage): 1 no global loads, 2 no split + LDS stores, 4 no fragment reads + MFMAs

@@ -526,49 +526,61 @@ __global__ __launch_bounds__(256 * GROUPS) void conv_gemm_v3_kernel(const GemmAr
 //     blocks that hold the rest of the tile (fixed order => deterministic sum) and runs the epilogue.
 // Owners wait only on LOWER block ids, which produced their contribution as the FIRST thing they did, so the
 // wait is short and cannot deadlock whatever the residency.  Cross-workgroup visibility follows the
-// agent-scope release/acquire recipe of cdna_hip_programming.md (Guideline 16); flags are zeroed by a
-// hipMemsetAsync in front of every launch; the spin is bounded.
+// agent-scope release/acquire recipe of cdna_hip_programming.md (Guideline 16).  Flags: the caller zero-fills the workspace
+// once (pfk.h); a contribution's flag is set by its producer and cleared by its single consumer, so every launch finds and
+// leaves the region zeroed (no memset node per launch: 5.6 us each at batch 1).  The spin is bounded; after a timed-out
+// fix-up (fault word != 0) the caller must zero the workspace again before reusing it.
 // -------------------------------------------------------------------------------------------------
-constexpr int SK_MAX_BLOCKS = 512;
-constexpr int SK_FAULT_SLOT = 1024;   // u32 index in the flag region (flags use [0, 512)): sticky count of timed-out fix-ups
+constexpr int SK_MAX_BLOCKS = 768;    // three resident blocks per CU on the swizzled 48 KB layout
+constexpr int SK_FAULT_SLOT = 1024;   // u32 index in the flag region (flags use [0, 768)): sticky count of timed-out fix-ups
 constexpr size_t SK_WS_BYTES = (size_t)SK_MAX_BLOCKS * (64 * 64 * 4 + 64);   // partials + flags (flags after the partials)
 
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void conv_gemm_sk_kernel(const GemmArgs a) {
+// LD = LDS row stride (36: padded, 55 KB per block; 32: XOR-swizzled, 48 KB), BPC = resident blocks per CU the launch counts on.
+// a.sk_groups == 8: the tile list is cut into 8 contiguous ranges at TILE boundaries, one per XCD (blockIdx.x % 8 — the hardware's
+// round-robin), and the stream-K split runs inside each range over the blocks of that XCD in dispatch order: neighbouring unit
+// ranges then share their A rows / weight panels through ONE L2, and a contribution still only ever flows from a lower to a higher
+// dispatch index (blocks x, x + 8, x + 16, ...), which is what makes the fix-up wait deadlock-free whatever the residency.
+template <int EPI, int LD, int BPC>
+__global__ __launch_bounds__(256, BPC) void conv_gemm_sk_kernel(const GemmArgs a) {
   constexpr int BM = 64, BN = 64, MT = 1, NT = 1;
-  constexpr int STAGE = (BM + BN) * LDS_LD;
+  constexpr int STAGE = (BM + BN) * LD;
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wid = tid >> 6;
   const int wm0 = (wid >> 1) * 32, wn0 = (wid & 1) * 32;
-  const int foff_a = (wm0 + (lane & 31)) * LDS_LD;
-  const int foff_b = BM * LDS_LD + (wn0 + (lane & 31)) * LDS_LD;
+  const int foff_a = (wm0 + (lane & 31)) * LD;
+  const int foff_b = BM * LD + (wn0 + (lane & 31)) * LD;
   int ko[4];
-  frag_offsets<LDS_LD>(ko, lane);
+  frag_offsets<LD>(ko, lane);
 
   __shared__ int s_lost;   // set by thread 0 when a partner's contribution timed out (read after the next barrier)
   if (threadIdx.x == 0) s_lost = 0;
-  const long long G = gridDim.x;
-  // NO XCD remap here: a block may only wait on blocks with a LOWER dispatch index (those are running or done whatever
-  // the residency), so the logical order of the unit ranges must be the dispatch order.
-  const long long lb = blockIdx.x;
+  // NO free XCD remap here: a block may only wait on blocks with a LOWER dispatch index (those are running or done whatever
+  // the residency), so inside a group the logical order of the unit ranges is the dispatch order.
+  // 32-bit unit arithmetic: the host only launches this kernel when units x blocks < 2^31
+  const int X = a.sk_groups;
+  const int d = blockIdx.x;
+  const int grp = d % X, rank = d / X;
+  const int Gx = (int)gridDim.x / X;                  // host: gridDim.x % X == 0
   const int S = a.sk_steps;
-  const long long U = a.sk_tiles * S;
-  const long long u0 = lb * U / G, u1 = (lb + 1) * U / G;
+  const int T = (int)a.sk_tiles;
+  const int tb = (int)((long long)T * grp / X), te = (int)((long long)T * (grp + 1) / X);
+  const int ubase = tb * S, Ux = (te - tb) * S;
+  const int u0 = ubase + (int)((unsigned)(rank * Ux) / (unsigned)Gx), u1 = ubase + (int)((unsigned)((rank + 1) * Ux) / (unsigned)Gx);
 
-  long long hi = u1;
+  int hi = u1;
   while (hi > u0) {
-    const long long tile = (hi - 1) / S;
-    const long long tbeg = tile * S;
-    const long long lo = u0 > tbeg ? u0 : tbeg;
-    const int s0 = (int)(lo - tbeg), s1 = (int)(hi - tbeg), nsteps = s1 - s0;
-    const int tile_n = (int)(tile % a.tiles_n);
-    const long long m0 = (tile / a.tiles_n) * BM;
+    const int tile = (hi - 1) / S;
+    const int tbeg = tile * S;
+    const int lo = u0 > tbeg ? u0 : tbeg;
+    const int s0 = lo - tbeg, s1 = hi - tbeg, nsteps = s1 - s0;
+    const int tile_n = tile % a.tiles_n;
+    const long long m0 = (long long)(tile / a.tiles_n) * BM;
     const int n0 = tile_n * BN;
 
-    Stager<BM, BN, LDS_LD> st(a, m0, n0, tid, 0);
+    Stager<BM, BN, LD> st(a, m0, n0, tid, 0);
     if (s0) st.seek(s0);
     f32x16 acc[MT][NT];
     zero_acc<MT, NT>(acc);
@@ -576,14 +588,14 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_sk_kernel(const GemmArgs a) 
     float* s_cur = smem;
     float* s_nxt = smem + STAGE;
     float* s_fill = smem + 2 * STAGE;
-    st.load(0 < nsteps); st.advance(); st.store(s_cur, s_cur + BM * LDS_LD);
-    st.load(1 < nsteps); st.advance(); st.store(s_nxt, s_nxt + BM * LDS_LD);
+    st.load(0 < nsteps); st.advance(); st.store(s_cur, s_cur + BM * LD);
+    st.load(1 < nsteps); st.advance(); st.store(s_nxt, s_nxt + BM * LD);
     st.load(2 < nsteps); st.advance();
     __syncthreads();
     Frags<MT, NT> f0, f1;
-    frag_read<MT, NT, LDS_LD>(f0, s_cur + foff_a, s_cur + foff_b, ko, 0);
+    frag_read<MT, NT, LD>(f0, s_cur + foff_a, s_cur + foff_b, ko, 0);
     for (int j = 0; j < nsteps; ++j) {
-      v3_step<BM, BN, MT, NT, 0, LDS_LD>(acc, f0, f1, st, s_cur + foff_a, s_cur + foff_b, s_nxt + foff_a, s_nxt + foff_b, s_fill,
+      v3_step<BM, BN, MT, NT, 0, LD>(acc, f0, f1, st, s_cur + foff_a, s_cur + foff_b, s_nxt + foff_a, s_nxt + foff_b, s_fill,
                                  j + 3 < nsteps, ko, std::make_integer_sequence<int, 16 * MT * NT>{});
       st.advance();
       float* t = s_cur; s_cur = s_nxt; s_nxt = s_fill; s_fill = t;
@@ -592,7 +604,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_sk_kernel(const GemmArgs a) 
 
     if (s1 < S) {
       // contribution: partial -> workspace slot of this block, then publish
-      float* mine = a.sk_ws + (lb * 4 + wid) * (16 * 64) + lane;
+      float* mine = a.sk_ws + ((long long)d * 4 + wid) * (16 * 64) + lane;
 #pragma unroll
       for (int r = 0; r < 16; ++r) mine[r * 64] = acc[0][0][r];
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -600,15 +612,16 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_sk_kernel(const GemmArgs a) 
       if (tid == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(a.sk_flags + lb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.sk_flags + d, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     } else {
       if (s0 > 0) {
-        // owner of a split tile: add the partials of blocks lb-1, lb-2, ... that cover [tbeg, lo)
-        for (long long k = lb - 1; k >= 0; --k) {
+        // owner of a split tile: add the partials of the group's blocks rank-1, rank-2, ... that cover [tbeg, lo)
+        for (int k = rank - 1; k >= 0; --k) {
+          const int slot = grp + k * X;                // that block's dispatch index
           if (tid == 0) {
             unsigned spins = 0;
-            while (__hip_atomic_load(a.sk_flags + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            while (__hip_atomic_load(a.sk_flags + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
               __builtin_amdgcn_s_sleep(4);
               if (++spins > (1u << 24)) {
                 // bounded spin (no hang under preemption / a debugger) — but a contribution that never arrived must not pass
@@ -620,12 +633,15 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_sk_kernel(const GemmArgs a) 
               }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            // every contribution has exactly one consumer (this owner): hand the flag back as 0, so the flag region is all-zero
+            // again when the kernel ends and the next launch needs no memset in front of it
+            __hip_atomic_store(a.sk_flags + slot, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
           __syncthreads();
-          const float* theirs = a.sk_ws + (k * 4 + wid) * (16 * 64) + lane;
+          const float* theirs = a.sk_ws + ((long long)slot * 4 + wid) * (16 * 64) + lane;
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[0][0][r] += theirs[r * 64];
-          if (k * U / G <= tbeg) break;   // block k's range starts at or before the tile: it was the last contributor
+          if (ubase + (int)((unsigned)(k * Ux) / (unsigned)Gx) <= tbeg) break;   // block k's range starts at or before the tile: it was the last contributor
         }
         if (s_lost) {
 #pragma unroll
@@ -639,23 +655,47 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_sk_kernel(const GemmArgs a) 
   }
 }
 
-int launch_sk(const GemmArgs& a, int epi, hipStream_t st) {
+// variant bits: 1 = swizzled 48 KB LDS layout, 2 = per-XCD tile groups, blocks per CU = 1 + (variant >> 2)  (1..3)
+int g_sk_variant = 4;     // padded layout, two blocks per CU, one group (the round-1 schedule)
+
+template <int EPI, int LD, int BPC>
+int launch_sk_one(const GemmArgs& g, unsigned G, hipStream_t st) {
+  constexpr size_t smem = 3 * 128 * LD * sizeof(float);
+  auto kern = conv_gemm_sk_kernel<EPI, LD, BPC>;
+  static pfk_device_once attr_once;
+  attr_once.run([&] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  });
+  hipLaunchKernelGGL(kern, dim3(G), dim3(256), smem, st, g);
+  return pfk_launch_status();
+}
+
+template <int LD, int BPC>
+int launch_sk_epi(const GemmArgs& g, int epi, unsigned G, hipStream_t st) {
+  switch (epi) {
+    case PFK_EPI_LINEAR: return launch_sk_one<PFK_EPI_LINEAR, LD, BPC>(g, G, st);
+    case PFK_EPI_GRU_ZR: return launch_sk_one<PFK_EPI_GRU_ZR, LD, BPC>(g, G, st);
+    case PFK_EPI_GRU_Q:  return launch_sk_one<PFK_EPI_GRU_Q, LD, BPC>(g, G, st);
+    default: return PFK_ERR_BAD_ARG;
+  }
+}
+
+int launch_sk(const GemmArgs& a, int epi, hipStream_t st, int variant) {
   GemmArgs g = a;
   g.tiles_n = (a.b_rows + 63) / 64;
   g.sk_tiles = ((a.M + 63) / 64) * g.tiles_n;
+  const bool swz = variant & 1;
+  int bpc = 1 + (variant >> 2);
+  if (bpc > 3 || (bpc == 3 && !swz)) return PFK_ERR_BAD_ARG;     // three padded blocks (165 KB) do not fit a CU's LDS
   const long long U = g.sk_tiles * g.sk_steps;
-  long long G = SK_MAX_BLOCKS;             // two resident 256-thread blocks per CU (55 KB LDS each)
+  long long G = 256LL * bpc;
   if (U / G < 6) G = U / 6 > 0 ? U / 6 : 1; // keep segments long enough to amortise the pipeline prologue
-  if (hipMemsetAsync(g.sk_flags, 0, (size_t)G * sizeof(unsigned), st) != hipSuccess) return PFK_ERR_LAUNCH;
-  constexpr size_t smem = 3 * 128 * LDS_LD * sizeof(float);
-  dim3 grid((unsigned)G), block(256);
-  switch (epi) {
-    case PFK_EPI_LINEAR: hipLaunchKernelGGL(conv_gemm_sk_kernel<PFK_EPI_LINEAR>, grid, block, smem, st, g); break;
-    case PFK_EPI_GRU_ZR: hipLaunchKernelGGL(conv_gemm_sk_kernel<PFK_EPI_GRU_ZR>, grid, block, smem, st, g); break;
-    case PFK_EPI_GRU_Q:  hipLaunchKernelGGL(conv_gemm_sk_kernel<PFK_EPI_GRU_Q>, grid, block, smem, st, g); break;
-    default: return PFK_ERR_BAD_ARG;
-  }
-  return pfk_launch_status();
+  if (U * (G + 1) >= 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;   // the kernel's unit arithmetic is 32-bit
+  g.sk_groups = 1;
+  if ((variant & 2) && g.sk_tiles >= 64 && G >= 64) { g.sk_groups = 8; G -= G % 8; }
+  if (bpc == 1) return swz ? launch_sk_epi<LDS_LDX, 1>(g, epi, (unsigned)G, st) : launch_sk_epi<LDS_LD, 1>(g, epi, (unsigned)G, st);
+  if (bpc == 2) return swz ? launch_sk_epi<LDS_LDX, 2>(g, epi, (unsigned)G, st) : launch_sk_epi<LDS_LD, 2>(g, epi, (unsigned)G, st);
+  return launch_sk_epi<LDS_LDX, 3>(g, epi, (unsigned)G, st);
 }
 
 // VARIANT: 0 = 4-wave double-buffered pipeline (v1), 1 = v3 one group, 2 = v3 two groups (in-block split-K);
@@ -720,12 +760,13 @@ int launch(const GemmArgs& a0, int epi, int batches, hipStream_t st) {
     // tile grid quantises badly on 256 CUs and K is long enough to amortise segment prologues + fix-up: it wins for
     // convc2 at batch 1 (330 tiles: 80 -> 65 us) and loses for 220-tile or short-K launches.
     const double fill = (double)blocks64 / (256.0 * (double)((blocks64 + 255) / 256));
-    const bool sk = a.sk_ws != nullptr && batches == 1 && blocks64 > 256 && blocks64 < 4 * 256 && fill < 0.75 &&
+    const bool sk_fits = blocks64 * (long long)a.sk_steps * (SK_MAX_BLOCKS + 1) < 0x7fffffffLL;   // 32-bit unit arithmetic
+    const bool sk = sk_fits && a.sk_ws != nullptr && batches == 1 && blocks64 > 256 && blocks64 < 4 * 256 && fill < 0.75 &&
                     a.sk_steps >= 24;
     // >= 3 tiles per CU: the swizzled 48 KB layout (cfg 10) keeps three blocks resident; below that the padded rows'
     // immediate-offset fragment reads are a few % faster (cfg 4).
     // a handful of output tiles with a very long K (GEMM-shaped callers with a tall reduction): only stream-K fills the chip
-    const bool sk_long = a.sk_ws != nullptr && batches == 1 && blocks64 <= 64 && a.sk_steps >= 128;
+    const bool sk_long = sk_fits && a.sk_ws != nullptr && batches == 1 && blocks64 <= 64 && a.sk_steps >= 128;
     // (round 2, after the LDS epilogue: with >= 3 tiles per CU the swizzled 3-stage kernel also wins for short K — c1 111 -> 104 us,
     //  mask conv2 163 -> 158 us at batch 8; below that the 2-stage kernel's cheaper prologue still does)
     cfg = (sk || sk_long) ? 9 : (blocks64 >= 3 * 256 ? 10 : (a.sk_steps < 16 ? 0 : 4));
@@ -740,7 +781,10 @@ int launch(const GemmArgs& a0, int epi, int batches, hipStream_t st) {
     case 6: return launch_cfg<128, 128, 64, 64, 1>(a, epi, batches, st);
     case 7: return launch_cfg<128, 64, 64, 32, 1>(a, epi, batches, st);
     case 8: return launch_cfg<64, 64, 32, 32, 2>(a, epi, batches, st);
-    case 9: return (a.sk_ws != nullptr && batches == 1) ? launch_sk(a, epi, st) : PFK_ERR_BAD_ARG;
+    case 9: return (a.sk_ws != nullptr && batches == 1) ? launch_sk(a, epi, st, g_sk_variant) : PFK_ERR_BAD_ARG;
+    // 30 + v: stream-K with schedule variant v (launch_sk), tuning only
+    case 30: case 31: case 32: case 33: case 34: case 35: case 36: case 37: case 38: case 39: case 40: case 41:
+      return (a.sk_ws != nullptr && batches == 1) ? launch_sk(a, epi, st, cfg - 30) : PFK_ERR_BAD_ARG;
     case 10: return launch_cfg<64, 64, 32, 32, 101>(a, epi, batches, st);
     // timing ablations of cfg 4 (results are garbage; used by scripts/conv_bench.py only)
     case 21: return epi == PFK_EPI_LINEAR ? launch_cfg<64, 64, 32, 32, 11>(a, epi, batches, st) : PFK_ERR_BAD_ARG;

@@ -129,6 +129,138 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
   }
 }
 
+// Variant with a 128 (output channels) x 128 (four K chunks) tile: the wave tile grows from 32x32 to 64x64 (four accumulators),
+// so a K-step of 32 pixels feeds 64 MFMAs per wave from 64 ds_read_b32 pairs-of-operands (one LDS read per MFMA instead of two)
+// and 8 instead of 5 global float4 loads per thread buy 4x the matrix work.  The four chunks of a block are consecutive entries
+// of the forward kernel's K enumeration: each has its own (source, tap, channel offset), i.e. its own zero-padding predicate.
+struct ChunkRef { const float* src; int ld, cch, c0, dy, dx, bias, live; };
+
+__device__ __forceinline__ ChunkRef chunk_ref(const WgradArgs& a, int chunk) {
+  ChunkRef c;
+  const int taps = a.kh * a.kw;
+  int r = chunk, cps = (a.ch0 + 31) >> 5;
+  c.src = a.src0; c.ld = a.ld0; c.cch = a.ch0;
+  if (a.nsrc > 1 && r >= taps * cps) {
+    r -= taps * cps; cps = (a.ch1 + 31) >> 5; c.src = a.src1; c.ld = a.ld1; c.cch = a.ch1;
+    if (a.nsrc > 2 && r >= taps * cps) { r -= taps * cps; cps = (a.ch2 + 31) >> 5; c.src = a.src2; c.ld = a.ld2; c.cch = a.ch2; }
+  }
+  c.live = chunk < a.chunks;
+  c.bias = a.with_bias && chunk == a.chunks - 1;
+  const int tap = (c.bias || !c.live) ? 0 : r / cps;
+  c.c0 = (c.bias || !c.live) ? 0 : (r - tap * cps) * 32;
+  c.dy = (c.bias || !c.live) ? 0 : tap / a.kw - (a.kh >> 1);
+  c.dx = (c.bias || !c.live) ? 0 : tap % a.kw - (a.kw >> 1);
+  return c;
+}
+
+__global__ __launch_bounds__(256, 2) void conv_wgrad4_kernel(const WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float wsm[];
+  float (*sY)[32][128] = reinterpret_cast<float (*)[32][128]>(wsm);                   // [2][32 pixels][128 output channels]
+  float (*sX)[32][128] = reinterpret_cast<float (*)[32][128]>(wsm + 2 * 32 * 128);     // [2][32 pixels][4 chunks x 32 channels]
+
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+  const int groups = (a.chunks + 3) >> 2;
+  const int grp = blockIdx.x % groups;
+  const int tile_m = blockIdx.x / groups;
+  const int split = blockIdx.y;
+  const int co0 = tile_m * 128;
+
+  const long long p_begin = (long long)split * a.px_per_split;
+  const long long p_end = min(a.M, p_begin + a.px_per_split);
+  const int steps = p_end > p_begin ? (int)((p_end - p_begin + 31) >> 5) : 0;
+
+  const int row = t >> 3, q = t & 7;
+  long long p = p_begin + row;
+  int x = (int)(p % a.W), y = (int)((p / a.W) % a.H);
+  const __amdgpu_buffer_rsrc_t rsy = rsrc_of(a.dy);
+  __amdgpu_buffer_rsrc_t rsx[4];
+  int tap_off[4], cdy[4], cdx[4], lds_[4];
+  bool c_ok[4], is_bias[4], yok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const ChunkRef c = chunk_ref(a, grp * 4 + i);
+    rsx[i] = rsrc_of(c.src);
+    tap_off[i] = (c.dy * a.W + c.dx) * c.ld + c.c0 + q * 4;
+    cdy[i] = c.dy; cdx[i] = c.dx;
+    c_ok[i] = c.live && !c.bias && c.c0 + q * 4 < c.cch;
+    is_bias[i] = c.bias;
+    yok[i] = co0 + q * 4 + 32 * i < a.cout;
+    lds_[i] = c.ld;
+  }
+
+  u32x4 rx[4], ry[4];
+  auto load = [&](void) {
+    const bool in = p < p_end;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool ok = in && c_ok[i] && (unsigned)(y + cdy[i]) < (unsigned)a.H && (unsigned)(x + cdx[i]) < (unsigned)a.W;
+      if (is_bias[i]) rx[i] = u32x4{(in && q == 0) ? 0x3f800000u : 0u, 0u, 0u, 0u};       // A = [1 0 0 ...] for every live pixel
+      else rx[i] = __builtin_amdgcn_raw_buffer_load_b128(rsx[i], ok ? (unsigned)((int)p * lds_[i] + tap_off[i]) * 4u : OOB, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      ry[i] = __builtin_amdgcn_raw_buffer_load_b128(rsy, (in && yok[i]) ? (unsigned)((int)p * a.dy_ld + co0 + q * 4 + 32 * i) * 4u : OOB, 0, 0);
+    p += 32;
+    x += 32;
+    while (x >= a.W) { x -= a.W; if (++y == a.H) y = 0; }
+  };
+  auto store = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<u32x4*>(&sX[buf][row][q * 4 + 32 * i]) = rx[i];
+      *reinterpret_cast<u32x4*>(&sY[buf][row][q * 4 + 32 * i]) = ry[i];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
+
+  if (steps > 0) {
+    load();
+    store(0);
+  }
+  __syncthreads();
+  const int l31 = lane & 31, hl = lane >> 5;
+  const int wm = (wid >> 1) * 64, wn = (wid & 1) * 64;
+  for (int s = 0; s < steps; ++s) {
+    const int buf = s & 1;
+    const bool more = s + 1 < steps;
+    if (more) load();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float a0 = sY[buf][2 * j + hl][wm + l31], a1 = sY[buf][2 * j + hl][wm + 32 + l31];
+      const float b0 = sX[buf][2 * j + hl][wn + l31], b1 = sX[buf][2 * j + hl][wn + 32 + l31];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (more) store(buf ^ 1);
+    __syncthreads();
+  }
+
+  // D: column j = lane & 31 (input channel of the chunk), rows i = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) (output channel)
+  float* out = a.part + (long long)split * a.cout * a.ktot;
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    const int chunk = grp * 4 + (wn >> 5) + n;
+    if (chunk >= a.chunks) continue;
+    const int kcol = chunk * 32 + l31;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int co = co0 + wm + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * hl;
+        if (co < a.cout) out[(long long)co * a.ktot + kcol] = acc[m][n][e];
+      }
+  }
+}
+
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
                                                            long long n, int splits) {
   const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -209,8 +341,10 @@ __global__ __launch_bounds__(256) void gru_b2_kernel(const float* __restrict__ d
   st4(dh + p * C + c, ld4(dh + p * C + c) + g * rr);
 }
 
-int pick_splits(long long tiles, long long M) {
-  long long s = 1024 / (tiles > 0 ? tiles : 1);
+int g_wgrad_variant = 0;   // 0: 128x32 tiles (conv_wgrad_kernel); 1: 128x128 tiles (conv_wgrad4_kernel) — pfk_debug_set_wgrad
+
+int pick_splits(long long tiles, long long M, long long target = 1024) {
+  long long s = target / (tiles > 0 ? tiles : 1);
   const long long max_s = M / 512 > 0 ? M / 512 : 1;     // >= 16 K-steps per slice
   if (s > max_s) s = max_s;
   if (s > 64) s = 64;
@@ -227,11 +361,15 @@ inline int ktot_of(const pfk_conv_desc* d) {
 
 extern "C" {
 
+void pfk_debug_set_wgrad(int variant) { g_wgrad_variant = variant; }
+
 long long pfk_conv_wgrad_workspace_bytes(const pfk_conv_desc* d, int with_bias) {
   if (!d || d->num_src < 1 || d->num_src > 3 || d->cout <= 0) return 0;
   const int ktot = ktot_of(d) + (with_bias ? 32 : 0);
   const long long M = (long long)d->B * d->H * d->W;
-  const int splits = pick_splits((long long)((d->cout + 127) / 128) * (ktot / 32), M);
+  const long long tm = (d->cout + 127) / 128;
+  const int s0 = pick_splits(tm * (ktot / 32), M), s1 = pick_splits(tm * ((ktot / 32 + 3) / 4), M, 512);
+  const int splits = s0 > s1 ? s0 : s1;      // either kernel variant may run
   return splits > 1 ? (long long)splits * d->cout * ktot * (long long)sizeof(float) : 0;
 }
 
@@ -260,7 +398,9 @@ int pfk_conv_wgrad_f32(const pfk_conv_desc* d, const float* dy, int dy_ld, float
   a.ktot = ktot_of(d) + (with_bias ? 32 : 0);
   a.chunks = a.ktot / 32;
   a.tiles_m = (d->cout + 127) / 128;
-  const int splits = pick_splits((long long)a.tiles_m * a.chunks, M);
+  const bool v4 = g_wgrad_variant == 1;
+  const int groups = (a.chunks + 3) / 4;
+  const int splits = v4 ? pick_splits((long long)a.tiles_m * groups, M, 512) : pick_splits((long long)a.tiles_m * a.chunks, M);
   a.px_per_split = ((M + splits - 1) / splits + 31) / 32 * 32;
   const long long n = (long long)d->cout * a.ktot;
   if (splits > 1) {
@@ -270,7 +410,16 @@ int pfk_conv_wgrad_f32(const pfk_conv_desc* d, const float* dy, int dy_ld, float
     a.part = dw_packed;
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)(a.tiles_m * a.chunks), (unsigned)splits), dim3(256), 0, st, a);
+  if (v4) {
+    constexpr size_t smem = 4 * 32 * 128 * sizeof(float);     // 64 KB: two resident blocks per CU
+    static pfk_device_once attr_once;
+    attr_once.run([&] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    });
+    hipLaunchKernelGGL(conv_wgrad4_kernel, dim3((unsigned)(a.tiles_m * groups), (unsigned)splits), dim3(256), smem, st, a);
+  } else {
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)(a.tiles_m * a.chunks), (unsigned)splits), dim3(256), 0, st, a);
+  }
   if (splits > 1)
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st,
                        static_cast<const float*>(workspace), dw_packed, n, splits);
