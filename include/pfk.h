@@ -64,7 +64,7 @@ const char* pfk_status_string(int status);
 void pfk_debug_set_tile(int cfg);
 /* tuning knob of the pyramid lookup: source pixels per workgroup, 4 (default) or 8. Not thread-safe. */
 void pfk_debug_set_lookup_pix(int pix);
-void pfk_debug_set_wgrad(int variant);      /* 0: 128x32-tile weight-gradient kernel, 1: 128x128 tiles (tuning knob) */
+void pfk_debug_set_wgrad(int variant);      /* weight-gradient tile height: 0 = by padding waste, 1 / 2 / 4 = forced 32 / 64 / 128 rows (tuning knob) */
 
 /* ---- K1: all-pairs correlation --------------------------------------------------------------
  * out[b][i][j] = scale * sum_d f1[b][i][d] * f2[b][j][d]        (fp32 MFMA, exact fp32 products)

@@ -656,7 +656,8 @@ __global__ __launch_bounds__(256, BPC) void conv_gemm_sk_kernel(const GemmArgs a
 }
 
 // variant bits: 1 = swizzled 48 KB LDS layout, 2 = per-XCD tile groups, blocks per CU = 1 + (variant >> 2)  (1..3)
-int g_sk_variant = 4;     // padded layout, two blocks per CU, one group (the round-1 schedule)
+int g_sk_variant = 6;     // padded layout, two blocks per CU, per-XCD groups: the best of the sweep (scripts/conv_bench.py cfg 30 + v at
+                          // batch 1: z|r conv 69.8 us with one group -> 63.7 us with XCD groups; swizzled / three per CU: 65.6 / 70.3)
 
 template <int EPI, int LD, int BPC>
 int launch_sk_one(const GemmArgs& g, unsigned G, hipStream_t st) {
@@ -754,22 +755,23 @@ int launch(const GemmArgs& a0, int epi, int batches, hipStream_t st) {
   } else {
     const long long tiles64 = (a.M + 63) / 64;
     const long long blocks64 = tiles64 * ((a.b_rows + 63) / 64);
-    // Measured on MI355X (scripts/conv_bench.py, batch 1 / 4 / 8): 64x64 tiles with the 3-stage hand-interleaved
-    // pipeline (cfg 4) win at every batch size once K is long; for short K (1x1 convs: <= 15 K-steps) the lighter
-    // 2-stage pipeline (cfg 0) has the cheaper prologue.  Stream-K (needs the caller's workspace) only where a small
-    // tile grid quantises badly on 256 CUs and K is long enough to amortise segment prologues + fix-up: it wins for
-    // convc2 at batch 1 (330 tiles: 80 -> 65 us) and loses for 220-tile or short-K launches.
+    // Measured on MI355X (scripts/conv_bench.py, batch 1 / 4 / 8): 64x64 tiles with the 3-stage hand-interleaved pipeline win at
+    // every batch size; what varies is the schedule around them.
     const double fill = (double)blocks64 / (256.0 * (double)((blocks64 + 255) / 256));
     const bool sk_fits = blocks64 * (long long)a.sk_steps * (SK_MAX_BLOCKS + 1) < 0x7fffffffLL;   // 32-bit unit arithmetic
-    const bool sk = sk_fits && a.sk_ws != nullptr && batches == 1 && blocks64 > 256 && blocks64 < 4 * 256 && fill < 0.75 &&
+    // Stream-K where the tile grid quantises badly on 256 CUs and K is long enough to amortise segment prologues + fix-up.
+    // Batch 1 (7040 pixels, round-2 sweep): z|r conv 440 tiles x 60 steps 72.5 -> 63.7 us, fh|mask conv1 880 x 36 80.5 -> 75.8,
+    // convc2 330 x 72 80.4 -> 62.5; it loses for 220-tile launches (q 41.8 -> 43.5, conv 47.8 -> 48.2: one tile per CU is
+    // already balanced) and for short K (convc1 18.7 -> 28.7, mask conv2 25.7 -> 37.6).
+    const bool sk = sk_fits && a.sk_ws != nullptr && batches == 1 && blocks64 > 256 && blocks64 < 4 * 256 && fill < 0.92 &&
                     a.sk_steps >= 24;
-    // >= 3 tiles per CU: the swizzled 48 KB layout (cfg 10) keeps three blocks resident; below that the padded rows'
-    // immediate-offset fragment reads are a few % faster (cfg 4).
     // a handful of output tiles with a very long K (GEMM-shaped callers with a tall reduction): only stream-K fills the chip
     const bool sk_long = sk_fits && a.sk_ws != nullptr && batches == 1 && blocks64 <= 64 && a.sk_steps >= 128;
-    // (round 2, after the LDS epilogue: with >= 3 tiles per CU the swizzled 3-stage kernel also wins for short K — c1 111 -> 104 us,
-    //  mask conv2 163 -> 158 us at batch 8; below that the 2-stage kernel's cheaper prologue still does)
-    cfg = (sk || sk_long) ? 9 : (blocks64 >= 3 * 256 ? 10 : (a.sk_steps < 16 ? 0 : 4));
+    // Tile grids: >= 3 tiles per CU: the swizzled 48 KB layout (cfg 10) keeps three blocks resident — also for short K since the
+    // LDS epilogue (c1 111 -> 104 us, mask conv2 163 -> 158 us at batch 8).  Below that the padded rows' immediate-offset fragment
+    // reads are a few % faster (cfg 4), down to one tile per CU for short K too (convc1 at batch 1: 18.7 vs 19.9 us on the
+    // 2-stage kernel); smaller short-K grids keep the 2-stage kernel's cheaper prologue (cfg 0).
+    cfg = (sk || sk_long) ? 9 : (blocks64 >= 3 * 256 ? 10 : ((a.sk_steps < 16 && blocks64 < 256) ? 0 : 4));
   }
   switch (cfg) {
     case 0: return launch_cfg<64, 64, 32, 32, 0>(a, epi, batches, st);

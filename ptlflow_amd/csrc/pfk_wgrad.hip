@@ -9,10 +9,12 @@
 // lane l reads LDS element [pixel 2j + (l >> 5)][l & 31] with ds_read_b32 — each half-wave reads 32 consecutive floats of
 // one row, conflict-free — one read pair per MFMA.
 //
-// Grid: (cout/128 tiles) x (ktot/32 chunks) x (pixel splits).  The output has few tiles and a very long reduction
-// (zr of RAFT: 2 x 60 tiles, 22 816+ pixels), so the pixel range is cut into `splits` slices that write partial tiles to a
-// workspace; a second kernel adds the slices in a fixed order (deterministic, no atomics) into the packed [cout][ktot]
-// layout of the forward weight.
+// Grid: (cout tiles) x (groups of K chunks) x (pixel splits); a tile is 32*CB output channels x 32*(4/CB) K columns, CB in
+// {4, 2, 1} picked per launch to pad cout the least.  The output has few tiles and a very long reduction (zr of RAFT: 2 x 60
+// tiles, 22 816+ pixels), so the pixel range is cut into `splits` slices that write partial tiles to a workspace; a second kernel
+// adds the slices in a fixed order (deterministic, no atomics) into the packed [cout][ktot] layout of the forward weight.
+// (A 128 x 128 tile with 64x64 wave tiles — half the LDS reads per MFMA — measured 5-30 % SLOWER on every training shape:
+// the loop is not LDS-bound, fewer resident waves per SIMD hurt more.)
 #include "pfk_common.h"
 
 namespace {
@@ -36,103 +38,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void* p) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
 }
 
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
-  __shared__ __attribute__((aligned(16))) float sY[2][32][128];
-  __shared__ __attribute__((aligned(16))) float sX[2][32][32];
-
-  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
-  const int chunk = blockIdx.x % a.chunks;
-  const int tile_m = blockIdx.x / a.chunks;
-  const int split = blockIdx.y;
-  const int co0 = tile_m * 128;
-
-  // chunk -> (source, tap, first channel): same enumeration as the forward kernel's K iterator
-  const int taps = a.kh * a.kw;
-  int r = chunk, cps = (a.ch0 + 31) >> 5;
-  const float* src = a.src0; int ld = a.ld0, cch = a.ch0;
-  if (a.nsrc > 1 && r >= taps * cps) {
-    r -= taps * cps; cps = (a.ch1 + 31) >> 5; src = a.src1; ld = a.ld1; cch = a.ch1;
-    if (a.nsrc > 2 && r >= taps * cps) { r -= taps * cps; cps = (a.ch2 + 31) >> 5; src = a.src2; ld = a.ld2; cch = a.ch2; }
-  }
-  const bool bias_chunk = a.with_bias && chunk == a.chunks - 1;
-  const int tap = bias_chunk ? 0 : r / cps, c0 = bias_chunk ? 0 : (r - tap * cps) * 32;
-  const int dy_ = bias_chunk ? 0 : tap / a.kw - (a.kh >> 1), dx_ = bias_chunk ? 0 : tap % a.kw - (a.kw >> 1);
-
-  const __amdgpu_buffer_rsrc_t rsx = rsrc_of(src), rsy = rsrc_of(a.dy);
-  const long long p_begin = (long long)split * a.px_per_split;
-  const long long p_end = min(a.M, p_begin + a.px_per_split);
-  const int steps = p_end > p_begin ? (int)((p_end - p_begin + 31) >> 5) : 0;
-
-  // this thread stages row (t >> 3) of every step: float4 q of the A chunk, float4 q + 8*i of the dY tile
-  const int row = t >> 3, q = t & 7;
-  long long p = p_begin + row;
-  int x = (int)(p % a.W), y = (int)((p / a.W) % a.H);
-  const bool c_ok = c0 + q * 4 < cch;
-  const int tap_off = (dy_ * a.W + dx_) * ld + c0 + q * 4;
-  bool yok[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) yok[i] = co0 + q * 4 + 32 * i < a.cout;
-
-  u32x4 rx, ry[4];
-  auto load = [&](void) {
-    const bool in = p < p_end;
-    const bool ok = in && c_ok && (unsigned)(y + dy_) < (unsigned)a.H && (unsigned)(x + dx_) < (unsigned)a.W;
-    if (bias_chunk) {   // A = [1 0 0 ...] for every live pixel
-      rx = u32x4{(in && q == 0) ? 0x3f800000u : 0u, 0u, 0u, 0u};
-    } else {
-      rx = __builtin_amdgcn_raw_buffer_load_b128(rsx, ok ? (unsigned)((int)p * ld + tap_off) * 4u : OOB, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      ry[i] = __builtin_amdgcn_raw_buffer_load_b128(rsy, (in && yok[i]) ? (unsigned)((int)p * a.dy_ld + co0 + q * 4 + 32 * i) * 4u : OOB, 0, 0);
-    p += 32;
-    x += 32;
-    while (x >= a.W) { x -= a.W; if (++y == a.H) y = 0; }
-  };
-  auto store = [&](int buf) {
-    *reinterpret_cast<u32x4*>(&sX[buf][row][q * 4]) = rx;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(&sY[buf][row][q * 4 + 32 * i]) = ry[i];
-  };
-
-  f32x16 acc;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-
-  if (steps > 0) {
-    load();
-    store(0);
-  }
-  __syncthreads();
-  const int l31 = lane & 31, hl = lane >> 5;
-  for (int s = 0; s < steps; ++s) {
-    const int buf = s & 1;
-    const bool more = s + 1 < steps;
-    if (more) load();
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const float av = sY[buf][2 * j + hl][wid * 32 + l31];
-      const float bv = sX[buf][2 * j + hl][l31];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
-    }
-    if (more) store(buf ^ 1);
-    __syncthreads();
-  }
-
-  // D: column j = lane & 31 (input channel), rows i = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) (output channel)
-  float* out = a.part + (long long)split * a.cout * a.ktot;
-  const int kcol = chunk * 32 + l31;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const int co = co0 + wid * 32 + (e & 3) + 8 * (e >> 2) + 4 * hl;
-    if (co < a.cout) out[(long long)co * a.ktot + kcol] = acc[e];
-  }
-}
-
-// Variant with a 128 (output channels) x 128 (four K chunks) tile: the wave tile grows from 32x32 to 64x64 (four accumulators),
-// so a K-step of 32 pixels feeds 64 MFMAs per wave from 64 ds_read_b32 pairs-of-operands (one LDS read per MFMA instead of two)
-// and 8 instead of 5 global float4 loads per thread buy 4x the matrix work.  The four chunks of a block are consecutive entries
-// of the forward kernel's K enumeration: each has its own (source, tap, channel offset), i.e. its own zero-padding predicate.
+// One (source, tap, 32-channel) entry of the forward kernel's K enumeration.
 struct ChunkRef { const float* src; int ld, cch, c0, dy, dx, bias, live; };
 
 __device__ __forceinline__ ChunkRef chunk_ref(const WgradArgs& a, int chunk) {
@@ -146,59 +52,65 @@ __device__ __forceinline__ ChunkRef chunk_ref(const WgradArgs& a, int chunk) {
   }
   c.live = chunk < a.chunks;
   c.bias = a.with_bias && chunk == a.chunks - 1;
-  const int tap = (c.bias || !c.live) ? 0 : r / cps;
-  c.c0 = (c.bias || !c.live) ? 0 : (r - tap * cps) * 32;
-  c.dy = (c.bias || !c.live) ? 0 : tap / a.kw - (a.kh >> 1);
-  c.dx = (c.bias || !c.live) ? 0 : tap % a.kw - (a.kw >> 1);
+  const bool plain = c.live && !c.bias;
+  const int tap = plain ? r / cps : 0;
+  c.c0 = plain ? (r - tap * cps) * 32 : 0;
+  c.dy = plain ? tap / a.kw - (a.kh >> 1) : 0;
+  c.dx = plain ? tap % a.kw - (a.kw >> 1) : 0;
   return c;
 }
 
-__global__ __launch_bounds__(256, 2) void conv_wgrad4_kernel(const WgradArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float wsm[];
-  float (*sY)[32][128] = reinterpret_cast<float (*)[32][128]>(wsm);                   // [2][32 pixels][128 output channels]
-  float (*sX)[32][128] = reinterpret_cast<float (*)[32][128]>(wsm + 2 * 32 * 128);     // [2][32 pixels][4 chunks x 32 channels]
+// CB = 32-row output-channel blocks per tile (4, 2 or 1); the block's four waves cover CB co-blocks x NCH = 4 / CB consecutive K
+// chunks, one 32x32 accumulator each, so the tile is (32 CB) output channels x (32 NCH) K columns.  The host picks CB to waste
+// the fewest MFMAs on channel padding (cout = 64: CB 2, not half-empty 128-row tiles; 96 and 192: three exact 32- / 64-row tiles).
+template <int CB>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
+  constexpr int NCH = 4 / CB, CO = 32 * CB, KC = 32 * NCH;
+  __shared__ __attribute__((aligned(16))) float sY[2][32][CO];
+  __shared__ __attribute__((aligned(16))) float sX[2][32][KC];
 
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
-  const int groups = (a.chunks + 3) >> 2;
+  const int groups = (a.chunks + NCH - 1) / NCH;
   const int grp = blockIdx.x % groups;
   const int tile_m = blockIdx.x / groups;
   const int split = blockIdx.y;
-  const int co0 = tile_m * 128;
+  const int co0 = tile_m * CO;
 
+  const __amdgpu_buffer_rsrc_t rsy = rsrc_of(a.dy);
   const long long p_begin = (long long)split * a.px_per_split;
   const long long p_end = min(a.M, p_begin + a.px_per_split);
   const int steps = p_end > p_begin ? (int)((p_end - p_begin + 31) >> 5) : 0;
 
+  // this thread stages row (t >> 3) of every step: float4 q of each of the NCH A chunks, float4 q + 8*i of the dY tile
   const int row = t >> 3, q = t & 7;
   long long p = p_begin + row;
   int x = (int)(p % a.W), y = (int)((p / a.W) % a.H);
-  const __amdgpu_buffer_rsrc_t rsy = rsrc_of(a.dy);
-  __amdgpu_buffer_rsrc_t rsx[4];
-  int tap_off[4], cdy[4], cdx[4], lds_[4];
-  bool c_ok[4], is_bias[4], yok[4];
+  __amdgpu_buffer_rsrc_t rsx[NCH];
+  int tap_off[NCH], cdy[NCH], cdx[NCH], cld[NCH];
+  bool c_ok[NCH], is_bias[NCH], yok[CB];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const ChunkRef c = chunk_ref(a, grp * 4 + i);
+  for (int i = 0; i < NCH; ++i) {
+    const ChunkRef c = chunk_ref(a, grp * NCH + i);
     rsx[i] = rsrc_of(c.src);
     tap_off[i] = (c.dy * a.W + c.dx) * c.ld + c.c0 + q * 4;
-    cdy[i] = c.dy; cdx[i] = c.dx;
+    cdy[i] = c.dy; cdx[i] = c.dx; cld[i] = c.ld;
     c_ok[i] = c.live && !c.bias && c.c0 + q * 4 < c.cch;
     is_bias[i] = c.bias;
-    yok[i] = co0 + q * 4 + 32 * i < a.cout;
-    lds_[i] = c.ld;
   }
+#pragma unroll
+  for (int i = 0; i < CB; ++i) yok[i] = co0 + q * 4 + 32 * i < a.cout;
 
-  u32x4 rx[4], ry[4];
+  u32x4 rx[NCH], ry[CB];
   auto load = [&](void) {
     const bool in = p < p_end;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NCH; ++i) {
       const bool ok = in && c_ok[i] && (unsigned)(y + cdy[i]) < (unsigned)a.H && (unsigned)(x + cdx[i]) < (unsigned)a.W;
-      if (is_bias[i]) rx[i] = u32x4{(in && q == 0) ? 0x3f800000u : 0u, 0u, 0u, 0u};       // A = [1 0 0 ...] for every live pixel
-      else rx[i] = __builtin_amdgcn_raw_buffer_load_b128(rsx[i], ok ? (unsigned)((int)p * lds_[i] + tap_off[i]) * 4u : OOB, 0, 0);
+      if (is_bias[i]) rx[i] = u32x4{(in && q == 0) ? 0x3f800000u : 0u, 0u, 0u, 0u};    // A = [1 0 0 ...] for every live pixel
+      else rx[i] = __builtin_amdgcn_raw_buffer_load_b128(rsx[i], ok ? (unsigned)((int)p * cld[i] + tap_off[i]) * 4u : OOB, 0, 0);
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < CB; ++i)
       ry[i] = __builtin_amdgcn_raw_buffer_load_b128(rsy, (in && yok[i]) ? (unsigned)((int)p * a.dy_ld + co0 + q * 4 + 32 * i) * 4u : OOB, 0, 0);
     p += 32;
     x += 32;
@@ -206,19 +118,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad4_kernel(const WgradArgs a) 
   };
   auto store = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<u32x4*>(&sX[buf][row][q * 4 + 32 * i]) = rx[i];
-      *reinterpret_cast<u32x4*>(&sY[buf][row][q * 4 + 32 * i]) = ry[i];
-    }
+    for (int i = 0; i < NCH; ++i) *reinterpret_cast<u32x4*>(&sX[buf][row][q * 4 + 32 * i]) = rx[i];
+#pragma unroll
+    for (int i = 0; i < CB; ++i) *reinterpret_cast<u32x4*>(&sY[buf][row][q * 4 + 32 * i]) = ry[i];
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc;
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
-#pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 
   if (steps > 0) {
     load();
@@ -226,38 +133,30 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad4_kernel(const WgradArgs a) 
   }
   __syncthreads();
   const int l31 = lane & 31, hl = lane >> 5;
-  const int wm = (wid >> 1) * 64, wn = (wid & 1) * 64;
+  const int wco = (wid % CB) * 32, wkc = (wid / CB) * 32;      // this wave's co block / chunk inside the tile
   for (int s = 0; s < steps; ++s) {
     const int buf = s & 1;
     const bool more = s + 1 < steps;
     if (more) load();
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      const float a0 = sY[buf][2 * j + hl][wm + l31], a1 = sY[buf][2 * j + hl][wm + 32 + l31];
-      const float b0 = sX[buf][2 * j + hl][wn + l31], b1 = sX[buf][2 * j + hl][wn + 32 + l31];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      const float av = sY[buf][2 * j + hl][wco + l31];
+      const float bv = sX[buf][2 * j + hl][wkc + l31];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
     }
     if (more) store(buf ^ 1);
     __syncthreads();
   }
 
-  // D: column j = lane & 31 (input channel of the chunk), rows i = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) (output channel)
+  // D: column j = lane & 31 (input channel), rows i = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) (output channel)
+  const int chunk = grp * NCH + wid / CB;
+  if (chunk >= a.chunks) return;
   float* out = a.part + (long long)split * a.cout * a.ktot;
+  const int kcol = chunk * 32 + l31;
 #pragma unroll
-  for (int n = 0; n < 2; ++n) {
-    const int chunk = grp * 4 + (wn >> 5) + n;
-    if (chunk >= a.chunks) continue;
-    const int kcol = chunk * 32 + l31;
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int co = co0 + wm + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * hl;
-        if (co < a.cout) out[(long long)co * a.ktot + kcol] = acc[m][n][e];
-      }
+  for (int e = 0; e < 16; ++e) {
+    const int co = co0 + wco + (e & 3) + 8 * (e >> 2) + 4 * hl;
+    if (co < a.cout) out[(long long)co * a.ktot + kcol] = acc[e];
   }
 }
 
@@ -341,7 +240,20 @@ __global__ __launch_bounds__(256) void gru_b2_kernel(const float* __restrict__ d
   st4(dh + p * C + c, ld4(dh + p * C + c) + g * rr);
 }
 
-int g_wgrad_variant = 0;   // 0: 128x32 tiles (conv_wgrad_kernel); 1: 128x128 tiles (conv_wgrad4_kernel) — pfk_debug_set_wgrad
+int g_wgrad_variant = 0;   // 0: tile height by padding waste (pick_cb); 1 / 2 / 4: forced CB — pfk_debug_set_wgrad
+
+// 32-row output-channel blocks per tile: the tallest tile among {4, 2, 1} blocks that pads cout the least
+int pick_cb(int cout) {
+  if (g_wgrad_variant == 1 || g_wgrad_variant == 2 || g_wgrad_variant == 4) return g_wgrad_variant;
+  int best = 4, waste = (cout + 127) / 128 * 128 - cout;
+  const int w2 = (cout + 63) / 64 * 64 - cout, w1 = (cout + 31) / 32 * 32 - cout;
+  if (w2 < waste) { best = 2; waste = w2; }
+  if (w1 < waste) best = 1;
+  return best;
+}
+
+// blocks of the main launch for a tile height: (cout tiles) x (K chunk groups)
+long long wgrad_tiles(int cout, int chunks, int cb) { return (long long)((cout + 32 * cb - 1) / (32 * cb)) * ((chunks + 4 / cb - 1) / (4 / cb)); }
 
 int pick_splits(long long tiles, long long M, long long target = 1024) {
   long long s = target / (tiles > 0 ? tiles : 1);
@@ -367,9 +279,11 @@ long long pfk_conv_wgrad_workspace_bytes(const pfk_conv_desc* d, int with_bias) 
   if (!d || d->num_src < 1 || d->num_src > 3 || d->cout <= 0) return 0;
   const int ktot = ktot_of(d) + (with_bias ? 32 : 0);
   const long long M = (long long)d->B * d->H * d->W;
-  const long long tm = (d->cout + 127) / 128;
-  const int s0 = pick_splits(tm * (ktot / 32), M), s1 = pick_splits(tm * ((ktot / 32 + 3) / 4), M, 512);
-  const int splits = s0 > s1 ? s0 : s1;      // either kernel variant may run
+  int splits = 1;
+  for (int cb = 1; cb <= 4; cb *= 2) {        // any tile height may run (pfk_debug_set_wgrad): size for the largest split count
+    const int sc = pick_splits(wgrad_tiles(d->cout, ktot / 32, cb), M);
+    splits = sc > splits ? sc : splits;
+  }
   return splits > 1 ? (long long)splits * d->cout * ktot * (long long)sizeof(float) : 0;
 }
 
@@ -397,10 +311,10 @@ int pfk_conv_wgrad_f32(const pfk_conv_desc* d, const float* dy, int dy_ld, float
   a.with_bias = with_bias ? 1 : 0;
   a.ktot = ktot_of(d) + (with_bias ? 32 : 0);
   a.chunks = a.ktot / 32;
-  a.tiles_m = (d->cout + 127) / 128;
-  const bool v4 = g_wgrad_variant == 1;
-  const int groups = (a.chunks + 3) / 4;
-  const int splits = v4 ? pick_splits((long long)a.tiles_m * groups, M, 512) : pick_splits((long long)a.tiles_m * a.chunks, M);
+  const int cb = pick_cb(d->cout);
+  a.tiles_m = (d->cout + 32 * cb - 1) / (32 * cb);
+  const int groups = (a.chunks + 4 / cb - 1) / (4 / cb);
+  const int splits = pick_splits((long long)a.tiles_m * groups, M);
   a.px_per_split = ((M + splits - 1) / splits + 31) / 32 * 32;
   const long long n = (long long)d->cout * a.ktot;
   if (splits > 1) {
@@ -410,16 +324,10 @@ int pfk_conv_wgrad_f32(const pfk_conv_desc* d, const float* dy, int dy_ld, float
     a.part = dw_packed;
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (v4) {
-    constexpr size_t smem = 4 * 32 * 128 * sizeof(float);     // 64 KB: two resident blocks per CU
-    static pfk_device_once attr_once;
-    attr_once.run([&] {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    });
-    hipLaunchKernelGGL(conv_wgrad4_kernel, dim3((unsigned)(a.tiles_m * groups), (unsigned)splits), dim3(256), smem, st, a);
-  } else {
-    hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)(a.tiles_m * a.chunks), (unsigned)splits), dim3(256), 0, st, a);
-  }
+  const dim3 grid((unsigned)(a.tiles_m * groups), (unsigned)splits);
+  if (cb == 4) hipLaunchKernelGGL(conv_wgrad_kernel<4>, grid, dim3(256), 0, st, a);
+  else if (cb == 2) hipLaunchKernelGGL(conv_wgrad_kernel<2>, grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(conv_wgrad_kernel<1>, grid, dim3(256), 0, st, a);
   if (splits > 1)
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st,
                        static_cast<const float*>(workspace), dw_packed, n, splits);

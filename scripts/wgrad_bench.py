@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Micro-benchmark + cross-check of pfk::conv_wgrad (K12) on the training shapes of BASELINE config 5 (GPU box).
-    python scripts/wgrad_bench.py [--variants 0,1] [--reps 20]
-variant 0 = 128x32 tiles (conv_wgrad_kernel), 1 = 128x128 tiles (conv_wgrad4_kernel).  The check is variant against a float64
+    python scripts/wgrad_bench.py [--variants 0,4,2,1] [--reps 20]
+variant 0 = the library's tile height (least channel padding), 4 / 2 / 1 = forced 128 / 64 / 32 output channels per tile
+(pfk_debug_set_wgrad).  The check is the last variant against a float64
 torch matmul of the unfolded input on the small shapes, and variant-vs-variant everywhere (different split counts => the sums
 differ in the last bits; the gate is relative to the gradient's scale); the parity gate proper is tests/test_gpu_train.py."""
 import argparse
@@ -39,7 +40,7 @@ def reference(xs, dy, B, H, W, kh, kw):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--variants", default="0,1")
+    ap.add_argument("--variants", default="0,4,2,1")
     ap.add_argument("--reps", type=int, default=20)
     args = ap.parse_args()
     variants = [int(v) for v in args.variants.split(",")]
