@@ -34,7 +34,8 @@ struct CorrBfArgs {
 __global__ __launch_bounds__(256, 4) void corr_bf16_kernel(const CorrBfArgs g) {
   __shared__ __attribute__((aligned(16))) char smem[STAGE];
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
-  const int wm0 = (wid >> 1) * 64, wn0 = (wid & 1) * 64;
+  const int wid_s = __builtin_amdgcn_readfirstlane(wid);
+  const int wm0 = (wid_s >> 1) * 64, wn0 = (wid_s & 1) * 64;
   const int bid = pfk_xcd_remap(blockIdx.x, gridDim.x);
   int tile_m, tile_n;
   tile_of(bid, g.tiles_m, g.tiles_n, g.supertile, tile_m, tile_n);
@@ -45,14 +46,10 @@ __global__ __launch_bounds__(256, 4) void corr_bf16_kernel(const CorrBfArgs g) {
   // staging role: 16-byte piece c16 (of the chunk's 128 B) of rows r0 + 32 * i, both operands
   const int c16 = t & 7, r0 = t >> 3;
   const int sub = c16 >> 2, ch = c16 & 3;
-  unsigned aoff[4], boff[4], soff[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = r0 + 32 * i;
-    aoff[i] = (m0 + row) < g.N1 ? (unsigned)(((m0 + row) * g.lda + c16 * 8) * 2) : OOB;
-    boff[i] = (n0 + row) < g.N2 ? (unsigned)(((n0 + row) * g.ldb + c16 * 8) * 2) : OOB;
-    soff[i] = (unsigned)(sub * PLANE + row * ROWB + ((ch ^ ((row >> 2) & 3)) << 4));
-  }
+  // rows r0 + 32 i: offsets are the row-0 offset + i * (32 rows), the LDS swizzle key ((row >> 2) & 3) does not depend on i
+  const unsigned aoff0 = (unsigned)(((m0 + r0) * g.lda + c16 * 8) * 2), a32 = (unsigned)(32 * g.lda * 2);
+  const unsigned boff0 = (unsigned)(((n0 + r0) * g.ldb + c16 * 8) * 2), b32 = (unsigned)(32 * g.ldb * 2);
+  const unsigned soff0 = (unsigned)(sub * PLANE + r0 * ROWB + ((ch ^ ((r0 >> 2) & 3)) << 4));
   const int frow = lane & 31, hl = lane >> 5;
   const int key = (frow >> 2) & 3;     // wave / MFMA-block row offsets are multiples of 32: same key
   const int ko0 = ((0 + hl) ^ key) << 4, ko1 = ((2 + hl) ^ key) << 4;
@@ -73,8 +70,8 @@ __global__ __launch_bounds__(256, 4) void corr_bf16_kernel(const CorrBfArgs g) {
     const bool ok = c * KC + c16 * 8 < g.D;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsa, (ok ? aoff[i] : OOB), c * KC * 2, 0);
-      rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsb, (ok ? boff[i] : OOB), c * KC * 2, 0);
+      ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsa, (ok && m0 + r0 + 32 * i < g.N1) ? aoff0 + i * a32 : OOB, c * KC * 2, 0);
+      rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsb, (ok && n0 + r0 + 32 * i < g.N2) ? boff0 + i * b32 : OOB, c * KC * 2, 0);
     }
   };
   load(0);
@@ -82,8 +79,8 @@ __global__ __launch_bounds__(256, 4) void corr_bf16_kernel(const CorrBfArgs g) {
     __syncthreads();                       // the previous chunk's fragments have been read
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<u32x4*>(smem + soff[i]) = ra[i];
-      *reinterpret_cast<u32x4*>(smem + 2 * PLANE + soff[i]) = rb[i];
+      *reinterpret_cast<u32x4*>(smem + soff0 + i * 32 * ROWB) = ra[i];
+      *reinterpret_cast<u32x4*>(smem + 2 * PLANE + soff0 + i * 32 * ROWB) = rb[i];
     }
     if (c + 1 < chunks) load(c + 1);       // in flight during this chunk's MFMAs
     __syncthreads();
@@ -105,6 +102,13 @@ __global__ __launch_bounds__(256, 4) void corr_bf16_kernel(const CorrBfArgs g) {
       }
   }
   __syncthreads();                         // operand stage is dead: reuse it for the output tile [128][128] bf16 (256-byte rows)
+  // The thread's coordinates are re-derived here from the wave id (an SGPR since the top) and the hardware lane count rather than
+  // kept live across the K loop: at 128 VGPRs (four blocks per CU) the loop otherwise spills them to scratch, and scratch stores
+  // are HBM writes (12 B per thread showed up as +9 % on the write counter of a kernel that is write-bound).
+  const int lane2 = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  const int t2 = wid_s * 64 + lane2;
+  const int frow2 = lane2 & 31, hl2 = lane2 >> 5;
+  const int wm2 = (wid_s >> 1) * 64, wn2 = (wid_s & 1) * 64;
   // D layout of a 32x32 block: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
   __bf16* tile = reinterpret_cast<__bf16*>(smem);
 #pragma unroll
@@ -113,8 +117,8 @@ __global__ __launch_bounds__(256, 4) void corr_bf16_kernel(const CorrBfArgs g) {
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = wm0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl;
-        const int col = wn0 + nt * 32 + frow;
+        const int row = wm2 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl2;
+        const int col = wn2 + nt * 32 + frow2;
         // 16-byte chunk index XOR-ed with the row: the 32 lanes of a half-wave write one row's 64 contiguous bytes either way,
         // and the row-wise 16-byte reads below spread over all banks
         tile[row * 128 + ((((col >> 3) ^ (row & 15)) << 3) | (col & 7))] = (__bf16)(acc[mt][nt][r] * g.scale);
@@ -124,7 +128,7 @@ __global__ __launch_bounds__(256, 4) void corr_bf16_kernel(const CorrBfArgs g) {
   const bool vec = (g.N2 & 7) == 0;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    const int piece = t + 256 * i;             // 2048 pieces of 8 bf16: row = piece / 16, 16-byte column chunk = piece % 16
+    const int piece = t2 + 256 * i;            // 2048 pieces of 8 bf16: row = piece / 16, 16-byte column chunk = piece % 16
     const int row = piece >> 4, cc = piece & 15;
     const long long grow = (long long)m0 + row;
     const int gcol = n0 + cc * 8;
@@ -134,8 +138,10 @@ __global__ __launch_bounds__(256, 4) void corr_bf16_kernel(const CorrBfArgs g) {
     if (vec && gcol + 8 <= g.N2) {
       *reinterpret_cast<u32x4*>(dst) = v;
     } else {
-      const __bf16* e = reinterpret_cast<const __bf16*>(&v);
-      for (int k = 0; k < 8 && gcol + k < g.N2; ++k) dst[k] = e[k];
+      unsigned short* d16 = reinterpret_cast<unsigned short*>(dst);   // constant indices after unrolling: v stays in registers
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (gcol + k < g.N2) d16[k] = (unsigned short)(v[k >> 1] >> (16 * (k & 1)));
     }
   }
 }

@@ -181,7 +181,13 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs& a, const f32x16 (&a
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = (v[e] < 0.f) ? 0.f : v[e];   // NaN-propagating like torch.relu
           }
-          v *= a.scale;
+          {
+            // (element-wise on purpose: `v *= a.scale` made hipcc park a 16-byte slice of the kernel arguments in SCRATCH at
+            // kernel entry and re-load it here — 16 B per thread of extra HBM writes, +25 % on WRITE_SIZE for every LINEAR launch)
+            const float sc = a.scale;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= sc;
+          }
           if (a.residual != nullptr) {
             if (full && vres) v = *reinterpret_cast<const f32x4*>(a.residual + p * a.residual_ld + n) + v;
             else {
