@@ -273,8 +273,9 @@ int pfk_altcorr_backward_f32(const float* fmap1, const float* fmap2, const float
 
 /* ---- weight gradient of the convolution above (torch.autograd of every nn.Conv2d in raft/update.py) ---
  * dw_packed[co][k(s,tap,c)] = sum_p dy[p][co] * src_s[p + tap][c]   — the packed [cout][ktot] layout of pfk_conv2d_f32's weight.
- * `d` describes the forward convolution (sources, B, H, W, kh, kw, cout; stride 1; weight/out/epilogue fields ignored);
- * dy [B*H*W][dy_ld] is the gradient w.r.t. the convolution output, cout % 4 == 0.  The reduction runs over pixels, cut
+ * `d` describes the forward convolution (sources, B, H, W, kh, kw, cout, stride; weight/out/epilogue fields ignored);
+ * dy [B*Ho*Wo][dy_ld] is the gradient w.r.t. the convolution output (Ho = (H-1)/stride + 1; stride 0 or 1: Ho = H), cout % 4 == 0;
+ * with a stride the product reads src_s at (yo*stride + dy, xo*stride + dx) — no zero-upsampled gradient is needed.  The reduction runs over pixels, cut
  * into slices whose partial results go through `workspace` (pfk_conv_wgrad_workspace_bytes(d) bytes, 16-byte aligned; may
  * be NULL when that is 0) and are added in a fixed order: deterministic, no atomics.  with_bias != 0 appends 32 columns to
  * every row of dw_packed ([cout][ktot + 32]); column ktot is the bias gradient sum_p dy[p][co] (computed as one more chunk

@@ -115,55 +115,62 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // FlowHead.conv2 (3x3, cin -> 2; raft/update.py:10,14) + RAFT loop bookkeeping (raft.py:174,178).
-// One wave per pixel: lanes split the input channels (float4 each, coalesced 1 KiB rows), two
-// butterfly reductions, lane 0 applies coords1 += delta and flow = coords1 - coords0.
-constexpr int FD_PIX = 4;   // consecutive pixels per wave: the tap's weights are loaded once for all of them
+// One wave per FD_PIX consecutive pixels of one image row: lanes split the input channels (float4 each, coalesced 1 KiB rows),
+// the wave walks the 3 x (FD_PIX + 2) input rows its pixels touch ONCE each and feeds every row to the (up to three) pixels that
+// use it — 3.75 row loads per pixel instead of 9 (the kernel is bound by these L2 reads).  Per pixel the taps still arrive in (ky, kx) order and the channel FMAs in
+// the same chain, so the sums are bit-identical to the tap-by-tap formulation (one row band — 6 weight float4s — at a time); two butterfly reductions per pixel, lane 0
+// applies coords1 += delta and flow = coords1 - coords0.
+constexpr int FD_PIX = 8;
 
 __global__ __launch_bounds__(256) void flow_delta_kernel(
     const float* __restrict__ in, int in_ld, int cin, const float* __restrict__ wgt,
     const float* __restrict__ bias, const float* __restrict__ coords0, float* coords1,
-    float* delta_out, float* flow_out, int flow_ld, long long M, int H, int W) {
+    float* delta_out, float* flow_out, int flow_ld, long long rows, int H, int W, int tpr) {
   const int lane = threadIdx.x & 63;
-  const long long p0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * FD_PIX;
-  if (p0 >= M) return;
-  int x[FD_PIX], y[FD_PIX];
-#pragma unroll
-  for (int q = 0; q < FD_PIX; ++q) {
-    const long long p = p0 + q;
-    x[q] = (int)(p % W);
-    y[q] = (p < M) ? (int)((p / W) % H) : -4;        // past the end: every tap out of range
-  }
+  const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long long rowid = w / tpr;                  // b * H + y
+  if (rowid >= rows) return;
+  const int x0 = (int)(w - rowid * tpr) * FD_PIX;
+  const int y = (int)(rowid % H);
   float s0[FD_PIX], s1[FD_PIX];
 #pragma unroll
   for (int q = 0; q < FD_PIX; ++q) { s0[q] = 0.f; s1[q] = 0.f; }
   for (int c = lane * 4; c < cin; c += 256) {
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll 1
+    for (int ky = 0; ky < 3; ++ky) {                // one row band at a time: 6 weight float4s + FD_PIX + 2 rows in registers
+      const int yy = y + ky - 1;
+      if ((unsigned)yy >= (unsigned)H) continue;    // zero padding: the row simply does not contribute (wave-uniform)
+      f32x4 wa[3], wb[3];
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
-        const float* w0 = wgt + (long long)((ky * 3 + kx) * 2) * cin;
-        const f32x4 a = *reinterpret_cast<const f32x4*>(w0 + c);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(w0 + cin + c);
+        wa[kx] = *reinterpret_cast<const f32x4*>(wgt + (long long)((ky * 3 + kx) * 2) * cin + c);
+        wb[kx] = *reinterpret_cast<const f32x4*>(wgt + (long long)((ky * 3 + kx) * 2 + 1) * cin + c);
+      }
+      const float* rowp = in + ((rowid + (ky - 1)) * W) * in_ld + c;
 #pragma unroll
-        for (int q = 0; q < FD_PIX; ++q) {
-          const int yy = y[q] + ky - 1, xx = x[q] + kx - 1;
-          if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {   // zero padding: the tap simply does not contribute
-            const f32x4 v = *reinterpret_cast<const f32x4*>(in + (p0 + q + (long long)(ky - 1) * W + (kx - 1)) * in_ld + c);
-            s0[q] = fmaf(v.x, a.x, fmaf(v.y, a.y, fmaf(v.z, a.z, fmaf(v.w, a.w, s0[q]))));
-            s1[q] = fmaf(v.x, b.x, fmaf(v.y, b.y, fmaf(v.z, b.z, fmaf(v.w, b.w, s1[q]))));
-          }
+      for (int xi = 0; xi < FD_PIX + 2; ++xi) {
+        const int xx = x0 - 1 + xi;
+        if ((unsigned)xx >= (unsigned)W) continue;  // wave-uniform
+        const f32x4 v = *reinterpret_cast<const f32x4*>(rowp + (long long)xx * in_ld);
+#pragma unroll
+        for (int kx = 2; kx >= 0; --kx) {            // pixel q = xi - kx sees this row as its tap kx (ascending kx per pixel as xi grows)
+          const int q = xi - kx;
+          if (q < 0 || q >= FD_PIX) continue;
+          const f32x4 a = wa[kx], b = wb[kx];
+          s0[q] = fmaf(v.x, a.x, fmaf(v.y, a.y, fmaf(v.z, a.z, fmaf(v.w, a.w, s0[q]))));
+          s1[q] = fmaf(v.x, b.x, fmaf(v.y, b.y, fmaf(v.z, b.z, fmaf(v.w, b.w, s1[q]))));
         }
       }
     }
   }
   const long long hw = (long long)H * W;
+  const long long bimg = rowid / H;
 #pragma unroll
   for (int q = 0; q < FD_PIX; ++q) {
     const float t0 = wave_sum(s0[q]), t1 = wave_sum(s1[q]);
-    const long long p = p0 + q;
-    if (lane == 0 && p < M) {
-      const long long b = p / hw, pix = p - b * hw;
-      const long long ix = (b * 2 + 0) * hw + pix, iy = (b * 2 + 1) * hw + pix;
+    if (lane == 0 && x0 + q < W) {
+      const long long p = rowid * W + x0 + q, pix = p - bimg * hw;
+      const long long ix = (bimg * 2 + 0) * hw + pix, iy = (bimg * 2 + 1) * hw + pix;
       const float dx = t0 + (bias ? bias[0] : 0.f);
       const float dy = t1 + (bias ? bias[1] : 0.f);
       const float c1x = __fadd_rn(coords1[ix], dx);
@@ -399,12 +406,13 @@ int pfk_flow_delta_f32(const float* in, int in_ld, int cin, const float* weight,
   if (cin <= 0 || in_ld < cin || (flow_out && flow_ld < 2)) return PFK_ERR_BAD_ARG;
   if (!pfk_aligned16(in) || !pfk_aligned16(weight) || (in_ld & 3) || (cin & 3))
     return PFK_ERR_ALIGNMENT;
-  const long long M = (long long)B * H * W;
-  const long long blocks = (M + 4 * FD_PIX - 1) / (4 * FD_PIX);
+  const int tpr = (W + FD_PIX - 1) / FD_PIX;          // waves per image row
+  const long long rows = (long long)B * H;
+  const long long blocks = (rows * tpr + 3) / 4;
   if (blocks > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(flow_delta_kernel, dim3((unsigned)blocks), dim3(256), 0,
                      static_cast<hipStream_t>(stream), in, in_ld, cin, weight, bias, coords0,
-                     coords1, delta_out, flow_out, flow_ld, M, H, W);
+                     coords1, delta_out, flow_out, flow_ld, rows, H, W, tpr);
   return pfk_launch_status();
 }
 

@@ -487,7 +487,7 @@ void forward_interpolate(const Tensor& flow, Tensor out) {
 
 // weight gradient in the packed [cout, ktot] layout; dy [M, cout] (cout % 4 == 0)
 void conv_wgrad(at::TensorList srcs, const Tensor& dy, int64_t B, int64_t H, int64_t W, int64_t kh, int64_t kw, Tensor out,
-                bool with_bias) {
+                bool with_bias, int64_t stride) {
   OpScope scope(dy);
   TORCH_CHECK(srcs.size() >= 1 && srcs.size() <= 3, "conv_wgrad: 1..3 sources");
   check_pm(dy, "dy"); check_dev_f32(out, "out");
@@ -500,7 +500,9 @@ void conv_wgrad(at::TensorList srcs, const Tensor& dy, int64_t B, int64_t H, int
   }
   d.num_src = srcs.size();
   d.B = B; d.H = H; d.W = W; d.kh = kh; d.kw = kw; d.cout = dy.size(1);
-  TORCH_CHECK(dy.size(0) == M, "conv_wgrad: dy rows != B*H*W");
+  TORCH_CHECK(stride >= 1, "conv_wgrad: stride");
+  d.stride = (int)stride;
+  TORCH_CHECK(dy.size(0) == B * ((H - 1) / stride + 1) * ((W - 1) / stride + 1), "conv_wgrad: dy rows != B*Ho*Wo");
   TORCH_CHECK(out.is_contiguous() && out.dim() == 2 && out.size(0) == d.cout && out.size(1) == pfk_conv_ktot(&d) + (with_bias ? 32 : 0),
               "conv_wgrad: out [cout, ktot (+32 with the bias column)]");
   const long long need = pfk_conv_wgrad_workspace_bytes(&d, with_bias);
@@ -556,7 +558,7 @@ TORCH_LIBRARY(pfk, m) {
   m.def("gru_gates_q(Tensor a_q, Tensor z, Tensor h, Tensor(a!) q, Tensor(b!) h_new) -> ()");
   m.def("gru_backward_q(Tensor dh_new, Tensor z, Tensor q, Tensor h, Tensor(a!) da_q, Tensor(b!) da_zr, Tensor(c!) dh) -> ()");
   m.def("gru_backward_zr(Tensor d_rh, Tensor h, Tensor r, Tensor(a!) da_zr, Tensor(b!) dh) -> ()");
-  m.def("conv_wgrad(Tensor[] srcs, Tensor dy, int B, int H, int W, int kh, int kw, Tensor(a!) out, bool with_bias=False) -> ()");
+  m.def("conv_wgrad(Tensor[] srcs, Tensor dy, int B, int H, int W, int kh, int kw, Tensor(a!) out, bool with_bias=False, int stride=1) -> ()");
   m.def("forward_interpolate(Tensor flow, Tensor(a!) out) -> ()");
   m.def("softmax_rows(Tensor(a!) x) -> ()");
   m.def("norm_bwd(Tensor x, Tensor dy, Tensor mean, Tensor rstd, Tensor(a!) dx, Tensor(b!) sum_g, Tensor(c!) sum_gxhat, int B, int HW, bool relu) -> ()");

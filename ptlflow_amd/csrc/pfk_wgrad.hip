@@ -27,6 +27,7 @@ struct WgradArgs {
   int ld0, ld1, ld2, ch0, ch1, ch2, nsrc;
   const float* dy; int dy_ld; int cout;
   int H, W, kh, kw;
+  int Ho, Wo, stride;     // output grid (dY rows = B*Ho*Wo = M); output (yo, xo) reads input (yo*stride + dy, xo*stride + dx)
   long long M;
   float* part;            // [splits][cout][ktot]  (== the output when splits == 1)
   int ktot, chunks, tiles_m;   // ktot / chunks include the bias chunk when with_bias
@@ -83,8 +84,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 
   // this thread stages row (t >> 3) of every step: float4 q of each of the NCH A chunks, float4 q + 8*i of the dY tile
   const int row = t >> 3, q = t & 7;
-  long long p = p_begin + row;
-  int x = (int)(p % a.W), y = (int)((p / a.W) % a.H);
+  long long p = p_begin + row;                     // output pixel (= dY row); its input pixel is (b, y*stride, x*stride)
+  int x = (int)(p % a.Wo), y = (int)((p / a.Wo) % a.Ho), bimg = (int)(p / ((long long)a.Wo * a.Ho));
+  const int sd = a.stride;
   __amdgpu_buffer_rsrc_t rsx[NCH];
   int tap_off[NCH], cdy[NCH], cdx[NCH], cld[NCH];
   bool c_ok[NCH], is_bias[NCH], yok[CB];
@@ -103,18 +105,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
   u32x4 rx[NCH], ry[CB];
   auto load = [&](void) {
     const bool in = p < p_end;
+    const int yi = y * sd, xi = x * sd;
+    const int pin = (bimg * a.H + yi) * a.W + xi;   // input pixel index (== p for stride 1)
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const bool ok = in && c_ok[i] && (unsigned)(y + cdy[i]) < (unsigned)a.H && (unsigned)(x + cdx[i]) < (unsigned)a.W;
+      const bool ok = in && c_ok[i] && (unsigned)(yi + cdy[i]) < (unsigned)a.H && (unsigned)(xi + cdx[i]) < (unsigned)a.W;
       if (is_bias[i]) rx[i] = u32x4{(in && q == 0) ? 0x3f800000u : 0u, 0u, 0u, 0u};    // A = [1 0 0 ...] for every live pixel
-      else rx[i] = __builtin_amdgcn_raw_buffer_load_b128(rsx[i], ok ? (unsigned)((int)p * cld[i] + tap_off[i]) * 4u : OOB, 0, 0);
+      else rx[i] = __builtin_amdgcn_raw_buffer_load_b128(rsx[i], ok ? (unsigned)(pin * cld[i] + tap_off[i]) * 4u : OOB, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < CB; ++i)
       ry[i] = __builtin_amdgcn_raw_buffer_load_b128(rsy, (in && yok[i]) ? (unsigned)((int)p * a.dy_ld + co0 + q * 4 + 32 * i) * 4u : OOB, 0, 0);
     p += 32;
     x += 32;
-    while (x >= a.W) { x -= a.W; if (++y == a.H) y = 0; }
+    while (x >= a.Wo) { x -= a.Wo; if (++y == a.Ho) { y = 0; ++bimg; } }
   };
   auto store = [&](int buf) {
 #pragma unroll
@@ -278,7 +282,8 @@ void pfk_debug_set_wgrad(int variant) { g_wgrad_variant = variant; }
 long long pfk_conv_wgrad_workspace_bytes(const pfk_conv_desc* d, int with_bias) {
   if (!d || d->num_src < 1 || d->num_src > 3 || d->cout <= 0) return 0;
   const int ktot = ktot_of(d) + (with_bias ? 32 : 0);
-  const long long M = (long long)d->B * d->H * d->W;
+  const int sd = d->stride > 1 ? d->stride : 1;
+  const long long M = (long long)d->B * ((d->H - 1) / sd + 1) * ((d->W - 1) / sd + 1);
   int splits = 1;
   for (int cb = 1; cb <= 4; cb *= 2) {        // any tile height may run (pfk_debug_set_wgrad): size for the largest split count
     const int sc = pick_splits(wgrad_tiles(d->cout, ktot / 32, cb), M);
@@ -291,15 +296,18 @@ int pfk_conv_wgrad_f32(const pfk_conv_desc* d, const float* dy, int dy_ld, float
                        long long workspace_bytes, pfk_stream_t stream) {
   if (!d || !dy || !dw_packed || d->num_src < 1 || d->num_src > 3) return PFK_ERR_BAD_ARG;
   if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->cout <= 0 || dy_ld < d->cout) return PFK_ERR_BAD_ARG;
-  if (d->kh <= 0 || d->kw <= 0 || !(d->kh & 1) || !(d->kw & 1) || d->stride > 1) return PFK_ERR_BAD_ARG;
+  if (d->kh <= 0 || d->kw <= 0 || !(d->kh & 1) || !(d->kw & 1) || d->stride < 0) return PFK_ERR_BAD_ARG;
   if ((d->cout & 3) || (dy_ld & 3) || !pfk_aligned16(dy) || !pfk_aligned16(dw_packed)) return PFK_ERR_ALIGNMENT;
   WgradArgs a{};
   const pfk_conv_src* s = d->src;
-  const long long M = (long long)d->B * d->H * d->W;
+  const int sd = d->stride > 1 ? d->stride : 1;
+  const int Ho = (d->H - 1) / sd + 1, Wo = (d->W - 1) / sd + 1;
+  const long long M = (long long)d->B * Ho * Wo;                 // dY rows: the OUTPUT grid
+  const long long Min = (long long)d->B * d->H * d->W;           // source rows
   for (int i = 0; i < d->num_src; ++i) {
     if (!s[i].ptr || s[i].channels <= 0 || s[i].ld < s[i].channels) return PFK_ERR_BAD_ARG;
     if (!pfk_aligned16(s[i].ptr) || (s[i].ld & 3) || (s[i].channels & 3)) return PFK_ERR_ALIGNMENT;
-    if (M * s[i].ld * 4 >= 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
+    if (Min * s[i].ld * 4 >= 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
   }
   if (M * dy_ld * 4 >= 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
   a.src0 = s[0].ptr; a.ld0 = s[0].ld; a.ch0 = s[0].channels;
@@ -308,6 +316,7 @@ int pfk_conv_wgrad_f32(const pfk_conv_desc* d, const float* dy, int dy_ld, float
   a.nsrc = d->num_src;
   a.dy = dy; a.dy_ld = dy_ld; a.cout = d->cout;
   a.H = d->H; a.W = d->W; a.kh = d->kh; a.kw = d->kw; a.M = M;
+  a.Ho = Ho; a.Wo = Wo; a.stride = sd;
   a.with_bias = with_bias ? 1 : 0;
   a.ktot = ktot_of(d) + (with_bias ? 32 : 0);
   a.chunks = a.ktot / 32;

@@ -39,10 +39,19 @@ def _segments(srcs: Sequence[torch.Tensor], real: Sequence[int]) -> List[Tuple[i
 
 
 class _Geometry:
-    __slots__ = ("B", "H", "W", "kh", "kw")
+    """Input grid (B, H, W), kernel and stride of one convolution; the output grid is (Ho, Wo) = ((H-1)//stride + 1, ...)."""
+    __slots__ = ("B", "H", "W", "kh", "kw", "stride")
 
-    def __init__(self, B, H, W, kh, kw):
-        self.B, self.H, self.W, self.kh, self.kw = B, H, W, kh, kw
+    def __init__(self, B, H, W, kh, kw, stride=1):
+        self.B, self.H, self.W, self.kh, self.kw, self.stride = B, H, W, kh, kw, stride
+
+    @property
+    def Ho(self):
+        return (self.H - 1) // self.stride + 1
+
+    @property
+    def Wo(self):
+        return (self.W - 1) // self.stride + 1
 
 
 def _workspace(device) -> torch.Tensor:
@@ -84,10 +93,9 @@ class _ConvPM(torch.autograd.Function):
         ops = torch.ops.pfk
         srcs = [s.contiguous() if s.stride(1) != 1 else s for s in srcs]
         cout = weight.shape[0]
-        M = g.B * g.H * g.W
-        out = torch.empty(M, cout, device=srcs[0].device, dtype=torch.float32)
+        out = torch.empty(g.B * g.Ho * g.Wo, cout, device=srcs[0].device, dtype=torch.float32)
         ops.conv2d(list(srcs), g.B, g.H, g.W, g.kh, g.kw, _fwd_pack(packs, weight, _segments(srcs, real)), None if bias is None else bias.detach().float().contiguous(),
-                   cout, EPI_LINEAR, relu, 1.0, out, None, None, None, _workspace(out.device))
+                   cout, EPI_LINEAR, relu, 1.0, out, None, None, None, _workspace(out.device), None, g.stride)
         ctx.g, ctx.relu, ctx.real, ctx.has_bias, ctx.packs = g, relu, real, bias is not None, packs
         ctx.save_for_backward(weight, out if relu else None, *srcs)
         return out
@@ -109,12 +117,18 @@ class _ConvPM(torch.autograd.Function):
         # channels of dY padded to a multiple of 4 for its role as a convolution source (flow head: cout = 2)
         dY_src = dY if cout % 4 == 0 else F.pad(dY, (0, round_up(cout, 4) - cout))
         segs = _segments(srcs, real)
-        # ---- dgrad: dX_s = conv(dY, W_s^T flipped)
+        # ---- dgrad: dX_s = conv(dY, W_s^T flipped); for a strided convolution the gradient is first spread over the input grid
+        # (zeros between the samples: the transposed convolution written as a stride-1 one)
+        dY_in = dY_src
+        if g.stride != 1 and any(need[6:]):
+            dY_in = torch.zeros(g.B, g.H, g.W, dY_src.shape[1], device=dY.device, dtype=torch.float32)
+            dY_in[:, ::g.stride, ::g.stride] = dY_src.view(g.B, g.Ho, g.Wo, -1)
+            dY_in = dY_in.view(M, -1)
         for i, (first, n, n_buf) in enumerate(segs):
             if not need[6 + i]:
                 continue
             dx = torch.empty(M, n_buf, device=dY.device, dtype=torch.float32)
-            ops.conv2d([dY_src], g.B, g.H, g.W, g.kh, g.kw, _dgrad_pack(packs, i, weight, (first, n, n_buf), dY_src.shape[1]), None, n_buf,
+            ops.conv2d([dY_in], g.B, g.H, g.W, g.kh, g.kw, _dgrad_pack(packs, i, weight, (first, n, n_buf), dY_src.shape[1]), None, n_buf,
                        EPI_LINEAR, False, 1.0, dx, None, None, None, ws)
             dsrcs[i] = dx
         # ---- wgrad: one launch (+ a deterministic slice reduction) straight from the pixel-major tensors, written in the packed
@@ -124,7 +138,7 @@ class _ConvPM(torch.autograd.Function):
             taps = g.kh * g.kw
             ktot = sum(taps * round_up(n_buf, 32) for _, _, n_buf in segs)
             packed = torch.empty(dY_src.shape[1], ktot + (32 if want_b else 0), device=dY.device, dtype=torch.float32)
-            ops.conv_wgrad(list(srcs), dY_src, g.B, g.H, g.W, g.kh, g.kw, packed, want_b)   # bias gradient = one more column
+            ops.conv_wgrad(list(srcs), dY_src, g.B, g.H, g.W, g.kh, g.kw, packed, want_b, g.stride)   # bias gradient = one more column
             dW = _unpack_wgrad(packed, weight.shape, segs, g).to(weight.dtype)
             if want_b:
                 db = packed[:cout, ktot].clone()
@@ -239,14 +253,16 @@ class _GruPass(torch.autograd.Function):
 
 
 def conv_pm(srcs: Sequence[torch.Tensor], weight: torch.Tensor, bias: Optional[torch.Tensor], B: int, H: int, W: int,
-            relu: bool = False, real: Optional[Sequence[int]] = None, packs: Optional[ConvPacks] = None) -> torch.Tensor:
-    """Differentiable "same" convolution (stride 1, odd kernel) of the channel-concatenation of ``srcs`` (pixel-major
-    ``[B*H*W, C_i]``, ``C_i % 4 == 0``) with a PyTorch-layout weight ``[cout, sum(real), kh, kw]``.  ``packs``: a
-    ``ConvPacks`` from ``packs_for`` to reuse the packed weights across calls."""
+            relu: bool = False, real: Optional[Sequence[int]] = None, packs: Optional[ConvPacks] = None,
+            stride: int = 1) -> torch.Tensor:
+    """Differentiable convolution (odd kernel, padding k//2, stride s: PyTorch's Conv2d(k, stride=s, padding=k//2)) of the
+    channel-concatenation of ``srcs`` (pixel-major ``[B*H*W, C_i]``, ``C_i % 4 == 0``) with a PyTorch-layout weight
+    ``[cout, sum(real), kh, kw]``; returns ``[B*Ho*Wo, cout]``.  ``packs``: a ``ConvPacks`` from ``packs_for`` to reuse the
+    packed weights across calls."""
     load_native()
     real = tuple(int(s.shape[1]) for s in srcs) if real is None else tuple(real)
     assert sum(real) == weight.shape[1], (real, tuple(weight.shape))
-    g = _Geometry(B, H, W, weight.shape[2], weight.shape[3])
+    g = _Geometry(B, H, W, weight.shape[2], weight.shape[3], int(stride))
     return _ConvPM.apply(weight, bias, g, relu, real, packs if packs is not None else ConvPacks(), *srcs)
 
 

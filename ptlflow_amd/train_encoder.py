@@ -9,9 +9,8 @@ Everything is pixel-major ``[B*H*W, C]`` between kernels, as in the inference en
 * stem 7x7/2 from the NCHW image   forward `pfk_conv_stem_f32`; weight / bias gradient `pfk_conv_stem_wgrad_f32` (the image needs
   no gradient);
 * 3x3 / 1x1 convolutions           `train.conv_pm` (forward, data gradient and weight gradient on the fp32-MFMA implicit-GEMM
-  kernels).  The four stride-2 convolutions are evaluated at stride 1 and subsampled — Conv2d(k, stride 2, padding k//2) is the
-  "same" convolution read at the even positions — so their backward is the stride-1 backward of a zero-upsampled gradient
-  (autograd of the slicing); ~12 % more encoder FLOPs, no extra kernels;
+  kernels).  The four stride-2 convolutions run strided in the forward kernel and in the weight-gradient kernel (which reads
+  the input at (2 yo + dy, 2 xo + dx)); only their data gradient is the stride-1 convolution of the zero-upsampled gradient;
 * InstanceNorm / BatchNorm(train)  statistics `pfk_instnorm_stats_f32` (a training-mode batch norm is the same reduction with the
   whole batch as one "image"), normalise `pfk_norm_apply_f32`, backward `pfk_norm_bwd_f32` (which also yields d gamma / d beta);
 * relu, residual add, the affine of BatchNorm   elementwise torch ops.
@@ -136,12 +135,6 @@ def _norm(kind: str, x: torch.Tensor, B: int, HW: int, bn: Optional[torch.nn.Mod
     return torch.relu(y) if relu else y
 
 
-def _subsample(x: torch.Tensor, B: int, H: int, W: int) -> torch.Tensor:
-    """pixel-major [B*H*W, C] -> rows at even (y, x): what a stride-2 convolution computes."""
-    C = x.shape[1]
-    return x.view(B, H, W, C)[:, ::2, ::2].reshape(-1, C)
-
-
 def encoder_train(enc: torch.nn.Module, img: torch.Tensor, cache: Optional[dict] = None) -> torch.Tensor:
     """`BasicEncoder.forward` / `SmallEncoder.forward` in training mode for the mirror's `Encoder` module (or any module
     with the reference's attribute names): ``img`` [B, 3, H, W] -> NCHW-shaped channels-last view [B, out_dim, H/8, W/8].
@@ -155,9 +148,7 @@ def encoder_train(enc: torch.nn.Module, img: torch.Tensor, cache: Optional[dict]
 
     def conv(x, mod, name, h, w, stride=1):
         wgt = mod.weight
-        k = wgt.shape[2]
-        y = conv_pm([x], wgt, mod.bias, B, h, w, False, None, packs_for(cache, name, [wgt]))
-        return _subsample(y, B, h, w) if stride != 1 else y
+        return conv_pm([x], wgt, mod.bias, B, h, w, False, None, packs_for(cache, name, [wgt]), stride)
 
     h, w = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     x = _Stem.apply(img, enc.conv1.weight, enc.conv1.bias)

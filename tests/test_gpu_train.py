@@ -59,6 +59,37 @@ def test_conv_pm_forward_and_gradients(gpu, B, H, W, cins, bufs, cout, kh, kw, r
         assert bool((s.grad[:, c:] == 0).all())
 
 
+@pytest.mark.parametrize("B,H,W,cin,cout,k", [
+    (2, 23, 31, 64, 96, 3),        # BasicEncoder layer2.0.conv1 (odd grid: Ho = 12, Wo = 16)
+    (1, 24, 18, 96, 128, 3),
+    (2, 23, 31, 64, 96, 1),        # the residual block's 1x1 stride-2 downsample
+    (1, 16, 40, 32, 32, 3),        # SmallEncoder bottleneck conv2 (32 channels, cout below one 64-row tile)
+])
+def test_strided_conv_pm_forward_and_gradients(gpu, B, H, W, cin, cout, k):
+    """Conv2d(k, stride 2, padding k//2) of the encoders (raft/extractor.py:20-22, 78-80): forward strided in the implicit-GEMM
+    kernel, weight gradient strided in the wgrad kernel (no zero-upsampled gradient), data gradient through the zero-upsampled
+    gradient — against float64 autograd of F.conv2d(stride=2)."""
+    from ptlflow_amd.train import conv_pm
+    torch.manual_seed(11)
+    x = torch.randn(B, cin, H, W, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(cout, cin, k, k, dtype=torch.float64) / math.sqrt(cin * k * k)).requires_grad_()
+    b = (torch.randn(cout, dtype=torch.float64) * 0.1).requires_grad_()
+    ref = F.conv2d(x, w, b, stride=2, padding=k // 2)
+    Ho, Wo = ref.shape[2:]
+    gout = torch.randn_like(ref)
+    ref.backward(gout)
+    pm = x.detach().float().permute(0, 2, 3, 1).reshape(B * H * W, cin).cuda().requires_grad_()
+    wg = w.detach().float().cuda().requires_grad_()
+    bg = b.detach().float().cuda().requires_grad_()
+    out = conv_pm([pm], wg, bg, B, H, W, False, [cin], None, 2)
+    assert out.shape == (B * Ho * Wo, cout)
+    out.backward(gout.float().permute(0, 2, 3, 1).reshape(B * Ho * Wo, cout).cuda())
+    rel_close(out.view(B, Ho, Wo, cout).permute(0, 3, 1, 2), ref, what="forward")
+    rel_close(wg.grad, w.grad, what="weight grad")
+    rel_close(bg.grad, b.grad, what="bias grad")
+    rel_close(pm.grad.view(B, H, W, cin).permute(0, 3, 1, 2), x.grad, what="input grad")
+
+
 @pytest.mark.parametrize("small", [False, True])
 def test_update_block_training_step(gpu, small):
     """One update-block call in a training graph: outputs and the gradient of a scalar loss w.r.t. every parameter and
