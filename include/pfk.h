@@ -251,6 +251,10 @@ int pfk_flow_from_coords_f32(const float* coords0, const float* coords1, float* 
  * (already multiplied by 0.25); out [B][2][8h][8w] NCHW. */
 int pfk_convex_upsample_f32(const float* flow, const float* mask, int mask_ld, float* out,
                             int B, int H, int W, pfk_stream_t stream);
+/* upflow8 (raft/utils.py:94-96, the mask-less upsampling of raft_small): out [B][2][8H][8W] = 8 * bilinear(coords1 - coords0,
+ * size 8x, align_corners = True); coords NCHW [B][2][H][W].  Index / weight arithmetic as torch's upsample_bilinear2d. */
+int pfk_upflow8_f32(const float* coords0, const float* coords1, float* out, int B, int H, int W, pfk_stream_t stream);
+
 /* same, with the flow read pixel-major (flow_pm[p*flow_ld + 0..1], e.g. the update engine's hx slice) */
 int pfk_convex_upsample_pm_f32(const float* flow_pm, int flow_ld, const float* mask, int mask_ld,
                                float* out, int B, int H, int W, pfk_stream_t stream);

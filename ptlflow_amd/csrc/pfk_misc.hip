@@ -199,6 +199,36 @@ __global__ __launch_bounds__(256) void flow_from_coords_kernel(const float* __re
   flow_out[p * flow_ld + 1] = c1[iy] - c0[iy];
 }
 
+// upflow8 (raft/utils.py:94-96; raft_small has no mask head): 8 * bilinear(flow, size = 8x, align_corners = True) with
+// flow = coords1 - coords0, NCHW [B][2][H][W] -> [B][2][8H][8W].  Index arithmetic as torch's upsample_bilinear2d: scale =
+// (in - 1) / (out - 1) in fp32, src = scale * dst, i0 = trunc(src), lambda1 = src - i0, i1 = i0 + (i0 < in - 1).  One thread
+// per output pixel (x fastest: coalesced stores; the 2 x 2 x 2 reads hit a tiny L2-resident input); write-bound.
+__global__ __launch_bounds__(256) void upflow8_kernel(const float* __restrict__ c0, const float* __restrict__ c1,
+                                                      float* __restrict__ out, int B, int H, int W) {
+  const int Ho = 8 * H, Wo = 8 * W;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long per = (long long)Ho * Wo;
+  if (idx >= per * B) return;
+  const int b = (int)(idx / per);
+  const int r = (int)(idx - (long long)b * per);
+  const int yo = r / Wo, xo = r - yo * Wo;
+  const float sy = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, sx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+  const float fy = sy * (float)yo, fx = sx * (float)xo;
+  const int y0 = (int)fy, x0 = (int)fx;
+  const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+  const float ly1 = fy - (float)y0, lx1 = fx - (float)x0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+  const long long hw = (long long)H * W;
+#pragma unroll
+  for (int ch = 0; ch < 2; ++ch) {
+    const float* p0 = c0 + ((long long)b * 2 + ch) * hw;
+    const float* p1 = c1 + ((long long)b * 2 + ch) * hw;
+    const float v00 = p1[y0 * W + x0] - p0[y0 * W + x0], v01 = p1[y0 * W + x1] - p0[y0 * W + x1];
+    const float v10 = p1[y1 * W + x0] - p0[y1 * W + x0], v11 = p1[y1 * W + x1] - p0[y1 * W + x1];
+    const float v = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
+    out[((long long)b * 2 + ch) * per + r] = 8.f * v;
+  }
+}
+
 // RAFT.upsample_flow (raft.py:112-123).  One wave per coarse pixel, lane = sy*8 + sx: the nine
 // mask reads are 256-byte coalesced rows, the 3x3 flow neighbourhood is broadcast.
 __global__ __launch_bounds__(256) void convex_upsample_kernel(const float* __restrict__ flow, int flow_ld,
@@ -433,6 +463,16 @@ int pfk_convex_upsample_f32(const float* flow, const float* mask, int mask_ld, f
   const long long M = (long long)B * H * W;
   hipLaunchKernelGGL(convex_upsample_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), flow, 0, mask, mask_ld, out, M, H, W);
+  return pfk_launch_status();
+}
+
+int pfk_upflow8_f32(const float* coords0, const float* coords1, float* out, int B, int H, int W, pfk_stream_t stream) {
+  if (!coords0 || !coords1 || !out || B <= 0 || H <= 0 || W <= 0) return PFK_ERR_BAD_ARG;
+  const long long n = (long long)B * 64 * H * W;
+  const long long blocks = (n + 255) / 256;
+  if (blocks > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(upflow8_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), coords0, coords1, out,
+                     B, H, W);
   return pfk_launch_status();
 }
 

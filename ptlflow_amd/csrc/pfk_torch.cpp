@@ -238,6 +238,17 @@ void convex_upsample(const Tensor& flow, const Tensor& mask, Tensor out) {
            "convex_upsample");
 }
 
+void upflow8(const Tensor& coords0, const Tensor& coords1, Tensor out) {
+  OpScope scope(coords0);
+  check_dev_f32(coords0, "coords0"); check_dev_f32(coords1, "coords1"); check_dev_f32(out, "out");
+  TORCH_CHECK(coords0.dim() == 4 && coords0.size(1) == 2 && coords0.is_contiguous() && coords1.is_contiguous() &&
+              coords1.sizes() == coords0.sizes(), "upflow8: coords [B, 2, H, W] contiguous");
+  const int64_t B = coords0.size(0), H = coords0.size(2), W = coords0.size(3);
+  TORCH_CHECK(out.is_contiguous() && out.dim() == 4 && out.size(0) == B && out.size(1) == 2 && out.size(2) == 8 * H && out.size(3) == 8 * W,
+              "upflow8: out [B, 2, 8H, 8W] contiguous");
+  check_ok(pfk_upflow8_f32(fptr(coords0), fptr(coords1), fptr(out), (int)B, (int)H, (int)W, cur_stream()), "upflow8");
+}
+
 void convex_upsample_pm(const Tensor& flow_pm, const Tensor& mask, Tensor out) {
   OpScope scope(flow_pm);
   check_pm(flow_pm, "flow_pm"); check_pm(mask, "mask"); check_dev_f32(out, "out");
@@ -587,6 +598,7 @@ TORCH_LIBRARY(pfk, m) {
   m.def("flow_from_coords(Tensor coords0, Tensor coords1, Tensor(a!) flow_out) -> ()");
   m.def("convex_upsample(Tensor flow, Tensor mask, Tensor(a!) out) -> ()");
   m.def("convex_upsample_pm(Tensor flow_pm, Tensor mask, Tensor(a!) out) -> ()");
+  m.def("upflow8(Tensor coords0, Tensor coords1, Tensor(a!) out) -> ()");
   m.def("altcorr_forward(Tensor fmap1, Tensor fmap2, Tensor coords, int radius) -> Tensor");
   m.def("altcorr_backward(Tensor fmap1, Tensor fmap2, Tensor coords, Tensor corr_grad, int radius) -> Tensor[]");
   m.def("corr_lookup_bwd(Tensor(a!)[] grad_levels, int[] lvl_h, int[] lvl_w, Tensor coords, int radius, Tensor grad_out) -> ()");
@@ -609,6 +621,7 @@ TORCH_LIBRARY_IMPL(pfk, CUDA, m) {
   m.impl("flow_from_coords", &flow_from_coords);
   m.impl("convex_upsample", &convex_upsample);
   m.impl("convex_upsample_pm", &convex_upsample_pm);
+  m.impl("upflow8", &upflow8);
   m.impl("altcorr_forward", &altcorr_forward);
   m.impl("altcorr_backward", &altcorr_backward);
   m.impl("corr_lookup_bwd", &corr_lookup_bwd);

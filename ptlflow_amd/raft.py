@@ -296,7 +296,7 @@ class RAFT(nn.Module):
         h, w = image1.shape[-2] // 8, image1.shape[-1] // 8
         eng = self.engine(x.device)
         eng.bind(B, h, w)
-        graphable = self.use_graph and self.spec.has_mask and not self.spec.aggregate and not self.alternate_corr
+        graphable = self.use_graph and not self.spec.aggregate and not self.alternate_corr
         # everything the recorded launch sequence depends on besides the buffers' addresses
         gkey = (B, h, w, x.device, self.iters, self.upsample_every_iter, self.corr_levels, self.corr_radius)
         st = self._graphs.get(gkey) if graphable else None
@@ -312,7 +312,7 @@ class RAFT(nn.Module):
                                     torch.arange(w, device=x.device, dtype=torch.float32), indexing="ij")
             coords0 = torch.stack([xs, ys], 0)[None].repeat(B, 1, 1, 1).contiguous()
             coords1 = coords0.clone()
-            flow_up = torch.empty(B, 2, 8 * h, 8 * w, device=x.device, dtype=torch.float32) if self.spec.has_mask else None
+            flow_up = torch.empty(B, 2, 8 * h, 8 * w, device=x.device, dtype=torch.float32)
         else:
             corr_fn, coords0, coords1, flow_up = st["corr"].update(fm[:B], fm[B:]), st["coords0"], st["coords1"], st["flow_up"]
             coords1.copy_(coords0)
@@ -361,7 +361,7 @@ class RAFT(nn.Module):
                 if has_mask:   # flow = coords1 - coords0 is already in the engine's hx slice (written by flow_delta)
                     ops.convex_upsample_pm(eng.flow_view, eng.mask, flow_up)
                 else:          # raft_small: upflow8 (raft/utils.py:94-96)
-                    flow_up = 8 * F.interpolate(coords1 - coords0, size=(8 * h, 8 * w), mode="bilinear", align_corners=True)
+                    ops.upflow8(coords0, coords1, flow_up)
         return flow_up
 
 

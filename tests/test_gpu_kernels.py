@@ -285,6 +285,18 @@ def test_convex_upsample(gpu):
     assert torch.equal(out, out2)
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 9, 13), (1, 55, 128), (1, 1, 5)])
+def test_upflow8(gpu, B, H, W):
+    """raft_small's upsampling (raft/utils.py:94-96): 8 * F.interpolate(flow, 8x, bilinear, align_corners=True) on CPU."""
+    torch.manual_seed(12)
+    c0 = torch.randn(B, 2, H, W) * 30
+    c1 = c0 + torch.randn(B, 2, H, W) * 4
+    ref = 8 * F.interpolate(c1 - c0, size=(8 * H, 8 * W), mode="bilinear", align_corners=True)
+    out = torch.zeros(B, 2, 8 * H, 8 * W, device=gpu)
+    torch.ops.pfk.upflow8(c0.cuda(), c1.cuda(), out)
+    close(out, ref, rtol=1e-5, atol=2e-5)
+
+
 def test_layout_roundtrip(gpu):
     torch.manual_seed(11)
     x = torch.randn(2, 126, 7, 45)

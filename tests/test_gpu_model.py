@@ -148,12 +148,14 @@ def test_alternate_corr_forward(gpu):
     assert mean <= 5e-3 and mx <= 5e-2, f"EPE mean {mean:.2e} max {mx:.2e}"
 
 
-def test_graph_replay_matches_eager(gpu):
+@pytest.mark.parametrize("small", [False, True])
+def test_graph_replay_matches_eager(gpu, small):
     """use_graph=True: the iteration loop recorded into a hipGraph must reproduce the eager forward bit for bit, for new inputs
-    of the same shape, after a shape change in between, and with a warm start."""
+    of the same shape, after a shape change in between, and with a warm start (raft and raft_small: the latter's upflow8 writes
+    into a fixed buffer too)."""
     from ptlflow_amd.raft import RAFT
-    eager = RAFT(iters=5).load_synthetic(11).eval().cuda()
-    graph = RAFT(iters=5, use_graph=True).load_synthetic(11).eval().cuda()
+    eager = RAFT(iters=5, small=small).load_synthetic(11).eval().cuda()
+    graph = RAFT(iters=5, small=small, use_graph=True).load_synthetic(11).eval().cuda()
     xs = [O.smooth_pair(1, 128, 192, seed=s).cuda() for s in (1, 2, 3)]
     other = O.smooth_pair(1, 136, 160, seed=7).cuda()
     prev = None
