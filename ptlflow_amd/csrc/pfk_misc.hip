@@ -114,75 +114,98 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-// FlowHead.conv2 (3x3, cin -> 2; raft/update.py:10,14) + RAFT loop bookkeeping (raft.py:174,178).
-// One wave per FD_PIX consecutive pixels of one image row: lanes split the input channels (float4 each, coalesced 1 KiB rows),
-// the wave walks the 3 x (FD_PIX + 2) input rows its pixels touch ONCE each and feeds every row to the (up to three) pixels that
-// use it — 3.75 row loads per pixel instead of 9 (the kernel is bound by these L2 reads).  Per pixel the taps still arrive in (ky, kx) order and the channel FMAs in
-// the same chain, so the sums are bit-identical to the tap-by-tap formulation (one row band — 6 weight float4s — at a time); two butterfly reductions per pixel, lane 0
-// applies coords1 += delta and flow = coords1 - coords0.
-constexpr int FD_PIX = 8;
+// one reduce-scatter step: of 2 N values a lane keeps the half selected by its bit OFF and adds the partner's copy of it
+template <int N, int OFF>
+__device__ __forceinline__ void rs_step(float* s, int lane) {
+  const bool up = (lane & OFF) != 0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const float lo = s[i], hi = s[N + i];
+    s[i] = (up ? hi : lo) + __shfl_xor(up ? lo : hi, OFF, 64);
+  }
+}
 
+// FlowHead.conv2 (3x3, cin -> 2; raft/update.py:10,14) + RAFT loop bookkeeping (raft.py:174,178).
+// One wave per PIX consecutive pixels of one image row: lanes split the input channels (float4 each, coalesced 1 KiB rows), the
+// wave walks the 3 x (PIX + 2) input rows its pixels touch ONCE each and feeds every row to the (up to three) pixels that use it
+// (3.75 row loads per pixel at PIX = 8 instead of 9), one row band — 6 weight float4s — at a time.  Per pixel the taps still
+// arrive in (ky, kx) order and the channel FMAs in the same chain, so the per-lane sums are those of the tap-by-tap formulation.
+// Tail: the 2 PIX per-lane sums are reduced over the 64 lanes by a reduce-scatter butterfly (offsets 32, 16, ... exactly the
+// pairing order of `wave_sum`, so every total has wave_sum's bits; 17 instead of 96 lane exchanges at PIX = 8) that leaves total
+// j in the lanes whose upper bits spell j — and THOSE lanes apply coords1 += delta and flow = coords1 - coords0 for their
+// (pixel, component) in parallel: one global round trip per wave instead of PIX dependent ones on lane 0 (which was most of this
+// kernel's time: it is a latency chain, not a bandwidth problem).
+template <int PIX>
 __global__ __launch_bounds__(256) void flow_delta_kernel(
     const float* __restrict__ in, int in_ld, int cin, const float* __restrict__ wgt,
     const float* __restrict__ bias, const float* __restrict__ coords0, float* coords1,
     float* delta_out, float* flow_out, int flow_ld, long long rows, int H, int W, int tpr) {
+  static_assert(PIX == 4 || PIX == 8, "two reduce-scatter depths are written out below");
   const int lane = threadIdx.x & 63;
-  const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  // wave-uniform on purpose (readfirstlane): the row / column tests below must be scalar branches, not per-lane ones whose phi
+  // copies of the 2 PIX accumulators doubled the kernel's registers
+  const long long w = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const long long rowid = w / tpr;                  // b * H + y
   if (rowid >= rows) return;
-  const int x0 = (int)(w - rowid * tpr) * FD_PIX;
+  const int x0 = (int)(w - rowid * tpr) * PIX;
   const int y = (int)(rowid % H);
-  float s0[FD_PIX], s1[FD_PIX];
+  float s[2 * PIX];                                 // s[o * PIX + q]: component o of pixel q
 #pragma unroll
-  for (int q = 0; q < FD_PIX; ++q) { s0[q] = 0.f; s1[q] = 0.f; }
+  for (int j = 0; j < 2 * PIX; ++j) s[j] = 0.f;
   for (int c = lane * 4; c < cin; c += 256) {
 #pragma unroll 1
-    for (int ky = 0; ky < 3; ++ky) {                // one row band at a time: 6 weight float4s + FD_PIX + 2 rows in registers
+    for (int ky = 0; ky < 3; ++ky) {                // one row band at a time: 6 weight float4s + PIX + 2 rows in registers
+      // zero padding without branches: an out-of-range row / column is read from a clamped (valid) address and replaced by zeros
+      // — the reference's padded convolution adds exactly these 0 * w terms; branches here cost phi copies of all accumulators
       const int yy = y + ky - 1;
-      if ((unsigned)yy >= (unsigned)H) continue;    // zero padding: the row simply does not contribute (wave-uniform)
+      const bool yvalid = (unsigned)yy < (unsigned)H;
       f32x4 wa[3], wb[3];
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
         wa[kx] = *reinterpret_cast<const f32x4*>(wgt + (long long)((ky * 3 + kx) * 2) * cin + c);
         wb[kx] = *reinterpret_cast<const f32x4*>(wgt + (long long)((ky * 3 + kx) * 2 + 1) * cin + c);
       }
-      const float* rowp = in + ((rowid + (ky - 1)) * W) * in_ld + c;
+      const float* rowp = in + ((rowid + (yvalid ? ky - 1 : 0)) * W) * in_ld + c;
 #pragma unroll
-      for (int xi = 0; xi < FD_PIX + 2; ++xi) {
+      for (int xi = 0; xi < PIX + 2; ++xi) {
         const int xx = x0 - 1 + xi;
-        if ((unsigned)xx >= (unsigned)W) continue;  // wave-uniform
-        const f32x4 v = *reinterpret_cast<const f32x4*>(rowp + (long long)xx * in_ld);
+        const bool valid = yvalid && (unsigned)xx < (unsigned)W;          // wave-uniform
+        const int xc = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+        f32x4 v = *reinterpret_cast<const f32x4*>(rowp + (long long)xc * in_ld);
+        if (!valid) v = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kx = 2; kx >= 0; --kx) {            // pixel q = xi - kx sees this row as its tap kx (ascending kx per pixel as xi grows)
           const int q = xi - kx;
-          if (q < 0 || q >= FD_PIX) continue;
+          if (q < 0 || q >= PIX) continue;
           const f32x4 a = wa[kx], b = wb[kx];
-          s0[q] = fmaf(v.x, a.x, fmaf(v.y, a.y, fmaf(v.z, a.z, fmaf(v.w, a.w, s0[q]))));
-          s1[q] = fmaf(v.x, b.x, fmaf(v.y, b.y, fmaf(v.z, b.z, fmaf(v.w, b.w, s1[q]))));
+          s[q] = fmaf(v.x, a.x, fmaf(v.y, a.y, fmaf(v.z, a.z, fmaf(v.w, a.w, s[q]))));
+          s[PIX + q] = fmaf(v.x, b.x, fmaf(v.y, b.y, fmaf(v.z, b.z, fmaf(v.w, b.w, s[PIX + q]))));
         }
       }
     }
   }
-  const long long hw = (long long)H * W;
-  const long long bimg = rowid / H;
+  // reduce-scatter: at offset `off` a lane keeps the half of its values selected by its bit `off` and adds the partner's copy
+  // of that half (own + partner's: the operands of wave_sum's step at the same offset)
+  rs_step<PIX, 32>(s, lane);                        // 2 PIX -> PIX values per lane
+  rs_step<PIX / 2, 16>(s, lane);
+  rs_step<PIX / 4, 8>(s, lane);
+  if constexpr (PIX == 8) rs_step<1, 4>(s, lane);
+  float tot = s[0];
 #pragma unroll
-  for (int q = 0; q < FD_PIX; ++q) {
-    const float t0 = wave_sum(s0[q]), t1 = wave_sum(s1[q]);
-    if (lane == 0 && x0 + q < W) {
-      const long long p = rowid * W + x0 + q, pix = p - bimg * hw;
-      const long long ix = (bimg * 2 + 0) * hw + pix, iy = (bimg * 2 + 1) * hw + pix;
-      const float dx = t0 + (bias ? bias[0] : 0.f);
-      const float dy = t1 + (bias ? bias[1] : 0.f);
-      const float c1x = __fadd_rn(coords1[ix], dx);
-      const float c1y = __fadd_rn(coords1[iy], dy);
-      coords1[ix] = c1x;
-      coords1[iy] = c1y;
-      if (delta_out) { delta_out[ix] = dx; delta_out[iy] = dy; }
-      if (flow_out) {
-        flow_out[p * flow_ld + 0] = __fsub_rn(c1x, coords0[ix]);
-        flow_out[p * flow_ld + 1] = __fsub_rn(c1y, coords0[iy]);
-      }
-    }
+  for (int off = (PIX == 8 ? 2 : 4); off >= 1; off >>= 1) tot += __shfl_xor(tot, off, 64);
+  // lane l now holds total j = l >> (PIX == 8 ? 2 : 3) (bit 5 of the lane = most significant bit of j = the component)
+  constexpr int REP = PIX == 8 ? 4 : 8;             // lanes per total
+  const int j = lane / REP, o = j / PIX, q = j - o * PIX;
+  if ((lane & (REP - 1)) == 0 && x0 + q < W) {
+    const long long hw = (long long)H * W;
+    const long long bimg = rowid / H;
+    const long long p = rowid * W + x0 + q, pix = p - bimg * hw;
+    const long long ic = (bimg * 2 + o) * hw + pix;
+    const float d = tot + (bias ? bias[o] : 0.f);
+    const float c1 = __fadd_rn(coords1[ic], d);
+    coords1[ic] = c1;
+    if (delta_out) delta_out[ic] = d;
+    if (flow_out) flow_out[p * flow_ld + o] = __fsub_rn(c1, coords0[ic]);
   }
 }
 
@@ -436,13 +459,19 @@ int pfk_flow_delta_f32(const float* in, int in_ld, int cin, const float* weight,
   if (cin <= 0 || in_ld < cin || (flow_out && flow_ld < 2)) return PFK_ERR_BAD_ARG;
   if (!pfk_aligned16(in) || !pfk_aligned16(weight) || (in_ld & 3) || (cin & 3))
     return PFK_ERR_ALIGNMENT;
-  const int tpr = (W + FD_PIX - 1) / FD_PIX;          // waves per image row
+  // 8 pixels per wave (fewest row loads) once that still gives every SIMD a few waves; 4 per wave below (batch 1: 7040 pixels)
   const long long rows = (long long)B * H;
+  const int pixw = rows * ((W + 7) / 8) >= 4096 ? 8 : 4;
+  const int tpr = (W + pixw - 1) / pixw;             // waves per image row
   const long long blocks = (rows * tpr + 3) / 4;
   if (blocks > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(flow_delta_kernel, dim3((unsigned)blocks), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), in, in_ld, cin, weight, bias, coords0,
-                     coords1, delta_out, flow_out, flow_ld, rows, H, W, tpr);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (pixw == 8)
+    hipLaunchKernelGGL(flow_delta_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, st, in, in_ld, cin, weight, bias, coords0,
+                       coords1, delta_out, flow_out, flow_ld, rows, H, W, tpr);
+  else
+    hipLaunchKernelGGL(flow_delta_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, in, in_ld, cin, weight, bias, coords0,
+                       coords1, delta_out, flow_out, flow_ld, rows, H, W, tpr);
   return pfk_launch_status();
 }
 
