@@ -56,7 +56,7 @@ enum pfk_status {
 };
 
 #define PFK_MAX_LEVELS 8
-#define PFK_ABI_VERSION 4
+#define PFK_ABI_VERSION 3
 
 int pfk_abi_version(void);
 const char* pfk_status_string(int status);
@@ -158,11 +158,9 @@ int pfk_convex_upsample_bwd_f32(const float* flow, int flow_ld, const float* mas
  * out[p][co] = epilogue( bias[co] + sum_{s, ky, kx, c} src[s][p + (ky-kh/2)*W + (kx-kw/2)][c]
  *                                                    * weight[co][k(s,ky,kx,c)] )
  * Input channels may come from up to 3 pixel-major sources (the reference's torch.cat operands).
- * Packed weight: row-major [cout][ktot]; k enumerates, for each source s in order, each 32-channel chunk of the source's
- * channels (padded up to a multiple of 32, pad weights = 0), each tap (ky major, kx minor), the 32 channels of the chunk:
- * k = base_s + ((chunk * kh*kw + tap) * 32 + c % 32), ktot = sum_s kh*kw*round_up(channels_s, 32) (pfk_conv_ktot()).
- * (ABI 4; ABI <= 3 had tap outside chunk.  All taps of a chunk being consecutive K-steps keeps an input line's kh*kw uses
- * within one L2 residency.) */
+ * Packed weight: row-major [cout][ktot]; k enumerates, for each source s in order, each tap
+ * (ky major, kx minor), the source's channels padded up to a multiple of 32 (pad weights = 0):
+ * ktot = sum_s kh*kw*round_up(channels_s, 32).  pfk_conv_ktot() returns it. */
 enum pfk_epilogue {
   PFK_EPI_LINEAR = 0,  /* v = (acc+bias) ; relu? ; v *= scale ; [v = residual[p*residual_ld+co] + v] ;
                           out[p*out_ld + out_coff + co] = v */
@@ -278,7 +276,7 @@ int pfk_altcorr_backward_f32(const float* fmap1, const float* fmap2, const float
                              int W1, int H2, int W2, int C, int radius, pfk_stream_t stream);
 
 /* ---- weight gradient of the convolution above (torch.autograd of every nn.Conv2d in raft/update.py) ---
- * dw_packed[co][k(s,chunk,tap,c)] = sum_p dy[p][co] * src_s[p + tap][c]   — the packed [cout][ktot] layout of pfk_conv2d_f32's weight.
+ * dw_packed[co][k(s,tap,c)] = sum_p dy[p][co] * src_s[p + tap][c]   — the packed [cout][ktot] layout of pfk_conv2d_f32's weight.
  * `d` describes the forward convolution (sources, B, H, W, kh, kw, cout, stride; weight/out/epilogue fields ignored);
  * dy [B*Ho*Wo][dy_ld] is the gradient w.r.t. the convolution output (Ho = (H-1)/stride + 1; stride 0 or 1: Ho = H), cout % 4 == 0;
  * with a stride the product reads src_s at (yo*stride + dy, xo*stride + dx) — no zero-upsampled gradient is needed.  The reduction runs over pixels, cut

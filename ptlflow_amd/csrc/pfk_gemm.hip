@@ -38,7 +38,7 @@ constexpr int LDS_LDX = 32;  // un-padded rows + XOR swizzle of the 16-byte chun
 // -------------------------------------------------------------------------------------------------
 // Staging: 256 threads move one K-step (BM + BN rows x 32 floats) global -> VGPR -> LDS.
 // Thread t owns float4 column (t & 7) of rows (t >> 3) + 32*i.  The K iterator walks
-// source -> 32-channel chunk -> tap (ky, kx).
+// source -> tap (ky, kx) -> 32-channel chunk.
 //
 // All loads are raw *buffer* loads with 32-bit byte offsets: a lane whose tap falls outside the
 // image (the convolution's zero padding), whose row is past M / cout, or whose channel chunk is
@@ -104,7 +104,7 @@ struct Stager {
     for (int i = 0; i < A_PT; ++i) abase[i] = (unsigned)(prow[i] * cld + c4) * 4u;
   }
 
-  // Per-tap work (every K-step of a multi-tap convolution): zero-padding predicate and tap offset folded into one VGPR per row.
+  // Per-tap work (once every cch/32 K-steps): zero-padding predicate and tap offset folded into one VGPR per row.
   __device__ __forceinline__ void set_tap() {
     const int dy = ky - ph, dx = kx - pw;
     const unsigned toff = (unsigned)((dy * W + dx) * cld * 4);
@@ -123,8 +123,8 @@ struct Stager {
       r -= taps * cps; sg = 1; cps = (ch1 + BK - 1) / BK;
       if (nsrc > 2 && r >= taps * cps) { r -= taps * cps; sg = 2; cps = (ch2 + BK - 1) / BK; }
     }
-    const int chunk = r / taps, tap = r - chunk * taps;
-    seg = sg; ky = tap / kw; kx = tap - ky * kw; c0 = chunk * BK; kofs = step * BK;
+    const int tap = r / cps;
+    seg = sg; ky = tap / kw; kx = tap - ky * kw; c0 = (r - tap * cps) * BK; kofs = step * BK;
     set_segment(sg);
     set_tap();
   }
@@ -175,33 +175,21 @@ struct Stager {
     else *reinterpret_cast<f32x4*>(stage + BM * LD + (r0 + 32 * (q - A_PT)) * LD + scol) = rb[q - A_PT];
   }
 
-  // K order: source -> 32-channel chunk -> tap.  The taps of one chunk follow each other, so a line of the input is used by
-  // all kh*kw taps within kh*kw consecutive K-steps of the same block (L2-resident whatever else streams through) instead of
-  // once per tap, a whole channel sweep apart (round 2 PMC: 1.4-2.3x the one-pass input bytes fetched with tap-major order).
   __device__ __forceinline__ void advance() {
     kofs += BK;
-    if (kh * kw == 1) {                      // 1x1: only the chunk moves, the tap predicate stays
-      c0 += BK;
-      if (c0 >= cch) {
-        c0 = 0;
-        ++seg;
-        if (seg < nsrc) { set_segment(seg); set_tap(); }
-      }
-      return;
-    }
-    if (++kx == kw) {
-      kx = 0;
-      if (++ky == kh) {
-        ky = 0;
-        c0 += BK;
-        if (c0 >= cch) {
-          c0 = 0;
+    c0 += BK;
+    if (c0 >= cch) {
+      c0 = 0;
+      if (++kx == kw) {
+        kx = 0;
+        if (++ky == kh) {
+          ky = 0;
           ++seg;
           if (seg < nsrc) set_segment(seg);
         }
       }
+      set_tap();
     }
-    set_tap();
   }
 
   __device__ __forceinline__ void store(float* dA, float* dB) const {

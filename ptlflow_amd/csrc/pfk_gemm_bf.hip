@@ -11,7 +11,7 @@
 // while they are staged: global fp32 -> VGPR -> cvt/sub/cvt -> LDS bf16 planes, so HBM traffic is the fp32 path's.
 // All kept terms go into one fp32 accumulator (smallest first within a K-block).
 //
-// Same implicit-GEMM structure as pfk_gemm.hip: K sub-step = (source, 32-channel chunk, tap) in the same order and padding
+// Same implicit-GEMM structure as pfk_gemm.hip: K sub-step = (source, tap, 32 channels) in the same order and padding
 // as the fp32 packed weight, raw buffer loads with hardware zero fill for the conv padding, un-padded 64-byte LDS rows
 // with the 16-byte chunk index XOR-swizzled, two LDS stages, fused epilogues.
 // Fragment use (32x32x16): lane l holds A[i = l & 31][k = 8*(l >> 5) .. +7] — one ds_read_b128 of chunk
@@ -100,31 +100,21 @@ struct StagerBF {
     }
   }
 
-  // K order: source -> 32-channel chunk -> tap (see Stager::advance in pfk_gemm.hip)
   __device__ __forceinline__ void advance() {
     kofs += BKB;
-    if (kh * kw == 1) {
-      c0 += BKB;
-      if (c0 >= cch) {
-        c0 = 0;
-        ++seg;
-        if (seg < nsrc) { set_segment(seg); set_tap(); }
-      }
-      return;
-    }
-    if (++kx == kw) {
-      kx = 0;
-      if (++ky == kh) {
-        ky = 0;
-        c0 += BKB;
-        if (c0 >= cch) {
-          c0 = 0;
+    c0 += BKB;
+    if (c0 >= cch) {
+      c0 = 0;
+      if (++kx == kw) {
+        kx = 0;
+        if (++ky == kh) {
+          ky = 0;
           ++seg;
           if (seg < nsrc) set_segment(seg);
         }
       }
+      set_tap();
     }
-    set_tap();
   }
 
   // ---- the staging work of one step, cut into small "units" that the kernel places between MFMAs ----------------

@@ -1,10 +1,10 @@
 // Weight gradient of the implicit-GEMM convolution: the transposed product
 //
-//   dW[co][k] = sum_p dY[p][co] * A[p][k],     A[p][k = (source, chunk, tap, channel in chunk)] = src_s[p + tap][c]  (zero outside the image)
+//   dW[co][k] = sum_p dY[p][co] * A[p][k],     A[p][k = (source, tap, channel)] = src_s[p + tap][c]  (zero outside the image)
 //
 // on the fp32 matrix cores, straight from the pixel-major tensors of the forward pass — no im2col, no transposes.  The
 // reduction index is the PIXEL: a K-step is 32 consecutive pixels, staged as they lie in memory (dY: 32 rows x 128 output
-// channels, A: 32 rows x 32 input channels of one (source, chunk, tap), with the tap's zero padding done by out-of-range
+// channels, A: 32 rows x 32 input channels of one (source, tap, chunk), with the tap's zero padding done by out-of-range
 // buffer offsets exactly as in the forward kernel).  v_mfma_f32_32x32x2_f32 wants A[i = co][k = pixel] and B[k = pixel][j = c]:
 // lane l reads LDS element [pixel 2j + (l >> 5)][l & 31] with ds_read_b32 — each half-wave reads 32 consecutive floats of
 // one row, conflict-free — one read pair per MFMA.
@@ -39,7 +39,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void* p) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
 }
 
-// One (source, 32-channel chunk, tap) entry of the forward kernel's K enumeration.
+// One (source, tap, 32-channel) entry of the forward kernel's K enumeration.
 struct ChunkRef { const float* src; int ld, cch, c0, dy, dx, bias, live; };
 
 __device__ __forceinline__ ChunkRef chunk_ref(const WgradArgs& a, int chunk) {
@@ -54,8 +54,8 @@ __device__ __forceinline__ ChunkRef chunk_ref(const WgradArgs& a, int chunk) {
   c.live = chunk < a.chunks;
   c.bias = a.with_bias && chunk == a.chunks - 1;
   const bool plain = c.live && !c.bias;
-  const int chk = plain ? r / taps : 0, tap = plain ? r - chk * taps : 0;     // K order: source -> chunk -> tap
-  c.c0 = chk * 32;
+  const int tap = plain ? r / cps : 0;
+  c.c0 = plain ? (r - tap * cps) * 32 : 0;
   c.dy = plain ? tap / a.kw - (a.kh >> 1) : 0;
   c.dx = plain ? tap % a.kw - (a.kw >> 1) : 0;
   return c;

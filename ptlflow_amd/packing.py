@@ -28,11 +28,7 @@ def pack_conv_weight(weight: torch.Tensor, segments: Sequence[Tuple[int, int, in
     for first, n, n_buf in segments:
         assert first + n <= cin and n_buf >= n and n_buf % 4 == 0
         w = weight[:, first:first + n].permute(0, 2, 3, 1)  # [cout, kh, kw, n]
-        cpad = round_up(n_buf, kpad)
-        w = F.pad(w, (0, cpad - n))
-        # K order inside a source: kpad-channel chunk -> tap (ky major) -> channel in chunk, i.e. all taps of a chunk are
-        # consecutive K-steps (the kernels' iterator: Stager::advance in csrc/pfk_gemm.hip)
-        w = w.reshape(cout, kh * kw, cpad // kpad, kpad).permute(0, 2, 1, 3)
+        w = F.pad(w, (0, round_up(n_buf, kpad) - n))
         parts.append(w.reshape(cout, -1))
     return torch.cat(parts, dim=1).contiguous()
 

@@ -173,8 +173,7 @@ def _unpack_wgrad(packed: torch.Tensor, weight_shape, segs, g: _Geometry) -> tor
     k0 = 0
     for first, n, n_buf in segs:
         cpad = round_up(n_buf, 32)
-        blk = packed[:cout, k0:k0 + taps * cpad].view(cout, cpad // 32, taps, 32).permute(0, 2, 1, 3)   # chunk-major -> tap-major
-        blk = blk.reshape(cout, g.kh, g.kw, cpad)[..., :n]
+        blk = packed[:cout, k0:k0 + taps * cpad].view(cout, g.kh, g.kw, cpad)[..., :n]
         dW[:, first:first + n] = blk.permute(0, 3, 1, 2)
         k0 += taps * cpad
     return dW

@@ -1,5 +1,5 @@
-"""Host-side weight re-layout: a CPU emulation of the kernel's K enumeration (source -> 32-channel chunk -> tap,
-zero padded) against F.conv2d proves the packed matrix is what pfk_conv2d_f32 expects."""
+"""Host-side weight re-layout: a CPU emulation of the kernel's K enumeration (source -> tap -> 32-channel
+chunk, zero padded) against F.conv2d proves the packed matrix is what pfk_conv2d_f32 expects."""
 import torch
 import torch.nn.functional as F
 
@@ -13,14 +13,10 @@ def emulate(srcs, chans_buf, packed, kh, kw, H, W):
     for s, cb in zip(srcs, chans_buf):
         img = s.view(1, H, W, cb).permute(0, 3, 1, 2)
         pad = F.pad(img, (kw // 2, kw // 2, kh // 2, kh // 2))
-        taps = []
         for ky in range(kh):
             for kx in range(kw):
                 tap = pad[:, :, ky:ky + H, kx:kx + W].permute(0, 2, 3, 1).reshape(M, cb)
-                taps.append(F.pad(tap, (0, round_up(cb, 32) - cb)))
-        for chunk in range(round_up(cb, 32) // 32):          # the device iterator: chunk outer, tap inner
-            for tap in taps:
-                cols.append(tap[:, chunk * 32:(chunk + 1) * 32])
+                cols.append(F.pad(tap, (0, round_up(cb, 32) - cb)))
     A = torch.cat(cols, 1)
     assert A.shape[1] == packed.shape[1]
     return A @ packed.t()
