@@ -75,12 +75,13 @@ f"lookup_kernel<4,4,float>: {lk['avg_us']} us, FETCH {lk['fetch_kb']} KB raw, WR
 "  VGPR spill (it also caught 3 spilled VGPRs + a dynamically indexed vector in `corr_bf16_kernel`: 400 -> 320 us with both removed).",
 "* **Fetch.**  The 1x1 convolutions read their (cold) input once: 1.04-1.07x — which also supports the x2 correction.  The multi-tap",
 "  convolutions read 1.4-2.3x their one-pass input.  The tap re-reads of the implicit GEMM are mostly absorbed by LDS / L2 (else 5-9x), and it is",
-"  not the halo (a 1x5 tile needs 68 pixels for 64 outputs and still reads 2.05x): the K order is (source, tap, 32-channel chunk), so a line is",
-"  touched again one whole tap later — 8 to 12 K-steps, during which an XCD's 96 resident blocks stream ~2.5 MB of activations plus the output",
-"  write-back through a 4 MB L2 — and about one re-use in two finds its line evicted.  It does not cost time: the multi-tap launches move",
-"  0.33-0.90 TB/s (the 1x1 ones 1.2-1.3 TB/s), 4-16 % of HBM bandwidth, next to a matrix pipe that is ~80 % busy.  The fix is a (source, chunk,",
-"  tap) K order (re-use distance one K-step: L2- and even L1-resident); it changes the packed-weight layout shared by the forward, dgrad, wgrad",
-"  and split-bf16 paths and is left alone while the kernels are MFMA-bound.",
+"  not the halo (a 1x5 tile needs 68 pixels for 64 outputs and still reads 2.05x).  Tested and REJECTED: the tap re-use distance.  With the K",
+"  order changed from (source, tap, chunk) to (source, chunk, tap) — every line's kh*kw uses in consecutive K-steps — FETCH moved by -5..-20 %",
+"  only (c2 106 -> 91 MB, zr1 199 -> 161, zr2 174 -> 196, fm 59 -> 55; gpurun_out/y_pmc_fetch) while the kernels lost 12 % (fm 536 -> 611 us:",
+"  the tap predicate becomes per-K-step vector work inside the hand-placed MFMA stream), so the change was reverted.  What remains is long-K",
+"  launches whose column tiles / co-resident blocks drift apart over 36-72 K-steps and re-fetch lines the 4 MB L2 has dropped in between (the",
+"  8-step 1x1 launches, which stay in lockstep, read 1.0x even with 9 column tiles).  It does not cost time: the multi-tap launches move",
+"  0.33-0.90 TB/s (the 1x1 ones 1.2-1.3 TB/s), 4-16 % of HBM bandwidth, next to a matrix pipe that is ~80 % busy.",
 "* **Issue.**  SQ_WAIT_ANY 11-12 % and MFMA-busy / SQ-busy = 26 on all big launches (busy cycles summed over the 4 SIMDs of 256 CUs against 32",
 "  shader-engine SQ counters: 26 / 32 = 0.81 of the SIMD cycles have the matrix pipe busy); GRBM_GUI_ACTIVE / 8 XCDs / duration = 2.36 GHz, so no",
 "  clock throttling hides in the fraction: fm at 123-126 TFLOP/s is 78-80 % of the 157.3 TFLOP/s fp32-MFMA peak, the rest is the per-tile",
