@@ -63,6 +63,11 @@ out = ["# r02_b — round 2: PMC traffic per launch of the update-block kernels 
 "|---|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|"] + rows + ["",
 f"lookup_kernel<4,4,float>: {lk['avg_us']} us, FETCH {lk['fetch_kb']} KB raw, WRITE {lk['write_kb']} KB (algorithmic output 56 320 x 324 x 4 B = 71 280 KB: 1.00x; its",
 "loads are 4-byte gathers from a 2.1 GB level-0 volume + three pooled levels, a width the x2 correction is not calibrated for).", "",
+"Correlation volume and pyramid of the same passes (once per forward, batch 8; identified by grid size): K1 `pfk_corr_volume_f32` (96 800 blocks of",
+"64x64, 16x16 supertile walk) FETCH 416.7 MB raw = **0.83 GB x2 against 0.115 GB of operands (7.2x; round 1: 6.4 GB = 53x)**, WRITE 1 548 800 KB =",
+"1.586 GB = 8 x 7040^2 x 4 B exactly (1.00x), 1.9-2.2 ms under the profiler (scripts/corr_bench.py: 2.03 ms = 100 TFLOP/s): the kernel's traffic is",
+"its own output; the operand re-reads left (each 1024-row supertile reads both 1 MB panels once) are half of that and not the limiter.",
+"K2 `pool2x2_kernel<float>` level 0 -> 1: FETCH x2 = 1.557 GB (the volume, once), WRITE 389 MB, 403-420 us = 4.7 TB/s.", "",
 "Reading the table:", "",
 "* **Write: calibrated, and a bug found with it.**  WRITE_SIZE = 64 B x TCC_EA0_WRREQ on this chip (the raw pass shows WRREQ == WRREQ_64B on every",
 "  kernel: the L2 only ever issues full 64-byte write requests here), and the GRU epilogues and the lookup reproduce their algorithmic bytes to",
