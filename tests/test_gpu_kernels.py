@@ -244,9 +244,13 @@ def test_conv_cin2(gpu, k, cout, W):
     close(unpm(out, B, H, W), ref)
 
 
-def test_flow_delta(gpu):
+@pytest.mark.parametrize("B,H,W,cin", [
+    (2, 11, 15, 256),       # 4 pixels per wave, ragged row ends (15 = 3 waves + 3 pixels)
+    (2, 48, 350, 256),      # >= 4096 waves of 8 pixels: the 8-pixel kernel, last wave of a row holds 6 pixels
+    (1, 5, 9, 128),         # raft_small's flow head width
+])
+def test_flow_delta(gpu, B, H, W, cin):
     torch.manual_seed(9)
-    B, H, W, cin = 2, 11, 15, 256
     x = torch.randn(B, cin, H, W)
     wt = torch.randn(2, cin, 3, 3) / 48
     bias = torch.randn(2)
