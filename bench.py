@@ -199,7 +199,9 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # under torch.distributed.run (RANK set) the process group is created even for one rank, so that a single-GPU box can
+    # exercise the RCCL branch (init, barrier, max-reduce) that the N > 1 runs rely on
+    if world > 1 or "RANK" in os.environ:
         import torch.distributed as dist  # noqa: F811
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
