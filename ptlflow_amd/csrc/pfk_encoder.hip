@@ -2,8 +2,8 @@
 // ptlflow/models/raft/extractor.py:122-194 BasicEncoder):
 //   * the stem: Conv2d(3, C, 7, stride 2, padding 3) read straight from the NCHW image (K = 147 is too thin for the
 //     32-channel K-steps of the MFMA kernels), VALU FMA kernel, output pixel-major;
-//   * instance-norm statistics (two-pass mean / variance per (image, channel), deterministic: per-chunk partials
-//     reduced in a fixed order, no atomics);
+//   * instance-norm statistics (one pass: sum and sum of squares per (image, channel) in double, deterministic: per-chunk
+//     partials reduced in a fixed order, no atomics), and their backward;
 //   * normalise + relu (+ residual add + relu) elementwise pass.
 // The 3x3 / 1x1 convolutions of the residual blocks (stride 1 and 2) run on pfk_conv2d_f32 / pfk_conv2d_bf16s;
 // batch-norm in eval mode is folded into their weights by the host (ptlflow_amd/encoder.py).
