@@ -221,6 +221,8 @@ def main():
         def make(prec, every_iter=not args.skip_dead_upsample):
             return RAFT(small=small, iters=args.iters, upsample_every_iter=every_iter, conv_precision=prec)
     model = make(args.conv_precision)
+    if os.environ.get("PFK_OVERLAP") == "0":          # experiment knob: mask head + upsampling on the main stream
+        model.overlap_mask_head = False
     model.load_synthetic(1234).eval()
     cpu_state = {k: v.clone() for k, v in model.state_dict().items()}
     model = model.to(dev)

@@ -122,9 +122,15 @@ def _param_tree(shapes: Dict[str, tuple]) -> nn.Module:
 class RAFT(nn.Module):
     def __init__(self, corr_levels: int = 4, corr_radius: Optional[int] = None, iters: int = 32, small: bool = False,
                  upsample_every_iter: bool = True, conv_precision: str = "fp32", native_encoders: bool = True,
-                 alternate_corr: bool = False, use_graph: bool = False):
+                 alternate_corr: bool = False, use_graph: bool = False, overlap_mask_head: bool = True):
         super().__init__()
         self.small = small
+        # True: the mask head's second convolution and the convex upsampling of iteration i — off the recurrent critical path:
+        # nothing of iteration i+1 reads their results — run on a second HIP stream next to iteration i+1's lookup / motion
+        # encoder / GRU, filling the idle CUs of those launches' tails (same kernels, same operands: bit-identical output).
+        # Eager loop only; the hipGraph path keeps one stream.
+        self.overlap_mask_head = overlap_mask_head
+        self._side_streams: Dict[torch.device, torch.cuda.Stream] = {}
         # True: the 32-iteration loop (lookup, update block, upsampling: ~20 launches per iteration) is captured once per
         # input shape into a hipGraph (torch.cuda.CUDAGraph) and replayed — it runs entirely on buffers with fixed addresses.
         # Pays when the forward is launch-bound (small frames, batch 1); models with a mask head and the materialised
@@ -352,16 +358,38 @@ class RAFT(nn.Module):
         ops = torch.ops.pfk
         has_mask = self.spec.has_mask
         h, w = coords0.shape[-2:]
+        side = None
+        if has_mask and self.overlap_mask_head and not torch.cuda.is_current_stream_capturing():
+            dev = coords0.device
+            side = self._side_streams.get(dev)
+            if side is None:
+                side = self._side_streams[dev] = torch.cuda.Stream(device=dev)
+        main = torch.cuda.current_stream(coords0.device)
+        side_done = None
         for it in range(self.iters):
             last = it == self.iters - 1
             corr_pm = corr_fn.lookup_pm(coords1)
             do_up = last or self.upsample_every_iter
-            eng.step(corr_pm, coords0, coords1, want_mask=do_up)
-            if do_up:
-                if has_mask:   # flow = coords1 - coords0 is already in the engine's hx slice (written by flow_delta)
-                    ops.convex_upsample_pm(eng.flow_view, eng.mask, flow_up)
-                else:          # raft_small: upflow8 (raft/utils.py:94-96)
-                    ops.upflow8(coords0, coords1, flow_up)
+            if side is None or not do_up:
+                eng.step(corr_pm, coords0, coords1, want_mask=do_up)
+                if do_up:
+                    if has_mask:   # flow = coords1 - coords0 is already in the engine's hx slice (written by flow_delta)
+                        ops.convex_upsample_pm(eng.flow_view, eng.mask, flow_up)
+                    else:          # raft_small: upflow8 (raft/utils.py:94-96)
+                        ops.upflow8(coords0, coords1, flow_up)
+                continue
+            eng.motion_and_gru(corr_pm)
+            if side_done is not None:      # the previous iteration's mask head / upsampling still read `fm` and the flow slice
+                main.wait_event(side_done)
+            eng.heads(coords0, coords1, None, want_mask=False)      # fh | mask conv1 (`fm`), flow head conv2 + coordinate update
+            forked = main.record_event()
+            side.wait_event(forked)
+            with torch.cuda.stream(side):
+                eng.mask_head(side_stream=True)
+                ops.convex_upsample_pm(eng.flow_view, eng.mask, flow_up)
+                side_done = side.record_event()
+        if side_done is not None:
+            main.wait_event(side_done)
         return flow_up
 
 

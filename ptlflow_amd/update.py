@@ -290,14 +290,15 @@ class UpdateEngine:
 
     # ------------------------------------------------------------------ one iteration
     def _conv(self, srcs: List[torch.Tensor], kh, kw, key, cout, relu=True, scale=1.0, out=None,
-              epi=EPI_LINEAR, h=None, z=None, rh=None):
+              epi=EPI_LINEAR, h=None, z=None, rh=None, workspace=True):
         B, H, W = self._shape
         prof = self.profile
         if prof is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
+        # the stream-K workspace belongs to ONE stream: a launch on a side stream goes without it (plain tile grid)
         self.ops.conv2d(srcs, B, H, W, kh, kw, self.w[key + ".w"], self.w.get(key + ".b"), cout, epi, relu, scale,
-                        out, h, z, rh, self.workspace)
+                        out, h, z, rh, self.workspace if workspace else None)
         if prof is not None:
             e1.record()
             prof.setdefault(key, []).append((e0, e1))
@@ -365,7 +366,14 @@ class UpdateEngine:
         self.ops.flow_delta(self.fm[:, : s.fh_hidden], self.w["fh2.w"], self.w["fh2.b"], coords0, coords1, delta_out,
                             self.flow_view if write_flow else None)
         if s.has_mask and want_mask:
-            self._conv([self.fm[:, s.fh_hidden:]], 1, 1, "mk", s.mask_channels, relu=False, scale=0.25, out=self.mask)
+            self.mask_head()
+
+    def mask_head(self, side_stream: bool = False) -> None:
+        """mask[1] + the 0.25 scale of raft/update.py:131-135,152 on the mask half of `fm` (written by `heads`); reads nothing
+        else of the iteration's state, so it may run on a side stream next to the following iteration (raft.py `_iterate`)."""
+        s = self.spec
+        self._conv([self.fm[:, s.fh_hidden:]], 1, 1, "mk", s.mask_channels, relu=False, scale=0.25, out=self.mask,
+                   workspace=not side_stream)
 
     def step(self, corr_pm: torch.Tensor, coords0: torch.Tensor, coords1: torch.Tensor, want_mask: bool = True) -> None:
         """One full RAFT iteration body after the lookup; updates hx (net, flow) and coords1 in place."""

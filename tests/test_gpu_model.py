@@ -167,3 +167,20 @@ def test_graph_replay_matches_eager(gpu, small):
         assert torch.equal(a["flows"], b["flows"]) and torch.equal(a["flow_small"], b["flow_small"]), f"forward {i}"
         prev = a["flow_small"] if x.shape == xs[0].shape else None
     assert len(graph._graphs) == 2
+
+
+@pytest.mark.parametrize("kind", ["raft", "gma"])
+def test_side_stream_mask_head_is_bit_identical(gpu, kind):
+    """overlap_mask_head=True runs mask conv2 + convex upsampling of iteration i on a second stream next to iteration i+1: same
+    kernels on the same operands, so the flows must not change by a bit — over repeated forwards (buffer re-use across forwards and
+    iterations is where a missing event would show) and with the per-iteration upsampling both on and off."""
+    from ptlflow_amd.raft import GMA, RAFT
+    make = (lambda **kw: GMA(iters=6, **kw)) if kind == "gma" else (lambda **kw: RAFT(iters=6, **kw))
+    for every in (True, False):
+        a = make(upsample_every_iter=every).load_synthetic(5).eval().cuda()
+        b = make(upsample_every_iter=every).load_synthetic(5).eval().cuda()
+        a.overlap_mask_head, b.overlap_mask_head = False, True
+        for seed in (1, 2, 1, 3):
+            x = O.smooth_pair(2, 136, 200, seed=seed).cuda()
+            fa, fb = a({"images": x}), b({"images": x})
+            assert torch.equal(fa["flows"], fb["flows"]) and torch.equal(fa["flow_small"], fb["flow_small"]), (every, seed)
