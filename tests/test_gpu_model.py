@@ -181,6 +181,6 @@ def test_side_stream_mask_head_is_bit_identical(gpu, kind):
         b = make(upsample_every_iter=every).load_synthetic(5).eval().cuda()
         a.overlap_mask_head, b.overlap_mask_head = False, True
         for seed in (1, 2, 1, 3):
-            x = O.smooth_pair(2, 136, 200, seed=seed).cuda()
+            x = O.smooth_pair(8, 480, 640, seed=seed).cuda()      # 8 x 60 x 80 = 38 400 pixels: above the side-stream threshold
             fa, fb = a({"images": x}), b({"images": x})
             assert torch.equal(fa["flows"], fb["flows"]) and torch.equal(fa["flow_small"], fb["flow_small"]), (every, seed)
