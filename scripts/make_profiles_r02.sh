@@ -10,12 +10,14 @@ echo "Commands (scripts/gpu_final3.sh): \`rocprofv3 --kernel-trace --output-form
 echo "--no-split-modes --no-extra-legs --no-batch1 [--batch 1 | --model gma --batch 4 | --model raft_small | --conv-precision bf16x3 |"
 echo "--conv-precision bf16] --steps K --warmup W\` and \`... -- python scripts/train_prof.py\` (4 training steps of RAFT, batch 10, 368x496,"
 echo "12 iterations).  Summaries by scripts/trace_stats.py (regs = VGPR count per dispatch; scratch must read 0 everywhere — tests/test_no_scratch.py)."
-echo "Same box, same tree, \`python bench.py\` (gpurun_out/g_bench.log): **68.3 frame-pairs/s fp32 (117.1 ms/step, batch 8), roofline fm 535.8 us ="
-echo "124.0 TFLOP/s = 0.788 of 157.3; batch-1 52.5, model_benchmark protocol 51.8 (19.31 ms median); bf16x6 83.5 (EPE 1.07e-5), bf16x3 131.9"
-echo "(EPE 6.8e-5); skip_dead_upsample 72.2 (bit-identical); gma fp32 45.6 (batch 4); raft bf16 184.2, gma bf16 105.6; train 85.4 samples/s"
-echo "(117.0 ms/step, encoders 38.2 ms); cpu_baseline 0.60 pairs/s (16 cores)**; EPE vs the CPU oracle 1.02e-5 mean / 5.7e-5 max; 227 GPU tests"
-echo "green, 3 skipped (gpurun_out/g_pytest.log).  Micro-benches of the same run: g_corr.log (K1 fp32 2026 us = 100 TF, K1 bf16 331 us = 2.39 TB/s,"
-echo "K2 484 us = 5.3 TB/s, K3 59.7 us = 2.74 TB/s), g_lookup.log (K7 level 0: 350.7 us at batch 8), g_conv_b1.log, g_conv_b8.log, g_wgrad.log."
+echo "Same box, same tree, \`python bench.py\` (gpurun_out/g_bench.log): **69.4 frame-pairs/s fp32 (115.4 ms/step, batch 8), roofline fm 534.8 us ="
+echo "124.2 TFLOP/s = 0.790 of 157.3; batch-1 53.2, model_benchmark protocol 52.6 (19.02 ms median); bf16x6 88.4 (EPE 1.07e-5), bf16x3 138.3"
+echo "(EPE 6.8e-5); skip_dead_upsample 72.7 (bit-identical); gma fp32 46.3 (batch 4); raft bf16 190.1, gma bf16 105.2; train 86.3 samples/s"
+echo "(115.9 ms/step, encoders 37.9 ms); cpu_baseline 0.64 pairs/s (16 cores)**; EPE vs the CPU oracle 1.02e-5 mean / 5.7e-5 max.  The whole GPU"
+echo "suite on this tree: 231 passed, 3 skipped (scripts/gpu_confirm.sh, gpurun_out/c_pytest.log; that run's bench line read 70.3 pairs/s / 0.806 on"
+echo "another box of the pool).  Micro-benches of the same run: g_corr.log (K1 fp32 1908 us = 106 TF, K1 bf16 315 us = 2.52 TB/s, K2 488 us ="
+echo "5.3 TB/s, K3 59.1 us = 2.77 TB/s), g_lookup.log (K7 level 0: 348.3 us at batch 8 = 16.6 TB/s of L2 gathers), g_conv_b1.log, g_conv_b8.log,"
+echo "g_wgrad.log.  In the fp32 tables the mask head's second convolution and the convex upsampling run on a second stream (batch 8, gma)."
 echo
 } > $P
 T="python scripts/trace_stats.py"
