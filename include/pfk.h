@@ -289,6 +289,15 @@ long long pfk_conv_wgrad_workspace_bytes(const pfk_conv_desc* d, int with_bias);
 int pfk_conv_wgrad_f32(const pfk_conv_desc* d, const float* dy, int dy_ld, float* dw_packed, int with_bias, void* workspace,
                        long long workspace_bytes, pfk_stream_t stream);
 
+/* The same weight gradient delivered in PyTorch's layouts (what autograd accumulates): dw [cout_real][cin][kh][kw] with cin =
+ * sum of real_channels[s] (the sources' real channels in order; real_channels[s] <= src[s].channels, the rest being the
+ * buffers' zero padding) and db [cout_real] (NULL: no bias gradient).  d->cout is dy's channel count (a multiple of 4, >=
+ * cout_real).  The slice reduction writes them directly — no packed intermediate, no un-packing copies.  workspace:
+ * pfk_conv_wgrad_unpacked_workspace_bytes(d, db != NULL) bytes, always required. */
+long long pfk_conv_wgrad_unpacked_workspace_bytes(const pfk_conv_desc* d, int with_bias);
+int pfk_conv_wgrad_unpacked_f32(const pfk_conv_desc* d, const int* real_channels, const float* dy, int dy_ld, int cout_real,
+                                float* dw, float* db, void* workspace, long long workspace_bytes, pfk_stream_t stream);
+
 /* Gate arithmetic of one ConvGRU / SepConvGRU pass for the training path (raft/update.py:24-32, 58-73), pixel-major
  * [M][C] tensors, C % 4 == 0; z, r, rh, q, h_new, da_q, dh are contiguous [M][C], a_zr / da_zr contiguous [M][2C]
  * (z half first), h / dh_new have their own row stride.

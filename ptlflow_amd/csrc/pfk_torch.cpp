@@ -417,6 +417,42 @@ void conv_stem(const Tensor& img, const Tensor& weight, const c10::optional<Tens
   check_ok(pfk_conv_stem_f32(fptr(img), fptr(weight), b, fptr(out), out.stride(0), B, H, W, cout, relu, cur_stream()), "conv_stem");
 }
 
+// weight / bias gradient in PyTorch's layouts: dw [cout, sum(reals), kh, kw], db [cout] (optional); dy [B*Ho*Wo, cout4]
+void conv_wgrad_unpacked(at::TensorList srcs, const Tensor& dy, int64_t B, int64_t H, int64_t W, int64_t kh, int64_t kw, Tensor dw,
+                         const c10::optional<Tensor>& db, at::IntArrayRef reals, int64_t stride) {
+  OpScope scope(dy);
+  TORCH_CHECK(srcs.size() >= 1 && srcs.size() <= 3 && reals.size() == srcs.size(), "conv_wgrad_unpacked: 1..3 sources, one real count each");
+  check_pm(dy, "dy"); check_dev_f32(dw, "dw");
+  pfk_conv_desc d{};
+  const int64_t M = B * H * W;
+  int real[3] = {0, 0, 0};
+  int64_t cin = 0;
+  for (size_t i = 0; i < srcs.size(); ++i) {
+    check_pm(srcs[i], "src");
+    TORCH_CHECK(srcs[i].size(0) == M, "conv_wgrad_unpacked: src rows != B*H*W");
+    d.src[i].ptr = fptr(srcs[i]); d.src[i].ld = srcs[i].stride(0); d.src[i].channels = srcs[i].size(1);
+    real[i] = (int)reals[i];
+    cin += reals[i];
+  }
+  d.num_src = srcs.size();
+  d.B = B; d.H = H; d.W = W; d.kh = kh; d.kw = kw; d.cout = dy.size(1);
+  TORCH_CHECK(stride >= 1, "conv_wgrad_unpacked: stride");
+  d.stride = (int)stride;
+  TORCH_CHECK(dy.size(0) == B * ((H - 1) / stride + 1) * ((W - 1) / stride + 1), "conv_wgrad_unpacked: dy rows != B*Ho*Wo");
+  TORCH_CHECK(dw.is_contiguous() && dw.dim() == 4 && dw.size(0) <= d.cout && dw.size(1) == cin && dw.size(2) == kh && dw.size(3) == kw,
+              "conv_wgrad_unpacked: dw [cout, sum(reals), kh, kw] contiguous");
+  float* dbp = nullptr;
+  if (db.has_value()) {
+    check_dev_f32(*db, "db");
+    TORCH_CHECK(db->is_contiguous() && db->numel() == dw.size(0), "conv_wgrad_unpacked: db [cout]");
+    dbp = fptr(*db);
+  }
+  const long long need = pfk_conv_wgrad_unpacked_workspace_bytes(&d, dbp != nullptr);
+  Tensor ws = at::empty({(int64_t)need}, dy.options().dtype(at::kByte));
+  check_ok(pfk_conv_wgrad_unpacked_f32(&d, real, fptr(dy), dy.stride(0), (int)dw.size(0), fptr(dw), dbp, ws.data_ptr(), need,
+                                       cur_stream()), "conv_wgrad_unpacked");
+}
+
 int64_t instnorm_workspace_bytes(int64_t B, int64_t C) { return pfk_instnorm_workspace_bytes((int)B, (int)C); }
 
 void instnorm_stats(const Tensor& x, int64_t B, int64_t HW, double eps, Tensor mean, Tensor rstd, Tensor workspace) {
@@ -570,6 +606,7 @@ TORCH_LIBRARY(pfk, m) {
   m.def("gru_backward_q(Tensor dh_new, Tensor z, Tensor q, Tensor h, Tensor(a!) da_q, Tensor(b!) da_zr, Tensor(c!) dh) -> ()");
   m.def("gru_backward_zr(Tensor d_rh, Tensor h, Tensor r, Tensor(a!) da_zr, Tensor(b!) dh) -> ()");
   m.def("conv_wgrad(Tensor[] srcs, Tensor dy, int B, int H, int W, int kh, int kw, Tensor(a!) out, bool with_bias=False, int stride=1) -> ()");
+  m.def("conv_wgrad_unpacked(Tensor[] srcs, Tensor dy, int B, int H, int W, int kh, int kw, Tensor(a!) dw, Tensor(b!)? db, int[] reals, int stride=1) -> ()");
   m.def("forward_interpolate(Tensor flow, Tensor(a!) out) -> ()");
   m.def("softmax_rows(Tensor(a!) x) -> ()");
   m.def("norm_bwd(Tensor x, Tensor dy, Tensor mean, Tensor rstd, Tensor(a!) dx, Tensor(b!) sum_g, Tensor(c!) sum_gxhat, int B, int HW, bool relu) -> ()");
@@ -636,6 +673,7 @@ TORCH_LIBRARY_IMPL(pfk, CUDA, m) {
   m.impl("gru_backward_q", &gru_backward_q);
   m.impl("gru_backward_zr", &gru_backward_zr);
   m.impl("conv_wgrad", &conv_wgrad);
+  m.impl("conv_wgrad_unpacked", &conv_wgrad_unpacked);
   m.impl("forward_interpolate", &forward_interpolate);
   m.impl("softmax_rows", &softmax_rows);
   m.impl("norm_bwd", &norm_bwd);

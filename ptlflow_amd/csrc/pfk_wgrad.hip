@@ -173,6 +173,33 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   *reinterpret_cast<f32x4*>(out + i) = s;
 }
 
+// The same slice reduction, written straight into PyTorch's layouts: dw [cout][cin][kh][kw] (cin = the sources' REAL channels
+// one after the other) and db [cout] — the inverse of the host's weight packing (ptlflow_amd/packing.py), so a training step
+// needs no per-call permute / copy kernels between the weight-gradient launch and autograd's accumulation.
+struct UnpackArgs {
+  const float* part; long long n; int splits;
+  int ktot, cout_real, taps, nseg, cin_total, with_bias;
+  int first[3], nreal[3], cpad[3];
+  float* dw; float* db;
+};
+
+__global__ __launch_bounds__(256) void wgrad_reduce_unpack_kernel(const UnpackArgs u) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)u.cout_real * u.ktot) return;
+  const int co = (int)(idx / u.ktot), k = (int)(idx - (long long)co * u.ktot);
+  float s = u.part[idx];
+  for (int j = 1; j < u.splits; ++j) s += u.part[(long long)j * u.n + idx];      // same fixed order as wgrad_reduce_kernel
+  int kk = k;
+  if (u.with_bias && k >= u.ktot - 32) {
+    if (k == u.ktot - 32 && u.db) u.db[co] = s;
+    return;
+  }
+  int sg = 0;
+  while (sg < u.nseg - 1 && kk >= u.taps * u.cpad[sg]) { kk -= u.taps * u.cpad[sg]; ++sg; }
+  const int tap = kk / u.cpad[sg], c = kk - tap * u.cpad[sg];
+  if (c < u.nreal[sg]) u.dw[((long long)co * u.cin_total + u.first[sg] + c) * u.taps + tap] = s;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // Gate arithmetic of one (Sep)ConvGRU pass for the training path (raft/update.py:24-32, 58-73), float4 per thread over
 // pixel-major [M][C] tensors.  Forward keeps what the backward needs (z, r, q); the derivative kernels produce the
@@ -292,13 +319,12 @@ long long pfk_conv_wgrad_workspace_bytes(const pfk_conv_desc* d, int with_bias) 
   return splits > 1 ? (long long)splits * d->cout * ktot * (long long)sizeof(float) : 0;
 }
 
-int pfk_conv_wgrad_f32(const pfk_conv_desc* d, const float* dy, int dy_ld, float* dw_packed, int with_bias, void* workspace,
-                       long long workspace_bytes, pfk_stream_t stream) {
-  if (!d || !dy || !dw_packed || d->num_src < 1 || d->num_src > 3) return PFK_ERR_BAD_ARG;
+// Validate, fill the kernel arguments (everything but `part`) and pick the split count.
+static int wgrad_plan(const pfk_conv_desc* d, const float* dy, int dy_ld, int with_bias, WgradArgs& a, int& cb, int& groups, int& splits) {
+  if (!d || !dy || d->num_src < 1 || d->num_src > 3) return PFK_ERR_BAD_ARG;
   if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->cout <= 0 || dy_ld < d->cout) return PFK_ERR_BAD_ARG;
   if (d->kh <= 0 || d->kw <= 0 || !(d->kh & 1) || !(d->kw & 1) || d->stride < 0) return PFK_ERR_BAD_ARG;
-  if ((d->cout & 3) || (dy_ld & 3) || !pfk_aligned16(dy) || !pfk_aligned16(dw_packed)) return PFK_ERR_ALIGNMENT;
-  WgradArgs a{};
+  if ((d->cout & 3) || (dy_ld & 3) || !pfk_aligned16(dy)) return PFK_ERR_ALIGNMENT;
   const pfk_conv_src* s = d->src;
   const int sd = d->stride > 1 ? d->stride : 1;
   const int Ho = (d->H - 1) / sd + 1, Wo = (d->W - 1) / sd + 1;
@@ -310,6 +336,7 @@ int pfk_conv_wgrad_f32(const pfk_conv_desc* d, const float* dy, int dy_ld, float
     if (Min * s[i].ld * 4 >= 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
   }
   if (M * dy_ld * 4 >= 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
+  a = WgradArgs{};
   a.src0 = s[0].ptr; a.ld0 = s[0].ld; a.ch0 = s[0].channels;
   if (d->num_src > 1) { a.src1 = s[1].ptr; a.ld1 = s[1].ld; a.ch1 = s[1].channels; }
   if (d->num_src > 2) { a.src2 = s[2].ptr; a.ld2 = s[2].ld; a.ch2 = s[2].channels; }
@@ -320,11 +347,29 @@ int pfk_conv_wgrad_f32(const pfk_conv_desc* d, const float* dy, int dy_ld, float
   a.with_bias = with_bias ? 1 : 0;
   a.ktot = ktot_of(d) + (with_bias ? 32 : 0);
   a.chunks = a.ktot / 32;
-  const int cb = pick_cb(d->cout);
+  cb = pick_cb(d->cout);
   a.tiles_m = (d->cout + 32 * cb - 1) / (32 * cb);
-  const int groups = (a.chunks + 4 / cb - 1) / (4 / cb);
-  const int splits = pick_splits((long long)a.tiles_m * groups, M);
+  groups = (a.chunks + 4 / cb - 1) / (4 / cb);
+  splits = pick_splits((long long)a.tiles_m * groups, M);
   a.px_per_split = ((M + splits - 1) / splits + 31) / 32 * 32;
+  return PFK_OK;
+}
+
+static void wgrad_run(const WgradArgs& a, int cb, int groups, int splits, hipStream_t st) {
+  const dim3 grid((unsigned)(a.tiles_m * groups), (unsigned)splits);
+  if (cb == 4) hipLaunchKernelGGL(conv_wgrad_kernel<4>, grid, dim3(256), 0, st, a);
+  else if (cb == 2) hipLaunchKernelGGL(conv_wgrad_kernel<2>, grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(conv_wgrad_kernel<1>, grid, dim3(256), 0, st, a);
+}
+
+int pfk_conv_wgrad_f32(const pfk_conv_desc* d, const float* dy, int dy_ld, float* dw_packed, int with_bias, void* workspace,
+                       long long workspace_bytes, pfk_stream_t stream) {
+  if (!dw_packed) return PFK_ERR_BAD_ARG;
+  if (!pfk_aligned16(dw_packed)) return PFK_ERR_ALIGNMENT;
+  WgradArgs a;
+  int cb, groups, splits;
+  const int rc = wgrad_plan(d, dy, dy_ld, with_bias, a, cb, groups, splits);
+  if (rc != PFK_OK) return rc;
   const long long n = (long long)d->cout * a.ktot;
   if (splits > 1) {
     if (!workspace || workspace_bytes < splits * n * (long long)sizeof(float) || !pfk_aligned16(workspace)) return PFK_ERR_BAD_ARG;
@@ -333,13 +378,46 @@ int pfk_conv_wgrad_f32(const pfk_conv_desc* d, const float* dy, int dy_ld, float
     a.part = dw_packed;
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const dim3 grid((unsigned)(a.tiles_m * groups), (unsigned)splits);
-  if (cb == 4) hipLaunchKernelGGL(conv_wgrad_kernel<4>, grid, dim3(256), 0, st, a);
-  else if (cb == 2) hipLaunchKernelGGL(conv_wgrad_kernel<2>, grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(conv_wgrad_kernel<1>, grid, dim3(256), 0, st, a);
+  wgrad_run(a, cb, groups, splits, st);
   if (splits > 1)
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st,
                        static_cast<const float*>(workspace), dw_packed, n, splits);
+  return pfk_launch_status();
+}
+
+long long pfk_conv_wgrad_unpacked_workspace_bytes(const pfk_conv_desc* d, int with_bias) {
+  if (!d || d->num_src < 1 || d->num_src > 3 || d->cout <= 0) return 0;
+  const long long packed = pfk_conv_wgrad_workspace_bytes(d, with_bias);
+  const long long one = (long long)d->cout * (ktot_of(d) + (with_bias ? 32 : 0)) * (long long)sizeof(float);
+  return packed > one ? packed : one;       // the slices always go through the workspace here, even a single one
+}
+
+int pfk_conv_wgrad_unpacked_f32(const pfk_conv_desc* d, const int* real_channels, const float* dy, int dy_ld, int cout_real,
+                                float* dw, float* db, void* workspace, long long workspace_bytes, pfk_stream_t stream) {
+  if (!dw || !real_channels || !workspace || cout_real <= 0 || !d || cout_real > d->cout) return PFK_ERR_BAD_ARG;
+  if (!pfk_aligned16(workspace)) return PFK_ERR_ALIGNMENT;
+  const int with_bias = db != nullptr;
+  WgradArgs a;
+  int cb, groups, splits;
+  const int rc = wgrad_plan(d, dy, dy_ld, with_bias, a, cb, groups, splits);
+  if (rc != PFK_OK) return rc;
+  const long long n = (long long)d->cout * a.ktot;
+  if (workspace_bytes < splits * n * (long long)sizeof(float)) return PFK_ERR_BAD_ARG;
+  a.part = static_cast<float*>(workspace);
+  UnpackArgs u{};
+  u.part = a.part; u.n = n; u.splits = splits; u.ktot = a.ktot; u.cout_real = cout_real; u.taps = d->kh * d->kw;
+  u.nseg = d->num_src; u.with_bias = with_bias; u.dw = dw; u.db = db;
+  int first = 0;
+  for (int i = 0; i < d->num_src; ++i) {
+    if (real_channels[i] <= 0 || real_channels[i] > d->src[i].channels) return PFK_ERR_BAD_ARG;
+    u.first[i] = first; u.nreal[i] = real_channels[i]; u.cpad[i] = (d->src[i].channels + 31) / 32 * 32;
+    first += real_channels[i];
+  }
+  u.cin_total = first;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  wgrad_run(a, cb, groups, splits, st);
+  const long long total = (long long)cout_real * a.ktot;
+  hipLaunchKernelGGL(wgrad_reduce_unpack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, u);
   return pfk_launch_status();
 }
 

@@ -109,7 +109,7 @@ class _ConvPM(torch.autograd.Function):
         M = g.B * g.H * g.W
         dY = dY.float().contiguous()
         if ctx.relu:
-            dY = dY * (out > 0)
+            dY = torch.ops.aten.threshold_backward(dY, out, 0.0)     # dY * (out > 0) in one kernel (what torch's relu backward runs)
         ws = _workspace(dY.device)
         need = ctx.needs_input_grad      # (weight, bias, g, relu, real, packs, *srcs)
         dW = db = None
@@ -131,17 +131,15 @@ class _ConvPM(torch.autograd.Function):
             ops.conv2d([dY_in], g.B, g.H, g.W, g.kh, g.kw, _dgrad_pack(packs, i, weight, (first, n, n_buf), dY_src.shape[1]), None, n_buf,
                        EPI_LINEAR, False, 1.0, dx, None, None, None, ws)
             dsrcs[i] = dx
-        # ---- wgrad: one launch (+ a deterministic slice reduction) straight from the pixel-major tensors, written in the packed
-        # [cout, ktot] layout of the forward weight and un-packed here (the inverse of pack_conv_weight)
+        # ---- wgrad: one launch + a deterministic slice reduction straight from the pixel-major tensors; the reduction writes
+        # PyTorch's [cout, cin, kh, kw] / [cout] layouts directly (pfk_conv_wgrad_unpacked_f32), the bias gradient being one more
+        # K chunk whose A operand is a column of ones
         want_b = ctx.has_bias and need[1]
         if need[0]:
-            taps = g.kh * g.kw
-            ktot = sum(taps * round_up(n_buf, 32) for _, _, n_buf in segs)
-            packed = torch.empty(dY_src.shape[1], ktot + (32 if want_b else 0), device=dY.device, dtype=torch.float32)
-            ops.conv_wgrad(list(srcs), dY_src, g.B, g.H, g.W, g.kh, g.kw, packed, want_b, g.stride)   # bias gradient = one more column
-            dW = _unpack_wgrad(packed, weight.shape, segs, g).to(weight.dtype)
-            if want_b:
-                db = packed[:cout, ktot].clone()
+            dW = torch.empty(weight.shape, device=dY.device, dtype=torch.float32)
+            db = torch.empty(cout, device=dY.device, dtype=torch.float32) if want_b else None
+            ops.conv_wgrad_unpacked(list(srcs), dY_src, g.B, g.H, g.W, g.kh, g.kw, dW, db, [n for _, n, _ in segs], g.stride)
+            dW = dW.to(weight.dtype)
         elif want_b:
             db = dY.sum(0)
         return (dW, db, None, None, None, None, *dsrcs)
@@ -240,16 +238,12 @@ class _GruPass(torch.autograd.Function):
         ops.gru_backward_zr(d_rh, h, r, da_zr, dh)
         dh = dgrad(da_zr, pk_zr, wzr, 0, C, residual=dh)          # + dh through the epilogue
         dx = dgrad(da_zr, pk_zr, wzr, 1, Cx, residual=dx)
-        taps = g.kh * g.kw
-        ktot = taps * (round_up(C, 32) + round_up(Cx, 32))
-        pq = torch.empty(C, ktot + 32, device=dev, dtype=torch.float32)
-        ops.conv_wgrad([rh, x], da_q, g.B, g.H, g.W, g.kh, g.kw, pq, True)
-        pzr = torch.empty(2 * C, ktot + 32, device=dev, dtype=torch.float32)
-        ops.conv_wgrad([h, x], da_zr, g.B, g.H, g.W, g.kh, g.kw, pzr, True)
-        dwq = _unpack_wgrad(pq, wq.shape, segs, g)
-        dwzr = _unpack_wgrad(pzr, wzr.shape, segs, g)
-        dbzr, dbq = pzr[:, ktot], pq[:, ktot].clone()
-        return (dh, dx, dwzr[:C], dwzr[C:], dwq, dbzr[:C].clone(), dbzr[C:].clone(), dbq, None, None, None, None)
+        reals = [n for _, n, _ in segs]
+        dwq, dbq = torch.empty(wq.shape, device=dev, dtype=torch.float32), torch.empty(C, device=dev, dtype=torch.float32)
+        ops.conv_wgrad_unpacked([rh, x], da_q, g.B, g.H, g.W, g.kh, g.kw, dwq, dbq, reals, 1)
+        dwzr, dbzr = torch.empty(wzr.shape, device=dev, dtype=torch.float32), torch.empty(2 * C, device=dev, dtype=torch.float32)
+        ops.conv_wgrad_unpacked([h, x], da_zr, g.B, g.H, g.W, g.kh, g.kw, dwzr, dbzr, reals, 1)
+        return (dh, dx, dwzr[:C], dwzr[C:], dwq, dbzr[:C], dbzr[C:], dbq, None, None, None, None)
 
 
 def conv_pm(srcs: Sequence[torch.Tensor], weight: torch.Tensor, bias: Optional[torch.Tensor], B: int, H: int, W: int,
