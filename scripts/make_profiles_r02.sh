@@ -14,7 +14,7 @@ echo "Same box, same tree, \`python bench.py\` (gpurun_out/g_bench.log): **69.4 
 echo "124.2 TFLOP/s = 0.790 of 157.3; batch-1 53.2, model_benchmark protocol 52.6 (19.02 ms median); bf16x6 88.4 (EPE 1.07e-5), bf16x3 138.3"
 echo "(EPE 6.8e-5); skip_dead_upsample 72.7 (bit-identical); gma fp32 46.3 (batch 4); raft bf16 190.1, gma bf16 105.2; train 86.3 samples/s"
 echo "(115.9 ms/step, encoders 37.9 ms); cpu_baseline 0.64 pairs/s (16 cores)**; EPE vs the CPU oracle 1.02e-5 mean / 5.7e-5 max.  The whole GPU"
-echo "suite on this tree: 231 passed, 3 skipped (scripts/gpu_confirm.sh, gpurun_out/c_pytest.log; that run's bench line read 70.3 pairs/s / 0.806 on"
+echo "suite on the final tree: 236 passed, 3 skipped (scripts/gpu_confirm.sh, gpurun_out/c_pytest.log; earlier confirm runs read up to 70.3 pairs/s / 0.806 on"
 echo "another box of the pool).  Micro-benches of the same run: g_corr.log (K1 fp32 1908 us = 106 TF, K1 bf16 315 us = 2.52 TB/s, K2 488 us ="
 echo "5.3 TB/s, K3 59.1 us = 2.77 TB/s), g_lookup.log (K7 level 0: 348.3 us at batch 8 = 16.6 TB/s of L2 gathers), g_conv_b1.log, g_conv_b8.log,"
 echo "g_wgrad.log.  In the fp32 tables the mask head's second convolution and the convex upsampling run on a second stream (batch 8, gma)."
