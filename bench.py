@@ -21,7 +21,13 @@ Besides the driver's contract fields the JSON line carries
                 (model_benchmark.py:421-466: torch.rand input, 1 warm-up + 10 synchronised forwards, median)
   split_bf16, skip_dead_upsample     the same forward with split-bf16 convolution products / without the reference's dead
                 per-iteration mask + upsample work (bit-identical output) — beside the headline, never as it
-  config3       BASELINE config 3: gma (fp32) and raft / gma with bf16 operands (bf16 convolutions, bf16 correlation volume)
+  dropin        the path a ptlflow user gets: a torch-only RAFT whose forward is the reference's own caller loop
+                (ptlflow_amd/seam_model.py: module-global `get_corr_block`, `update_block(net, inp, corr, flow)` on NCHW tensors,
+                `upsample_flow` in torch ops) with `ptlflow_amd.patch.accelerate` applied; batch 1, the reference's protocol
+  config3       BASELINE config 3: gma (fp32), raft / gma with bf16 operands (bf16 convolutions, bf16 correlation volume), and
+                SEA-RAFT's correlation path (per-level volumes against the halved fmap2 + 4 / 12 lookups, sea_raft/corr.py:71-117)
+                in fp32 and bf16 — every leg with its end-point / lookup error against the CPU oracle
+  config4       BASELINE config 4 on one GPU: raft on KITTI-sized 375x1242 pairs, batch 8 per GPU, fp32
   train         BASELINE config 5 on one GPU: a full RAFT training step (batch 10, 368x496, 12 iterations; forward, sequence
                 loss, backward, clip, AdamW), every kernel libpfk's; samples/s
 """
@@ -83,6 +89,8 @@ def parse():
                          "or split-bf16 MFMA (include/pfk.h, pfk_conv2d_bf16s)")
     ap.add_argument("--no-split-modes", action="store_true", help="skip the extra split-bf16 legs (`split_bf16` in the output)")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the model_benchmark-protocol, gma, bf16 and training legs")
+    ap.add_argument("--torch-baseline", action="store_true",
+                    help="dropin leg: also time the un-patched torch / MIOpen forward of the same model (first call compiles MIOpen kernels)")
     ap.add_argument("--cpu-forwards", type=int, default=3)
     ap.add_argument("--cpu-budget-s", type=float, default=30.0, help="stop timing CPU forwards after this many seconds")
     return ap.parse_args()
@@ -117,7 +125,7 @@ def timed(fn, warmup: int, steps: int) -> float:
     return (time.perf_counter() - t0) / steps
 
 
-def protocol_leg(model, dev, H, W):
+def protocol_leg(model, dev, H, W, n: int = 10):
     """The reference's own benchmarking protocol (model_benchmark.py:421-466, utils/timer.py:81-96): batch 1, `torch.rand`
     images in [0, 1], one warm-up forward, then >= 10 forwards each bracketed by a device synchronisation; the MEDIAN wall
     time is what `model_benchmark-all.csv` publishes."""
@@ -126,16 +134,84 @@ def protocol_leg(model, dev, H, W):
     model(one)
     torch.cuda.synchronize()
     times = []
-    for _ in range(10):
+    for _ in range(n):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         model(one)
         torch.cuda.synchronize()
         times.append(time.perf_counter() - t0)
     times.sort()
-    med = 0.5 * (times[4] + times[5])
+    med = 0.5 * (times[(n - 1) // 2] + times[n // 2])
     return {"value": 1.0 / med, "unit": "frame-pairs/s", "ms_median": 1e3 * med, "ms_min": 1e3 * times[0], "ms_max": 1e3 * times[-1],
             "protocol": "model_benchmark.py: batch 1, torch.rand input, 1 warm-up + 10 synchronised forwards, median"}
+
+
+def _epe(flow_gpu, flow_ref):
+    """(mean, max) end-point error of one [1, 2, H, W] flow against the CPU reference flow."""
+    d = (flow_gpu.float().cpu() - flow_ref).pow(2).sum(1).sqrt()
+    return float(d.mean()), float(d.max())
+
+
+def dropin_leg(cpu_state, dev, H, W, iters, pair_cpu, ref_flows, torch_baseline=False):
+    """Throughput of the drop-in SEAM path (what `ptlflow.get_model("raft")` + `patch.accelerate(model)` runs): the reference's
+    caller loop — raft.py:125-194 — in torch, seams B1 / B3 / B4 on libpfk.  Batch 1, model_benchmark.py's protocol.  The
+    caller keeps NCHW tensors between the seams, computes `coords1 + delta_flow`, `coords1 - coords0` and the convex upsampling
+    (softmax + unfold + weighted sum, raft.py:112-123) in torch ops every iteration, exactly like the reference."""
+    from ptlflow_amd import patch
+    from ptlflow_amd.seam_model import SeamRAFT
+    m = SeamRAFT(iters=iters).eval()
+    m.load_state_dict(cpu_state, strict=True)
+    m = m.to(dev)
+    leg = {}
+    if torch_baseline:      # stock PyTorch-ROCm ops (MIOpen convolutions, matmul / avg_pool2d / grid_sample): today's ptlflow on this GPU
+        t = protocol_leg(m, dev, H, W, n=5)
+        leg["torch_rocm_unpatched"] = {"value": t["value"], "unit": "frame-pairs/s", "ms_median": t["ms_median"],
+                                       "what": "the same model object before patch.accelerate: stock PyTorch-ROCm ops"}
+    patch.accelerate(m)
+    try:
+        out = m({"images": pair_cpu.to(dev)})
+        if ref_flows is not None:
+            mean, mx = _epe(out["flows"][:1, 0], ref_flows)
+            leg["epe_vs_cpu"] = {"mean": mean, "max": mx, "gate": 1e-3}
+        leg.update(protocol_leg(m, dev, H, W))
+    finally:
+        patch.restore(m)
+    leg["what"] = ("ptlflow_amd.seam_model.SeamRAFT (torch-only RAFT, the reference's caller loop: module-global get_corr_block, "
+                   "update_block(net, inp, corr, flow), torch upsample_flow) + ptlflow_amd.patch.accelerate: seams B1/B3/B4 on libpfk")
+    return leg
+
+
+def sea_raft_corr_leg(dev, bf16: bool, batch=8, h=55, w=128, D=256, check=True):
+    """BASELINE config 3, SEA-RAFT side: its correlation path on the shared kernels (sea_raft/corr.py:71-117) at the 436x1024
+    grid — four per-level volumes (fmap1 x fmap2 halved l times, `pfk_fmap_pool2x2_f32` + K1 / K1b) and the per-iteration
+    radius-4 lookup (K3) — for SEA-RAFT's 4 (sea_raft_s / _m) and 12 (sea_raft_l) iterations.  The ConvNeXt update block and
+    the ResNet encoders of that family are out of scope, so pairs/s here is of the correlation path alone.
+    `err_vs_cpu_fp32`: the last lookup of pair 0 against the CPU oracle's fp32 pyramid + lookup on the same maps / coordinates."""
+    from ptlflow_amd.corr import CorrBlock
+    g = torch.Generator().manual_seed(77)
+    f1 = torch.randn(batch, D, h, w, generator=g) * 0.5
+    f2 = torch.randn(batch, D, h, w, generator=g) * 0.5
+    base = torch.stack(torch.meshgrid(torch.arange(w, dtype=torch.float32), torch.arange(h, dtype=torch.float32), indexing="xy"), 0)
+    coords = [(base[None] + torch.rand(batch, 2, h, w, generator=g) * 16 - 8).contiguous() for _ in range(12)]
+    dt = torch.bfloat16 if bf16 else torch.float32
+    d1, d2 = f1.to(dev).to(dt), f2.to(dev).to(dt)
+    dc = [c.to(dev) for c in coords]
+    blk = CorrBlock(d1, d2, num_levels=4, radius=4, pyramid="bilinear_f2")
+    leg = {"batch": batch, "grid": f"{h}x{w}", "dim": D, "volume_dtype": str(blk.volume_dtype).replace("torch.", "")}
+    for iters in (4, 12):
+        def run():
+            blk.update(d1, d2)
+            for i in range(iters):
+                blk.lookup_pm(dc[i])
+        sec = timed(run, 2, 10)
+        leg[f"iters{iters}"] = {"value": batch / sec, "unit": "frame-pairs/s (correlation path only)", "ms_per_step": 1e3 * sec}
+    if check:
+        from oracle import raft_oracle as O  # checker only
+        got = blk(dc[11])[:1].float().cpu()
+        want = O.lookup(O.sea_correlation_pyramid(f1[:1], f2[:1], 4), coords[11][:1], 4)
+        err = (got - want).abs()
+        leg["err_vs_cpu_fp32"] = {"max_abs": float(err.max()), "mean_abs": float(err.mean()), "ref_max_abs": float(want.abs().max())}
+    return leg
 
 
 def train_leg(dev, batch=10, H=368, W=496, iters=12, steps=4, warmup=2):
@@ -196,15 +272,23 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # PFK_BENCH_SHARED_DEVICE=1: every rank uses cuda:0 and the process group runs on gloo — a smoke of the N > 1 branch (rank
+    # env, barrier, max-over-ranks, whole-job throughput) on a box with ONE GPU, where RCCL refuses two ranks on one device.
+    # Its numbers are not a scaling measurement: the ranks time-share one chip.
+    shared = os.environ.get("PFK_BENCH_SHARED_DEVICE") == "1"
+    dev_index = 0 if shared else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     # under torch.distributed.run (RANK set) the process group is created even for one rank, so that a single-GPU box can
     # exercise the RCCL branch (init, barrier, max-reduce) that the N > 1 runs rely on
     if world > 1 or "RANK" in os.environ:
         import torch.distributed as dist  # noqa: F811
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+        if shared:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
 
     import ptlflow_amd
     from ptlflow_amd.raft import GMA, RAFT
@@ -242,6 +326,10 @@ def main():
 
     elapsed = timed_steps(one_step, args.steps, args.warmup, torch.cuda.synchronize)
     out = state["out"]
+    # stream-K fix-ups that timed out would have poisoned tiles with NaN: a timed run with a non-zero count is not a result
+    faults = model.engine(dev).faults()
+    if faults:
+        raise SystemExit(f"stream-K workspace reports {faults} timed-out fix-up(s): results invalid")
 
     pairs = args.batch * args.steps * world
     result = {
@@ -259,12 +347,15 @@ def main():
         "dtype": "f32" if args.conv_precision == "fp32" else
                  f"f32 storage/accumulate, update-block conv products as split bf16 ({args.conv_precision})",
         "data": "synthetic",
+        "streamk_faults": faults,
         "config": {"workload": f"{args.model} random-init (seeded), {args.height}x{args.width} frame pairs, {args.iters} iterations, "
                                f"{args.conv_precision}, batch {args.batch}/GPU, eval forward incl. encoders, "
                                + ("dead mask/upsample work skipped on non-final iterations" if args.skip_dead_upsample
                                   else "mask head + convex upsample on every iteration as the reference"),
                    "global_batch": args.batch * world, "parallelism": f"dp{world} (independent replicas, no collectives)"},
     }
+    if shared:
+        result["config"]["shared_device"] = "all ranks on cuda:0 over gloo (N > 1 code-path smoke on a one-GPU box, not a scaling number)"
 
     if rank == 0:
         if args.batch > 1 and not args.no_batch1:
@@ -308,27 +399,45 @@ def main():
             from oracle import raft_oracle as O  # checker + reported baseline only
             cores = host_cores()
             torch.set_num_threads(cores)
-            times = []
-            ref = None
-            t_start = time.perf_counter()
-            for i in range(args.cpu_forwards + 1):
-                c0 = time.perf_counter()
-                if args.model == "gma":
-                    ref = O.gma_forward(cpu_state, images_cpu[:1], iters=args.iters)
-                else:
-                    ref = O.raft_forward(cpu_state, images_cpu[:1], iters=args.iters, small=small)
-                dt = time.perf_counter() - c0
-                # the first forward is a warm-up unless the budget leaves room for nothing else
-                if i or dt > args.cpu_budget_s / 2:
-                    times.append(dt)
-                if time.perf_counter() - t_start > args.cpu_budget_s:
-                    break
-            times.sort()
+
+            def cpu_times(fn):
+                times, res, t_start = [], None, time.perf_counter()
+                for i in range(args.cpu_forwards + 1):
+                    c0 = time.perf_counter()
+                    res = fn()
+                    dt = time.perf_counter() - c0
+                    # the first forward is a warm-up unless the budget leaves room for nothing else
+                    if i or dt > args.cpu_budget_s / 2:
+                        times.append(dt)
+                    if time.perf_counter() - t_start > args.cpu_budget_s:
+                        break
+                times.sort()
+                return times, res
+
+            if args.model == "gma":
+                times, ref = cpu_times(lambda: O.gma_forward(cpu_state, images_cpu[:1], iters=args.iters))
+            else:
+                times, ref = cpu_times(lambda: O.raft_forward(cpu_state, images_cpu[:1], iters=args.iters, small=small))
             med = times[len(times) // 2]
             result["cpu_baseline"] = {"value": 1.0 / med, "unit": "frame-pairs/s", "cores": cores,
                                       "kind": "port",
                                       "sample": f"{len(times)} full forward(s) on the first frame pair of the batch, median; "
-                                                f"torch {torch.__version__} CPU, {cores} threads"}
+                                                f"torch {torch.__version__} CPU, {cores} threads",
+                                      "note": "the port (oracle/raft_oracle.py) is bit-identical to the reference forward and ~12 % slower "
+                                              "(its explicit gather lookup vs grid_sample; 2.46 s vs 2.20 s on 8 cores in the build container)"}
+            # where the reference tree itself is present (the build container; never the GPU box) time IT: kind "reference"
+            try:
+                from oracle import ref_loader
+                if ref_loader.reference_available() and args.model in ("raft", "raft_small"):
+                    rm = ref_loader.build_raft(small=small, iters=args.iters)
+                    rm.load_state_dict(cpu_state, strict=False)
+                    with torch.no_grad():
+                        rt, _ = cpu_times(lambda: rm({"images": images_cpu[:1]}))
+                    result["cpu_baseline"].update({"value": 1.0 / rt[len(rt) // 2], "kind": "reference", "port_value": 1.0 / med,
+                                                   "sample": f"{len(rt)} forward(s) of the reference's own RAFT.forward "
+                                                             f"(/root/reference through oracle/ref_loader.py), median; {cores} threads"})
+            except Exception:
+                pass
             mean, mx = O.epe(out["flows"][:1, 0].float().cpu(), ref["flows"][:, 0])
             result["epe_vs_cpu"] = {"mean": mean, "max": mx, "gate": 1e-3}
         else:
@@ -382,25 +491,71 @@ def main():
         if world == 1 and default_cfg and not args.no_extra_legs:
             del out
             torch.cuda.empty_cache()
-            # (a) like-for-like with the reference's published protocol (batch 1, rand, median of 10)
+            check = not args.no_cpu_baseline            # the CPU oracle as the CHECKER of every extra leg (never timed here)
+            if check:
+                from oracle import raft_oracle as O
+            ref_raft = ref["flows"][:, 0] if ref is not None else None      # CPU forward of the cpu_baseline leg: same weights, pair 0
+            # (a) like-for-like with the reference's published protocol (batch 1, rand, median of 10) on the mirror ...
             result["model_benchmark_protocol"] = protocol_leg(model, dev, args.height, args.width)
             del model
             torch.cuda.empty_cache()
-            # (b) BASELINE config 3: gma on the shared CorrBlock / GRU path (fp32), and bf16 operands for raft and gma
+            # ... and on the drop-in seam path (the reference's caller loop, seams B1 / B3 / B4 patched)
+            try:
+                result["dropin"] = dropin_leg(cpu_state, dev, args.height, args.width, args.iters, images_cpu[:1], ref_raft,
+                                              args.torch_baseline)
+            except Exception as e:  # a leg must never take the headline line down with it
+                result["dropin"] = {"error": repr(e)[:300]}
+            torch.cuda.empty_cache()
+            # (b) BASELINE config 3: gma on the shared CorrBlock / GRU path (fp32), bf16 operands for raft and gma, and SEA-RAFT's
+            # correlation path; EPE of pair 0 against the CPU oracle's fp32 forward with the same weights
             legs = {}
+            ref_gma = None
             for name, ctor, b in (("gma_fp32", lambda: GMA(iters=32), 4), ("raft_bf16", lambda: RAFT(iters=32, conv_precision="bf16"), 8),
                                   ("gma_bf16", lambda: GMA(iters=32, conv_precision="bf16"), 4)):
                 try:
-                    m = ctor().load_synthetic(1234).eval().to(dev)
+                    m = ctor().load_synthetic(1234).eval()
+                    if check and name == "gma_fp32":
+                        ref_gma = O.gma_forward({k: v.clone() for k, v in m.state_dict().items()},
+                                                smooth_pair(1, args.height, args.width, seed=1234), iters=32)["flows"][:, 0]
+                    m = m.to(dev)
                     xin = {"images": smooth_pair(b, args.height, args.width, seed=1234).to(dev)}
                     sec = timed(lambda: m(xin), 2, 5)
                     legs[name] = {"value": b / sec, "unit": "frame-pairs/s", "ms_per_step": 1e3 * sec, "batch": b}
+                    target = ref_gma if name.startswith("gma") else ref_raft
+                    if target is not None:
+                        mean, mx = _epe(m(xin)["flows"][:1, 0], target)
+                        legs[name].update({"epe_mean": mean, "epe_max": mx, "epe_against": "cpu fp32 forward of the same model"})
                     del m, xin
                     torch.cuda.empty_cache()
-                except Exception as e:  # a leg must never take the headline line down with it
+                except Exception as e:
                     legs[name] = {"error": repr(e)[:300]}
+            for name, bf in (("sea_raft_corr_f32", False), ("sea_raft_corr_bf16", True)):
+                try:
+                    legs[name] = sea_raft_corr_leg(dev, bf, check=check)
+                except Exception as e:
+                    legs[name] = {"error": repr(e)[:300]}
+                torch.cuda.empty_cache()
             result["config3"] = legs
-            # (c) BASELINE config 5: the training step
+            # (c) BASELINE config 4 on one GPU: KITTI-sized pairs (375x1242 -> padded 376x1248, 47x156 grid), batch 8 per GPU
+            try:
+                m = RAFT(iters=32).eval()
+                m.load_state_dict(cpu_state)
+                m = m.to(dev)
+                xk = smooth_pair(8, 375, 1242, seed=4321)
+                xin = {"images": xk.to(dev)}
+                sec = timed(lambda: m(xin), 2, 5)
+                leg = {"value": 8 / sec, "unit": "frame-pairs/s", "ms_per_step": 1e3 * sec, "batch": 8,
+                       "config": "raft, 375x1242 (KITTI), 32 iterations, fp32, batch 8 per GPU (BASELINE config 4: 64 pairs over 8 GPUs, no collectives)"}
+                if check:
+                    rk = O.raft_forward(cpu_state, xk[:1], iters=32)["flows"][:, 0]
+                    mean, mx = _epe(m(xin)["flows"][:1, 0], rk)
+                    leg["epe_vs_cpu"] = {"mean": mean, "max": mx, "gate": 1e-3}
+                result["config4"] = leg
+                del m, xin
+                torch.cuda.empty_cache()
+            except Exception as e:
+                result["config4"] = {"error": repr(e)[:300]}
+            # (d) BASELINE config 5: the training step
             try:
                 result["train"] = train_leg(dev)
             except Exception as e:

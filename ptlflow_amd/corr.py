@@ -15,6 +15,7 @@ convolution reads it without any transpose.
 from __future__ import annotations
 
 import math
+import weakref
 from typing import List, Optional
 
 import torch
@@ -51,14 +52,22 @@ class _PyramidToken(torch.autograd.Function):
     def forward(ctx, fmap1, fmap2, block):
         block._build(fmap1.detach(), fmap2.detach())
         block._zero_grad_levels()
-        ctx.block = block
+        # weak: block -> _token -> grad_fn (this ctx) -> block would be a reference cycle that keeps a step's N x N pyramid and
+        # its equally large gradient buffers alive until the cyclic GC runs.  Every lookup node holds the block strongly, and
+        # this backward only runs when a lookup's gradient reaches the token, so the block is alive whenever it is needed.
+        ctx.block_ref = weakref.ref(block)
         ctx.save_for_backward(fmap1, fmap2)
         return fmap1.new_zeros(1, dtype=torch.float32)
 
     @staticmethod
     def backward(ctx, _g):
         fmap1, fmap2 = ctx.saved_tensors
-        d1, d2 = ctx.block._volume_backward(fmap1, fmap2)
+        block = ctx.block_ref()
+        if block is None:       # no lookup node of this block is left in the graph: nothing was scattered
+            return torch.zeros_like(fmap1), torch.zeros_like(fmap2), None
+        d1, d2 = block._volume_backward(fmap1, fmap2)
+        for g in block.grad_levels:     # consumed: a second backward over a retained graph starts from zero again
+            g.zero_()
         return d1, d2, None
 
 
@@ -93,9 +102,11 @@ class CorrBlock:
                  pyramid: str = "avgpool", volume_dtype: Optional[torch.dtype] = None):
         """``volume_dtype``: storage type of the pyramid — ``torch.float32`` (exact fp32 products on the fp32 matrix cores, the
         parity path) or ``torch.bfloat16`` (bf16 operands and a bf16 volume: what the reference's matmul yields under
-        ``torch.autocast(bfloat16)``; half the HBM bytes).  Default: bf16 when the feature maps arrive in a 16-bit type (the
-        caller is running under autocast), fp32 otherwise.  The lookup's arithmetic and output are fp32 either way
-        (``F.grid_sample`` is an fp32 op under autocast)."""
+        ``torch.autocast(bfloat16)``; half the HBM bytes).  Default: bf16 only when the feature maps arrive in bfloat16 (the
+        caller runs under bf16 autocast), fp32 otherwise — in particular for float16 maps (the reference's own reduced-precision
+        mode is ``model.half()``, validate.py:243-244 / model_benchmark.py:317-319): fp16 operands are exact in the fp32 volume,
+        rounding them to bf16 would lose 3 mantissa bits the reference's fp16 matmul keeps.  The lookup's arithmetic is fp32
+        either way; the result is cast to the maps' dtype like the reference's."""
         if not fmap1.is_cuda:
             raise RuntimeError("ptlflow_amd.CorrBlock needs GPU tensors (no CPU fallback)")
         if not 1 <= radius <= 4:
@@ -118,7 +129,7 @@ class CorrBlock:
         self._token: Optional[torch.Tensor] = None
         needs_graph = torch.is_grad_enabled() and (fmap1.requires_grad or fmap2.requires_grad)
         if volume_dtype is None:
-            volume_dtype = torch.bfloat16 if fmap1.dtype in (torch.bfloat16, torch.float16) and not needs_graph else torch.float32
+            volume_dtype = torch.bfloat16 if fmap1.dtype == torch.bfloat16 and not needs_graph else torch.float32
         if volume_dtype not in (torch.float32, torch.bfloat16):
             raise ValueError("volume_dtype must be torch.float32 or torch.bfloat16")
         if needs_graph and volume_dtype != torch.float32:

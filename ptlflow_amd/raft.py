@@ -268,6 +268,11 @@ class RAFT(nn.Module):
                                 torch.arange(w, device=x.device, dtype=torch.float32), indexing="ij")
         coords0 = torch.stack([xs, ys], 0)[None].repeat(B, 1, 1, 1).contiguous()
         coords1 = coords0.clone()
+        prev = inputs.get("prev_preds")
+        if prev is not None and prev.get("flow_small") is not None:      # warm start applies in training mode too (raft.py:162-167)
+            fwd = torch.empty_like(coords1)
+            torch.ops.pfk.forward_interpolate(prev["flow_small"].detach().to(device=x.device, dtype=torch.float32).contiguous(), fwd)
+            coords1 = coords1 + fwd
         P = dict(self.update_block.named_parameters())
         cache: dict = {}
         hpm = net.permute(0, 2, 3, 1).reshape(M, self.hidden_dim)
@@ -332,6 +337,7 @@ class RAFT(nn.Module):
             ops.forward_interpolate(prev["flow_small"].to(device=x.device, dtype=torch.float32).contiguous(), fwd)
             coords1.add_(fwd)
 
+        eng.watch_faults()          # a timed-out stream-K fix-up of an earlier forward raises here (no host sync)
         eng.load_state(net, inp)
         self._after_context(eng, inp)
         ops.flow_from_coords(coords0, coords1, eng.flow_view)
@@ -415,8 +421,10 @@ class _RelPosEmb(nn.Module):
 
 
 class _Attention(nn.Module):
-    """GMA attention, content-only mode (gma_utils.py:33-78): one [B,1,N,N] softmax map per forward (torch ops: it is
-    computed once, outside the iteration loop)."""
+    """Parameter holder + torch fall-back for GMA's attention, content-only mode (gma_utils.py:33-78): one [B,1,N,N] softmax
+    map per forward.  `GMA._attention` computes it on libpfk (to_qk on the MFMA conv kernel, the N x N similarity on K1, the
+    row softmax kernel); this module's own `forward` (torch ops) only serves several heads or a width that is not a multiple
+    of 32."""
 
     def __init__(self, dim: int = 128, heads: int = 1, dim_head: int = 128, max_pos_size: int = 160):
         super().__init__()

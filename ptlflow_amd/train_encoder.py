@@ -122,6 +122,12 @@ def _norm(kind: str, x: torch.Tensor, B: int, HW: int, bn: Optional[torch.nn.Mod
         v = (x - m).square().mean(0, keepdim=True)
         y = (x - m) * torch.rsqrt(v + EPS) * bn.weight + bn.bias
         return torch.relu(y) if relu else y
+    if not bn.training and bn.running_mean is not None:
+        # a BatchNorm put in eval inside a training model (the reference's `freeze_bn`, raft.py:93-101): running statistics as
+        # constants, no buffer update — an affine map of x, differentiable w.r.t. x, weight and bias through plain torch ops
+        scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+        y = (x - bn.running_mean) * scale + bn.bias
+        return torch.relu(y) if relu else y
     xh, mean, rstd = _Norm.apply(x, 1, B * HW, False)
     y = xh * bn.weight + bn.bias
     if bn.track_running_stats and bn.running_mean is not None:

@@ -114,6 +114,8 @@ class UpdateEngine:
         self.spec = spec
         self.device = device
         self._shape: Optional[Tuple[int, int, int]] = None
+        self._fault_host: Optional[torch.Tensor] = None
+        self._fault_event = None
         # optional per-launch instrumentation: key -> [(start_event, end_event)], and key -> algorithmic FLOPs
         self.profile: Optional[Dict[str, list]] = None
         self.flops: Dict[str, float] = {}
@@ -217,6 +219,28 @@ class UpdateEngine:
         tiles are NaN in any case, so this is for telling *why* an output went NaN."""
         off = self.ops.conv_workspace_fault_offset()
         return int(self.workspace[off: off + 4].view(torch.int32).item())
+
+    def watch_faults(self) -> None:
+        """Called once per forward by the callers (RAFT mirror, PfkUpdateBlock): raise if an EARLIER forward's fault word came
+        back non-zero, then queue a non-blocking read-back of the current one into pinned host memory.  No host
+        synchronisation: a timed-out fix-up (whose tile is NaN already) is reported one forward later, and the workspace is
+        zero-filled again before raising — a producer that published after its consumer gave up leaves its flag set, which the
+        next launch on the same workspace would otherwise take for a fresh partial (stale data, not NaN)."""
+        if self._fault_host is None:
+            self._fault_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self._fault_event = None
+        if self._fault_event is not None and self._fault_event.query():
+            n = int(self._fault_host[0])
+            self._fault_event = None
+            if n:
+                self.workspace.zero_()
+                raise RuntimeError(f"libpfk: {n} stream-K fix-up(s) timed out in an earlier forward (its affected tiles are NaN); "
+                                   "the workspace has been re-initialised")
+        if self._fault_event is None and not torch.cuda.is_current_stream_capturing():
+            off = self.ops.conv_workspace_fault_offset()
+            self._fault_host.copy_(self.workspace[off: off + 4].view(torch.int32), non_blocking=True)
+            self._fault_event = torch.cuda.Event()
+            self._fault_event.record()
 
     # views into hx
     @property
@@ -472,6 +496,7 @@ class PfkUpdateBlock(torch.nn.Module):
         # forwards apart.  Within a forward the loop passes the same `inp` object every iteration: identity + _version.
         new_forward = net.data_ptr() != eng.hx.data_ptr()
         if new_forward:
+            eng.watch_faults()
             ops.nchw_to_pm(net.float().contiguous(), eng.h_view)
         if new_forward or inp is not self._inp_ref or inp._version != self._inp_version:
             ops.nchw_to_pm(inp.float().contiguous(), eng.inp_view)

@@ -1,6 +1,8 @@
 """BASELINE config 3 (gma + the shared CorrBlock / GRU path in bf16): the parity gate SURVEY.md §8d prescribes.
 
-The reference's bf16 mode is `torch.autocast(bfloat16)` around the same forward (validate.py:243-244, model_benchmark.py:311).
+BASELINE.json asks for bf16; the reference itself has no bf16 switch — its only reduced-precision mode is `model.half()`
+(fp16: validate.py:243-244, model_benchmark.py:317-319) — so the bf16 oracle is the reference's forward run under
+`torch.autocast("cpu", bfloat16)`, the standard way to put that forward in bf16.
 Its own distance from the fp32 forward — the "autocast-CPU gap" — is measured here, on the same seeded input, by running the
 CPU oracle under `torch.autocast("cpu", bfloat16)` (bit-identical to the live reference under autocast:
 tests/test_oracle_vs_reference.py::test_oracle_under_autocast_is_the_reference_under_autocast).  Gate:

@@ -60,8 +60,9 @@ def test_degenerate_64x128_nan_pattern(gpu):
 
 
 def test_batch_independence(gpu):
-    """Frame pairs are independent units: a batch of 2 equals two batches of 1 (the encoders go
-    through MIOpen, whose algorithm choice may depend on the batch size, hence a tolerance, not bit-equality)."""
+    """Frame pairs are independent units: a batch of 2 equals two batches of 1 (the convolution
+    kernels pick their schedule — tile grid vs stream-K split — by grid size, which changes a tile's summation order, hence a
+    tolerance, not bit-equality)."""
     from ptlflow_amd.raft import RAFT
     m = RAFT(iters=3).load_synthetic(7).eval().cuda()
     x = O.smooth_pair(2, 128, 160, 3).cuda()
@@ -81,6 +82,21 @@ def test_gma_forward(gpu):
     ref = O.gma_forward(P, x, iters=6)
     out = model.cuda()({"images": x.cuda()})
     mean, mx = O.epe(out["flows"][:, 0].cpu(), ref["flows"][:, 0])
+    assert mean <= 1e-3 and mx <= 1e-2, f"EPE mean {mean:.2e} max {mx:.2e}"
+
+
+def test_gma_headline_config(gpu):
+    """BASELINE.json configs[2], fp32 side: gma at 436x1024, 32 iterations (attention map 7040 x 7040, aggregation GEMM and the
+    512-input SepConvGRU on libpfk) vs the CPU oracle — the shape the `config3.gma_fp32` bench leg times."""
+    from ptlflow_amd.raft import GMA
+    model = GMA(iters=32).load_synthetic(1234).eval()
+    P = {k: v.clone() for k, v in model.state_dict().items()}
+    x = O.smooth_pair(1, 436, 1024, seed=1234)
+    ref = O.gma_forward(P, x, iters=32)
+    out = model.cuda()({"images": x.cuda()})
+    assert tuple(out["flows"].shape) == (1, 1, 2, 436, 1024)
+    mean, mx = O.epe(out["flows"][:, 0].cpu(), ref["flows"][:, 0])
+    print(f"gma headline EPE mean {mean:.3e} max {mx:.3e}")
     assert mean <= 1e-3 and mx <= 1e-2, f"EPE mean {mean:.2e} max {mx:.2e}"
 
 

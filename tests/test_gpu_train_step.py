@@ -86,7 +86,8 @@ def _run(gpu, small, B, H, W, iters, tol):
 
 
 def test_train_step_raft(gpu):
-    _run(gpu, False, 2, 368, 496, 3, 5e-4)
+    """BASELINE config 5's recurrence depth: 12 iterations (raft-train1-chairs.yaml), 368x496 crops."""
+    _run(gpu, False, 2, 368, 496, 12, 5e-4)
 
 
 def test_train_step_raft_small(gpu):
