@@ -62,6 +62,8 @@ int pfk_abi_version(void);
 const char* pfk_status_string(int status);
 /* tuning/debug knob: force the implicit-GEMM tile configuration (-1 = heuristic). Not thread-safe. */
 void pfk_debug_set_tile(int cfg);
+/* test hook: n / d through the multiplier arithmetic the persistent convolution kernel decodes its tiles with (n < 2^31, d >= 1) */
+unsigned pfk_debug_fastdiv(unsigned n, unsigned d);
 /* tuning knob of the pyramid lookup: source pixels per workgroup, 4 (default) or 8. Not thread-safe. */
 void pfk_debug_set_lookup_pix(int pix);
 void pfk_debug_set_wgrad(int variant);      /* weight-gradient tile height: 0 = by padding waste, 1 / 2 / 4 = forced 32 / 64 / 128 rows (tuning knob) */

@@ -36,6 +36,13 @@ struct GemmArgs {
   int sk_steps;            // K-steps per tile (host-computed)
   long long sk_tiles;      // output tiles
   int sk_groups;           // stream-K: 1, or 8 = one contiguous tile range per XCD (blockIdx.x % 8), stream-K inside each
+  // persistent pipelined kernel (conv_gemm_pp_kernel): tile decode without runtime divisions
+  unsigned wo_mul, ho_mul, tn_mul;   // magic multipliers for / Wo, / Ho, / tiles_n (fastdiv_u32)
+  int wo_sh, ho_sh, tn_sh;
+  int pp_tiles_m;          // row tiles per batch element
+  int pp_tiles_pb;         // tiles per batch element (pp_tiles_m * tiles_n)
+  int pp_batches;          // batch elements folded into the tile index (correlation volume)
+  int pp_whole;            // 1: blocks get whole tiles only (no partial-tile hand-off, no workspace)
   const void* wbf;         // split-bf16 path: weight planes [nsplit][cout][ktot] bf16, same k order as `weight`
   long long wbf_plane_bytes;
   int dbg;                 // split-bf16 timing ablations (results are garbage): 1 no global loads, 2 no split + LDS stores, 4 no fragment reads + MFMAs
@@ -63,6 +70,23 @@ __device__ __forceinline__ void tile_of(int bid, int tiles_m, int tiles_n, int S
   const int l2 = local - col * hb * S;
   tile_m = m_base + l2 / wb;
   tile_n = n_base + l2 - (l2 / wb) * wb;
+}
+
+// Division of n < 2^31 by a launch-invariant d through a host-made multiplier (Granlund & Montgomery 1994, N = 32):
+//   l = ceil(log2 d), mul = floor(2^32 (2^l - d) / d) + 1,  n / d = (mulhi(mul, n) + n) >> l   (no overflow: mulhi(..) <= n < 2^31)
+// three instructions instead of the ~30 of a runtime 32-bit (or ~100 of a 64-bit) division.
+static inline void fastdiv_make(unsigned d, unsigned& mul, int& sh) {
+  int l = 0;
+  while ((1ull << l) < d) ++l;
+  mul = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1ull);
+  sh = l;
+}
+__host__ __device__ __forceinline__ unsigned fastdiv_u32(unsigned n, unsigned mul, int sh) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (__umulhi(n, mul) + n) >> sh;
+#else
+  return (unsigned)((((unsigned long long)n * mul) >> 32) + n) >> sh;
+#endif
 }
 
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }

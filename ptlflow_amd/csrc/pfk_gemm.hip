@@ -22,6 +22,9 @@
 // bias, relu, scale, sigmoid gates + r*h, tanh + GRU blend, and write straight into channel
 // slices of pixel-major buffers (no torch.cat).
 #include "pfk_gemm.h"
+#ifndef PP_EXP
+#define PP_EXP 0
+#endif
 
 #include <mutex>
 #include <utility>
@@ -66,32 +69,62 @@ struct Stager {
   unsigned wvoff[B_PT];
   f32x4 ra[A_PT], rb[B_PT];
 
-  __device__ __forceinline__ Stager(const GemmArgs& a, long long m0, int n0, int t, long long batch) {
+  struct NoTile {};
+  // wave-uniform state and the thread's place in the staging pattern; the tile is chosen by retarget()
+  __device__ __forceinline__ Stager(const GemmArgs& a, int t, NoTile) {
     H = a.H; W = a.W; kh = a.kh; kw = a.kw; ph = a.kh >> 1; pw = a.kw >> 1; nsrc = a.nsrc;
     ld0 = a.ld0; ld1 = a.ld1; ld2 = a.ld2; ch0 = a.ch0; ch1 = a.ch1; ch2 = a.ch2;
-    rs0 = make_rsrc(a.src0 + batch * a.a_bs);
     rs1 = make_rsrc(a.src1);
     rs2 = make_rsrc(a.src2);
-    rsw = make_rsrc(a.weight + batch * a.b_bs);
     c4 = (t & 7) * 4;
     r0 = t >> 3;
     // LD == 32: chunk' = chunk ^ ((row >> 1) & 7) — a 16-lane ds_read_b128 group (16 rows, one logical chunk) then
     // covers all 16 sixteen-byte slots of the 256-byte bank row: conflict-free without padding.  (row + 32*i keeps the key.)
     scol = LD == 32 ? ((((t & 7) ^ ((r0 >> 1) & 7))) << 2) : c4;
+  }
+
+  __device__ __forceinline__ Stager(const GemmArgs& a, long long m0, int n0, int t, long long batch) : Stager(a, t, NoTile{}) {
+    retarget<false>(a, m0, n0, batch);
+    set_segment(0);
+    set_tap();
+  }
+
+  // Point the stager at output tile (m0, n0) of batch element `batch`: per-row pixel coordinates / base rows, weight-row offsets
+  // and the batch-dependent descriptors.  FAST: 32-bit arithmetic with the host-made multipliers of GemmArgs (M < 2^31 rows is
+  // implied by the 32-bit byte offsets the kernels address their sources with) — the persistent kernels re-target once per tile.
+  template <bool FAST>
+  __device__ __forceinline__ void retarget(const GemmArgs& a, long long m0, int n0, long long batch) {
+    rs0 = make_rsrc(a.src0 + batch * a.a_bs);
+    rsw = make_rsrc(a.weight + batch * a.b_bs);
 #pragma unroll
     for (int i = 0; i < A_PT; ++i) {
-      const long long p = m0 + r0 + 32 * i;
-      pok[i] = p < a.M;
-      const long long prow_o = p / a.Wo;                       // b*Ho + yo
-      px[i] = (int)(p - prow_o * a.Wo) * a.stride;             // input coordinates of the centre tap
-      py[i] = (int)(prow_o % a.Ho) * a.stride;
-      prow[i] = (int)(((prow_o / a.Ho) * a.H + py[i]) * a.W + px[i]);
+      if constexpr (FAST) {
+        const unsigned p = (unsigned)m0 + (unsigned)(r0 + 32 * i);
+        pok[i] = (long long)p < a.M;
+        const unsigned prow_o = fastdiv_u32(p, a.wo_mul, a.wo_sh);          // b*Ho + yo
+        const unsigned bimg = fastdiv_u32(prow_o, a.ho_mul, a.ho_sh);
+        px[i] = (int)(p - prow_o * (unsigned)a.Wo) * a.stride;              // input coordinates of the centre tap
+        py[i] = (int)(prow_o - bimg * (unsigned)a.Ho) * a.stride;
+        prow[i] = (int)((bimg * (unsigned)a.H + (unsigned)py[i]) * (unsigned)a.W + (unsigned)px[i]);
+      } else {
+        const long long p = m0 + r0 + 32 * i;
+        pok[i] = p < a.M;
+        const long long prow_o = p / a.Wo;                       // b*Ho + yo
+        px[i] = (int)(p - prow_o * a.Wo) * a.stride;             // input coordinates of the centre tap
+        py[i] = (int)(prow_o % a.Ho) * a.stride;
+        prow[i] = (int)(((prow_o / a.Ho) * a.H + py[i]) * a.W + px[i]);
+      }
     }
 #pragma unroll
     for (int i = 0; i < B_PT; ++i) {
       const int n = n0 + r0 + 32 * i;
       wvoff[i] = n < a.b_rows ? (unsigned)(n * a.ktot + c4) * 4u : OOB;
     }
+  }
+
+  // K iterator back to the first K-step of the (re-targeted) tile
+  __device__ __forceinline__ void rewind() {
+    seg = 0; ky = 0; kx = 0; c0 = 0; kofs = 0;
     set_segment(0);
     set_tap();
   }
@@ -126,6 +159,30 @@ struct Stager {
     const int tap = r / cps;
     seg = sg; ky = tap / kw; kx = tap - ky * kw; c0 = (r - tap * cps) * BK; kofs = step * BK;
     set_segment(sg);
+    set_tap();
+  }
+
+  // seek() for the persistent kernel, whose stager lives across tile boundaries: there the segment's parameters are read from
+  // the kernel-argument block at a runtime offset (scalar loads) — selecting among the struct's own members by a runtime index
+  // made hipcc keep them in a scratch array and lose the uniformity of everything derived from it (waterfall loops around
+  // every buffer load of the K loop).  GemmArgs keeps src0..2 / ld0..2 / ch0..2 contiguous for this.
+  __device__ __forceinline__ void seek_args(const GemmArgs& a, long long batch, int step) {
+    const int taps = kh * kw;
+    int r = step, sg = 0, cps = (a.ch0 + BK - 1) / BK;
+    if (nsrc > 1 && r >= taps * cps) {
+      r -= taps * cps; sg = 1; cps = (a.ch1 + BK - 1) / BK;
+      if (nsrc > 2 && r >= taps * cps) { r -= taps * cps; sg = 2; cps = (a.ch2 + BK - 1) / BK; }
+    }
+    const int tap = r / cps;
+    seg = sg; ky = tap / kw; kx = tap - ky * kw; c0 = (r - tap * cps) * BK; kofs = step * BK;
+    const float* const* srcv = &a.src0;
+    const float* p = srcv[sg];
+    if (sg == 0) p += batch * a.a_bs;
+    rs = make_rsrc(p);
+    cld = (&a.ld0)[sg];
+    cch = (&a.ch0)[sg];
+#pragma unroll
+    for (int i = 0; i < A_PT; ++i) abase[i] = (unsigned)(prow[i] * cld + c4) * 4u;
     set_tap();
   }
 
@@ -655,6 +712,252 @@ __global__ __launch_bounds__(256, BPC) void conv_gemm_sk_kernel(const GemmArgs a
   }
 }
 
+// -------------------------------------------------------------------------------------------------
+// Variant 5: PERSISTENT, cross-tile PIPELINED stream-K ("pp").  Same 64x64 tile, 3-stage LDS ring and hand-placed MFMA / filler
+// stream as variants 3 / 4, but the K pipeline never drains between tiles: a block owns a contiguous range of (tile, K-step)
+// units — the stream-K split of variant 4, balanced to +-1 K-step over all blocks, per-XCD tile groups — and the stager simply
+// keeps running three K-steps ahead of the MFMAs ACROSS tile (segment) boundaries.  What variants 3 / 4 pay per tile and this
+// one pays once per block:
+//   * the pipeline prologue (two dependent global round trips before the first MFMA) — the next tile's first K-steps are already
+//     in LDS / in flight while the current tile finishes;
+//   * workgroup launch + Stager construction (six 64-bit divisions per thread) — re-targeting uses host-made multipliers;
+//   * the dispatch tail: with tiles handed out whole, the last round of a 3-blocks-per-CU grid runs 1-2 blocks per CU.
+// The epilogue of a finished tile borrows the LDS stage the pipeline has just freed (its data was consumed by the tile's last
+// K-step; it is only overwritten by the NEXT step's fillers, behind one extra barrier per tile), so the LDS footprint — and the
+// three (LD = 32) / two (LD = 36) resident blocks per CU — is unchanged; the co-resident blocks' MFMAs cover the epilogue.
+// Partial tiles: identical protocol to variant 4 (contribution from the block's FIRST segment, fixed-order fix-up by the owner,
+// self-clearing agent-scope flags, bounded spin + sticky fault word).  pp_whole = 1 cuts the unit ranges at tile boundaries
+// instead (no workspace needed: short-K launches such as the correlation volume, or callers without a workspace).
+// -------------------------------------------------------------------------------------------------
+struct SegIter {   // the block's segments, top tile first (so that a contribution is published as early as possible)
+  int tile, tbeg, hi, u0, S;
+  __device__ __forceinline__ void init(int u0_, int u1_, int S_) {
+    u0 = u0_; hi = u1_; S = S_;
+    tile = u1_ > u0_ ? (u1_ - 1) / S_ : 0;
+    tbeg = tile * S_;
+  }
+  __device__ __forceinline__ bool next(int& t, int& s0, int& s1) {
+    if (hi <= u0) return false;
+    const int lo = u0 > tbeg ? u0 : tbeg;
+    t = tile; s0 = lo - tbeg; s1 = hi - tbeg;
+    hi = lo; --tile; tbeg -= S;
+    return true;
+  }
+};
+
+__device__ __forceinline__ void pp_decode(const GemmArgs& a, int tile, long long& m0, int& n0, long long& batch) {
+  int local = tile, b = 0;
+  if (a.pp_batches > 1) { b = tile / a.pp_tiles_pb; local = tile - b * a.pp_tiles_pb; }
+  int tm, tn;
+  if (a.supertile > 0) {
+    tile_of(local, a.pp_tiles_m, a.tiles_n, a.supertile, tm, tn);
+  } else {
+    tm = (int)fastdiv_u32((unsigned)local, a.tn_mul, a.tn_sh);
+    tn = local - tm * a.tiles_n;
+  }
+  m0 = (long long)tm * 64; n0 = tn * 64; batch = b;
+}
+
+// the stager moves ONE step forward in the block's flattened (segment, K-step) order
+template <int LD>
+__device__ __forceinline__ void pp_advance(const GemmArgs& a, Stager<64, 64, LD>& st, SegIter& ps, int& left) {
+  if (--left > 0) { st.advance(); return; }
+  int t, s0, s1;
+  if (!ps.next(t, s0, s1)) return;          // past the block's last step: the remaining loads are dead (live = false)
+  long long m0, batch; int n0;
+  pp_decode(a, t, m0, n0, batch);
+  st.template retarget<true>(a, m0, n0, batch);
+  if (s0) st.seek_args(a, batch, s0); else st.rewind();
+  left = s1 - s0;
+}
+
+template <int EPI, int LD, int BPC>
+__global__ __launch_bounds__(256, BPC) void conv_gemm_pp_kernel(const GemmArgs a) {
+  constexpr int BM = 64, BN = 64, MT = 1, NT = 1;
+  constexpr int STAGE = (BM + BN) * LD;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = tid >> 6;
+  const int wm0 = (wid >> 1) * 32, wn0 = (wid & 1) * 32;
+  const int foff_a = (wm0 + (lane & 31)) * LD;
+  const int foff_b = BM * LD + (wn0 + (lane & 31)) * LD;
+  int ko[4];
+  frag_offsets<LD>(ko, lane);
+
+  __shared__ int s_lost;   // set by thread 0 when a partner's contribution timed out (read after the next barrier)
+  if (threadIdx.x == 0) s_lost = 0;
+  // unit range of this block: group = XCD (blockIdx.x % X, the hardware's round-robin), rank = dispatch order inside the group;
+  // a contribution only ever flows from a lower to a higher rank (variant 4's deadlock-freedom argument)
+  const int X = a.sk_groups;
+  const int d = blockIdx.x;
+  const int grp = d % X, rank = d / X;
+  const int Gx = (int)gridDim.x / X;                  // host: gridDim.x % X == 0
+  const int S = a.sk_steps;
+  const int T = (int)a.sk_tiles;
+  const int tb = (int)((long long)T * grp / X), te = (int)((long long)T * (grp + 1) / X);
+  const int ubase = tb * S, Ux = (te - tb) * S;
+  int u0, u1;
+  if (a.pp_whole) {
+    u0 = (tb + (int)((long long)rank * (te - tb) / Gx)) * S;
+    u1 = (tb + (int)((long long)(rank + 1) * (te - tb) / Gx)) * S;
+  } else {   // 32-bit unit arithmetic: the host only launches this split when units x blocks < 2^31
+    u0 = ubase + (int)((unsigned)(rank * Ux) / (unsigned)Gx);
+    u1 = ubase + (int)((unsigned)((rank + 1) * Ux) / (unsigned)Gx);
+  }
+  const int total = u1 - u0;
+  if (total <= 0) return;   // block-uniform, before any barrier
+
+  SegIter cs, ps;
+  cs.init(u0, u1, S);
+  ps.init(u0, u1, S);
+  Stager<BM, BN, LD> st(a, tid, typename Stager<BM, BN, LD>::NoTile{});
+  int p_left;
+  {
+    int t, s0, s1;
+    ps.next(t, s0, s1);
+    long long m0, batch; int n0;
+    pp_decode(a, t, m0, n0, batch);
+    st.template retarget<true>(a, m0, n0, batch);
+    if (s0) st.seek_args(a, batch, s0); else st.rewind();
+    p_left = s1 - s0;
+  }
+
+  float* s_cur = smem;
+  float* s_nxt = smem + STAGE;
+  float* s_fill = smem + 2 * STAGE;
+  // the ONLY pipeline prologue of the block: flattened steps 0 and 1 into LDS, step 2 into registers
+  st.load(0 < total); pp_advance<LD>(a, st, ps, p_left); st.store(s_cur, s_cur + BM * LD);
+  st.load(1 < total); pp_advance<LD>(a, st, ps, p_left); st.store(s_nxt, s_nxt + BM * LD);
+  st.load(2 < total); pp_advance<LD>(a, st, ps, p_left);
+  __syncthreads();
+  Frags<MT, NT> f0, f1;
+  frag_read<MT, NT, LD>(f0, s_cur + foff_a, s_cur + foff_b, ko, 0);
+
+  int g = 0;            // flattened step index of the MFMA side
+  int tile, s0, s1;
+  while (cs.next(tile, s0, s1)) {
+    long long m0, batch; int n0;
+    pp_decode(a, tile, m0, n0, batch);
+    const int nsteps = s1 - s0;
+    f32x16 acc[MT][NT];
+    zero_acc<MT, NT>(acc);
+    for (int j = 0; j < nsteps; ++j, ++g) {
+      v3_step<BM, BN, MT, NT, 0, LD>(acc, f0, f1, st, s_cur + foff_a, s_cur + foff_b, s_nxt + foff_a, s_nxt + foff_b, s_fill,
+                                     g + 3 < total, ko, std::make_integer_sequence<int, 16 * MT * NT>{});
+      pp_advance<LD>(a, st, ps, p_left);
+      float* t = s_cur; s_cur = s_nxt; s_nxt = s_fill; s_fill = t;
+      __syncthreads();
+    }
+    // Behind the segment's last barrier: s_fill is the stage the last K-step consumed — free until the next step's fillers —
+    // and f0 already holds the next segment's first fragments (read from s_cur before the barrier).
+
+    if (s1 < S) {
+      // contribution: partial -> workspace slot of this block, then publish
+      float* mine = a.sk_ws + ((long long)d * 4 + wid) * (16 * 64) + lane;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mine[r * 64] = acc[0][0][r];
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(a.sk_flags + d, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    } else {
+      if (s0 > 0) {
+        // owner of a split tile: add the partials of the group's blocks rank-1, rank-2, ... that cover [tbeg, tbeg + s0)
+        const int tbeg = tile * S;
+        for (int k = rank - 1; k >= 0; --k) {
+          const int slot = grp + k * X;                // that block's dispatch index
+          if (tid == 0) {
+            unsigned spins = 0;
+            while (__hip_atomic_load(a.sk_flags + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+              __builtin_amdgcn_s_sleep(4);
+              if (++spins > (1u << 24)) {      // see variant 4: count it in the sticky fault word and poison the tile
+                atomicAdd(a.sk_flags + SK_FAULT_SLOT, 1u);
+                s_lost = 1;
+                break;
+              }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(a.sk_flags + slot, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // single consumer: hand it back as 0
+          }
+          __syncthreads();
+          const float* theirs = a.sk_ws + ((long long)slot * 4 + wid) * (16 * 64) + lane;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[0][0][r] += theirs[r * 64];
+          if (ubase + (int)((unsigned)(k * Ux) / (unsigned)Gx) <= tbeg) break;   // block k's range starts at or before the tile: last contributor
+        }
+        if (s_lost) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[0][0][r] = __builtin_nanf("");
+        }
+      }
+      epilogue_lds<MT, NT, EPI>(a, acc, m0 + wm0, n0 + wn0, lane, batch, s_fill, wid);
+    }
+    if (g < total) __syncthreads();   // the epilogue's scratch (s_fill) is the target of the next step's LDS fillers
+  }
+}
+
+
+template <int EPI, int LD, int BPC>
+int launch_pp_one(const GemmArgs& g, unsigned G, hipStream_t st) {
+  constexpr size_t smem = 3 * 128 * LD * sizeof(float);
+  auto kern = conv_gemm_pp_kernel<EPI, LD, BPC>;
+  static pfk_device_once attr_once;
+  attr_once.run([&] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  });
+  hipLaunchKernelGGL(kern, dim3(G), dim3(256), smem, st, g);
+  return pfk_launch_status();
+}
+
+template <int LD, int BPC>
+int launch_pp_epi(const GemmArgs& g, int epi, unsigned G, hipStream_t st) {
+  switch (epi) {
+    case PFK_EPI_LINEAR: return launch_pp_one<PFK_EPI_LINEAR, LD, BPC>(g, G, st);
+    case PFK_EPI_GRU_ZR: return launch_pp_one<PFK_EPI_GRU_ZR, LD, BPC>(g, G, st);
+    case PFK_EPI_GRU_Q:  return launch_pp_one<PFK_EPI_GRU_Q, LD, BPC>(g, G, st);
+    default: return PFK_ERR_BAD_ARG;
+  }
+}
+
+// variant bits: 1 = swizzled 48 KB LDS layout, 2 = per-XCD tile groups, 16 = whole tiles only; blocks per CU = 1 + ((variant >> 2) & 3)
+// (default: as many as the layout allows — 3 swizzled, 2 padded — when those bits are 0)
+int launch_pp(const GemmArgs& a, int epi, int batches, hipStream_t st, int variant) {
+  GemmArgs g = a;
+  if (a.M >= 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
+  g.tiles_n = (a.b_rows + 63) / 64;
+  g.pp_tiles_m = (int)((a.M + 63) / 64);
+  const long long tiles_pb = (long long)g.pp_tiles_m * g.tiles_n;
+  const long long tiles = tiles_pb * batches;
+  if (tiles <= 0 || tiles_pb > 0x7fffffffLL || tiles * a.sk_steps >= 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
+  g.pp_tiles_pb = (int)tiles_pb;
+  g.pp_batches = batches;
+  g.sk_tiles = tiles;
+  g.supertile = (g.pp_tiles_m >= 32 && g.tiles_n >= 32) ? 16 : 0;
+  fastdiv_make((unsigned)a.Wo, g.wo_mul, g.wo_sh);
+  fastdiv_make((unsigned)a.Ho, g.ho_mul, g.ho_sh);
+  fastdiv_make((unsigned)g.tiles_n, g.tn_mul, g.tn_sh);
+  const bool swz = variant & 1;
+  int bpc = (variant >> 2) & 3;
+  bpc = bpc ? bpc : (swz ? 3 : 2);
+  if (bpc > 3 || (bpc == 3 && !swz)) return PFK_ERR_BAD_ARG;     // three padded blocks (165 KB) do not fit a CU's LDS
+  const long long U = tiles * a.sk_steps;
+  long long G = 256LL * bpc;
+  g.pp_whole = ((variant & 16) || a.sk_ws == nullptr || batches > 1 || a.sk_steps < 12) ? 1 : 0;
+  if (g.pp_whole) { if (G > tiles) G = tiles; }
+  else if (U / G < 6) G = U / 6 > 0 ? U / 6 : 1;   // keep segments long enough to amortise a fix-up
+  if (!g.pp_whole && U * (G + 1) >= 0x7fffffffLL) g.pp_whole = 1;   // the split's unit arithmetic is 32-bit
+  g.sk_groups = 1;
+  if ((variant & 2) && tiles >= 64 && G >= 64) { g.sk_groups = 8; G -= G % 8; }
+  if (bpc == 1) return swz ? launch_pp_epi<LDS_LDX, 1>(g, epi, (unsigned)G, st) : launch_pp_epi<LDS_LD, 1>(g, epi, (unsigned)G, st);
+  if (bpc == 2) return swz ? launch_pp_epi<LDS_LDX, 2>(g, epi, (unsigned)G, st) : launch_pp_epi<LDS_LD, 2>(g, epi, (unsigned)G, st);
+  return launch_pp_epi<LDS_LDX, 3>(g, epi, (unsigned)G, st);
+}
+
 // variant bits: 1 = swizzled 48 KB LDS layout, 2 = per-XCD tile groups, blocks per CU = 1 + (variant >> 2)  (1..3)
 int g_sk_variant = 6;     // padded layout, two blocks per CU, per-XCD groups: the best of the sweep (scripts/conv_bench.py cfg 30 + v at
                           // batch 1: z|r conv 69.8 us with one group -> 63.7 us with XCD groups; swizzled / three per CU: 65.6 / 70.3)
@@ -773,6 +1076,7 @@ int launch(const GemmArgs& a0, int epi, int batches, hipStream_t st) {
     // 2-stage kernel); smaller short-K grids keep the 2-stage kernel's cheaper prologue (cfg 0).
     cfg = (sk || sk_long) ? 9 : (blocks64 >= 3 * 256 ? 10 : ((a.sk_steps < 16 && blocks64 < 256) ? 0 : 4));
   }
+  if (cfg >= 50 && cfg < 82) return launch_pp(a, epi, batches, st, cfg - 50);   // 50 + v: persistent pipelined stream-K, schedule variant v
   switch (cfg) {
     case 0: return launch_cfg<64, 64, 32, 32, 0>(a, epi, batches, st);
     case 1: return launch_cfg<64, 128, 32, 64, 0>(a, epi, batches, st);
@@ -867,6 +1171,12 @@ void pfk_debug_set_tile(int cfg) {
   else { g_force_tile = cfg; if (cfg < 0) g_bf_cfg = 0; }
 }
 
+unsigned pfk_debug_fastdiv(unsigned n, unsigned d) {
+  unsigned mul; int sh;
+  fastdiv_make(d, mul, sh);
+  return fastdiv_u32(n, mul, sh);
+}
+
 long long pfk_conv_workspace_bytes(void) { return (long long)SK_WS_BYTES; }
 
 long long pfk_conv_workspace_fault_offset(void) { return (long long)SK_MAX_BLOCKS * 64 * 64 * 4 + (long long)SK_FAULT_SLOT * 4; }
@@ -917,6 +1227,7 @@ int pfk_corr_volume_f32(const float* f1, int ld1, const float* f2, int ld2, floa
   a.relu = 0; a.scale = scale;
   a.out = out; a.out_ld = N2; a.out_coff = 0;
   a.M = N1;
+  a.sk_steps = a.ktot / BK;
   a.a_bs = (long long)N1 * ld1; a.b_bs = (long long)N2 * ld2; a.o_bs = (long long)N1 * N2;
   return launch(a, PFK_EPI_LINEAR, B, static_cast<hipStream_t>(stream));
 }

@@ -63,3 +63,23 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".h")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", txt, flags=re.M), f"{f} imports the oracle"
+
+
+def test_fastdiv_multipliers_are_exact():
+    """The persistent convolution kernel turns a tile index / pixel index into coordinates with host-made multipliers
+    (pfk_gemm.h `fastdiv_u32`): exact for every n < 2^31 — edges, powers of two and random pairs."""
+    import ctypes
+    import random
+    import ptlflow_amd
+    lib = ctypes.CDLL(str(ptlflow_amd.LIBPFK_PATH))
+    f = lib.pfk_debug_fastdiv
+    f.restype = ctypes.c_uint
+    f.argtypes = [ctypes.c_uint, ctypes.c_uint]
+    rng = random.Random(3)
+    ds = list(range(1, 300)) + [2 ** k for k in range(1, 31)] + [2 ** k + e for k in range(3, 30) for e in (-1, 1)] + \
+         [rng.randint(1, 2 ** 31 - 1) for _ in range(300)] + [7040, 56320, 7332, 2852, 1242, 1248, 156, 47, 62, 46, 110, 115]
+    for d in ds:
+        ns = [0, 1, d - 1, d, d + 1, 2 * d - 1, 2 * d, 2 ** 31 - 1, 2 ** 31 - d, 2 ** 30] + [rng.randint(0, 2 ** 31 - 1) for _ in range(40)]
+        for n in ns:
+            if 0 <= n < 2 ** 31:
+                assert f(n, d) == n // d, (n, d)
