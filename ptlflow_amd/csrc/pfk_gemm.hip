@@ -771,7 +771,7 @@ __device__ __forceinline__ void pp_advance(const GemmArgs& a, Stager<64, 64, LD>
   left = s1 - s0;
 }
 
-template <int EPI, int LD, int BPC>
+template <int EPI, int LD, int BPC, int ABL = 0>
 __global__ __launch_bounds__(256, BPC) void conv_gemm_pp_kernel(const GemmArgs a) {
   constexpr int BM = 64, BN = 64, MT = 1, NT = 1;
   constexpr int STAGE = (BM + BN) * LD;
@@ -844,8 +844,8 @@ __global__ __launch_bounds__(256, BPC) void conv_gemm_pp_kernel(const GemmArgs a
     f32x16 acc[MT][NT];
     zero_acc<MT, NT>(acc);
     for (int j = 0; j < nsteps; ++j, ++g) {
-      v3_step<BM, BN, MT, NT, 0, LD>(acc, f0, f1, st, s_cur + foff_a, s_cur + foff_b, s_nxt + foff_a, s_nxt + foff_b, s_fill,
-                                     g + 3 < total, ko, std::make_integer_sequence<int, 16 * MT * NT>{});
+      v3_step<BM, BN, MT, NT, ABL, LD>(acc, f0, f1, st, s_cur + foff_a, s_cur + foff_b, s_nxt + foff_a, s_nxt + foff_b, s_fill,
+                                       g + 3 < total, ko, std::make_integer_sequence<int, 16 * MT * NT>{});
       pp_advance<LD>(a, st, ps, p_left);
       float* t = s_cur; s_cur = s_nxt; s_nxt = s_fill; s_fill = t;
       __syncthreads();
@@ -902,10 +902,10 @@ __global__ __launch_bounds__(256, BPC) void conv_gemm_pp_kernel(const GemmArgs a
 }
 
 
-template <int EPI, int LD, int BPC>
+template <int EPI, int LD, int BPC, int ABL = 0>
 int launch_pp_one(const GemmArgs& g, unsigned G, hipStream_t st) {
   constexpr size_t smem = 3 * 128 * LD * sizeof(float);
-  auto kern = conv_gemm_pp_kernel<EPI, LD, BPC>;
+  auto kern = conv_gemm_pp_kernel<EPI, LD, BPC, ABL>;
   static pfk_device_once attr_once;
   attr_once.run([&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -926,7 +926,7 @@ int launch_pp_epi(const GemmArgs& g, int epi, unsigned G, hipStream_t st) {
 
 // variant bits: 1 = swizzled 48 KB LDS layout, 2 = per-XCD tile groups, 16 = whole tiles only; blocks per CU = 1 + ((variant >> 2) & 3)
 // (default: as many as the layout allows — 3 swizzled, 2 padded — when those bits are 0)
-int launch_pp(const GemmArgs& a, int epi, int batches, hipStream_t st, int variant) {
+int launch_pp(const GemmArgs& a, int epi, int batches, hipStream_t st, int variant, int abl = 0) {
   GemmArgs g = a;
   if (a.M >= 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
   g.tiles_n = (a.b_rows + 63) / 64;
@@ -953,6 +953,15 @@ int launch_pp(const GemmArgs& a, int epi, int batches, hipStream_t st, int varia
   if (!g.pp_whole && U * (G + 1) >= 0x7fffffffLL) g.pp_whole = 1;   // the split's unit arithmetic is 32-bit
   g.sk_groups = 1;
   if ((variant & 2) && tiles >= 64 && G >= 64) { g.sk_groups = 8; G -= G % 8; }
+  if (abl) {   // timing ablations (results are garbage; scripts/conv_bench.py): linear epilogue, swizzled x3 or padded x2 only
+    if (epi != PFK_EPI_LINEAR || !((swz && bpc == 3) || (!swz && bpc == 2))) return PFK_ERR_BAD_ARG;
+    switch (abl) {
+      case 1: return swz ? launch_pp_one<PFK_EPI_LINEAR, LDS_LDX, 3, 1>(g, (unsigned)G, st) : launch_pp_one<PFK_EPI_LINEAR, LDS_LD, 2, 1>(g, (unsigned)G, st);
+      case 2: return swz ? launch_pp_one<PFK_EPI_LINEAR, LDS_LDX, 3, 2>(g, (unsigned)G, st) : launch_pp_one<PFK_EPI_LINEAR, LDS_LD, 2, 2>(g, (unsigned)G, st);
+      case 3: return swz ? launch_pp_one<PFK_EPI_LINEAR, LDS_LDX, 3, 3>(g, (unsigned)G, st) : launch_pp_one<PFK_EPI_LINEAR, LDS_LD, 2, 3>(g, (unsigned)G, st);
+      default: return PFK_ERR_BAD_ARG;
+    }
+  }
   if (bpc == 1) return swz ? launch_pp_epi<LDS_LDX, 1>(g, epi, (unsigned)G, st) : launch_pp_epi<LDS_LD, 1>(g, epi, (unsigned)G, st);
   if (bpc == 2) return swz ? launch_pp_epi<LDS_LDX, 2>(g, epi, (unsigned)G, st) : launch_pp_epi<LDS_LD, 2>(g, epi, (unsigned)G, st);
   return launch_pp_epi<LDS_LDX, 3>(g, epi, (unsigned)G, st);
@@ -1077,6 +1086,8 @@ int launch(const GemmArgs& a0, int epi, int batches, hipStream_t st) {
     cfg = (sk || sk_long) ? 9 : (blocks64 >= 3 * 256 ? 10 : ((a.sk_steps < 16 && blocks64 < 256) ? 0 : 4));
   }
   if (cfg >= 50 && cfg < 82) return launch_pp(a, epi, batches, st, cfg - 50);   // 50 + v: persistent pipelined stream-K, schedule variant v
+  if (cfg >= 82 && cfg < 85) return launch_pp(a, epi, batches, st, 3, cfg - 81);   // timing ablations 1..3 of variant 3 (swizzled x3, XCD groups)
+  if (cfg >= 85 && cfg < 88) return launch_pp(a, epi, batches, st, 2, cfg - 84);   // ... of variant 2 (padded x2, XCD groups)
   switch (cfg) {
     case 0: return launch_cfg<64, 64, 32, 32, 0>(a, epi, batches, st);
     case 1: return launch_cfg<64, 128, 32, 64, 0>(a, epi, batches, st);
@@ -1092,6 +1103,14 @@ int launch(const GemmArgs& a0, int epi, int batches, hipStream_t st) {
     case 30: case 31: case 32: case 33: case 34: case 35: case 36: case 37: case 38: case 39: case 40: case 41:
       return (a.sk_ws != nullptr && batches == 1) ? launch_sk(a, epi, st, cfg - 30) : PFK_ERR_BAD_ARG;
     case 10: return launch_cfg<64, 64, 32, 32, 101>(a, epi, batches, st);
+    // bigger tiles on the swizzled layout: 64x128 / 128x64 (72 KB: two blocks per CU), 128x128 (96 KB: one)
+    case 11: return launch_cfg<64, 128, 32, 64, 101>(a, epi, batches, st);
+    case 12: return launch_cfg<128, 64, 64, 32, 101>(a, epi, batches, st);
+    case 13: return launch_cfg<128, 128, 64, 64, 101>(a, epi, batches, st);
+    // MFMA-only skeletons of the bigger padded tiles (timing ablations)
+    case 27: return epi == PFK_EPI_LINEAR ? launch_cfg<64, 128, 32, 64, 31>(a, epi, batches, st) : PFK_ERR_BAD_ARG;
+    case 28: return epi == PFK_EPI_LINEAR ? launch_cfg<128, 128, 64, 64, 31>(a, epi, batches, st) : PFK_ERR_BAD_ARG;
+    case 29: return epi == PFK_EPI_LINEAR ? launch_cfg<128, 64, 64, 32, 31>(a, epi, batches, st) : PFK_ERR_BAD_ARG;
     // timing ablations of cfg 4 (results are garbage; used by scripts/conv_bench.py only)
     case 21: return epi == PFK_EPI_LINEAR ? launch_cfg<64, 64, 32, 32, 11>(a, epi, batches, st) : PFK_ERR_BAD_ARG;
     case 22: return epi == PFK_EPI_LINEAR ? launch_cfg<64, 64, 32, 32, 21>(a, epi, batches, st) : PFK_ERR_BAD_ARG;

@@ -122,7 +122,8 @@ def _param_tree(shapes: Dict[str, tuple]) -> nn.Module:
 class RAFT(nn.Module):
     def __init__(self, corr_levels: int = 4, corr_radius: Optional[int] = None, iters: int = 32, small: bool = False,
                  upsample_every_iter: bool = True, conv_precision: str = "fp32", native_encoders: bool = True,
-                 alternate_corr: bool = False, use_graph: bool = False, overlap_mask_head: bool = True):
+                 alternate_corr: bool = False, use_graph: Optional[bool] = None, overlap_mask_head: bool = True,
+                 fork_branches: Optional[bool] = None):
         super().__init__()
         self.small = small
         # True: the mask head's second convolution and the convex upsampling of iteration i — off the recurrent critical path:
@@ -130,12 +131,18 @@ class RAFT(nn.Module):
         # encoder / GRU, filling the idle CUs of those launches' tails (same kernels, same operands: bit-identical output).
         # Eager loop only; the hipGraph path keeps one stream.
         self.overlap_mask_head = overlap_mask_head
-        self._side_streams: Dict[torch.device, torch.cuda.Stream] = {}
+        # None: fork the independent branches of an iteration (flow branch of the motion encoder; mask conv2 + upsampling) onto
+        # side streams only while the loop is being captured into a hipGraph; True / False: always / never (`_iterate`)
+        self.fork_branches = fork_branches
+        self._side_streams: Dict[tuple, torch.cuda.Stream] = {}
         # True: the 32-iteration loop (lookup, update block, upsampling: ~20 launches per iteration) is captured once per
-        # input shape into a hipGraph (torch.cuda.CUDAGraph) and replayed — it runs entirely on buffers with fixed addresses.
-        # Pays when the forward is launch-bound (small frames, batch 1); models with a mask head and the materialised
-        # volume only (no GMA aggregate, no alternate_corr).
+        # input shape into a hipGraph (torch.cuda.CUDAGraph) and replayed — it runs entirely on buffers with fixed addresses —
+        # with the independent branches of an iteration forked onto concurrent graph branches (`_iterate_forked`).  Pays in
+        # the small-grid regime (batch 1: 110..880-tile launches on 256 CUs); models with the materialised volume only (no GMA
+        # aggregate, no alternate_corr).  None (default): automatically below 28160 grid pixels (4 x 55x128), the regime it was
+        # measured to pay in; the first forward of a shape runs eagerly and records, later ones replay (bit-identical).
         self.use_graph = use_graph
+        self.max_graphs = 4          # recorded shapes kept (oldest dropped first): each holds its loop buffers and pyramid
         self._graphs: Dict[tuple, dict] = {}
         # True: never materialise the N x N volume, compute the lookup windows on demand (raft.py `alternate_corr`,
         # raft/corr.py:67-101) — the memory / time trade for high resolutions
@@ -303,11 +310,23 @@ class RAFT(nn.Module):
         B = image1.shape[0]
 
         fnet, cnet_fn = self.encoders(x.device)
+        # the context network only needs frame 1 and shares nothing with the feature network: in the small-batch regime (where
+        # the encoders' launches do not fill the chip) it runs on a side stream next to fnet + the correlation volume
+        enc_side = None
+        if self.native_encoders and B * image1.shape[-2] * image1.shape[-1] <= 2 * 440 * 1024:
+            main = torch.cuda.current_stream(x.device)
+            enc_side = self._stream(x.device, "enc")
+            enc_side.wait_event(main.record_event())
+            with torch.cuda.stream(enc_side):
+                cnet = cnet_fn(image1)
+                cnet_done = enc_side.record_event()
         fm = fnet(torch.cat([image1, image2], 0))
         h, w = image1.shape[-2] // 8, image1.shape[-1] // 8
         eng = self.engine(x.device)
         eng.bind(B, h, w)
-        graphable = self.use_graph and not self.spec.aggregate and not self.alternate_corr
+        want_graph = self.use_graph if self.use_graph is not None else B * h * w < 28160
+        # (per-launch HIP-event instrumentation — bench.py's roofline leg — needs real launches)
+        graphable = want_graph and not self.spec.aggregate and not self.alternate_corr and eng.profile is None
         # everything the recorded launch sequence depends on besides the buffers' addresses
         gkey = (B, h, w, x.device, self.iters, self.upsample_every_iter, self.corr_levels, self.corr_radius)
         st = self._graphs.get(gkey) if graphable else None
@@ -327,7 +346,11 @@ class RAFT(nn.Module):
         else:
             corr_fn, coords0, coords1, flow_up = st["corr"].update(fm[:B], fm[B:]), st["coords0"], st["coords1"], st["flow_up"]
             coords1.copy_(coords0)
-        cnet = cnet_fn(image1)
+        if enc_side is None:
+            cnet = cnet_fn(image1)
+        else:
+            torch.cuda.current_stream(x.device).wait_event(cnet_done)
+            cnet.record_stream(torch.cuda.current_stream(x.device))     # allocated on the side stream, consumed here
         net, inp = torch.split(cnet, [self.hidden_dim, self.context_dim], dim=1)
         net, inp = torch.tanh(net), torch.relu(inp)
 
@@ -351,6 +374,8 @@ class RAFT(nn.Module):
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
                     self._iterate(corr_fn, eng, coords0, coords1, flow_up)
+                while len(self._graphs) >= self.max_graphs:
+                    self._graphs.pop(next(iter(self._graphs)))
                 self._graphs[gkey] = {"graph": graph, "corr": corr_fn, "coords0": coords0, "coords1": coords1,
                                                      "flow_up": flow_up, "engine": eng, "hx_ptr": eng.hx.data_ptr()}
         out_up = self.unpad(flow_up, pads)
@@ -359,21 +384,39 @@ class RAFT(nn.Module):
             out_up = out_up.clone()
         return {"flows": out_up[:, None], "flow_small": flow_small}
 
+    def _stream(self, dev: torch.device, which: str) -> "torch.cuda.Stream":
+        key = (dev, which)
+        st = self._side_streams.get(key)
+        if st is None:
+            st = self._side_streams[key] = torch.cuda.Stream(device=dev)
+        return st
+
     def _iterate(self, corr_fn, eng: UpdateEngine, coords0, coords1, flow_up):
-        """The recurrent loop of raft.py:169-187 on fixed buffers: lookup -> update block -> coordinate update -> upsampling."""
+        """The recurrent loop of raft.py:169-187 on fixed buffers: lookup -> update block -> coordinate update -> upsampling.
+
+        Three schedules of the SAME launches on the same operands (bit-identical results, tests/test_gpu_model.py):
+        * serial — everything on the current stream;
+        * mask branch on a side stream (eager, >= 28160 pixels): mask conv2 + convex upsampling of iteration i next to iteration i+1;
+        * forked (`fork_branches`, meant for the captured hipGraph where a fork / join is a graph edge, not a host call): the
+          independent branches of one iteration run concurrently — the motion encoder's flow branch (convf1 -> convf2, reads
+          only the flow slice) next to lookup -> convc1 -> convc2; mask conv2 + upsampling next to the coordinate update and
+          the next iteration — so the 110..440-tile launches of the batch-1 regime fill each other's idle CUs
+          (update.py:104-112: `cor` and `flo` only meet in `conv`; :152: the mask head reads `net` only)."""
         ops = torch.ops.pfk
         has_mask = self.spec.has_mask
         h, w = coords0.shape[-2:]
+        dev = coords0.device
+        capturing = torch.cuda.is_current_stream_capturing()
+        pixels = coords0.shape[0] * h * w
+        fork = self.fork_branches if self.fork_branches is not None else capturing
+        if fork and not self.spec.aggregate and not self.alternate_corr:
+            return self._iterate_forked(corr_fn, eng, coords0, coords1, flow_up)
         side = None
         # (measured, one MI355X: +0.9 % at batch 8 of 436x1024; -1.4 % at batch 1, where the loop's launches are short and the extra
         #  events cost more than the filled tails give back: only for >= 4 x 7040 pixels)
-        if (has_mask and self.overlap_mask_head and coords0.shape[0] * h * w >= 28160
-                and not torch.cuda.is_current_stream_capturing()):
-            dev = coords0.device
-            side = self._side_streams.get(dev)
-            if side is None:
-                side = self._side_streams[dev] = torch.cuda.Stream(device=dev)
-        main = torch.cuda.current_stream(coords0.device)
+        if has_mask and self.overlap_mask_head and pixels >= 28160 and not capturing:
+            side = self._stream(dev, "mask")
+        main = torch.cuda.current_stream(dev)
         side_done = None
         for it in range(self.iters):
             last = it == self.iters - 1
@@ -399,6 +442,46 @@ class RAFT(nn.Module):
                 side_done = side.record_event()
         if side_done is not None:
             main.wait_event(side_done)
+        return flow_up
+
+    def _iterate_forked(self, corr_fn, eng: UpdateEngine, coords0, coords1, flow_up):
+        ops = torch.ops.pfk
+        has_mask = self.spec.has_mask
+        dev = coords0.device
+        main = torch.cuda.current_stream(dev)
+        s_flow, s_mask = self._stream(dev, "flow"), self._stream(dev, "mask")
+        mask_done = None
+        for it in range(self.iters):
+            last = it == self.iters - 1
+            do_up = last or self.upsample_every_iter
+            # fork: the flow branch needs the flow slice of hx (written by the previous coordinate update, on main)
+            s_flow.wait_event(main.record_event())
+            with torch.cuda.stream(s_flow):
+                eng.motion_flow(branch=True)
+                flow_done = s_flow.record_event()
+            corr_pm = corr_fn.lookup_pm(coords1)
+            eng.motion_corr(corr_pm)
+            main.wait_event(flow_done)                                # join: `conv` reads both halves of corflo
+            eng.motion_join()
+            eng.gru()
+            if mask_done is not None:      # the previous mask branch still reads the mask half of `fm` and the flow slice
+                main.wait_event(mask_done)
+            eng.heads_conv1()
+            if has_mask and do_up:
+                s_mask.wait_event(main.record_event())
+                with torch.cuda.stream(s_mask):
+                    eng.mask_head(side_stream=True)                   # next to the coordinate update
+                eng.flow_delta(coords0, coords1)
+                s_mask.wait_event(main.record_event())                # the upsampling reads the NEW flow slice
+                with torch.cuda.stream(s_mask):
+                    ops.convex_upsample_pm(eng.flow_view, eng.mask, flow_up)
+                    mask_done = s_mask.record_event()
+            else:
+                eng.flow_delta(coords0, coords1)
+                if do_up and not has_mask:
+                    ops.upflow8(coords0, coords1, flow_up)
+        if mask_done is not None:
+            main.wait_event(mask_done)
         return flow_up
 
 

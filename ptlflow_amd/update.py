@@ -209,8 +209,13 @@ class UpdateEngine:
             self.vbuf = z(s.motion_channels)
             self.vT = torch.zeros(B, s.motion_channels, round_up(N, 32), device=dev, dtype=torch.float32)
             self.attn = None
-        # scratch for the stream-K conv schedule (partials + flags); all launches are on one stream, so one is enough
-        self.workspace = torch.zeros(self.ops.conv_workspace_bytes(), device=dev, dtype=torch.uint8)
+        # scratch for the stream-K conv schedules (partials + flags), one per stream that may run convolutions concurrently: the
+        # main chain, the flow branch of the motion encoder and the mask branch (RAFT._iterate's forked mode) — with its own
+        # workspace a branch's launches pick the same schedule as in the serial order (bit-identical results)
+        nws = self.ops.conv_workspace_bytes()
+        self.workspace = torch.zeros(nws, device=dev, dtype=torch.uint8)
+        self.workspace_flow = torch.zeros(nws, device=dev, dtype=torch.uint8)
+        self.workspace_mask = torch.zeros(nws, device=dev, dtype=torch.uint8)
         self._shape = (B, H, W)
 
     def faults(self) -> int:
@@ -218,7 +223,7 @@ class UpdateEngine:
         convolution result so far is complete.  Reads one word back from the device (synchronises the stream); affected
         tiles are NaN in any case, so this is for telling *why* an output went NaN."""
         off = self.ops.conv_workspace_fault_offset()
-        return int(self.workspace[off: off + 4].view(torch.int32).item())
+        return sum(int(ws[off: off + 4].view(torch.int32).item()) for ws in (self.workspace, self.workspace_flow, self.workspace_mask))
 
     def watch_faults(self) -> None:
         """Called once per forward by the callers (RAFT mirror, PfkUpdateBlock): raise if an EARLIER forward's fault word came
@@ -227,18 +232,20 @@ class UpdateEngine:
         zero-filled again before raising — a producer that published after its consumer gave up leaves its flag set, which the
         next launch on the same workspace would otherwise take for a fresh partial (stale data, not NaN)."""
         if self._fault_host is None:
-            self._fault_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self._fault_host = torch.zeros(3, dtype=torch.int32).pin_memory()
             self._fault_event = None
         if self._fault_event is not None and self._fault_event.query():
-            n = int(self._fault_host[0])
+            n = int(self._fault_host.sum())
             self._fault_event = None
             if n:
-                self.workspace.zero_()
+                for ws in (self.workspace, self.workspace_flow, self.workspace_mask):
+                    ws.zero_()
                 raise RuntimeError(f"libpfk: {n} stream-K fix-up(s) timed out in an earlier forward (its affected tiles are NaN); "
                                    "the workspace has been re-initialised")
         if self._fault_event is None and not torch.cuda.is_current_stream_capturing():
             off = self.ops.conv_workspace_fault_offset()
-            self._fault_host.copy_(self.workspace[off: off + 4].view(torch.int32), non_blocking=True)
+            for i, ws in enumerate((self.workspace, self.workspace_flow, self.workspace_mask)):
+                self._fault_host[i: i + 1].copy_(ws[off: off + 4].view(torch.int32), non_blocking=True)
             self._fault_event = torch.cuda.Event()
             self._fault_event.record()
 
@@ -320,9 +327,11 @@ class UpdateEngine:
         if prof is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        # the stream-K workspace belongs to ONE stream: a launch on a side stream goes without it (plain tile grid)
+        # a stream-K workspace belongs to ONE stream: `workspace` = True (the main chain's), a branch's own tensor, or False
+        # (none: plain tile grid)
+        ws = self.workspace if workspace is True else (workspace if isinstance(workspace, torch.Tensor) else None)
         self.ops.conv2d(srcs, B, H, W, kh, kw, self.w[key + ".w"], self.w.get(key + ".b"), cout, epi, relu, scale,
-                        out, h, z, rh, self.workspace if workspace else None)
+                        out, h, z, rh, ws)
         if prof is not None:
             e1.record()
             prof.setdefault(key, []).append((e0, e1))
@@ -333,17 +342,32 @@ class UpdateEngine:
 
     def motion(self, corr_pm: torch.Tensor) -> None:
         """BasicMotionEncoder / SmallMotionEncoder (update.py:104-112 / :85-91) into its hx slice; `flow` must already be in hx."""
+        self.motion_corr(corr_pm)
+        self.motion_flow()
+        self.motion_join()
+
+    def motion_corr(self, corr_pm: torch.Tensor) -> None:
+        """correlation branch: convc1 [-> convc2] into corflo[:, :c] (update.py:105-106 / :86)"""
         s = self.spec
-        B, H, W = self._shape
         if s.c2:
             self._conv([corr_pm], 1, 1, "c1", s.c1, out=self.cor1)
             self._conv([self.cor1], 3, 3, "c2", s.c2, out=self.corflo[:, : s.c2])
-            cor_c = s.c2
         else:
             self._conv([corr_pm], 1, 1, "c1", s.c1, out=self.corflo[:, : s.c1])
-            cor_c = s.c1
+
+    def motion_flow(self, branch: bool = False) -> None:
+        """flow branch: convf1 -> convf2 into corflo[:, c:] (update.py:107-108 / :87-88); reads only the flow slice of hx, so it
+        may run next to the lookup and the correlation branch (`branch=True`: on another stream, with its own workspace)."""
+        s = self.spec
+        B, H, W = self._shape
+        cor_c = s.c2 if s.c2 else s.c1
         self.ops.conv_cin2(self.flow_view, self.w["f1.w"], self.w["f1.b"], self.flo1, B, H, W, 7, True)
-        self._conv([self.flo1], 3, 3, "f2", s.f2, out=self.corflo[:, cor_c: cor_c + s.f2])
+        self._conv([self.flo1], 3, 3, "f2", s.f2, out=self.corflo[:, cor_c: cor_c + s.f2],
+                   workspace=self.workspace_flow if branch else True)
+
+    def motion_join(self) -> None:
+        """conv over cat([cor, flo]) into the motion slice of hx (update.py:110-112 / :89-91)"""
+        s = self.spec
         o = s.hidden + s.context
         self._conv([self.corflo], 3, 3, "cv", s.enc_out, out=self.hx[:, o: o + s.enc_out])
 
@@ -385,19 +409,29 @@ class UpdateEngine:
               want_mask: bool = True, write_flow: bool = True) -> None:
         """update.py:13-14 + :152 and the coordinate bookkeeping of raft.py:174,178."""
         s = self.spec
-        nf = s.fh_hidden * (2 if s.has_mask else 1)
-        self._conv([self.h_view], 3, 3, "fm", nf, out=self.fm)
-        self.ops.flow_delta(self.fm[:, : s.fh_hidden], self.w["fh2.w"], self.w["fh2.b"], coords0, coords1, delta_out,
-                            self.flow_view if write_flow else None)
+        self.heads_conv1()
+        self.flow_delta(coords0, coords1, delta_out, write_flow)
         if s.has_mask and want_mask:
             self.mask_head()
 
+    def heads_conv1(self) -> None:
+        """flow-head conv1 | mask conv1 as ONE GEMM over h (update.py:13, :138-139) -> fm"""
+        s = self.spec
+        self._conv([self.h_view], 3, 3, "fm", s.fh_hidden * (2 if s.has_mask else 1), out=self.fm)
+
+    def flow_delta(self, coords0: torch.Tensor, coords1: torch.Tensor, delta_out: Optional[torch.Tensor] = None,
+                   write_flow: bool = True) -> None:
+        """flow-head conv2 + `coords1 += delta`, `flow = coords1 - coords0` (update.py:14, raft.py:174,178) on the flow half of fm"""
+        s = self.spec
+        self.ops.flow_delta(self.fm[:, : s.fh_hidden], self.w["fh2.w"], self.w["fh2.b"], coords0, coords1, delta_out,
+                            self.flow_view if write_flow else None)
+
     def mask_head(self, side_stream: bool = False) -> None:
-        """mask[1] + the 0.25 scale of raft/update.py:131-135,152 on the mask half of `fm` (written by `heads`); reads nothing
+        """mask[1] + the 0.25 scale of raft/update.py:131-135,152 on the mask half of `fm` (written by `heads_conv1`); reads nothing
         else of the iteration's state, so it may run on a side stream next to the following iteration (raft.py `_iterate`)."""
         s = self.spec
         self._conv([self.fm[:, s.fh_hidden:]], 1, 1, "mk", s.mask_channels, relu=False, scale=0.25, out=self.mask,
-                   workspace=not side_stream)
+                   workspace=self.workspace_mask if side_stream else True)
 
     def step(self, corr_pm: torch.Tensor, coords0: torch.Tensor, coords1: torch.Tensor, want_mask: bool = True) -> None:
         """One full RAFT iteration body after the lookup; updates hx (net, flow) and coords1 in place."""

@@ -13,8 +13,8 @@ ap.add_argument("--batch", type=int, default=1)
 ap.add_argument("--conv-precision", default="fp32")
 args = ap.parse_args()
 x = smooth_pair(args.batch, args.height, args.width, seed=1).cuda()
-for use_graph in (False, True):
-    m = RAFT(use_graph=use_graph, conv_precision=args.conv_precision).load_synthetic(1).eval().cuda()
+for use_graph, fork in ((False, False), (False, True), (True, None), (True, False)):
+    m = RAFT(use_graph=use_graph, fork_branches=fork, conv_precision=args.conv_precision).load_synthetic(1).eval().cuda()
     for _ in range(3):
         m({"images": x})
     torch.cuda.synchronize()
@@ -23,4 +23,4 @@ for use_graph in (False, True):
         m({"images": x})
     torch.cuda.synchronize()
     ms = 1e2 * (time.perf_counter() - t0)
-    print(f"{args.height}x{args.width} batch {args.batch} {args.conv_precision} use_graph={use_graph}: {ms:.2f} ms / forward ({args.batch * 1e3 / ms:.1f} pairs/s)")
+    print(f"{args.height}x{args.width} batch {args.batch} {args.conv_precision} use_graph={use_graph} fork_branches={fork}: {ms:.2f} ms / forward ({args.batch * 1e3 / ms:.1f} pairs/s)")

@@ -170,8 +170,8 @@ def test_graph_replay_matches_eager(gpu, small):
     of the same shape, after a shape change in between, and with a warm start (raft and raft_small: the latter's upflow8 writes
     into a fixed buffer too)."""
     from ptlflow_amd.raft import RAFT
-    eager = RAFT(iters=5, small=small).load_synthetic(11).eval().cuda()
-    graph = RAFT(iters=5, small=small, use_graph=True).load_synthetic(11).eval().cuda()
+    eager = RAFT(iters=5, small=small, use_graph=False).load_synthetic(11).eval().cuda()
+    graph = RAFT(iters=5, small=small, use_graph=True).load_synthetic(11).eval().cuda()      # forked branches inside the graph
     xs = [O.smooth_pair(1, 128, 192, seed=s).cuda() for s in (1, 2, 3)]
     other = O.smooth_pair(1, 136, 160, seed=7).cuda()
     prev = None
@@ -183,6 +183,25 @@ def test_graph_replay_matches_eager(gpu, small):
         assert torch.equal(a["flows"], b["flows"]) and torch.equal(a["flow_small"], b["flow_small"]), f"forward {i}"
         prev = a["flow_small"] if x.shape == xs[0].shape else None
     assert len(graph._graphs) == 2
+
+
+@pytest.mark.parametrize("small,B,H,W,every", [(False, 1, 436, 1024, True), (False, 2, 184, 320, False), (True, 1, 184, 320, True)])
+def test_forked_branches_are_bit_identical(gpu, small, B, H, W, every):
+    """`fork_branches=True` (what the captured graph uses): the motion encoder's flow branch next to lookup -> convc1 -> convc2,
+    mask conv2 + upsampling next to the coordinate update and the following iteration, cnet next to fnet — the same launches on
+    the same operands with per-branch stream-K workspaces, so every output bit must equal the serial schedule's; repeated
+    forwards on fresh inputs (a missing event shows up as a stale buffer), eagerly and through the default auto-graph."""
+    from ptlflow_amd.raft import RAFT
+    serial = RAFT(iters=6, small=small, upsample_every_iter=every, use_graph=False, fork_branches=False).load_synthetic(5).eval().cuda()
+    forked = RAFT(iters=6, small=small, upsample_every_iter=every, use_graph=False, fork_branches=True).load_synthetic(5).eval().cuda()
+    auto = RAFT(iters=6, small=small, upsample_every_iter=every).load_synthetic(5).eval().cuda()
+    for seed in (1, 2, 1, 3):
+        x = O.smooth_pair(B, H, W, seed=seed).cuda()
+        a, b, c = serial({"images": x}), forked({"images": x}), auto({"images": x})
+        torch.cuda.synchronize()
+        assert torch.equal(a["flows"], b["flows"]) and torch.equal(a["flow_small"], b["flow_small"]), f"forked, seed {seed}"
+        assert torch.equal(a["flows"], c["flows"]) and torch.equal(a["flow_small"], c["flow_small"]), f"auto graph, seed {seed}"
+    assert len(auto._graphs) == 1            # below 28160 grid pixels the default records the loop and replays it
 
 
 @pytest.mark.parametrize("kind", ["raft", "gma"])
