@@ -1084,6 +1084,13 @@ int launch(const GemmArgs& a0, int epi, int batches, hipStream_t st) {
     // reads are a few % faster (cfg 4), down to one tile per CU for short K too (convc1 at batch 1: 18.7 vs 19.9 us on the
     // 2-stage kernel); smaller short-K grids keep the 2-stage kernel's cheaper prologue (cfg 0).
     cfg = (sk || sk_long) ? 9 : (blocks64 >= 3 * 256 ? 10 : ((a.sk_steps < 16 && blocks64 < 256) ? 0 : 4));
+    // Round 3, batch 8 (scripts/conv_bench.py, three boxes): 64x128 tiles on the swizzled layout (72 KB: two blocks per CU, two
+    // accumulators and 32 MFMAs per wave and barrier, 12 instead of 16 B/clk/CU of operand traffic) beat 64x64 x3 where the
+    // output width is a multiple of 128 and the grid still has >= 3 rounds of them: fh|mask conv1 526 -> 513 us (129 TFLOP/s),
+    // z|r convs 457..528 -> 436 us, convc1 108 -> 101 us; they lose on cout 192 / 126 / 576 (padding) and cout 128 (one column).
+    if (cfg == 10 && batches == 1 && a.b_rows >= 256 && (a.b_rows & 127) == 0 && tiles64 * (a.b_rows / 128) >= 6 * 256 &&
+        a.sk_steps >= 8)
+      cfg = 11;
   }
   if (cfg >= 50 && cfg < 82) return launch_pp(a, epi, batches, st, cfg - 50);   // 50 + v: persistent pipelined stream-K, schedule variant v
   if (cfg >= 82 && cfg < 85) return launch_pp(a, epi, batches, st, 3, cfg - 81);   // timing ablations 1..3 of variant 3 (swizzled x3, XCD groups)

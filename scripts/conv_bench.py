@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--H", type=int, default=55)
     ap.add_argument("--W", type=int, default=128)
     ap.add_argument("--only", default="")
+    ap.add_argument("--rounds", type=int, default=1, help="time every cfg `rounds` times in round-robin order and report the median "
+                    "(box-to-box and warm-up drift is +-5 %: only interleaved A/B numbers of one run are comparable)")
     args = ap.parse_args()
     cfgs = [int(c) for c in args.cfgs.split(",")]
     B, H, W = args.batch, args.H, args.W
@@ -63,6 +65,7 @@ def main():
         zbuf0 = torch.rand(M, Ch, device=dev)
         flops = 2.0 * M * cout * kh * kw * cin
         line = f"{name:4s} cout={cout:3d} K={kh*kw*cin:5d} {flops/1e9:5.2f} GF |"
+        runs = []
         for cfg in cfgs:
             ops.debug_set_tile(-1)
             ops.debug_set_tile(cfg if cfg < 100 else 100 + cfg % 100 + 10 * (cfg // 1000))
@@ -71,7 +74,7 @@ def main():
             out = torch.zeros(M, cout, device=dev)
             hbuf, zbuf, rh = hbuf0.clone(), zbuf0.clone(), torch.zeros(M, Ch, device=dev)
 
-            def run():
+            def run(packed=packed, out=out, hbuf=hbuf, zbuf=zbuf, rh=rh):      # bound now: later rounds call it again
                 if epi == 0:
                     ops.conv2d(xs, B, H, W, kh, kw, packed, bias, cout, 0, False, 1.0, out, None, None, None, ws)
                 elif epi == 1:
@@ -106,6 +109,21 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             us = 1e3 * e0.elapsed_time(e1) / args.reps
+            runs.append((cfg, run, [us], err))
+        for _ in range(args.rounds - 1):         # further rounds, round-robin over the configurations
+            for cfg, run, samples, _err in runs:
+                ops.debug_set_tile(-1)
+                ops.debug_set_tile(cfg if cfg < 100 else 100 + cfg % 100 + 10 * (cfg // 1000))
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(args.reps):
+                    run()
+                e1.record()
+                torch.cuda.synchronize()
+                samples.append(1e3 * e0.elapsed_time(e1) / args.reps)
+        for cfg, run, samples, err in runs:
+            samples.sort()
+            us = samples[len(samples) // 2]
             tot[cfg] += us
             line += f" cfg{cfg:4d}: {us:7.1f} us {flops/us/1e6:6.1f} TF err {err:.1e} |"
         print(line, flush=True)

@@ -17,6 +17,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 PP = {"swz3_xcd": 53, "pad2_xcd": 52, "swz3": 51, "swz2_xcd": 50 + 1 + 2 + 8, "swz3_xcd_whole": 53 + 16, "pad2_whole": 50 + 16}
+TILES = {"64x64_swz": 10, "64x128_swz": 11, "128x64_swz": 12, "128x128_swz": 13}
 
 
 def pm(x):
@@ -106,6 +107,9 @@ def test_pp_kernel_matches_reference_and_tile_kernel(gpu, c):
         assert all(torch.equal(a, b_) for a, b_ in zip(got, again)), f"{name}: not deterministic from launch to launch"
         if name.endswith("whole"):
             assert all(torch.equal(a, b_) for a, b_ in zip(got, base)), f"{name}: differs from the tile-per-block kernel"
+    for name, cfg in TILES.items():         # tile-per-block kernels: same K order per output element -> the same bits
+        got = run(cfg)
+        assert all(torch.equal(a, b_) for a, b_ in zip(got, base)), f"{name}: differs from the 64x64 tile kernel"
     off = ops.conv_workspace_fault_offset()
     assert int(ws[off: off + 4].view(torch.int32).item()) == 0
     assert bool((ws[ops.conv_workspace_bytes() - 768 * 64:][: 768 * 4] == 0).all()), "flag region not handed back zeroed"
