@@ -11,7 +11,9 @@ What gets replaced:
   patch target is the *model module's* global, not `corr.py`;
 * seam B3 — ``model.update_block`` is wrapped by `PfkUpdateBlock`, which keeps the original sub-modules
   (state_dict keys, checkpoints and optimizers are untouched) and only overrides ``forward``;
-* seam B4 — ``model.fnet`` / ``model.cnet`` (`BasicEncoder`) are wrapped by `PfkEncoder` the same way.
+* seam B4 — ``model.fnet`` / ``model.cnet`` (`BasicEncoder`) are wrapped by `PfkEncoder` the same way;
+* seam B5 — ``model.upsample_flow`` (raft.py:112-123, a method the loop calls every iteration) is shadowed on the instance by
+  the convex-upsampling kernel after a behaviour probe (`_UpsampleSeam`).
 
 Dispatch is by *implementation identity*, never by class name alone: about two dozen ptlflow families call their block
 ``BasicUpdateBlock`` with different layers and ``forward`` signatures (sea_raft/update.py:39-54 is a ConvNeXt stack that
@@ -182,9 +184,58 @@ def _make_corr_hook(module_name: str, original):
     return get_corr_block
 
 
+_UPSAMPLE = "_pfk_original_upsample_flow"
+
+
+class _UpsampleSeam:
+    """Seam B5 — `model.upsample_flow(flow, mask)` (raft.py:112-123; the same method in gma.py:130-141, ccmr.py:128-139):
+    8x convex upsampling, called once per iteration by the reference's loop, in the reference five torch kernels over a
+    [B, 576, h, w] mask (softmax, unfold, multiply, sum, permute-copy).  The replacement is `pfk_convex_upsample_f32`.
+
+    Dispatch by BEHAVIOUR, not by name: on the first GPU call the model's own method and the kernel are run on a small random
+    input; the kernel is used from then on only if they agree to 1e-5 (so a family whose `upsample_flow` does something else —
+    another scale, a different neighbourhood — keeps its own code).  Gradient graphs, CPU tensors, other mask widths and
+    dtypes always take the original."""
+
+    def __init__(self, original):
+        self.original = original
+        self.ok = None          # None: not probed yet; True / False: the probe's verdict
+
+    @staticmethod
+    def _kernel(flow: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+        B, _, H, W = flow.shape
+        pm = mask.permute(0, 2, 3, 1)
+        pm = pm.reshape(B * H * W, 576) if pm.is_contiguous() else pm.contiguous().view(B * H * W, 576)   # PfkUpdateBlock's mask: a view
+        out = torch.empty(B, 2, 8 * H, 8 * W, device=flow.device, dtype=torch.float32)
+        torch.ops.pfk.convex_upsample(flow.contiguous(), pm, out)
+        return out
+
+    def _probe(self, device) -> bool:
+        g = torch.Generator().manual_seed(5)
+        flow = (torch.randn(2, 2, 5, 7, generator=g) * 3).to(device)
+        mask = torch.randn(2, 576, 5, 7, generator=g).to(device)
+        try:
+            with torch.no_grad():
+                want = self.original(flow, mask)
+            got = self._kernel(flow, mask)
+            return tuple(want.shape) == tuple(got.shape) and float((want.float() - got).abs().max()) <= 1e-5
+        except Exception:
+            return False
+
+    def __call__(self, flow, mask):
+        eligible = (flow.is_cuda and flow.dtype == torch.float32 and mask.dtype == torch.float32 and mask.dim() == 4 and
+                    mask.shape[1] == 576 and flow.dim() == 4 and flow.shape[1] == 2 and
+                    not (torch.is_grad_enabled() and (flow.requires_grad or mask.requires_grad)))
+        if not eligible:
+            return self.original(flow, mask)
+        if self.ok is None:
+            self.ok = self._probe(flow.device)
+        return self._kernel(flow, mask) if self.ok else self.original(flow, mask)
+
+
 def accelerate(model: torch.nn.Module, corr: bool = True, update_block: bool = True,
-               conv_precision: str = "fp32", encoders: bool = True) -> torch.nn.Module:
-    """Patch seams B1/B3/B4 of a ptlflow model instance in place and return it.
+               conv_precision: str = "fp32", encoders: bool = True, upsample: bool = True) -> torch.nn.Module:
+    """Patch seams B1/B3/B4 (+ B5, the model's `upsample_flow` method) of a ptlflow model instance in place and return it.
 
     ``conv_precision``: "fp32" (default, the parity path) or a split-bf16 mode of the convolutions
     ("bf16x6", "bf16x3", "bf16"), see ``UpdateEngine``."""
@@ -206,10 +257,17 @@ def accelerate(model: torch.nn.Module, corr: bool = True, update_block: bool = T
             enc = getattr(model, attr, None)
             if enc is not None and not isinstance(enc, PfkEncoder) and match_encoder(enc):
                 setattr(model, attr, PfkEncoder(enc, conv_precision, small=type(enc).__name__ == "SmallEncoder"))
+    if upsample and callable(getattr(model, "upsample_flow", None)) and _UPSAMPLE not in model.__dict__:
+        # an instance attribute shadows the class's method; nn.Module.__setattr__ stores plain callables in __dict__
+        model.__dict__[_UPSAMPLE] = model.upsample_flow
+        model.__dict__["upsample_flow"] = _UpsampleSeam(model.upsample_flow)
     return model
 
 
 def restore(model: torch.nn.Module) -> torch.nn.Module:
+    if _UPSAMPLE in model.__dict__:
+        del model.__dict__[_UPSAMPLE]
+        model.__dict__.pop("upsample_flow", None)
     mod = sys.modules.get(type(model).__module__)
     if mod is not None and hasattr(mod, _ORIG):
         mod.get_corr_block = getattr(mod, _ORIG)

@@ -433,7 +433,8 @@ class RAFT(nn.Module):
             eng.motion_and_gru(corr_pm)
             if side_done is not None:      # the previous iteration's mask head / upsampling still read `fm` and the flow slice
                 main.wait_event(side_done)
-            eng.heads(coords0, coords1, None, want_mask=False)      # fh | mask conv1 (`fm`), flow head conv2 + coordinate update
+            eng.heads_conv1(True)                    # fh | mask conv1 (`fm`): the mask half is consumed on the side stream
+            eng.flow_delta(coords0, coords1)         # flow head conv2 + coordinate update
             forked = main.record_event()
             side.wait_event(forked)
             with torch.cuda.stream(side):
@@ -466,7 +467,7 @@ class RAFT(nn.Module):
             eng.gru()
             if mask_done is not None:      # the previous mask branch still reads the mask half of `fm` and the flow slice
                 main.wait_event(mask_done)
-            eng.heads_conv1()
+            eng.heads_conv1(want_mask=do_up)
             if has_mask and do_up:
                 s_mask.wait_event(main.record_event())
                 with torch.cuda.stream(s_mask):

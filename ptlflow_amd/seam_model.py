@@ -174,7 +174,7 @@ def convex_upsample_torch(flow: torch.Tensor, mask: torch.Tensor) -> torch.Tenso
     """8x convex upsampling in torch ops (what raft.py:112-123 computes): softmax over the 9 neighbours, weighted sum of the
     3x3 neighbourhood of 8*flow, sub-pixel shuffle."""
     B, _, h, w = flow.shape
-    wgt = torch.softmax(mask.view(B, 1, 9, 8, 8, h, w), dim=2)
+    wgt = torch.softmax(mask.view(B, 1, 9, 8, 8, h, w), dim=2)      # (a view also of PfkUpdateBlock's channels-last mask: only dim 1 is split)
     nb = F.unfold(8 * flow, 3, padding=1).view(B, 2, 9, 1, 1, h, w)
     up = (wgt * nb).sum(2)                                   # [B, 2, 8, 8, h, w]
     return up.permute(0, 1, 4, 2, 5, 3).reshape(B, 2, 8 * h, 8 * w)
@@ -196,6 +196,11 @@ class SeamRAFT(nn.Module):
             self.hidden_dim, self.context_dim = 128, 128
             self.fnet, self.cnet = BasicEncoder(256, "instance"), BasicEncoder(256, "batch")
             self.update_block = BasicUpdateBlock(cc, 128)
+
+    def upsample_flow(self, flow: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+        """A METHOD of the model, as in the reference (raft.py:112-123) — seam B5: `patch.accelerate` shadows it on the instance
+        with the convex-upsampling kernel once a behaviour probe has shown the two agree."""
+        return convex_upsample_torch(flow, mask)
 
     @staticmethod
     def _pad_amounts(H: int, W: int):
@@ -229,7 +234,7 @@ class SeamRAFT(nn.Module):
             if up_mask is None:
                 flow_up = 8 * F.interpolate(coords1 - coords0, size=(8 * h, 8 * w), mode="bilinear", align_corners=True)
             else:
-                flow_up = convex_upsample_torch(coords1 - coords0, up_mask)
+                flow_up = self.upsample_flow(coords1 - coords0, up_mask)
             flow_up = flow_up[..., pads[2]: 8 * h - pads[3], pads[0]: 8 * w - pads[1]]
         return {"flows": flow_up[:, None], "flow_small": coords1 - coords0}
 

@@ -174,6 +174,10 @@ class UpdateEngine:
             w["fm.b"] = torch.cat([g("flow_head.conv1.bias"), g("mask.0.bias")]).contiguous()
             w["mk.w"] = pk(g("mask.2.weight"), seg1(256))
             w["mk.b"] = g("mask.2.bias").contiguous()
+            # flow-head conv1 alone: the iterations whose mask is never looked at (`upsample_every_iter=False`) skip the mask half
+            w["fh.w"] = pk(g("flow_head.conv1.weight"), seg1(Ch))
+            w["fh.b"] = g("flow_head.conv1.bias").contiguous()
+            self._real_cin["fh"] = s.hidden
         else:
             w["fm.w"] = pk(g("flow_head.conv1.weight"), seg1(Ch))
             w["fm.b"] = g("flow_head.conv1.bias").contiguous()
@@ -409,15 +413,22 @@ class UpdateEngine:
               want_mask: bool = True, write_flow: bool = True) -> None:
         """update.py:13-14 + :152 and the coordinate bookkeeping of raft.py:174,178."""
         s = self.spec
-        self.heads_conv1()
+        self.heads_conv1(want_mask)
         self.flow_delta(coords0, coords1, delta_out, write_flow)
         if s.has_mask and want_mask:
             self.mask_head()
 
-    def heads_conv1(self) -> None:
-        """flow-head conv1 | mask conv1 as ONE GEMM over h (update.py:13, :138-139) -> fm"""
+    def heads_conv1(self, want_mask: bool = True) -> None:
+        """flow-head conv1 | mask conv1 as ONE GEMM over h (update.py:13, :138-139) -> fm; without `want_mask` only the flow-head
+        half (same K order per output element: the flow half's bits do not depend on whether the mask half rides along)"""
         s = self.spec
-        self._conv([self.h_view], 3, 3, "fm", s.fh_hidden * (2 if s.has_mask else 1), out=self.fm)
+        B, H, W = self._shape
+        # (only where neither launch falls into the stream-K window of 257..1023 tiles — there the two GEMMs would cut their tiles
+        #  at different K positions and the flow half's last bits would depend on the mode)
+        if s.has_mask and not want_mask and B * H * W >= 28160:
+            self._conv([self.h_view], 3, 3, "fh", s.fh_hidden, out=self.fm[:, : s.fh_hidden])
+        else:
+            self._conv([self.h_view], 3, 3, "fm", s.fh_hidden * (2 if s.has_mask else 1), out=self.fm)
 
     def flow_delta(self, coords0: torch.Tensor, coords1: torch.Tensor, delta_out: Optional[torch.Tensor] = None,
                    write_flow: bool = True) -> None:

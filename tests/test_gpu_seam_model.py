@@ -37,6 +37,8 @@ def test_accelerated_seam_model_vs_oracle(gpu, small, H, W, iters):
         assert isinstance(seam_model.get_corr_block(f, f), CorrBlock)                 # seam B1 is live on this module
         outs = [seam({"images": x.to(gpu)}) for x in xs]
         again = seam({"images": xs[0].to(gpu)})
+        if not small:     # seam B5: the model's own upsample_flow method is shadowed by the kernel after the behaviour probe
+            assert isinstance(seam.upsample_flow, patch._UpsampleSeam) and seam.upsample_flow.ok is True
     finally:
         patch.restore(seam)
     for o, r in zip(outs, refs):
@@ -48,6 +50,34 @@ def test_accelerated_seam_model_vs_oracle(gpu, small, H, W, iters):
         assert ms <= 1e-3
     # pair 1 again after pair 2: every op on this path is libpfk's or an elementwise torch op -> bit-identical
     assert torch.equal(again["flows"], outs[0]["flows"])
+
+
+def test_upsample_seam_dispatches_by_behaviour(gpu):
+    """Seam B5 replaces `model.upsample_flow` only if the model's method agrees with the kernel on a probe: a method that computes
+    something else (here: a x4 factor) keeps running its own code; gradient-carrying and CPU calls always do."""
+    from ptlflow_amd import patch
+    from ptlflow_amd.seam_model import SeamRAFT, convex_upsample_torch
+
+    class Odd(SeamRAFT):
+        def upsample_flow(self, flow, mask):
+            return 0.5 * convex_upsample_torch(flow, mask)
+
+    g = torch.Generator().manual_seed(2)
+    flow, mask = torch.randn(1, 2, 6, 9, generator=g).to(gpu), torch.randn(1, 576, 6, 9, generator=g).to(gpu)
+    for cls, expect in ((SeamRAFT, True), (Odd, False)):
+        m = cls(iters=1).eval().to(gpu)
+        want = m.upsample_flow(flow, mask)
+        patch.accelerate(m)
+        try:
+            got = m.upsample_flow(flow, mask)
+            assert m.upsample_flow.ok is expect
+            assert float((got - want).abs().max()) <= 1e-5
+            # a gradient graph goes to the original
+            fg = flow.clone().requires_grad_(True)
+            assert m.upsample_flow(fg, mask).requires_grad
+        finally:
+            patch.restore(m)
+        assert "upsample_flow" not in m.__dict__
 
 
 def test_seam_model_unpatched_gpu_is_the_torch_path(gpu):
