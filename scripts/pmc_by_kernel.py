@@ -11,9 +11,9 @@ for d in dirs:
             n = r["Kernel_Name"]
             if match and not any(m in n for m in match):
                 continue
-            a = acc[n[:70]][r["Counter_Name"]]
+            a = acc[n[:110]][r["Counter_Name"]]
             a[0] += float(r["Counter_Value"]); a[1] += 1
-            a = acc[n[:70]]["_dur_us"]
+            a = acc[n[:110]]["_dur_us"]
             a[0] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3; a[1] += 1
 for n, cs in acc.items():
     print(n)
