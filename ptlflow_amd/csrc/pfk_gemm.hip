@@ -1075,6 +1075,8 @@ int launch_cfg(const GemmArgs& a, int epi, int batches, hipStream_t st) {
 }
 
 int g_force_tile = -1;  // debug/tuning knob, see pfk_debug_set_tile
+int g_small_swizzled = 0;   // tuning knob (pfk_debug_set_tile(301)): small grids on the 48 KB swizzled layout too, so that a block of a
+                            // concurrently running launch (forked branches) still fits next to two of them on a CU
 
 // Configurations: 0-3 = v1 (64x64, 64x128, 128x128, 128x64); 4-7 = v3 one group, same tiles;
 // 8 = v3 two groups 64x64 (in-block split-K); 9 = stream-K on 64x64 tiles (needs a workspace); 10 = cfg 4 on swizzled LDS.
@@ -1112,6 +1114,7 @@ int launch(const GemmArgs& a0, int epi, int batches, hipStream_t st) {
     // accumulators and 32 MFMAs per wave and barrier, 12 instead of 16 B/clk/CU of operand traffic) beat 64x64 x3 where the
     // output width is a multiple of 128 and the grid still has >= 3 rounds of them: fh|mask conv1 526 -> 513 us (129 TFLOP/s),
     // z|r convs 457..528 -> 436 us, convc1 108 -> 101 us; they lose on cout 192 / 126 / 576 (padding) and cout 128 (one column).
+    if (g_small_swizzled && (cfg == 4 || cfg == 0)) cfg = 10;
     if (cfg == 10 && batches == 1 && a.b_rows >= 256 && (a.b_rows & 127) == 0 && tiles64 * (a.b_rows / 128) >= 6 * 256 &&
         a.sk_steps >= 8)
       cfg = 11;
@@ -1217,6 +1220,8 @@ int desc_to_args(const pfk_conv_desc* d, GemmArgs& a, int kpad) {
 extern "C" {
 
 void pfk_debug_set_tile(int cfg) {
+  if (cfg >= 300) { g_small_swizzled = cfg - 300; return; }      // 301: small grids on the swizzled layout, 300: off
+  if (cfg >= 200) { g_sk_variant = cfg - 200; return; }          // 200 + v: stream-K schedule variant (launch_sk)
   if (cfg >= 100) g_bf_cfg = cfg - 100;   // split-bf16 tile configuration (0 = heuristic)
   else { g_force_tile = cfg; if (cfg < 0) g_bf_cfg = 0; }
 }

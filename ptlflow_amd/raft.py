@@ -122,7 +122,7 @@ def _param_tree(shapes: Dict[str, tuple]) -> nn.Module:
 class RAFT(nn.Module):
     def __init__(self, corr_levels: int = 4, corr_radius: Optional[int] = None, iters: int = 32, small: bool = False,
                  upsample_every_iter: bool = True, conv_precision: str = "fp32", native_encoders: bool = True,
-                 alternate_corr: bool = False, use_graph: Optional[bool] = None, overlap_mask_head: bool = True,
+                 alternate_corr: bool = False, use_graph: bool = False, overlap_mask_head: bool = True,
                  fork_branches: Optional[bool] = None):
         super().__init__()
         self.small = small
@@ -137,10 +137,12 @@ class RAFT(nn.Module):
         self._side_streams: Dict[tuple, torch.cuda.Stream] = {}
         # True: the 32-iteration loop (lookup, update block, upsampling: ~20 launches per iteration) is captured once per
         # input shape into a hipGraph (torch.cuda.CUDAGraph) and replayed — it runs entirely on buffers with fixed addresses —
-        # with the independent branches of an iteration forked onto concurrent graph branches (`_iterate_forked`).  Pays in
-        # the small-grid regime (batch 1: 110..880-tile launches on 256 CUs); models with the materialised volume only (no GMA
-        # aggregate, no alternate_corr).  None (default): automatically below 28160 grid pixels (4 x 55x128), the regime it was
-        # measured to pay in; the first forward of a shape runs eagerly and records, later ones replay (bit-identical).
+        # with the independent branches of an iteration forked onto concurrent graph branches (`_iterate_forked`); models with the
+        # materialised volume only (no GMA aggregate, no alternate_corr).  The first forward of a shape runs eagerly and records,
+        # later ones replay (bit-identical).  Opt-in: measured on MI355X / ROCm 7 at batch 1 of 436x1024 (round 3) it buys
+        # nothing — 19.04 ms replayed vs 19.06 ms eager: the loop is execution-bound, kernel-to-kernel dependency gaps are the same
+        # inside a graph, and forked graph branches did not run concurrently (19.19 ms); eager forks on real streams gained
+        # 0.3 ms only once every block was 48 KB (three per CU), which itself costs 0.5 ms.
         self.use_graph = use_graph
         self.max_graphs = 4          # recorded shapes kept (oldest dropped first): each holds its loop buffers and pyramid
         self._graphs: Dict[tuple, dict] = {}
@@ -324,9 +326,8 @@ class RAFT(nn.Module):
         h, w = image1.shape[-2] // 8, image1.shape[-1] // 8
         eng = self.engine(x.device)
         eng.bind(B, h, w)
-        want_graph = self.use_graph if self.use_graph is not None else B * h * w < 28160
         # (per-launch HIP-event instrumentation — bench.py's roofline leg — needs real launches)
-        graphable = want_graph and not self.spec.aggregate and not self.alternate_corr and eng.profile is None
+        graphable = self.use_graph and not self.spec.aggregate and not self.alternate_corr and eng.profile is None
         # everything the recorded launch sequence depends on besides the buffers' addresses
         gkey = (B, h, w, x.device, self.iters, self.upsample_every_iter, self.corr_levels, self.corr_radius)
         st = self._graphs.get(gkey) if graphable else None
