@@ -256,7 +256,17 @@ def train_leg(dev, batch=10, H=368, W=496, iters=12, steps=4, warmup=2):
         opt.zero_grad(set_to_none=True)
 
     enc = timed(enc_only, 1, 3)
+    launches = None
+    try:     # kernel launches of one whole step (forward, loss, backward, clip, optimizer), counted by the profiler on an extra step
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            step()
+            torch.cuda.synchronize()
+        launches = sum(1 for e in prof.events() if str(getattr(e, "device_type", "")).endswith("CUDA"))
+    except Exception:
+        pass
     return {"value": batch / sec, "unit": "samples/s", "ms_per_step": 1e3 * sec, "loss": float(last["loss"]),
+            "launches_per_step": launches,
             "encoders_fwd_bwd_ms": 1e3 * enc, "encoder_share": enc / sec,
             "encoders_on": "libpfk" if model.native_encoders else "torch/MIOpen",
             "config": f"raft train step, batch {batch}, {H}x{W}, {iters} iterations, fp32, sequence loss + backward + clip 1.0 + AdamW; "
@@ -377,14 +387,20 @@ def main():
             achieved = s["gflop_per_launch"] / (s["avg_us"] * 1e-6) / 1e3  # TFLOP/s
             traffic = None
             try:   # PMC counters cannot be read from inside this process: take the committed rocprofv3 figures if they cover this launch
-                rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["entries"].get(f"{dom.rstrip('12')}@b{args.batch}")
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+                rec = pmc["entries"].get(f"{dom.rstrip('12')}@b{args.batch}")
                 if rec and (args.height, args.width, small) == (436, 1024, False):
-                    # MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports half the bytes of 16-B/lane coalesced reads
-                    # (what this kernel issues) -> doubled; WRITE_SIZE taken as reported (KB)
+                    import hashlib
+                    h = hashlib.sha256()
+                    for f in ("pfk_gemm.hip", "pfk_gemm.h"):
+                        h.update(open(os.path.join(ROOT, "ptlflow_amd", "csrc", f), "rb").read())
+                    # MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports half the bytes of the 128-byte requests these kernels
+                    # cause (calibrated in profiles/r03_b) -> doubled; WRITE_SIZE taken as reported (KB)
                     traffic = {"bytes": (2 * rec["fetch_kb"] + rec["write_kb"]) * 1024,
                                "algorithmic_bytes": int(s["bytes_per_launch"]) if s.get("bytes_per_launch") else None,
-                               "source": "profiles/pmc_traffic.json (rocprofv3 FETCH_SIZE x2 [gfx950 correction] + WRITE_SIZE, "
-                                         "separate --pmc passes of this command)"}
+                               "stale": h.hexdigest()[:16] != pmc.get("kernel_source_sha16"),
+                               "source": "profiles/pmc_traffic.json (rocprofv3 TCC_EA0_RDREQ x 128 B / FETCH_SIZE x2 + WRITE_SIZE, separate "
+                                         "--pmc passes; `stale`: the kernel sources changed since that measurement)"}
             except Exception:
                 pass
             result["roofline"] = {"kernel": f"conv_gemm_kernel[{dom}]", "bound": "mfma", "achieved": achieved,

@@ -56,7 +56,7 @@ enum pfk_status {
 };
 
 #define PFK_MAX_LEVELS 8
-#define PFK_ABI_VERSION 3
+#define PFK_ABI_VERSION 4
 
 int pfk_abi_version(void);
 const char* pfk_status_string(int status);
@@ -294,11 +294,13 @@ int pfk_conv_wgrad_f32(const pfk_conv_desc* d, const float* dy, int dy_ld, float
 /* The same weight gradient delivered in PyTorch's layouts (what autograd accumulates): dw [cout_real][cin][kh][kw] with cin =
  * sum of real_channels[s] (the sources' real channels in order; real_channels[s] <= src[s].channels, the rest being the
  * buffers' zero padding) and db [cout_real] (NULL: no bias gradient).  d->cout is dy's channel count (a multiple of 4, >=
- * cout_real).  The slice reduction writes them directly — no packed intermediate, no un-packing copies.  workspace:
+ * cout_real).  The slice reduction writes them directly — no packed intermediate, no un-packing copies.  accumulate != 0:
+ * dw / db += the gradient (the recurrent iterations of a training step add into one buffer per parameter instead of leaving
+ * eleven additions per parameter to the autograd engine); 0: overwrite.  workspace:
  * pfk_conv_wgrad_unpacked_workspace_bytes(d, db != NULL) bytes, always required. */
 long long pfk_conv_wgrad_unpacked_workspace_bytes(const pfk_conv_desc* d, int with_bias);
 int pfk_conv_wgrad_unpacked_f32(const pfk_conv_desc* d, const int* real_channels, const float* dy, int dy_ld, int cout_real,
-                                float* dw, float* db, void* workspace, long long workspace_bytes, pfk_stream_t stream);
+                                float* dw, float* db, int accumulate, void* workspace, long long workspace_bytes, pfk_stream_t stream);
 
 /* Gate arithmetic of one ConvGRU / SepConvGRU pass for the training path (raft/update.py:24-32, 58-73), pixel-major
  * [M][C] tensors, C % 4 == 0; z, r, rh, q, h_new, da_q, dh are contiguous [M][C], a_zr / da_zr contiguous [M][2C]

@@ -419,7 +419,7 @@ void conv_stem(const Tensor& img, const Tensor& weight, const c10::optional<Tens
 
 // weight / bias gradient in PyTorch's layouts: dw [cout, sum(reals), kh, kw], db [cout] (optional); dy [B*Ho*Wo, cout4]
 void conv_wgrad_unpacked(at::TensorList srcs, const Tensor& dy, int64_t B, int64_t H, int64_t W, int64_t kh, int64_t kw, Tensor dw,
-                         const c10::optional<Tensor>& db, at::IntArrayRef reals, int64_t stride) {
+                         const c10::optional<Tensor>& db, at::IntArrayRef reals, int64_t stride, bool accumulate) {
   OpScope scope(dy);
   TORCH_CHECK(srcs.size() >= 1 && srcs.size() <= 3 && reals.size() == srcs.size(), "conv_wgrad_unpacked: 1..3 sources, one real count each");
   check_pm(dy, "dy"); check_dev_f32(dw, "dw");
@@ -449,8 +449,8 @@ void conv_wgrad_unpacked(at::TensorList srcs, const Tensor& dy, int64_t B, int64
   }
   const long long need = pfk_conv_wgrad_unpacked_workspace_bytes(&d, dbp != nullptr);
   Tensor ws = at::empty({(int64_t)need}, dy.options().dtype(at::kByte));
-  check_ok(pfk_conv_wgrad_unpacked_f32(&d, real, fptr(dy), dy.stride(0), (int)dw.size(0), fptr(dw), dbp, ws.data_ptr(), need,
-                                       cur_stream()), "conv_wgrad_unpacked");
+  check_ok(pfk_conv_wgrad_unpacked_f32(&d, real, fptr(dy), dy.stride(0), (int)dw.size(0), fptr(dw), dbp, accumulate ? 1 : 0,
+                                       ws.data_ptr(), need, cur_stream()), "conv_wgrad_unpacked");
 }
 
 int64_t instnorm_workspace_bytes(int64_t B, int64_t C) { return pfk_instnorm_workspace_bytes((int)B, (int)C); }
@@ -606,7 +606,7 @@ TORCH_LIBRARY(pfk, m) {
   m.def("gru_backward_q(Tensor dh_new, Tensor z, Tensor q, Tensor h, Tensor(a!) da_q, Tensor(b!) da_zr, Tensor(c!) dh) -> ()");
   m.def("gru_backward_zr(Tensor d_rh, Tensor h, Tensor r, Tensor(a!) da_zr, Tensor(b!) dh) -> ()");
   m.def("conv_wgrad(Tensor[] srcs, Tensor dy, int B, int H, int W, int kh, int kw, Tensor(a!) out, bool with_bias=False, int stride=1) -> ()");
-  m.def("conv_wgrad_unpacked(Tensor[] srcs, Tensor dy, int B, int H, int W, int kh, int kw, Tensor(a!) dw, Tensor(b!)? db, int[] reals, int stride=1) -> ()");
+  m.def("conv_wgrad_unpacked(Tensor[] srcs, Tensor dy, int B, int H, int W, int kh, int kw, Tensor(a!) dw, Tensor(b!)? db, int[] reals, int stride=1, bool accumulate=False) -> ()");
   m.def("forward_interpolate(Tensor flow, Tensor(a!) out) -> ()");
   m.def("softmax_rows(Tensor(a!) x) -> ()");
   m.def("norm_bwd(Tensor x, Tensor dy, Tensor mean, Tensor rstd, Tensor(a!) dx, Tensor(b!) sum_g, Tensor(c!) sum_gxhat, int B, int HW, bool relu) -> ()");

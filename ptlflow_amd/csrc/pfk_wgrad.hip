@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // needs no per-call permute / copy kernels between the weight-gradient launch and autograd's accumulation.
 struct UnpackArgs {
   const float* part; long long n; int splits;
-  int ktot, cout_real, taps, nseg, cin_total, with_bias;
+  int ktot, cout_real, taps, nseg, cin_total, with_bias, accumulate;
   int first[3], nreal[3], cpad[3];
   float* dw; float* db;
 };
@@ -191,13 +191,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_unpack_kernel(const UnpackAr
   for (int j = 1; j < u.splits; ++j) s += u.part[(long long)j * u.n + idx];      // same fixed order as wgrad_reduce_kernel
   int kk = k;
   if (u.with_bias && k >= u.ktot - 32) {
-    if (k == u.ktot - 32 && u.db) u.db[co] = s;
+    if (k == u.ktot - 32 && u.db) u.db[co] = u.accumulate ? u.db[co] + s : s;
     return;
   }
   int sg = 0;
   while (sg < u.nseg - 1 && kk >= u.taps * u.cpad[sg]) { kk -= u.taps * u.cpad[sg]; ++sg; }
   const int tap = kk / u.cpad[sg], c = kk - tap * u.cpad[sg];
-  if (c < u.nreal[sg]) u.dw[((long long)co * u.cin_total + u.first[sg] + c) * u.taps + tap] = s;
+  if (c < u.nreal[sg]) {
+    float* dst = u.dw + ((long long)co * u.cin_total + u.first[sg] + c) * u.taps + tap;
+    *dst = u.accumulate ? *dst + s : s;     // (one thread per element: the running sum's order is the order of the calls)
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -393,7 +396,7 @@ long long pfk_conv_wgrad_unpacked_workspace_bytes(const pfk_conv_desc* d, int wi
 }
 
 int pfk_conv_wgrad_unpacked_f32(const pfk_conv_desc* d, const int* real_channels, const float* dy, int dy_ld, int cout_real,
-                                float* dw, float* db, void* workspace, long long workspace_bytes, pfk_stream_t stream) {
+                                float* dw, float* db, int accumulate, void* workspace, long long workspace_bytes, pfk_stream_t stream) {
   if (!dw || !real_channels || !workspace || cout_real <= 0 || !d || cout_real > d->cout) return PFK_ERR_BAD_ARG;
   if (!pfk_aligned16(workspace)) return PFK_ERR_ALIGNMENT;
   const int with_bias = db != nullptr;
@@ -406,7 +409,7 @@ int pfk_conv_wgrad_unpacked_f32(const pfk_conv_desc* d, const int* real_channels
   a.part = static_cast<float*>(workspace);
   UnpackArgs u{};
   u.part = a.part; u.n = n; u.splits = splits; u.ktot = a.ktot; u.cout_real = cout_real; u.taps = d->kh * d->kw;
-  u.nseg = d->num_src; u.with_bias = with_bias; u.dw = dw; u.db = db;
+  u.nseg = d->num_src; u.with_bias = with_bias; u.dw = dw; u.db = db; u.accumulate = accumulate != 0;
   int first = 0;
   for (int i = 0; i < d->num_src; ++i) {
     if (real_channels[i] <= 0 || real_channels[i] > d->src[i].channels) return PFK_ERR_BAD_ARG;

@@ -291,7 +291,8 @@ class RAFT(nn.Module):
             coords1 = coords1.detach()
             corr_pm = corr_fn.lookup_pm(coords1)
             fpm = (coords1 - coords0).permute(0, 2, 3, 1).reshape(M, 2)
-            hpm, mask_pm, delta_pm = update_block_train_pm(P, self.spec, hpm, ipm, corr_pm, fpm, B, h, w, cache)
+            hpm, mask_pm, delta_pm = update_block_train_pm(P, self.spec, hpm, ipm, corr_pm, fpm, B, h, w, cache,
+                                                           accumulate_wgrad=True)      # `cache` lives for this step only
             coords1 = coords1 + delta_pm.view(B, h, w, 2).permute(0, 3, 1, 2)
             flow = coords1 - coords0
             if mask_pm is not None:

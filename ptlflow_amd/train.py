@@ -67,21 +67,64 @@ _workspace.cache = {}
 
 class ConvPacks:
     """Packed forms of one convolution weight (forward and per-source dgrad), built lazily and reused for as long as the
-    parameter versions in ``key`` do not change — i.e. for all recurrent iterations of a training step."""
-    __slots__ = ("key", "fwd", "dgrad")
+    parameter versions in ``key`` do not change — i.e. for all recurrent iterations of a training step.
 
-    def __init__(self, key=None):
+    ``acc``: gradient accumulators of a step-scoped entry (`packs_for(..., accumulate=True)`): the weight-gradient launches of
+    all recurrent uses add into ONE buffer per parameter (`pfk_conv_wgrad_unpacked_f32(accumulate=1)`) and a `_Flush` node
+    hands the total to autograd once — instead of every use returning its own gradient and the engine adding them (eleven
+    small additions per parameter and step at 12 iterations)."""
+    __slots__ = ("key", "fwd", "dgrad", "accumulate", "acc", "alias", "extra")
+
+    def __init__(self, key=None, accumulate=False):
         self.key, self.fwd, self.dgrad = key, None, {}
+        self.accumulate = accumulate
+        self.acc = None          # {position among the parameters given to _Flush: accumulator}, None before the first use
+        self.alias = None        # the parameters as seen by the uses of this step (outputs of _Flush)
+        self.extra = {}          # per-step derived tensors (the z|r weight concatenation)
 
 
-def packs_for(cache: Optional[dict], name: str, params: Sequence[torch.Tensor]) -> ConvPacks:
+def packs_for(cache: Optional[dict], name: str, params: Sequence[torch.Tensor], accumulate: bool = False) -> ConvPacks:
+    """``accumulate=True`` only for a ``cache`` that lives for ONE forward / backward (the mirror's training forward creates a
+    fresh dict per step): the accumulators belong to that step's graph."""
     key = tuple((p.data_ptr(), p._version) for p in params)
     if cache is None:
         return ConvPacks(key)
     entry = cache.get(name)
     if entry is None or entry.key != key:
-        entry = cache[name] = ConvPacks(key)
+        entry = cache[name] = ConvPacks(key, accumulate)
     return entry
+
+
+class _Flush(torch.autograd.Function):
+    """Identity on a group of parameters whose uses accumulate their gradients in ``packs.acc`` (and return None): this node
+    sits between the parameters and ALL their uses, so the engine runs its backward after the last use — whatever the order,
+    however many uses — and it hands the totals on.  (Uses that never ran simply did not contribute; nothing is counted.)"""
+
+    @staticmethod
+    def forward(ctx, packs, *params):
+        ctx.set_materialize_grads(False)
+        ctx.packs = packs
+        return tuple(p.view_as(p) for p in params)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        acc, ctx.packs.acc = ctx.packs.acc, None
+        out = []
+        for i, g in enumerate(grads):          # accumulated total, plus whatever a use returned the ordinary way
+            a = None if acc is None else acc.get(i)
+            out.append(a if g is None else (g if a is None else a + g))
+        return (None, *out)
+
+
+def step_params(packs: ConvPacks, *params):
+    """The parameters as the uses of this step see them: aliases behind one `_Flush` node (accumulating entries) or themselves."""
+    if not packs.accumulate or not any(p is not None and p.requires_grad for p in params) or not torch.is_grad_enabled():
+        return params
+    if packs.alias is None:
+        real = [p for p in params if p is not None]
+        out = iter(_Flush.apply(packs, *real))
+        packs.alias = tuple(None if p is None else next(out) for p in params)
+    return packs.alias
 
 
 class _ConvPM(torch.autograd.Function):
@@ -135,7 +178,16 @@ class _ConvPM(torch.autograd.Function):
         # PyTorch's [cout, cin, kh, kw] / [cout] layouts directly (pfk_conv_wgrad_unpacked_f32), the bias gradient being one more
         # K chunk whose A operand is a column of ones
         want_b = ctx.has_bias and need[1]
-        if need[0]:
+        if need[0] and packs.accumulate and packs.alias is not None:
+            # step-scoped entry: add into the parameter's accumulators; `_Flush` returns the totals once (weight, [bias])
+            first = packs.acc is None
+            if first:
+                packs.acc = {0: torch.empty(weight.shape, device=dY.device, dtype=torch.float32)}
+                if want_b:
+                    packs.acc[1] = torch.empty(cout, device=dY.device, dtype=torch.float32)
+            ops.conv_wgrad_unpacked(list(srcs), dY_src, g.B, g.H, g.W, g.kh, g.kw, packs.acc[0], packs.acc.get(1),
+                                    [n for _, n, _ in segs], g.stride, not first)
+        elif need[0]:
             dW = torch.empty(weight.shape, device=dY.device, dtype=torch.float32)
             db = torch.empty(cout, device=dY.device, dtype=torch.float32) if want_b else None
             ops.conv_wgrad_unpacked(list(srcs), dY_src, g.B, g.H, g.W, g.kh, g.kw, dW, db, [n for _, n, _ in segs], g.stride)
@@ -192,8 +244,10 @@ class _GruPass(torch.autograd.Function):
         M, C = h.shape
         dev = h.device
         ws = _workspace(dev)
-        wzr = torch.cat([wz.detach(), wr.detach()], 0).float()
-        bzr = torch.cat([bz.detach(), br.detach()], 0).float().contiguous()
+        if "wzr" not in pk_zr.extra:      # once per (parameter version): the z and r convolutions run as one
+            pk_zr.extra["wzr"] = torch.cat([wz.detach(), wr.detach()], 0).float()
+            pk_zr.extra["bzr"] = torch.cat([bz.detach(), br.detach()], 0).float().contiguous()
+        wzr, bzr = pk_zr.extra["wzr"], pk_zr.extra["bzr"]
         segs = [(0, C, C), (C, x_real, x.shape[1])]
         a_zr = torch.empty(M, 2 * C, device=dev, dtype=torch.float32)
         ops.conv2d([h, x], g.B, g.H, g.W, g.kh, g.kw, _fwd_pack(pk_zr, wzr, segs), bzr, 2 * C, EPI_LINEAR, False, 1.0, a_zr,
@@ -239,6 +293,18 @@ class _GruPass(torch.autograd.Function):
         dh = dgrad(da_zr, pk_zr, wzr, 0, C, residual=dh)          # + dh through the epilogue
         dx = dgrad(da_zr, pk_zr, wzr, 1, Cx, residual=dx)
         reals = [n for _, n, _ in segs]
+        if pk_zr.accumulate and pk_zr.alias is not None and pk_q.alias is not None:
+            # step-scoped entries: every pass of every iteration adds into one buffer per parameter; `_Flush` returns the totals
+            first = pk_q.acc is None
+            if first:
+                dwq, dbq = torch.empty(wq.shape, device=dev, dtype=torch.float32), torch.empty(C, device=dev, dtype=torch.float32)
+                dwzr, dbzr = torch.empty(wzr.shape, device=dev, dtype=torch.float32), torch.empty(2 * C, device=dev, dtype=torch.float32)
+                pk_q.acc = {0: dwq, 1: dbq}
+                pk_zr.extra["dwzr"], pk_zr.extra["dbzr"] = dwzr, dbzr
+                pk_zr.acc = {0: dwzr[:C], 1: dwzr[C:], 2: dbzr[:C], 3: dbzr[C:]}      # (wz, wr, bz, br) as given to _Flush
+            ops.conv_wgrad_unpacked([rh, x], da_q, g.B, g.H, g.W, g.kh, g.kw, pk_q.acc[0], pk_q.acc[1], reals, 1, not first)
+            ops.conv_wgrad_unpacked([h, x], da_zr, g.B, g.H, g.W, g.kh, g.kw, pk_zr.extra["dwzr"], pk_zr.extra["dbzr"], reals, 1, not first)
+            return (dh, dx, None, None, None, None, None, None, None, None, None, None)
         dwq, dbq = torch.empty(wq.shape, device=dev, dtype=torch.float32), torch.empty(C, device=dev, dtype=torch.float32)
         ops.conv_wgrad_unpacked([rh, x], da_q, g.B, g.H, g.W, g.kh, g.kw, dwq, dbq, reals, 1)
         dwzr, dbzr = torch.empty(wzr.shape, device=dev, dtype=torch.float32), torch.empty(2 * C, device=dev, dtype=torch.float32)
@@ -257,7 +323,9 @@ def conv_pm(srcs: Sequence[torch.Tensor], weight: torch.Tensor, bias: Optional[t
     real = tuple(int(s.shape[1]) for s in srcs) if real is None else tuple(real)
     assert sum(real) == weight.shape[1], (real, tuple(weight.shape))
     g = _Geometry(B, H, W, weight.shape[2], weight.shape[3], int(stride))
-    return _ConvPM.apply(weight, bias, g, relu, real, packs if packs is not None else ConvPacks(), *srcs)
+    packs = packs if packs is not None else ConvPacks()
+    weight, bias = step_params(packs, weight, bias)
+    return _ConvPM.apply(weight, bias, g, relu, real, packs, *srcs)
 
 
 # --------------------------------------------------------------------------------------------------------------------
@@ -277,15 +345,18 @@ def _pad4(x: torch.Tensor) -> torch.Tensor:
     return x if c % 4 == 0 else F.pad(x, (0, round_up(c, 4) - c))
 
 
-def update_block_train_pm(P: Dict[str, torch.Tensor], spec, h, i, c, f, B: int, H: int, W: int, cache: Optional[dict] = None):
+def update_block_train_pm(P: Dict[str, torch.Tensor], spec, h, i, c, f, B: int, H: int, W: int, cache: Optional[dict] = None,
+                          accumulate_wgrad: bool = False):
     """BasicUpdateBlock.forward / SmallUpdateBlock.forward (update.py:144-153 / :122-128) with every convolution on
     ``conv_pm``, on pixel-major tensors: ``h`` [M, Ch], ``i`` [M, Ci], ``c`` [M, corr channels], ``f`` [M, 2] ->
     ``(h', mask [M, 576] | None, delta [M, 2])``.  ``P``: the block's named parameters; ``cache``: a dict that keeps the packed
-    weights between the recurrent calls of one training step."""
+    weights between the recurrent calls of one training step.  ``accumulate_wgrad`` (only with a ``cache`` that is created per
+    step): the recurrent calls add their weight gradients into one buffer per parameter (`ConvPacks.acc`, `_Flush`)."""
+    acc = accumulate_wgrad and cache is not None
 
     def conv(srcs, name, relu=False, real=None):
         w = P[name + ".weight"]
-        return conv_pm(srcs, w, P.get(name + ".bias"), B, H, W, relu, real, packs_for(cache, name, [w]))
+        return conv_pm(srcs, w, P.get(name + ".bias"), B, H, W, relu, real, packs_for(cache, name, [w], acc))
 
     # motion encoder (update.py:104-112 / :85-91)
     cor = conv([_pad4(c)], "encoder.convc1", True, [c.shape[1]])
@@ -294,16 +365,28 @@ def update_block_train_pm(P: Dict[str, torch.Tensor], spec, h, i, c, f, B: int, 
     flo = conv([_pad4(f)], "encoder.convf1", True, [2])
     flo = conv([flo], "encoder.convf2", True)
     out = conv([cor, flo], "encoder.conv", True)
-    motion = torch.cat([out, f], 1)                      # enc_out + 2
-    x = _pad4(torch.cat([i, motion], 1))
+    # x = [inp | motion features (encoder out | flow) | zero pad to a multiple of 4] in ONE concatenation (update.py:112 + :146)
     x_real = spec.context + spec.motion_channels
+    parts = [i, out, f]
+    if x_real % 4:
+        zkey = ("zpad", i.shape[0], round_up(x_real, 4) - x_real, i.device)
+        z = cache.get(zkey) if cache is not None else None
+        if z is None:
+            z = torch.zeros(i.shape[0], round_up(x_real, 4) - x_real, device=i.device, dtype=torch.float32)
+            if cache is not None:
+                cache[zkey] = z
+        parts.append(z)
+    x = torch.cat(parts, 1)
     # GRU passes (update.py:58-73 / :24-32): one fused autograd node per pass (z and r share a convolution)
     for kh, kw, sfx in spec.gru_passes:
         names = [f"gru.conv{k}{sfx}" for k in "zrq"]
-        h = _GruPass.apply(h, x, *(P[n + ".weight"] for n in names), *(P[n + ".bias"] for n in names),
-                           _Geometry(B, H, W, kh, kw), x_real,
-                           packs_for(cache, "zr" + sfx, [P[names[0] + ".weight"], P[names[1] + ".weight"]]),
-                           packs_for(cache, "q" + sfx, [P[names[2] + ".weight"]]))
+        wz, wr, wq = (P[n + ".weight"] for n in names)
+        bz, br, bq = (P[n + ".bias"] for n in names)
+        pk_zr = packs_for(cache, "zr" + sfx, [wz, wr], acc)
+        pk_q = packs_for(cache, "q" + sfx, [wq], acc)
+        wz, wr, bz, br = step_params(pk_zr, wz, wr, bz, br)
+        wq, bq = step_params(pk_q, wq, bq)
+        h = _GruPass.apply(h, x, wz, wr, wq, bz, br, bq, _Geometry(B, H, W, kh, kw), x_real, pk_zr, pk_q)
     # heads (update.py:6-14, 138-142, 152)
     delta = conv([conv([h], "flow_head.conv1", True)], "flow_head.conv2")
     mask = None

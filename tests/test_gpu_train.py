@@ -146,3 +146,38 @@ def test_training_graph_falls_back_when_asked(gpu):
     x = torch.zeros(1, 128, 8, 8, device=gpu, requires_grad=True)
     with pytest.raises(Exception):       # the parameter holder has no forward of its own
         ub(x, x, torch.zeros(1, 324, 8, 8, device=gpu), torch.zeros(1, 2, 8, 8, device=gpu))
+
+
+def test_wgrad_accumulate_flag_and_flush_node(gpu):
+    """`conv_wgrad_unpacked(accumulate=True)` adds into dw / db; the step-scoped accumulation of the recurrent uses of one
+    parameter (`ConvPacks.acc` + `_Flush`) hands autograd the same total as the per-use gradients it replaces."""
+    import math
+    from ptlflow_amd.train import conv_pm, packs_for
+    ops = torch.ops.pfk
+    g = torch.Generator().manual_seed(4)
+    B, H, W, cin, cout = 2, 11, 17, 36, 40
+    M = B * H * W
+    x = torch.randn(M, cin, generator=g).to(gpu)
+    dy = torch.randn(M, cout, generator=g).to(gpu)
+    dw1, db1 = torch.empty(cout, cin, 3, 3, device=gpu), torch.empty(cout, device=gpu)
+    ops.conv_wgrad_unpacked([x], dy, B, H, W, 3, 3, dw1, db1, [cin], 1)
+    dw2, db2 = dw1.clone(), db1.clone()
+    ops.conv_wgrad_unpacked([x], dy, B, H, W, 3, 3, dw2, db2, [cin], 1, True)
+    assert torch.equal(dw2, dw1 + dw1) and torch.equal(db2, db1 + db1)
+    # three recurrent uses of one weight: accumulating entry vs plain autograd
+    w = (torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(9 * cin)).to(gpu)
+    b = (torch.randn(cout, generator=g) * 0.1).to(gpu)
+    xs = [torch.randn(M, cin, generator=g).to(gpu) for _ in range(3)]
+
+    def grads(accumulate):
+        wp, bp = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        cache = {}
+        loss = 0.0
+        for k, xi in enumerate(xs):
+            y = conv_pm([xi], wp, bp, B, H, W, relu=True, packs=packs_for(cache, "c", [wp], accumulate))
+            loss = loss + (k + 1) * y.square().mean()
+        loss.backward()
+        return wp.grad, bp.grad
+
+    (gw0, gb0), (gw1, gb1) = grads(False), grads(True)
+    assert float((gw1 - gw0).abs().max()) <= 1e-6 * float(gw0.abs().max()) and float((gb1 - gb0).abs().max()) <= 1e-6 * float(gb0.abs().max())
