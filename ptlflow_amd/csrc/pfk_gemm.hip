@@ -86,36 +86,26 @@ struct Stager {
   __device__ __forceinline__ Stager(const GemmArgs& a, long long m0, int n0, int t, long long batch) : Stager(a, t, NoTile{}) {
     // multiplier arithmetic (launch() fills the multipliers) instead of six 64-bit divisions: 640 instructions fewer at the head of
     // every tile — which an A/B on the MI355X priced at 0.3 % (4 % on the 8-step mask conv2): the co-resident blocks hide them
-    retarget<true>(a, m0, n0, batch);
+    retarget(a, m0, n0, batch);
     set_segment(0);
     set_tap();
   }
 
   // Point the stager at output tile (m0, n0) of batch element `batch`: per-row pixel coordinates / base rows, weight-row offsets
-  // and the batch-dependent descriptors.  FAST: 32-bit arithmetic with the host-made multipliers of GemmArgs (M < 2^31 rows is
-  // implied by the 32-bit byte offsets the kernels address their sources with) — the persistent kernels re-target once per tile.
-  template <bool FAST>
+  // and the batch-dependent descriptors.  32-bit arithmetic with the host-made multipliers of GemmArgs (M < 2^31 rows is implied
+  // by the 32-bit byte offsets the kernels address their sources with; launch() / launch_pp() fill the multipliers).
   __device__ __forceinline__ void retarget(const GemmArgs& a, long long m0, int n0, long long batch) {
     rs0 = make_rsrc(a.src0 + batch * a.a_bs);
     rsw = make_rsrc(a.weight + batch * a.b_bs);
 #pragma unroll
     for (int i = 0; i < A_PT; ++i) {
-      if constexpr (FAST) {
-        const unsigned p = (unsigned)m0 + (unsigned)(r0 + 32 * i);
-        pok[i] = (long long)p < a.M;
-        const unsigned prow_o = fastdiv_u32(p, a.wo_mul, a.wo_sh);          // b*Ho + yo
-        const unsigned bimg = fastdiv_u32(prow_o, a.ho_mul, a.ho_sh);
-        px[i] = (int)(p - prow_o * (unsigned)a.Wo) * a.stride;              // input coordinates of the centre tap
-        py[i] = (int)(prow_o - bimg * (unsigned)a.Ho) * a.stride;
-        prow[i] = (int)((bimg * (unsigned)a.H + (unsigned)py[i]) * (unsigned)a.W + (unsigned)px[i]);
-      } else {
-        const long long p = m0 + r0 + 32 * i;
-        pok[i] = p < a.M;
-        const long long prow_o = p / a.Wo;                       // b*Ho + yo
-        px[i] = (int)(p - prow_o * a.Wo) * a.stride;             // input coordinates of the centre tap
-        py[i] = (int)(prow_o % a.Ho) * a.stride;
-        prow[i] = (int)(((prow_o / a.Ho) * a.H + py[i]) * a.W + px[i]);
-      }
+      const unsigned p = (unsigned)m0 + (unsigned)(r0 + 32 * i);
+      pok[i] = (long long)p < a.M;
+      const unsigned prow_o = fastdiv_u32(p, a.wo_mul, a.wo_sh);          // b*Ho + yo
+      const unsigned bimg = fastdiv_u32(prow_o, a.ho_mul, a.ho_sh);
+      px[i] = (int)(p - prow_o * (unsigned)a.Wo) * a.stride;              // input coordinates of the centre tap
+      py[i] = (int)(prow_o - bimg * (unsigned)a.Ho) * a.stride;
+      prow[i] = (int)((bimg * (unsigned)a.H + (unsigned)py[i]) * (unsigned)a.W + (unsigned)px[i]);
     }
 #pragma unroll
     for (int i = 0; i < B_PT; ++i) {
@@ -786,7 +776,7 @@ __device__ __forceinline__ void pp_advance(const GemmArgs& a, Stager<64, 64, LD>
   if (!ps.next(t, s0, s1, rel)) return;     // past the block's last step: the remaining loads are dead (live = false)
   long long m0, batch; int n0;
   pp_decode(a, t, m0, n0, batch);
-  st.template retarget<true>(a, m0, n0, batch);
+  st.retarget(a, m0, n0, batch);
   if (s0) st.seek_args(a, batch, s0); else st.rewind();
   left = s1 - s0;
 }
@@ -842,7 +832,7 @@ __global__ __launch_bounds__(256, BPC) void conv_gemm_pp_kernel(const GemmArgs a
     ps.next(t, s0, s1, rel);
     long long m0, batch; int n0;
     pp_decode(a, t, m0, n0, batch);
-    st.template retarget<true>(a, m0, n0, batch);
+    st.retarget(a, m0, n0, batch);
     if (s0) st.seek_args(a, batch, s0); else st.rewind();
     p_left = s1 - s0;
   }
