@@ -913,6 +913,10 @@ __global__ __launch_bounds__(256, BPC) void conv_gemm_pp_kernel(const GemmArgs a
       }
       epilogue_lds<MT, NT, EPI>(a, acc, m0 + wm0, n0 + wn0, lane, batch, s_fill, wid);
     }
+    // Drain the vector-memory counter HERE, once per tile (the epilogue's stores, the fix-up's loads, the prefetch issued three
+    // steps ago): with stores of unknown count pending at the K loop's entry hipcc waited `vmcnt(0)` inside every K-step instead
+    // of the counted `vmcnt(3)` the tile kernel gets.  (A real S_WAITCNT, which the compiler's counter model sees.)
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) expcnt(7) lgkmcnt(15)
     if (g < total) __syncthreads();   // the epilogue's scratch (s_fill) is the target of the next step's LDS fillers
   }
 }
