@@ -1086,9 +1086,10 @@ int launch(const GemmArgs& a0, int epi, int batches, hipStream_t st) {
   if (g_force_tile >= 0) {
     cfg = g_force_tile;
   } else if (a.b_rows >= 2048 && a.M >= 2048) {
-    cfg = 10;   // big square-ish GEMM with a short K (correlation volume: 8 K-steps, 198 MB of output per pair): the epilogue
-                // dominates, so small tiles with three resident blocks per CU (one storing while two multiply) beat 128x128
-                // (2.05 vs 2.7 ms at batch 8)
+    cfg = 11;   // big square-ish GEMM with a short K (correlation volume: 8 K-steps, 198 MB of output per pair): the epilogue
+                // dominates, so small tiles with several resident blocks per CU (one storing while the others multiply) beat
+                // 128x128 (2.05 vs 2.7 ms at batch 8); round 3: 64x128 on the swizzled layout beats 64x64 x3 — 1815 vs 1868 us at
+                // batch 8 (111.9 TFLOP/s = 0.71), 276 vs 299 us at batch 1 (scripts/corr_bench.py, gpurun_out/r3p_corr.log)
   } else {
     const long long tiles64 = (a.M + 63) / 64;
     const long long blocks64 = tiles64 * ((a.b_rows + 63) / 64);

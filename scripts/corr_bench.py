@@ -31,7 +31,7 @@ for B in (1, 8):
     us = timeit(lambda: ops.corr_volume(f1, f2, 1 / 16.0, vol))
     print(f"K1 fp32 B={B}: {us:.1f} us  {flop/us/1e6:.1f} TFLOP/s ({100*flop/us/1e6/157.3:.1f}% of 157.3)  write {4*B*N*N/us/1e6:.2f} TB/s")
     ref = vol.clone()
-    for cfg in (4, 10, 53, 52, 51, 61, 57):   # v3 64x64 padded / swizzled tile grids; 50+v: persistent pipelined kernel (1 swizzled, 2 XCD groups, 4*bpc)
+    for cfg in (4, 10, 11, 12, 13, 53, 51):   # v3 64x64 padded / swizzled tile grids; 50+v: persistent pipelined kernel (1 swizzled, 2 XCD groups, 4*bpc)
         ops.debug_set_tile(cfg)
         try:
             us = timeit(lambda: ops.corr_volume(f1, f2, 1 / 16.0, vol), n=10)
