@@ -12,17 +12,24 @@
 // with 1..3 blocks per CU, operands from an L2-resident or an HBM-sized array.  Prints MFMA-pipe utilisation per variant:
 // the number the product kernel's 0.80 has to be read against.
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <cstdio>
 #include <vector>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BAR = 1, FR = 2, ST = 4, LD = 8, DMA = 16, FR4 = 32;   // FR4: four fragment sets, each re-read for the NEXT step right after its last use
+constexpr int BAR = 1, FR = 2, ST = 4, LD = 8, DMA = 16, FR4 = 32, AG = 64;   // AG: accumulator in AccVGPRs (inline asm)
+//   // FR4: four fragment sets, each re-read for the NEXT step right after its last use
 constexpr int STAGE = 128 * 32;   // floats: 64 A rows + 64 B rows of 32
 
+// shader-clock cycles (s_memtime) and 100 MHz wall ticks (s_memrealtime) summed over the blocks of a launch: their ratio is the
+// shader clock the chip actually sustained under this loop body
+__device__ unsigned long long g_clk[2];
+
 template <int MODE, int BPC>
-__global__ __launch_bounds__(256, BPC) void probe(const float* __restrict__ src, unsigned src_bytes_mask, float* out, int steps) {
+__global__ __launch_bounds__(256, BPC) void probe(const float* __restrict__ src, unsigned src_bytes_mask, float* out, int steps,
+                                                  unsigned row_stride /* bytes between the 32 rows a piece covers; 128 = one contiguous 4 KB piece */) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r0 = tid >> 3;
@@ -41,6 +48,7 @@ __global__ __launch_bounds__(256, BPC) void probe(const float* __restrict__ src,
   }
   for (int i = tid; i < 3 * STAGE; i += 256) smem[i] = 0.001f * (float)(i & 63);
   __syncthreads();
+  const unsigned long long c0 = clock64(), w0 = wall_clock64();
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -52,8 +60,8 @@ __global__ __launch_bounds__(256, BPC) void probe(const float* __restrict__ src,
   float* s_nxt = smem + STAGE;
   float* s_fill = smem + 2 * STAGE;
   // per-thread global byte offset of its 16 bytes in a 16 KB K-step slab; slabs walk through the source array
-  const unsigned goff_reg = (unsigned)(r0 * 128 + (tid & 7) * 16);
-  const unsigned goff_dma = (unsigned)(r0 * 128 + gcol * 4);
+  const unsigned goff_reg = (unsigned)r0 * row_stride + (unsigned)(tid & 7) * 16u;
+  const unsigned goff_dma = (unsigned)r0 * row_stride + (unsigned)gcol * 4u;
   unsigned slab = (unsigned)(blockIdx.x * 7919u) * 16384u;
   if constexpr ((MODE & FR) != 0) {
     fa0 = *reinterpret_cast<const f32x4*>(s_cur + foff_a + ko[0]);
@@ -80,7 +88,7 @@ __global__ __launch_bounds__(256, BPC) void probe(const float* __restrict__ src,
             const int q = s;
             if constexpr ((MODE & ST) != 0) *reinterpret_cast<f32x4*>(s_fill + (r0 + 32 * q) * 32 + scol) = ra[q];
             if constexpr ((MODE & LD) != 0)
-              ra[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, goff_reg + (unsigned)q * 4096u, sbase, 0));
+              ra[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, goff_reg + (unsigned)q * 32u * row_stride, sbase, 0));
             __builtin_amdgcn_sched_barrier(0);
           }
         }
@@ -94,8 +102,13 @@ __global__ __launch_bounds__(256, BPC) void probe(const float* __restrict__ src,
     for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        if ((kk & 1) == 0) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[s], fb0[s], acc, 0, 0, 0);
-        else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[s], fb1[s], acc, 0, 0, 0);
+        if constexpr ((MODE & AG) != 0) {
+          if ((kk & 1) == 0) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(fa0[s]), "v"(fb0[s]));
+          else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(fa1[s]), "v"(fb1[s]));
+        } else {
+          if ((kk & 1) == 0) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[s], fb0[s], acc, 0, 0, 0);
+          else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[s], fb1[s], acc, 0, 0, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (s == 0 && (MODE & FR)) {     // next sub-step's fragments right after the first MFMA of this one
           const float* base = kk < 3 ? s_cur : s_nxt;
@@ -115,11 +128,11 @@ __global__ __launch_bounds__(256, BPC) void probe(const float* __restrict__ src,
             // wave-uniform LDS base of this wave's 8 rows of piece q; each lane lands at base + lane * 16
             float* dst = s_fill + (q * 32 + wid * 8) * 32;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16,
-                                                     goff_dma + (unsigned)q * 4096u, sbase, 0, 0);
+                                                     goff_dma + (unsigned)q * 32u * row_stride, sbase, 0, 0);
           } else {
             if constexpr ((MODE & ST) != 0) *reinterpret_cast<f32x4*>(s_fill + (r0 + 32 * q) * 32 + scol) = ra[q];
             if constexpr ((MODE & LD) != 0)
-              ra[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, goff_reg + (unsigned)q * 4096u, sbase, 0));
+              ra[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, goff_reg + (unsigned)q * 32u * row_stride, sbase, 0));
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -137,14 +150,22 @@ __global__ __launch_bounds__(256, BPC) void probe(const float* __restrict__ src,
     }
   }
   // keep everything alive
+  if constexpr ((MODE & AG) != 0) asm volatile("s_nop 15\n s_nop 15" ::: "memory");   // MFMA -> accvgpr read hazard is ours with inline asm
   float v = 0.f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) v += acc[r];
 #pragma unroll
   for (int q = 0; q < 4; ++q) v += ra[q][0];
+  if (tid == 0) {
+    atomicAdd(&g_clk[0], clock64() - c0);
+    atomicAdd(&g_clk[1], wall_clock64() - w0);
+  }
   if (v == 123.456f) out[blockIdx.x * 256 + tid] = v + s_cur[tid];
 }
 
+unsigned g_row_stride = 128;
+double g_sustain_s = 0.0;        // > 0: repeat the launch for this long before the timed ones (lets power management settle)
+double g_last_mhz = 0.0;
 template <int MODE, int BPC>
 double run(const float* src, unsigned mask, float* out, int steps) {
   auto kern = probe<MODE, BPC>;
@@ -152,18 +173,30 @@ double run(const float* src, unsigned mask, float* out, int steps) {
   const int grid = 256 * BPC;
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 3 * STAGE * 4, 0, src, mask, out, steps / 4);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 3 * STAGE * 4, 0, src, mask, out, steps / 4, g_row_stride);
   hipDeviceSynchronize();
+  if (g_sustain_s > 0.0) {
+    const auto t0 = std::chrono::steady_clock::now();
+    while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < g_sustain_s) {
+      for (int i = 0; i < 8; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 3 * STAGE * 4, 0, src, mask, out, steps, g_row_stride);
+      hipDeviceSynchronize();
+    }
+  }
+  unsigned long long zero[2] = {0, 0};
+  hipMemcpyToSymbol(HIP_SYMBOL(g_clk), zero, sizeof zero);
   float best = 1e30f;
   for (int rep = 0; rep < 3; ++rep) {
     hipEventRecord(e0);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 3 * STAGE * 4, 0, src, mask, out, steps);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 3 * STAGE * 4, 0, src, mask, out, steps, g_row_stride);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
     hipEventElapsedTime(&ms, e0, e1);
     if (ms < best) best = ms;
   }
+  unsigned long long clk[2];
+  hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_clk), sizeof clk);
+  g_last_mhz = clk[1] ? 100.0 * (double)clk[0] / (double)clk[1] : 0.0;
   const double mfmas = (double)grid * 4 * steps * 16;
   const double tf = mfmas * 4096.0 / (best * 1e-3) / 1e12;
   return tf;
@@ -198,5 +231,25 @@ int main() {
   row<FR | ST | LD>("loads + stores, NO barrier", l2, l2mask, hbm, hbmmask, out, steps);
   row<BAR | FR4>("4 fragment sets (12 MFMAs ahead)", l2, l2mask, hbm, hbmmask, out, steps);
   row<BAR | FR4 | ST | LD>("4 fragment sets + loads + stores", l2, l2mask, hbm, hbmmask, out, steps);
+  row<BAR | FR | AG>("fragment reads, acc in AGPRs", l2, l2mask, hbm, hbmmask, out, steps);
+  row<BAR | FR | ST | LD | AG>("product step, acc in AGPRs", l2, l2mask, hbm, hbmmask, out, steps);
+  // the product kernel's operand rows are not contiguous: 128-byte row pieces at the activation / weight row strides
+  for (unsigned stride : {1552u, 4608u}) {
+    g_row_stride = stride;
+    char name[64];
+    snprintf(name, sizeof name, "product step, rows %u B apart", stride);
+    row<BAR | FR | ST | LD>(name, l2, l2mask, hbm, hbmmask, out, steps);
+  }
+  g_row_stride = 128;
+  // sustained shader clock: the same bodies after 1.5 s of back-to-back launches; MHz = s_memtime / s_memrealtime * 100
+  g_sustain_s = 1.5;
+  printf("sustained (1.5 s of launches first), x3 blocks per CU:\n");
+  { double tf = run<0, 3>(l2, l2mask, out, steps);                  printf("  MFMA chain only        %6.1f TFLOP/s  %7.1f MHz\n", tf, g_last_mhz); }
+  { double tf = run<BAR, 3>(l2, l2mask, out, steps);                printf("  + barrier              %6.1f TFLOP/s  %7.1f MHz\n", tf, g_last_mhz); }
+  { double tf = run<BAR | FR, 3>(l2, l2mask, out, steps);           printf("  + fragment reads       %6.1f TFLOP/s  %7.1f MHz\n", tf, g_last_mhz); }
+  { double tf = run<BAR | FR | ST | LD, 3>(l2, l2mask, out, steps); printf("  product step (L2)      %6.1f TFLOP/s  %7.1f MHz\n", tf, g_last_mhz); }
+  { double tf = run<BAR | FR | ST | LD, 3>(hbm, hbmmask, out, steps); printf("  product step (HBM)     %6.1f TFLOP/s  %7.1f MHz\n", tf, g_last_mhz); }
+  g_sustain_s = 0.0;
+  { double tf = run<BAR | FR | ST | LD, 3>(l2, l2mask, out, steps); printf("  product step, cold     %6.1f TFLOP/s  %7.1f MHz\n", tf, g_last_mhz); }
   return 0;
 }

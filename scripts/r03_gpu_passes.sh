@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 3: the GPU passes behind profiles/r03_a / r03_b (each was one `gpurun -- bash scripts/r03_gpu_passes.sh <pass>` call;
-# logs under gpurun_out/r3<pass>_*).  Usage: bash scripts/r03_gpu_passes.sh b|c|d|e|f|g|h|i|j|k|l|m|n|o
+# logs under gpurun_out/r3<pass>_*).  Usage: bash scripts/r03_gpu_passes.sh b|c|d|e|f|g|h|i|j|k|l|m|n|o|p
 O=$GRAFT_REPO_ROOT/gpurun_out; mkdir -p $O
 case "$1" in
 b)
@@ -120,6 +120,16 @@ o)
   timeout 600 python -m pytest tests/test_gpu_conv_pp.py -m gpu -q --tb=short -x 2>&1 | tail -3
   timeout 600 python scripts/conv_bench.py --batch 8 --cfgs=10,53,69,52,11 --reps 10 --rounds 3 > $O/r3o_conv_b8.log 2>&1; cat $O/r3o_conv_b8.log | cut -c1-420
   timeout 600 python scripts/conv_bench.py --batch 1 --cfgs=-1,52,53 --reps 20 --rounds 3 > $O/r3o_conv_b1.log 2>&1; cat $O/r3o_conv_b1.log | cut -c1-300
+  ;;
+p)
+  # round 3: does the shader clock hold under the K loop?  probe with s_memtime / s_memrealtime, and rocm-smi polled under the real fm conv
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-value scripts/mfma_probe.hip -o /tmp/mfma_probe 2>&1 | grep -E "error"
+  timeout 400 /tmp/mfma_probe > $O/r3p_probe.log 2>&1; tail -n 16 $O/r3p_probe.log | cut -c1-200
+  ( for i in $(seq 1 60); do rocm-smi --showclocks --showpower 2>/dev/null | grep -E "sclk|Socket Power|mclk" | tr -s ' ' | tr '\n' ';'; echo; sleep 0.25; done ) > $O/r3p_smi.log 2>&1 &
+  SMI=$!
+  timeout 300 python scripts/conv_bench.py --batch 8 --cfgs=10,11 --reps 200 --rounds 3 --only fm > $O/r3p_conv_b8.log 2>&1; cat $O/r3p_conv_b8.log | cut -c1-300
+  wait $SMI; sort $O/r3p_smi.log | uniq -c | sort -rn | head -8 | cut -c1-250
+  timeout 600 python -m pytest tests/test_gpu_conv_pp.py tests/test_gpu_kernels.py -m gpu -q --tb=short -x -k "volume or corr" 2>&1 | tail -3
   ;;
 *) echo "unknown pass $1"; exit 2;;
 esac
