@@ -302,6 +302,85 @@ __global__ __launch_bounds__(256) void convex_upsample_kernel(const float* __res
   out[(b * 2 + 1) * HW8 + o] = oy;
 }
 
+// The same arithmetic, four coarse pixels per wave: lane = pixel-in-group * 16 + float4 index inside the 64 mask floats of a tap
+// (sy = idx >> 1, sx = 4 * (idx & 1) .. +3), so a tap is ONE 1 KiB load per wave (9 per 4 pixels instead of 36 of 256 bytes) and an
+// output row piece of the group is 128 contiguous bytes.  Every output element runs the scalar kernel's operation sequence
+// (max, exp, sum, one reciprocal, taps in order): the two kernels produce the same bits.  Needs 16-byte aligned mask rows.
+__global__ __launch_bounds__(256) void convex_upsample4_kernel(const float* __restrict__ flow, int flow_ld,
+                                                               const float* __restrict__ mask,
+                                                               int mask_ld, float* __restrict__ out,
+                                                               long long M, int H, int W) {
+  const int lane = threadIdx.x & 63;
+  const long long p = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+  if (p >= M) return;
+  const int idx = lane & 15;
+  const long long hw = (long long)H * W;
+  const long long b = p / hw;
+  const int pix = (int)(p - b * hw);
+  const int y = pix / W, x = pix - y * W;
+  const f32x4* mrow = reinterpret_cast<const f32x4*>(mask + p * mask_ld) + idx;
+  f32x4 m[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) m[k] = mrow[k * 16];
+  float vx[9], vy[9];
+  const float* fx = flow + (b * 2 + 0) * hw;
+  const float* fy = flow + (b * 2 + 1) * hw;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
+    vx[k] = 0.f; vy[k] = 0.f;
+    if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
+      if (flow_ld > 0) {
+        const float* f = flow + (b * hw + (long long)yy * W + xx) * flow_ld;
+        vx[k] = 8.0f * f[0];
+        vy[k] = 8.0f * f[1];
+      } else {
+        vx[k] = 8.0f * fx[yy * W + xx];
+        vy[k] = 8.0f * fy[yy * W + xx];
+      }
+    }
+  }
+  f32x4 ox, oy;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) mx = fmaxf(mx, m[k][c]);
+    float e[9], sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { e[k] = expf(m[k][c] - mx); sum += e[k]; }
+    const float inv = 1.0f / sum;
+    float ax = 0.f, ay = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const float wk = e[k] * inv;
+      ax += wk * vx[k];
+      ay += wk * vy[k];
+    }
+    ox[c] = ax;
+    oy[c] = ay;
+  }
+  const int sy = idx >> 1, sx = (idx & 1) * 4;
+  const long long HW8 = hw * 64;
+  const long long o = (long long)(8 * y + sy) * (8 * W) + 8 * x + sx;
+  *reinterpret_cast<f32x4*>(out + (b * 2 + 0) * HW8 + o) = ox;
+  *reinterpret_cast<f32x4*>(out + (b * 2 + 1) * HW8 + o) = oy;
+}
+
+int launch_convex_upsample(const float* flow, int flow_ld, const float* mask, int mask_ld, float* out, long long M, int H, int W,
+                           hipStream_t st) {
+  if (pfk_aligned16(mask) && pfk_aligned16(out) && (mask_ld & 3) == 0) {
+    const long long blocks = (M + 15) / 16;
+    if (blocks > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(convex_upsample4_kernel, dim3((unsigned)blocks), dim3(256), 0, st, flow, flow_ld, mask, mask_ld, out, M, H, W);
+  } else {
+    const long long blocks = (M + 3) / 4;
+    if (blocks > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(convex_upsample_kernel, dim3((unsigned)blocks), dim3(256), 0, st, flow, flow_ld, mask, mask_ld, out, M, H, W);
+  }
+  return pfk_launch_status();
+}
+
 // 32x32 LDS tile transposes between NCHW ([C][HW] per image) and pixel-major ([HW][ld]).
 __global__ __launch_bounds__(256) void nchw_to_pm_kernel(const float* __restrict__ in,
                                                          float* __restrict__ out, int out_ld,
@@ -489,10 +568,7 @@ int pfk_flow_from_coords_f32(const float* coords0, const float* coords1, float* 
 int pfk_convex_upsample_f32(const float* flow, const float* mask, int mask_ld, float* out, int B,
                             int H, int W, pfk_stream_t stream) {
   if (!flow || !mask || !out || mask_ld < 576 || B <= 0 || H <= 0 || W <= 0) return PFK_ERR_BAD_ARG;
-  const long long M = (long long)B * H * W;
-  hipLaunchKernelGGL(convex_upsample_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), flow, 0, mask, mask_ld, out, M, H, W);
-  return pfk_launch_status();
+  return launch_convex_upsample(flow, 0, mask, mask_ld, out, (long long)B * H * W, H, W, static_cast<hipStream_t>(stream));
 }
 
 int pfk_upflow8_f32(const float* coords0, const float* coords1, float* out, int B, int H, int W, pfk_stream_t stream) {
@@ -508,10 +584,7 @@ int pfk_upflow8_f32(const float* coords0, const float* coords1, float* out, int 
 int pfk_convex_upsample_pm_f32(const float* flow_pm, int flow_ld, const float* mask, int mask_ld, float* out,
                                int B, int H, int W, pfk_stream_t stream) {
   if (!flow_pm || !mask || !out || flow_ld < 2 || mask_ld < 576 || B <= 0 || H <= 0 || W <= 0) return PFK_ERR_BAD_ARG;
-  const long long M = (long long)B * H * W;
-  hipLaunchKernelGGL(convex_upsample_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), flow_pm, flow_ld, mask, mask_ld, out, M, H, W);
-  return pfk_launch_status();
+  return launch_convex_upsample(flow_pm, flow_ld, mask, mask_ld, out, (long long)B * H * W, H, W, static_cast<hipStream_t>(stream));
 }
 
 int pfk_nchw_to_pm_f32(const float* in, float* out, int out_ld, int out_coff, int B, int C, int H,

@@ -287,6 +287,13 @@ def test_convex_upsample(gpu):
     hx[:, 382:384] = pm(flow)
     torch.ops.pfk.convex_upsample_pm(hx[:, 382:384], pm(mask), out2)
     assert torch.equal(out, out2)
+    # rows that are not 16-byte aligned take the one-pixel-per-wave kernel: same operation sequence, same bits as the
+    # four-pixels-per-wave kernel above
+    wide = torch.zeros(B * H * W, 577, device=gpu)
+    wide[:, :576] = pm(mask)
+    out3 = torch.zeros_like(out)
+    torch.ops.pfk.convex_upsample(flow.cuda(), wide[:, :576], out3)
+    assert torch.equal(out, out3)
 
 
 @pytest.mark.parametrize("B,H,W", [(2, 9, 13), (1, 55, 128), (1, 1, 5)])
