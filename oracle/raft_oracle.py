@@ -593,10 +593,11 @@ def sequence_loss(flow_preds: Sequence[Tensor], flow_gt: Tensor, valid: Tensor, 
 
 
 def raft_forward_train(P: Params, images: Tensor, iters: int = 12, small: bool = False, corr_levels: int = 4,
-                       corr_radius: Optional[int] = None) -> List[Tensor]:
+                       corr_radius: Optional[int] = None, gma: bool = False) -> List[Tensor]:
     """RAFT.forward in TRAINING mode (raft.py:125-193, `self.training` branch): differentiable w.r.t. every tensor of
     ``P`` (pass float64 leaves with requires_grad for a float64-autograd gradient oracle); returns ``flow_preds``.
-    `coords1` is detached at the top of every iteration (raft.py:171); BatchNorm (cnet) uses batch statistics."""
+    `coords1` is detached at the top of every iteration (raft.py:171); BatchNorm (cnet) uses batch statistics.
+    ``gma``: GMA.forward's training branch (gma/gma.py:141-214) — one attention map per forward, GMAUpdateBlock."""
     global _BN_TRAIN
     if corr_radius is None:
         corr_radius = 3 if small else 4
@@ -618,11 +619,15 @@ def raft_forward_train(P: Params, images: Tensor, iters: int = 12, small: bool =
     coords1 = coords_grid(B, h, w, x.dtype)
     U = sub(P, "update_block")
     step = small_update_block if small else basic_update_block
+    attn = gma_attention(P, inp, heads=1) if gma else None
     preds = []
     for _ in range(iters):
         coords1 = coords1.detach()
         corr = lookup(pyramid, coords1, corr_radius)
-        net, up_mask, delta = step(U, net, inp, corr, coords1 - coords0)
+        if gma:
+            net, up_mask, delta = gma_update_block(U, net, inp, corr, coords1 - coords0, attn)
+        else:
+            net, up_mask, delta = step(U, net, inp, corr, coords1 - coords0)
         coords1 = coords1 + delta
         flow_up = upflow8(coords1 - coords0) if up_mask is None else convex_upsample(coords1 - coords0, up_mask)
         preds.append(unpad(flow_up, pads))

@@ -253,8 +253,6 @@ class RAFT(nn.Module):
         from .train import convex_upsample, update_block_train_pm
         from .train_encoder import encoder_train
         load_native()
-        if self.spec.aggregate:
-            raise RuntimeError("training mode of the GMA mirror is not implemented (the aggregate branch has no backward kernels)")
         images = inputs["images"]
         if not images.is_cuda:
             raise RuntimeError("ptlflow_amd.RAFT needs GPU inputs (no CPU fallback)")
@@ -284,6 +282,8 @@ class RAFT(nn.Module):
             coords1 = coords1 + fwd
         P = dict(self.update_block.named_parameters())
         cache: dict = {}
+        # GMA (gma.py:176-177): the attention map of the context features, torch ops under autograd (`_Attention.forward`)
+        attention = self.att(inp) if self.spec.aggregate else None
         hpm = net.permute(0, 2, 3, 1).reshape(M, self.hidden_dim)
         ipm = inp.permute(0, 2, 3, 1).reshape(M, self.context_dim)
         preds = []
@@ -292,7 +292,8 @@ class RAFT(nn.Module):
             corr_pm = corr_fn.lookup_pm(coords1)
             fpm = (coords1 - coords0).permute(0, 2, 3, 1).reshape(M, 2)
             hpm, mask_pm, delta_pm = update_block_train_pm(P, self.spec, hpm, ipm, corr_pm, fpm, B, h, w, cache,
-                                                           accumulate_wgrad=True)      # `cache` lives for this step only
+                                                           accumulate_wgrad=True,      # `cache` lives for this step only
+                                                           attention=attention)
             coords1 = coords1 + delta_pm.view(B, h, w, 2).permute(0, 3, 1, 2)
             flow = coords1 - coords0
             if mask_pm is not None:

@@ -346,7 +346,7 @@ def _pad4(x: torch.Tensor) -> torch.Tensor:
 
 
 def update_block_train_pm(P: Dict[str, torch.Tensor], spec, h, i, c, f, B: int, H: int, W: int, cache: Optional[dict] = None,
-                          accumulate_wgrad: bool = False):
+                          accumulate_wgrad: bool = False, attention: Optional[torch.Tensor] = None):
     """BasicUpdateBlock.forward / SmallUpdateBlock.forward (update.py:144-153 / :122-128) with every convolution on
     ``conv_pm``, on pixel-major tensors: ``h`` [M, Ch], ``i`` [M, Ci], ``c`` [M, corr channels], ``f`` [M, 2] ->
     ``(h', mask [M, 576] | None, delta [M, 2])``.  ``P``: the block's named parameters; ``cache``: a dict that keeps the packed
@@ -366,8 +366,14 @@ def update_block_train_pm(P: Dict[str, torch.Tensor], spec, h, i, c, f, B: int, 
     flo = conv([flo], "encoder.convf2", True)
     out = conv([cor, flo], "encoder.conv", True)
     # x = [inp | motion features (encoder out | flow) | zero pad to a multiple of 4] in ONE concatenation (update.py:112 + :146)
-    x_real = spec.context + spec.motion_channels
+    x_real = spec.x_channels
     parts = [i, out, f]
+    if spec.aggregate:
+        mf = torch.cat([out, f], 1)
+        v = conv([mf], "aggregator.to_v")                                        # 1x1, no bias
+        N = H * W
+        agg = torch.bmm(attention.reshape(B, N, N).float(), v.view(B, N, v.shape[1])).reshape(B * N, v.shape[1])
+        parts = [i, mf, mf + P["aggregator.gamma"] * agg]
     if x_real % 4:
         zkey = ("zpad", i.shape[0], round_up(x_real, 4) - x_real, i.device)
         z = cache.get(zkey) if cache is not None else None
