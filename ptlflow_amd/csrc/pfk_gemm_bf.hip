@@ -30,12 +30,14 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int BKB = 32;            // channels per K sub-step (same K order / padding as the fp32 path's packed weight)
 constexpr int ROWB = 64;           // bytes per LDS row: 32 bf16
 
-// 256 threads stage SUB K-sub-steps per barrier: thread t owns channels (t & 3)*8 .. +7 of rows (t >> 2) + 64*i of both
-// operands.  LDS rows are 64 bytes = four 16-byte chunks; chunk' = chunk ^ ((row >> 2) & 3) makes both the
+// TH threads (256 or 512) stage SUB K-sub-steps per barrier: thread t owns channels (t & 3)*8 .. +7 of rows (t >> 2) + RP*i
+// (RP = TH / 4 rows per pass) of both operands.  LDS rows are 64 bytes = four 16-byte chunks; chunk' = chunk ^ ((row >> 2) & 3) makes both the
 // ds_write_b128 (8 lanes = 2 rows) and the fragment ds_read_b128 (MI355X_MICROARCH.md lane groups) conflict-free.
-template <int NS, int BM, int BN, int SUB>
+template <int NS, int BM, int BN, int SUB, int TH = 256, int NSETS = 2>
 struct StagerBF {
-  static constexpr int A_PT = BM / 64, B_PT = BN / 64;
+  static constexpr int RP = TH / 4;
+  static_assert(BM % RP == 0 && BN % RP == 0, "tile rows must be a multiple of the rows staged per pass");
+  static constexpr int A_PT = BM / RP, B_PT = BN / RP;
   static constexpr int A_PLANE = BM * ROWB, B_PLANE = BN * ROWB, SUBSTAGE = NS * (A_PLANE + B_PLANE);
   int H, W, kh, kw, ph, pw, nsrc;
   int ld0, ld1, ld2, ch0, ch1, ch2;
@@ -45,12 +47,14 @@ struct StagerBF {
   int seg = 0, ky = 0, kx = 0, c0 = 0, kofs = 0;
   int pos = 0, total;
   int c8, r0;
-  unsigned sbyte;             // byte offset of this thread's 16-byte chunk inside a plane (row r0; row r0 + 64*i: + i*64*ROWB)
+  unsigned sbyte;             // byte offset of this thread's 16-byte chunk inside a plane (row r0; row r0 + RP*i: + i*RP*ROWB)
   int prow[A_PT], py[A_PT], px[A_PT];
   bool pok[A_PT];
   unsigned abase[A_PT], aoff[A_PT], wvoff[B_PT];
-  f32x4 ra[2][SUB][A_PT][2];   // two register sets: the loads of step j+2 are issued while step j+1's wait to be split
-  u32x4 rb[2][SUB][NS][B_PT];
+  // NSETS = 2: two register sets, the loads of step j+2 are issued while step j+1's wait to be split; NSETS = 1 (the 64x64-wave-tile
+  // configurations, which have no registers to spare): a register is split + stored and then reloaded within the same step
+  f32x4 ra[NSETS][SUB][A_PT][2];
+  u32x4 rb[NSETS][SUB][NS][B_PT];
 
   __device__ __forceinline__ StagerBF(const GemmArgs& a, long long m0, int n0, int t) {
     H = a.H; W = a.W; kh = a.kh; kw = a.kw; ph = a.kh >> 1; pw = a.kw >> 1; nsrc = a.nsrc;
@@ -67,7 +71,7 @@ struct StagerBF {
 #pragma unroll
     for (int i = 0; i < A_PT; ++i) {
       // multiplier arithmetic (launch_bf fills the multipliers; M < 2^31): three instructions per division instead of ~100
-      const unsigned p = (unsigned)m0 + (unsigned)(r0 + 64 * i);
+      const unsigned p = (unsigned)m0 + (unsigned)(r0 + RP * i);
       pok[i] = (long long)p < a.M;
       const unsigned prow_o = fastdiv_u32(p, a.wo_mul, a.wo_sh);            // b*Ho + yo
       const unsigned bimg = fastdiv_u32(prow_o, a.ho_mul, a.ho_sh);
@@ -77,7 +81,7 @@ struct StagerBF {
     }
 #pragma unroll
     for (int i = 0; i < B_PT; ++i) {
-      const int n = n0 + r0 + 64 * i;
+      const int n = n0 + r0 + RP * i;
       wvoff[i] = n < a.b_rows ? (unsigned)(n * a.ktot + c8) * 2u : OOB;
     }
     set_segment(0);
@@ -171,11 +175,11 @@ struct StagerBF {
   // stage layout: [sub-step][A planes 0..NS-1][B planes 0..NS-1], planes [rows][64 B]
   template <int U, int I, int PL>
   __device__ __forceinline__ void store_a(char* stage) const {
-    *reinterpret_cast<u32x4*>(stage + U * SUBSTAGE + PL * A_PLANE + I * 64 * ROWB + sbyte) = pa[PL];
+    *reinterpret_cast<u32x4*>(stage + U * SUBSTAGE + PL * A_PLANE + I * RP * ROWB + sbyte) = pa[PL];
   }
   template <int S, int U, int PL, int I>
   __device__ __forceinline__ void store_b(char* stage) const {
-    *reinterpret_cast<u32x4*>(stage + U * SUBSTAGE + NS * A_PLANE + PL * B_PLANE + I * 64 * ROWB + sbyte) = rb[S][U][PL][I];
+    *reinterpret_cast<u32x4*>(stage + U * SUBSTAGE + NS * A_PLANE + PL * B_PLANE + I * RP * ROWB + sbyte) = rb[S][U][PL][I];
   }
 
   // Unit X of a step, in order per sub-step: B stores | per row chunk: split pieces, A stores | load setup, A loads,
@@ -186,20 +190,21 @@ struct StagerBF {
   template <int S, int X>
   __device__ __forceinline__ void unit(char* other) {
     constexpr int U = X / UNITS_PER_SUB, x = X % UNITS_PER_SUB;
+    constexpr int SL = NSETS == 2 ? S : 0, SS = NSETS == 2 ? 1 - S : 0;     // set that receives the loads / set that is stored
     if constexpr (x < U_BST) {
-      store_b<1 - S, U, x / B_PT, x % B_PT>(other);
+      store_b<SS, U, x / B_PT, x % B_PT>(other);
     } else if constexpr (x < U_BST + U_AST) {
       constexpr int y = x - U_BST, I = y / U_ROW, z = y % U_ROW;
-      if constexpr (z < 2 * NS) split_piece<1 - S, U, I, z / NS, z % NS>();
+      if constexpr (z < 2 * NS) split_piece<SS, U, I, z / NS, z % NS>();
       else store_a<U, I, z - 2 * NS>(other);
     } else if constexpr (x == U_BST + U_AST) {
       load_setup();
     } else if constexpr (x < U_BST + U_AST + 1 + U_ALD) {
       constexpr int y = x - (U_BST + U_AST + 1);
-      load_a<S, U, y / 2, y % 2>();
+      load_a<SL, U, y / 2, y % 2>();
     } else if constexpr (x < U_BST + U_AST + 1 + U_ALD + U_BLD) {
       constexpr int y = x - (U_BST + U_AST + 1 + U_ALD);
-      load_b<S, U, y / B_PT, y % B_PT>();
+      load_b<SL, U, y / B_PT, y % B_PT>();
     } else {
       load_done();
     }
@@ -227,8 +232,8 @@ struct StagerBF {
   }
 };
 
-// Block tile BM x BN, four waves as 2 x 2, wave tile (BM/2) x (BN/2) = MT x NT 32x32 MFMA blocks; two LDS stages of
-// SUB K-sub-steps each.  Big tiles amortise the split (VALU) and the LDS traffic over more MFMAs — per 16-channel
+// Block tile BM x BN, WM x WN waves (2 x 2, or 2 x 4 with 512 threads), wave tile (BM/WM) x (BN/WN) = MT x NT 32x32 MFMA blocks;
+// two LDS stages of SUB K-sub-steps each.  Big tiles amortise the split (VALU) and the LDS traffic over more MFMAs — per 16-channel
 // K-block a wave reads (MT + NT) * NS fragments for MT * NT * NS(NS+1)/2 MFMAs.
 // t-th kept product term a_i * b_j (i + j < NS), smallest first
 template <int NS> constexpr int term_a(int t) {
@@ -249,26 +254,30 @@ template <int NS> constexpr int term_b(int t) {
 // register double-buffered per K-block: the reads of block g+1 are the first fillers of block g; the staging units of
 // StagerBF::unit are spread evenly over all MFMA slots.  Only the first block's fragment reads (right after the
 // barrier) are exposed — the co-resident block's wave covers them.
-template <int EPI, int NS, int BM, int BN, int SUB>
+template <int EPI, int NS, int BM, int BN, int SUB, int WM = 2, int WN = 2, int NSETS = 2>
 struct KStep {
-  using St = StagerBF<NS, BM, BN, SUB>;
-  static constexpr int MT = BM / 64, NT = BN / 64;
+  // fragment registers: double-buffered per K-block, except three planes on 64x64 wave tiles (96 registers would not fit next to
+  // the 64 accumulators): there the next block's fragments are read behind the block's last MFMA and the SIMD's other wave covers
+  // the LDS latency
+  static constexpr int FD = (NS == 3 && WM * WN == 8 && BM / (32 * WM) * (BN / (32 * WN)) >= 4) ? 1 : 2;
+  using St = StagerBF<NS, BM, BN, SUB, 64 * WM * WN, NSETS>;
+  static constexpr int MT = BM / (32 * WM), NT = BN / (32 * WN);
   static constexpr int T = NS * (NS + 1) / 2;
   static constexpr int NB = 2 * SUB, MPB = T * MT * NT, NM = NB * MPB;
   static constexpr int NFR = (MT + NT) * NS;          // fragment reads per K-block
   static constexpr int RU = (NFR + 1) / 2;            // ... as units of two
   static_assert(RU <= MPB, "not enough MFMA slots for the fragment reads");
   int a_row, b_row, ko0, ko1;
-  bf16x8 fa[2][MT][NS], fb[2][NT][NS];
+  bf16x8 fa[FD][MT][NS], fb[FD][NT][NS];
 
   template <int G, int E>
   __device__ __forceinline__ void read_one(const char* stage) {
     if constexpr (E < NFR) {
       const char* base = stage + (G >> 1) * St::SUBSTAGE + ((G & 1) ? ko1 : ko0);
       if constexpr (E < MT * NS)
-        fa[G & 1][E / NS][E % NS] = *reinterpret_cast<const bf16x8*>(base + a_row + (E % NS) * St::A_PLANE + (E / NS) * 32 * ROWB);
+        fa[G & (FD - 1)][E / NS][E % NS] = *reinterpret_cast<const bf16x8*>(base + a_row + (E % NS) * St::A_PLANE + (E / NS) * 32 * ROWB);
       else
-        fb[G & 1][(E - MT * NS) / NS][(E - MT * NS) % NS] =
+        fb[G & (FD - 1)][(E - MT * NS) / NS][(E - MT * NS) % NS] =
             *reinterpret_cast<const bf16x8*>(base + b_row + ((E - MT * NS) % NS) * St::B_PLANE + ((E - MT * NS) / NS) * 32 * ROWB);
     }
   }
@@ -281,11 +290,15 @@ struct KStep {
   __device__ __forceinline__ void slot(f32x16 (&acc)[MT][NT], St& st, const char* cur, char* other) {
     constexpr int G = Q / MPB, R = Q % MPB;
     constexpr int t = R / (MT * NT), mt = (R / NT) % MT, nt = R % NT;
-    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[G & 1][mt][term_a<NS>(t)], fb[G & 1][nt][term_b<NS>(t)], acc[mt][nt], 0, 0, 0);
+    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[G & (FD - 1)][mt][term_a<NS>(t)], fb[G & (FD - 1)][nt][term_b<NS>(t)], acc[mt][nt], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (G + 1 < NB && R < RU) {       // next K-block's fragments, >= MPB - RU MFMAs ahead of their first use
+    if constexpr (FD == 2 && G + 1 < NB && R < RU) {       // next K-block's fragments, >= MPB - RU MFMAs ahead of their first use
       read_one<G + 1, 2 * R>(cur);
       read_one<G + 1, 2 * R + 1>(cur);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (FD == 1 && G + 1 < NB && R == MPB - 1) {   // single buffer: behind the block's last MFMA
+      read_block<G + 1>(cur, std::make_integer_sequence<int, NFR>{});
       __builtin_amdgcn_sched_barrier(0);
     }
     constexpr int X0 = Q * St::UNITS / NM, X1 = (Q + 1) * St::UNITS / NM;
@@ -307,21 +320,24 @@ struct KStep {
   }
 };
 
-// two resident blocks per CU (=> <= 256 registers) whenever two of them fit in the 160 KB of LDS
-constexpr int bf_blocks_per_cu(int ns, int bm, int bn, int sub) { return 2 * (2 * sub * ns * (bm + bn) * ROWB) <= 160 * 1024 ? 2 : 1; }
+// two resident blocks per CU (=> <= 256 registers) whenever two of them fit in the 160 KB of LDS; an eight-wave block stays alone
+// (two of them would cap a lane at 128 registers)
+constexpr int bf_blocks_per_cu(int ns, int bm, int bn, int sub, int waves) {
+  return (waves <= 4 && 2 * (2 * sub * ns * (bm + bn) * ROWB) <= 160 * 1024) ? 2 : 1;
+}
 
-template <int EPI, int NS, int BM, int BN, int SUB>
-__global__ __launch_bounds__(256, bf_blocks_per_cu(NS, BM, BN, SUB)) void conv_gemm_bf_kernel(const GemmArgs a) {
-  using St = StagerBF<NS, BM, BN, SUB>;
-  constexpr int MT = BM / 64, NT = BN / 64;
+template <int EPI, int NS, int BM, int BN, int SUB, int WM = 2, int WN = 2, int NSETS = 2>
+__global__ __launch_bounds__(64 * WM * WN, bf_blocks_per_cu(NS, BM, BN, SUB, WM * WN)) void conv_gemm_bf_kernel(const GemmArgs a) {
+  using St = StagerBF<NS, BM, BN, SUB, 64 * WM * WN, NSETS>;
+  constexpr int MT = BM / (32 * WM), NT = BN / (32 * WN);
   constexpr int A_PLANE = St::A_PLANE, STAGE = SUB * St::SUBSTAGE;
   extern __shared__ __attribute__((aligned(16))) char smem_bf[];   // [2][STAGE]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wid = tid >> 6;
-  const int wm0 = (wid >> 1) * (BM / 2);
-  const int wn0 = (wid & 1) * (BN / 2);
+  const int wm0 = (wid / WN) * (BM / WM);
+  const int wn0 = (wid % WN) * (BN / WN);
 
   const int bid = pfk_xcd_remap(blockIdx.x, gridDim.x);
   const int tile_n = bid % a.tiles_n;
@@ -351,10 +367,16 @@ __global__ __launch_bounds__(256, bf_blocks_per_cu(NS, BM, BN, SUB)) void conv_g
   // and j+2 (issued during step j); LDS holds steps j and j+1; one barrier per step.
   char* const stage0 = smem_bf;
   char* const stage1 = smem_bf + STAGE;
-  KStep<EPI, NS, BM, BN, SUB> ks{a_row, b_row, ko0, ko1};
-  st.template load_all<0>();
-  st.template load_all<1>();
-  st.template store_all<0>(stage0);
+  KStep<EPI, NS, BM, BN, SUB, WM, WN, NSETS> ks{a_row, b_row, ko0, ko1};
+  if constexpr (NSETS == 2) {
+    st.template load_all<0>();
+    st.template load_all<1>();
+    st.template store_all<0>(stage0);
+  } else {                      // one register set: step 0 through the registers into stage 0, then step 1 into the registers
+    st.template load_all<0>();
+    st.template store_all<0>(stage0);
+    st.template load_all<0>();
+  }
   __syncthreads();
   for (int step = 0; step < nsteps; step += 2) {
     ks.template run<0>(acc, st, stage0, stage1);   // MFMAs on stage0, loads -> set 0, set 1 -> stage1
@@ -366,7 +388,7 @@ __global__ __launch_bounds__(256, bf_blocks_per_cu(NS, BM, BN, SUB)) void conv_g
   epilogue_lds<MT, NT, EPI>(a, acc, m0 + wm0, n0 + wn0, lane, 0, reinterpret_cast<float*>(smem_bf), wid);   // behind the loop's final barrier
 }
 
-template <int EPI, int NS, int BM, int BN, int SUB>
+template <int EPI, int NS, int BM, int BN, int SUB, int WM = 2, int WN = 2, int NSETS = 2>
 int launch_bf_one(const GemmArgs& a, hipStream_t st) {
   GemmArgs g = a;
   if (a.M >= 0x7fffffffLL || a.Wo <= 0 || a.Ho <= 0) return PFK_ERR_UNSUPPORTED;   // 32-bit pixel arithmetic in the stager
@@ -378,32 +400,38 @@ int launch_bf_one(const GemmArgs& a, hipStream_t st) {
   if (nblk <= 0 || nblk > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
   constexpr size_t smem = 2 * (size_t)SUB * NS * (BM + BN) * ROWB;
   static_assert(smem <= 160 * 1024, "LDS budget");
-  auto kern = conv_gemm_bf_kernel<EPI, NS, BM, BN, SUB>;
+  static_assert(WM * WN * 4096 <= (int)smem, "the LDS epilogue needs 4 KB per wave");
+  auto kern = conv_gemm_bf_kernel<EPI, NS, BM, BN, SUB, WM, WN, NSETS>;
   static pfk_device_once attr_once;   // one per template instantiation and device; safe with several host threads
   attr_once.run([&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   });
-  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), smem, st, g);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * WM * WN), smem, st, g);
   return pfk_launch_status();
 }
 
-template <int NS, int BM, int BN, int SUB>
+template <int NS, int BM, int BN, int SUB, int WM = 2, int WN = 2, int NSETS = 2>
 int launch_bf_epi(const GemmArgs& g, int epi, hipStream_t st) {
   switch (epi) {
-    case PFK_EPI_LINEAR: return launch_bf_one<PFK_EPI_LINEAR, NS, BM, BN, SUB>(g, st);
-    case PFK_EPI_GRU_ZR: return launch_bf_one<PFK_EPI_GRU_ZR, NS, BM, BN, SUB>(g, st);
-    case PFK_EPI_GRU_Q:  return launch_bf_one<PFK_EPI_GRU_Q, NS, BM, BN, SUB>(g, st);
+    case PFK_EPI_LINEAR: return launch_bf_one<PFK_EPI_LINEAR, NS, BM, BN, SUB, WM, WN, NSETS>(g, st);
+    case PFK_EPI_GRU_ZR: return launch_bf_one<PFK_EPI_GRU_ZR, NS, BM, BN, SUB, WM, WN, NSETS>(g, st);
+    case PFK_EPI_GRU_Q:  return launch_bf_one<PFK_EPI_GRU_Q, NS, BM, BN, SUB, WM, WN, NSETS>(g, st);
     default: return PFK_ERR_BAD_ARG;
   }
 }
 
-// tile configurations: 1 = 64x64 (two sub-steps per barrier), 2 = 128x64, 3 = 128x128
+// tile configurations: 1 = 64x64 (two sub-steps per barrier), 2 = 128x64, 3 = 128x128, 4 = 128x128 with eight waves (2 x 4: every
+// thread splits and stages half as much per MFMA)
 template <int NS>
 int launch_bf_ns(const GemmArgs& g, int epi, int cfg, hipStream_t st) {
   switch (cfg) {
     case 1: return launch_bf_epi<NS, 64, 64, 2>(g, epi, st);
     case 2: return launch_bf_epi<NS, 128, 64, 1>(g, epi, st);
     case 3: return launch_bf_epi<NS, 128, 128, 1>(g, epi, st);
+    case 4: return launch_bf_epi<NS, 128, 128, 1, 2, 4>(g, epi, st);
+    // 64x64 wave tiles (half the fragment bytes per MFMA of the configurations above) with eight waves: 256x128 / 128x256
+    case 5: return launch_bf_epi<NS, 256, 128, 1, 4, 2, 1>(g, epi, st);
+    case 6: return launch_bf_epi<NS, 128, 256, 1, 2, 4, 1>(g, epi, st);
     default: return PFK_ERR_BAD_ARG;
   }
 }
@@ -426,9 +454,25 @@ int launch_bf(const GemmArgs& a0, int epi, int nsplit, hipStream_t st) {
     const long long tm = (a.M + 127) / 128;
     const long long b2 = tm * ((a.b_rows + 63) / 64), b3 = tm * ((a.b_rows + 127) / 128);
     const int pad128 = (a.b_rows + 127) / 128 * 128;
-    if (nsplit == 3) cfg = b2 >= 160 ? 2 : 1;
+    // three planes (round 3, scripts/conv_bench.py at batch 1 / 2 / 8): the eight-wave 128x128 tile wins wherever it has >= 200
+    // blocks and pads <= 10 % of the columns — fh|mask conv1 397 -> 357 us (186 TFLOP/s of fp32-equivalent work), z|r 343 -> 331,
+    // q 187 -> 161, conv 218 -> 193 at batch 8; fh|mask conv1 56.7 -> 50.2 us at batch 1 — and loses below (z|r at batch 1: 110
+    // blocks, 63.6 -> 73.4 us) and on cout 192 / 576 / 64
+    if (nsplit == 3) cfg = (b3 >= 200 && (pad128 - a.b_rows) * 10 <= a.b_rows) ? 4 : (b2 >= 160 ? 2 : 1);
     else if (b3 >= 384) cfg = (pad128 - a.b_rows) * 10 > a.b_rows ? 2 : 3;       // > 10 % padded columns at BN = 128
     else cfg = b2 >= 400 ? 2 : 1;
+    // 64x64 wave tiles on eight waves (256x128 / 128x256: half the fragment bytes per MFMA — the split kernels are LDS-bound — and
+    // half the split work): they win from 220 blocks up on K >= 10 steps, even with a third of the columns padded (cout 192 -> 256);
+    // batch 8, three planes: z|r 335 -> 288 us, q 183 -> 144, conv 214 -> 172, fh|mask conv1 360 -> 340, convc2 313 -> 288;
+    // 110 blocks lose everywhere (q at batch 4: 85 -> 122 us), mask conv2 (8 K-steps) ties.  Two planes: the same except the
+    // largest grid (fh|mask conv1 at batch 8: 197 us on two resident 128x128 blocks vs 205).
+    if (nsplit >= 2 && a.sk_steps >= 10) {
+      const int pad256 = (a.b_rows + 255) / 256 * 256;
+      const long long nb6 = tm * (pad256 / 256), nb5 = ((a.M + 255) / 256) * (pad128 / 128);
+      const bool skip = nsplit == 2 && nb6 >= 800 && cfg == 3;
+      if (!skip && (pad256 - a.b_rows) * 3 <= a.b_rows && nb6 >= 220) cfg = 6;
+      else if (!skip && (pad128 - a.b_rows) * 3 <= a.b_rows && nb5 >= 220) cfg = 5;
+    }
   }
   switch (nsplit) {
     case 1: return launch_bf_ns<1>(a, epi, cfg, st);

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 3: the GPU passes behind profiles/r03_a / r03_b (each was one `gpurun -- bash scripts/r03_gpu_passes.sh <pass>` call;
-# logs under gpurun_out/r3<pass>_*).  Usage: bash scripts/r03_gpu_passes.sh b|c|d|e|f|g|h|i|j|k|l|m|n|o|p
+# logs under gpurun_out/r3<pass>_*).  Usage: bash scripts/r03_gpu_passes.sh b|c|d|e|f|g|h|i|j|k|l|m|n|o|p|q
 O=$GRAFT_REPO_ROOT/gpurun_out; mkdir -p $O
 case "$1" in
 b)
@@ -130,6 +130,18 @@ p)
   timeout 300 python scripts/conv_bench.py --batch 8 --cfgs=10,11 --reps 200 --rounds 3 --only fm > $O/r3p_conv_b8.log 2>&1; cat $O/r3p_conv_b8.log | cut -c1-300
   wait $SMI; sort $O/r3p_smi.log | uniq -c | sort -rn | head -8 | cut -c1-250
   timeout 600 python -m pytest tests/test_gpu_conv_pp.py tests/test_gpu_kernels.py -m gpu -q --tb=short -x -k "volume or corr" 2>&1 | tail -3
+  ;;
+q)
+  # round 3: where does the split-bf16 kernel (K8) stand?  tile ladder at batch 8, then counters of fm for bf16x6 128x64, bf16x3 128x128 and fp32
+  timeout 600 python scripts/conv_bench.py --batch 8 --cfgs=10,300,301,302,303,200,201,202,203 --reps 10 --rounds 3 --only fm,zr1,c2,q1,mk > $O/r3q_conv_b8.log 2>&1; cat $O/r3q_conv_b8.log | cut -c1-500
+  cd /tmp && export TMPDIR=/tmp
+  i=0
+  for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS" "SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VALU GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_INSTS_LDS_LOAD SQ_INSTS_LDS_STORE SQ_INST_LEVEL_LDS"; do
+    i=$((i+1))
+    timeout 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $O/r3q_pmc_$i -- python $GRAFT_REPO_ROOT/scripts/conv_bench.py --batch 8 --cfgs=10,302,203 --only fm --reps 3 > $O/r3q_pmc_$i.log 2>&1
+    tail -3 $O/r3q_pmc_$i.log | cut -c1-200
+  done
+  python $GRAFT_REPO_ROOT/scripts/pmc_by_kernel.py $O/r3q_pmc_* --match=conv_gemm > $O/r3q_counters.txt; cat $O/r3q_counters.txt
   ;;
 *) echo "unknown pass $1"; exit 2;;
 esac

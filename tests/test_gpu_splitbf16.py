@@ -134,6 +134,23 @@ def test_split_gru_bf16x6(gpu, B, H, W, Ch, Cx, passes):
     close(unpm(hx[:, :Ch], B, H, W), ref, rtol=2e-5, atol=3e-5)
 
 
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6])
+def test_split_conv_every_tile_configuration(gpu, tile):
+    """The four tile configurations of the split kernel forced one by one (`debug_set_tile(100 + t)`: 64x64, 128x64, 128x128 with
+    four waves, 128x128 with eight waves) through the linear cases (ragged M, cout 40 / 96 / 126, partial K-steps) at 2 and 3
+    planes and through both fused GRU epilogues."""
+    torch.ops.pfk.debug_set_tile(100 + tile)
+    try:
+        for nsplit in (2, 3):
+            for case in CASES:
+                test_split_conv_linear(gpu, nsplit, *case)
+            test_split_conv_multi_source(gpu, nsplit)
+        test_split_gru_bf16x6(gpu, 1, 12, 16, 128, 256, ((1, 5, "1"), (5, 1, "2")))
+        test_split_gru_bf16x6(gpu, 2, 10, 14, 96, 148, ((3, 3, ""),))
+    finally:
+        torch.ops.pfk.debug_set_tile(100)
+
+
 def _epe(precisions, H, W, iters, small=False, seed=1234):
     from ptlflow_amd.raft import RAFT
     base = RAFT(small=small, iters=iters).load_synthetic(seed).eval()
