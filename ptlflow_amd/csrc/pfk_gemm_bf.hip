@@ -249,6 +249,13 @@ template <int NS> constexpr int term_b(int t) {
   return 0;
 }
 
+// Term order of the single-fragment-buffer schedule (three planes): a1 b1 | a0 b2 | a2 b0 | a0 b1 | a1 b0 | a0 b0 — still the three
+// 2^-16 terms first and a0 b0 last, but plane 2 retires after the third term, plane 1 after the fifth and plane 0 after the sixth,
+// and the block opens with the one term that needs no plane-0 fragment: each plane's registers are re-read for the NEXT K-block
+// as soon as they retire, and the plane-0 reads (issued behind the block's last MFMA) have the a1 b1 MFMAs of the next block to land.
+constexpr int term1_a(int t) { constexpr int v[6] = {1, 0, 2, 0, 1, 0}; return v[t]; }
+constexpr int term1_b(int t) { constexpr int v[6] = {1, 2, 0, 1, 0, 0}; return v[t]; }
+
 // One K-step of a wave as a hand-placed instruction stream: MFMA, filler, MFMA, filler ...  (sched_barrier(0) after
 // every item pins the order).  A step has NB = 2*SUB 16-channel K-blocks of MPB = T*MT*NT MFMAs; fragments are
 // register double-buffered per K-block: the reads of block g+1 are the first fillers of block g; the staging units of
@@ -285,21 +292,33 @@ struct KStep {
   __device__ __forceinline__ void read_block(const char* stage, std::integer_sequence<int, E...>) {
     (read_one<G, E>(stage), ...);
   }
+  // plane PL of every A and B fragment of K-block G
+  template <int G, int PL, int... I>
+  __device__ __forceinline__ void read_plane_seq(const char* stage, std::integer_sequence<int, I...>) {
+    ((I < MT ? read_one<G, (I < MT ? I : 0) * NS + PL>(stage) : read_one<G, MT * NS + (I < MT ? 0 : I - MT) * NS + PL>(stage)), ...);
+  }
+  template <int G, int PL>
+  __device__ __forceinline__ void read_plane(const char* stage) {
+    read_plane_seq<G, PL>(stage, std::make_integer_sequence<int, MT + NT>{});
+  }
 
   template <int S, int Q>
   __device__ __forceinline__ void slot(f32x16 (&acc)[MT][NT], St& st, const char* cur, char* other) {
     constexpr int G = Q / MPB, R = Q % MPB;
     constexpr int t = R / (MT * NT), mt = (R / NT) % MT, nt = R % NT;
-    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[G & (FD - 1)][mt][term_a<NS>(t)], fb[G & (FD - 1)][nt][term_b<NS>(t)], acc[mt][nt], 0, 0, 0);
+    constexpr int ta = FD == 1 ? term1_a(t) : term_a<NS>(t), tb = FD == 1 ? term1_b(t) : term_b<NS>(t);
+    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[G & (FD - 1)][mt][ta], fb[G & (FD - 1)][nt][tb], acc[mt][nt], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (FD == 2 && G + 1 < NB && R < RU) {       // next K-block's fragments, >= MPB - RU MFMAs ahead of their first use
       read_one<G + 1, 2 * R>(cur);
       read_one<G + 1, 2 * R + 1>(cur);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if constexpr (FD == 1 && G + 1 < NB && R == MPB - 1) {   // single buffer: behind the block's last MFMA
-      read_block<G + 1>(cur, std::make_integer_sequence<int, NFR>{});
-      __builtin_amdgcn_sched_barrier(0);
+    if constexpr (FD == 1 && G + 1 < NB) {                 // single buffer: a plane is re-read for the next K-block when it retires
+      constexpr int MN = MT * NT;
+      if constexpr (R == 3 * MN - 1) { read_plane<G + 1, 2>(cur); __builtin_amdgcn_sched_barrier(0); }
+      else if constexpr (R == 5 * MN - 1) { read_plane<G + 1, 1>(cur); __builtin_amdgcn_sched_barrier(0); }
+      else if constexpr (R == 6 * MN - 1) { read_plane<G + 1, 0>(cur); __builtin_amdgcn_sched_barrier(0); }
     }
     constexpr int X0 = Q * St::UNITS / NM, X1 = (Q + 1) * St::UNITS / NM;
     unit_range<S, X0>(st, other, std::make_integer_sequence<int, X1 - X0>{});
@@ -314,7 +333,14 @@ struct KStep {
   }
   template <int S>
   __device__ __forceinline__ void run(f32x16 (&acc)[MT][NT], St& st, const char* cur, char* other) {
-    read_block<0>(cur, std::make_integer_sequence<int, NFR>{});
+    if constexpr (FD == 1) {       // in the order the terms need them: a1 b1, then a0 (b2), then a2 b0
+      read_plane<0, 1>(cur);
+      __builtin_amdgcn_sched_barrier(0);
+      read_plane<0, 0>(cur);
+      read_plane<0, 2>(cur);
+    } else {
+      read_block<0>(cur, std::make_integer_sequence<int, NFR>{});
+    }
     __builtin_amdgcn_sched_barrier(0);
     slots<S>(acc, st, cur, other, std::make_integer_sequence<int, NM>{});
   }

@@ -163,6 +163,69 @@ __global__ __launch_bounds__(256, BPC) void probe(const float* __restrict__ src,
   if (v == 123.456f) out[blockIdx.x * 256 + tid] = v + s_cur[tid];
 }
 
+// bf16 matrix pipe alone: four independent accumulators per wave, v_mfma_f32_32x32x16_bf16 back to back (no LDS, no memory) — the
+// sustained rate and shader clock the split-bf16 kernels (K8) have to be read against
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+template <int BPC>
+__global__ __launch_bounds__(256, BPC) void probe_bf16(float* out, int steps) {
+  const unsigned long long c0 = clock64(), w0 = wall_clock64();
+  f32x16 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  bf16x8 a, b;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { a[e] = (__bf16)(0.001f * (float)(threadIdx.x + e)); b[e] = (__bf16)(0.002f * (float)(e + 1)); }
+  for (int j = 0; j < steps; ++j) {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+    }
+  }
+  if (threadIdx.x == 0) {
+    atomicAdd(&g_clk[0], clock64() - c0);
+    atomicAdd(&g_clk[1], wall_clock64() - w0);
+  }
+  float v = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v += acc[i][r];
+  if (v == 123.456f) out[blockIdx.x * 256 + threadIdx.x] = v;
+}
+
+template <int BPC>
+void run_bf16(float* out, double sustain_s) {
+  const int grid = 256 * BPC, steps = 400;
+  auto kern = probe_bf16<BPC>;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  const auto t0 = std::chrono::steady_clock::now();
+  do {
+    for (int i = 0; i < 8; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, out, steps);
+    hipDeviceSynchronize();
+  } while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < sustain_s);
+  unsigned long long zero[2] = {0, 0};
+  hipMemcpyToSymbol(HIP_SYMBOL(g_clk), zero, sizeof zero);
+  float best = 1e30f;
+  for (int rep = 0; rep < 3; ++rep) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, out, steps);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    if (ms < best) best = ms;
+  }
+  unsigned long long clk[2];
+  hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_clk), sizeof clk);
+  const double mfmas = (double)grid * 4 * steps * 48;
+  printf("  bf16 MFMA chain x%d blocks/CU, %s: %7.1f TFLOP/s (nominal dense peak 2516)  %7.1f MHz\n", BPC, sustain_s > 0 ? "sustained" : "cold     ",
+         mfmas * 32768.0 / (best * 1e-3) / 1e12, clk[1] ? 100.0 * (double)clk[0] / (double)clk[1] : 0.0);
+}
+
 unsigned g_row_stride = 128;
 double g_sustain_s = 0.0;        // > 0: repeat the launch for this long before the timed ones (lets power management settle)
 double g_last_mhz = 0.0;
@@ -241,6 +304,7 @@ int main() {
     row<BAR | FR | ST | LD>(name, l2, l2mask, hbm, hbmmask, out, steps);
   }
   g_row_stride = 128;
+  run_bf16<1>(out, 0.0); run_bf16<2>(out, 0.0); run_bf16<2>(out, 1.5); run_bf16<1>(out, 1.5);
   // sustained shader clock: the same bodies after 1.5 s of back-to-back launches; MHz = s_memtime / s_memrealtime * 100
   g_sustain_s = 1.5;
   printf("sustained (1.5 s of launches first), x3 blocks per CU:\n");
