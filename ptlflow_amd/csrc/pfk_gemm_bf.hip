@@ -492,12 +492,16 @@ int launch_bf(const GemmArgs& a0, int epi, int nsplit, hipStream_t st) {
     // batch 8, three planes: z|r 335 -> 288 us, q 183 -> 144, conv 214 -> 172, fh|mask conv1 360 -> 340, convc2 313 -> 288;
     // 110 blocks lose everywhere (q at batch 4: 85 -> 122 us), mask conv2 (8 K-steps) ties.  Two planes: the same except the
     // largest grid (fh|mask conv1 at batch 8: 197 us on two resident 128x128 blocks vs 205).
-    if (nsplit >= 2 && a.sk_steps >= 10) {
+    // One plane (plain bf16 operands, batch 8, gpurun_out/r3y_conv_b8.log): eight waves on the 128x128 tile beat two four-wave
+    // blocks by 3-7 % (fh|mask conv1 113.9 -> 106.1 us = 626 TFLOP/s, q 69 -> 66); 128x256 wins on z|r (123 -> 112), convc2
+    // (113 -> 93) and convc1, 256x128 nowhere.
+    if (nsplit == 1 && cfg == 3) cfg = 4;
+    if (a.sk_steps >= 10) {
       const int pad256 = (a.b_rows + 255) / 256 * 256;
       const long long nb6 = tm * (pad256 / 256), nb5 = ((a.M + 255) / 256) * (pad128 / 128);
-      const bool skip = nsplit == 2 && nb6 >= 800 && cfg == 3;
+      const bool skip = nsplit <= 2 && nb6 >= 800 && (cfg == 3 || cfg == 4);
       if (!skip && (pad256 - a.b_rows) * 3 <= a.b_rows && nb6 >= 220) cfg = 6;
-      else if (!skip && (pad128 - a.b_rows) * 3 <= a.b_rows && nb5 >= 220) cfg = 5;
+      else if (!skip && nsplit >= 2 && (pad128 - a.b_rows) * 3 <= a.b_rows && nb5 >= 220) cfg = 5;
     }
   }
   switch (nsplit) {

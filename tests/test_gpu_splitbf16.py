@@ -137,14 +137,17 @@ def test_split_gru_bf16x6(gpu, B, H, W, Ch, Cx, passes):
 @pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6])
 def test_split_conv_every_tile_configuration(gpu, tile):
     """The four tile configurations of the split kernel forced one by one (`debug_set_tile(100 + t)`: 64x64, 128x64, 128x128 with
-    four waves, 128x128 with eight waves) through the linear cases (ragged M, cout 40 / 96 / 126, partial K-steps) at 2 and 3
+    four waves, 128x128 with eight waves) through the linear cases (ragged M, cout 40 / 96 / 126, partial K-steps) at 1, 2 and 3
     planes and through both fused GRU epilogues."""
     torch.ops.pfk.debug_set_tile(100 + tile)
     try:
-        for nsplit in (2, 3):
+        for nsplit in (1, 2, 3):
             for case in CASES:
                 test_split_conv_linear(gpu, nsplit, *case)
-            test_split_conv_multi_source(gpu, nsplit)
+            if nsplit > 1:
+                test_split_conv_multi_source(gpu, nsplit)
+        for case in CASES:
+            test_plain_bf16_is_exact_on_bf16_operands(gpu, *case)
         test_split_gru_bf16x6(gpu, 1, 12, 16, 128, 256, ((1, 5, "1"), (5, 1, "2")))
         test_split_gru_bf16x6(gpu, 2, 10, 14, 96, 148, ((3, 3, ""),))
     finally:
