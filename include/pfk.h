@@ -66,6 +66,7 @@ void pfk_debug_set_tile(int cfg);
 unsigned pfk_debug_fastdiv(unsigned n, unsigned d);
 /* tuning knob of the pyramid lookup: source pixels per workgroup, 4 (default) or 8. Not thread-safe. */
 void pfk_debug_set_lookup_pix(int pix);
+void pfk_debug_set_altcorr(int mode);       /* on-demand correlation forward: 0 = heuristic, 1 = per-pixel kernel, 2 / 3 = window-sharing MFMA kernel on 8x4 / 8x8 patches */
 void pfk_debug_set_wgrad(int variant);      /* weight-gradient tile height: 0 = by padding waste, 1 / 2 / 4 = forced 32 / 64 / 128 rows (tuning knob) */
 
 /* ---- K1: all-pairs correlation --------------------------------------------------------------

@@ -86,6 +86,305 @@ __global__ __launch_bounds__(256) void altcorr_fwd_kernel(const float* __restric
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Window-sharing formulation on the fp32 matrix cores (round 3).  Neighbouring pixels look at nearly the same part of fmap2:
+// an 8 x TPY patch of fmap1 pixels whose flow is locally smooth has all its (2r+2)^2 windows inside one bounding box of
+// roughly (8 + 2r + 1 + spread) x (TPY + 2r + 1 + spread) points.  The block computes the box once,
+//     S[pixel i][box point j] = <fmap1[i, :], fmap2[j, :]>          a [8 TPY x C] x [C x NP] GEMM, v_mfma_f32_32x32x2_f32,
+// with the box rows staged through LDS exactly once per block (the per-pixel kernel above re-reads every fmap2 row once per pixel
+// that touches it: ~100 KB of L2 gathers per pixel; here 8-16 KB), and every pixel then picks its own (2r+2)^2 taps out of S and
+// combines them with the same bilinear formula.  The box is clipped to the map (points outside are zeros anyway); pixels with
+// non-finite / absurd coordinates stay outside the box (all their taps are zero, as in the per-pixel kernel); a patch whose
+// clipped box has more than WS_NP_MAX points (strongly divergent flow) is left to altcorr_fwd_overflow_kernel, launched right behind:
+// the per-pixel algorithm on just those patches (both kernels take the decision with the same patch_box()).
+// K step = 16 channels (64-byte LDS rows, 16-byte chunk index XOR (row >> 2) & 3: conflict-free ds_write_b128 / ds_read_b128),
+// two LDS stages, registers prefetch the next step; four waves split the box points (column blocks of 32, interleaved).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int WS_NP_MAX = 512;                 // box points per block (16 column blocks of 32)
+constexpr int WS_BK = 16;                      // channels per K step
+constexpr int WS_ROWB = WS_BK * 4;             // 64-byte LDS rows
+typedef unsigned int ws_u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned WS_OOB = 0x80000000u;
+
+// per-pixel algorithm of altcorr_fwd_kernel for one pixel per wave (wave-local: no workgroup barrier)
+__device__ __forceinline__ void altcorr_pixel(const float* __restrict__ f1, const float* __restrict__ f2, float* __restrict__ out,
+                                              bool live, long long p, long long b, int pix, float x, float y, long long hw, int H2,
+                                              int W2, int C, int r, float* s_tap_w, int lane) {
+  const int g = lane >> 4, cl = lane & 15;
+  const int rd = 2 * r + 1, n = rd + 1, ntaps = n * n;
+  const float fx = floorf(x), fy = floorf(y);
+  const float dx = x - fx, dy = y - fy;
+  const int x0 = (fabsf(fx) < 1.0e9f) ? (int)fx - r : -(1 << 30);
+  const int y0 = (fabsf(fy) < 1.0e9f) ? (int)fy - r : -(1 << 30);
+  f32x4 a[MAX_C4];
+#pragma unroll
+  for (int i = 0; i < MAX_C4; ++i) {
+    const int c = cl * 4 + i * 64;
+    a[i] = (live && c < C) ? *reinterpret_cast<const f32x4*>(f1 + p * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (int t0 = 0; t0 < ntaps; t0 += 4) {
+    const int t = t0 + g;
+    const int iy = t / n, ix = t - iy * n;
+    const int yy = y0 + iy, xx = x0 + ix;
+    const bool ok = live && t < ntaps && (unsigned)yy < (unsigned)H2 && (unsigned)xx < (unsigned)W2;
+    float acc = 0.f;
+    if (ok) {
+      const float* row = f2 + ((b * H2 + yy) * (long long)W2 + xx) * C;
+#pragma unroll
+      for (int i = 0; i < MAX_C4; ++i) {
+        const int c = cl * 4 + i * 64;
+        if (c < C) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(row + c);
+          acc = fmaf(a[i].x, v.x, fmaf(a[i].y, v.y, fmaf(a[i].z, v.z, fmaf(a[i].w, v.w, acc))));
+        }
+      }
+    }
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 16);
+    if (cl == 0 && t < ntaps) s_tap_w[t] = acc;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // s_tap_w is this wave's own: in-order LDS, no workgroup barrier
+  if (live) {
+    const float ex = 1.0f - dx, ey = 1.0f - dy;
+    float* o = out + b * rd * rd * hw + pix;
+    for (int k = lane; k < rd * rd; k += 64) {
+      const int ox = k / rd, oy = k - ox * rd;
+      const float s00 = s_tap_w[oy * n + ox], s01 = s_tap_w[oy * n + ox + 1];
+      const float s10 = s_tap_w[(oy + 1) * n + ox], s11 = s_tap_w[(oy + 1) * n + ox + 1];
+      o[k * hw] = s00 * ey * ex + s01 * ey * dx + s10 * dy * ex + s11 * dy * dx;
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // reads done before the next pixel's taps overwrite them
+}
+
+// Coordinates of the 8 x TPY patch at (py0, px0) — lane l < 8 TPY is pixel (l >> 3, l & 7) — and the bounding box {x0, y0, w, h} of
+// the windows of its finite pixels, clipped to the map (a window entirely outside contributes nothing).  One full wave; every
+// lane returns the box.  The window-sharing kernel and the overflow kernel both decide with THIS function.
+constexpr int WS_FAR = -(1 << 30);
+template <int TPY>
+__device__ __forceinline__ void patch_box(const float* __restrict__ coords, long long b, int py0, int px0, int H1, int W1, int H2,
+                                          int W2, int r, int lane, float& x, float& y, int& x0, int& y0, int (&box)[4]) {
+  constexpr int TP = 8 * TPY;
+  const int n = 2 * r + 2;
+  const int yy = py0 + (lane >> 3), xx = px0 + (lane & 7);
+  const bool inside = lane < TP && yy < H1 && xx < W1;
+  x = 0.f; y = 0.f; x0 = WS_FAR; y0 = WS_FAR;
+  if (inside) {
+    const long long p = b * ((long long)H1 * W1) + (long long)yy * W1 + xx;
+    x = coords[p * 2 + 0];
+    y = coords[p * 2 + 1];
+    const float fx = floorf(x), fy = floorf(y);
+    x0 = (fabsf(fx) < 1.0e9f) ? (int)fx - r : WS_FAR;
+    y0 = (fabsf(fy) < 1.0e9f) ? (int)fy - r : WS_FAR;
+  }
+  const bool use = inside && x0 != WS_FAR && y0 != WS_FAR && x0 < W2 && y0 < H2 && x0 + n > 0 && y0 + n > 0;
+  int lo_x = use ? max(x0, 0) : (1 << 30), hi_x = use ? min(x0 + n, W2) : -(1 << 30);
+  int lo_y = use ? max(y0, 0) : (1 << 30), hi_y = use ? min(y0 + n, H2) : -(1 << 30);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    lo_x = min(lo_x, __shfl_xor(lo_x, off, 64)); hi_x = max(hi_x, __shfl_xor(hi_x, off, 64));
+    lo_y = min(lo_y, __shfl_xor(lo_y, off, 64)); hi_y = max(hi_y, __shfl_xor(hi_y, off, 64));
+  }
+  const bool any = hi_x > lo_x && hi_y > lo_y;
+  box[0] = any ? lo_x : 0; box[1] = any ? lo_y : 0; box[2] = any ? hi_x - lo_x : 0; box[3] = any ? hi_y - lo_y : 0;
+}
+
+// The patches the window-sharing kernel skipped (box of more than WS_NP_MAX points): the per-pixel algorithm, one pixel per wave
+// as in altcorr_fwd_kernel (four consecutive pixels of a patch row per block); a wave whose patch fits leaves after the box test.
+template <int TPY>
+__global__ __launch_bounds__(256) void altcorr_fwd_overflow_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                                   const float* __restrict__ coords, float* __restrict__ out,
+                                                                   int H1, int W1, int H2, int W2, int C, int r, int tiles_x,
+                                                                   int tiles_y, int force) {
+  constexpr int TP = 8 * TPY, SUBS = TP / 4;
+  __shared__ float s_tap[4][104];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int tile = blockIdx.x / SUBS, sub = blockIdx.x % SUBS;
+  const int txi = tile % tiles_x, tyi = (tile / tiles_x) % tiles_y;
+  const long long b = tile / (tiles_x * tiles_y);
+  const int px0 = txi * 8, py0 = tyi * TPY;
+  __shared__ float s_xy[4][2];
+  __shared__ int s_over;
+  if (wid == 0) {                                       // one box test per block
+    float x, y;
+    int x0, y0, box[4];
+    patch_box<TPY>(coords, b, py0, px0, H1, W1, H2, W2, r, lane, x, y, x0, y0, box);
+    if (lane >= sub * 4 && lane < sub * 4 + 4) { s_xy[lane - sub * 4][0] = x; s_xy[lane - sub * 4][1] = y; }
+    if (lane == 0) s_over = force || (long long)box[2] * box[3] > WS_NP_MAX;
+  }
+  __syncthreads();
+  if (!s_over) return;
+  const long long hw = (long long)H1 * W1;
+  const int q = sub * 4 + wid;                          // pixel of the patch
+  const float xq = s_xy[wid][0], yq = s_xy[wid][1];
+  const int yy = py0 + (q >> 3), xx = px0 + (q & 7);
+  const bool live = yy < H1 && xx < W1;
+  const int pix = yy * W1 + xx;
+  altcorr_pixel(f1, f2, out, live, b * hw + pix, b, pix, xq, yq, hw, H2, W2, C, r, s_tap[wid], lane);
+}
+
+template <int TPY>
+__global__ __launch_bounds__(256, 2) void altcorr_fwd_ws_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                                const float* __restrict__ coords, float* __restrict__ out,
+                                                                int B, int H1, int W1, int H2, int W2, int C, int r,
+                                                                int tiles_x, int tiles_y) {
+  constexpr int TP = 8 * TPY, MT = TP / 32;
+  static_assert(TP == 32 || TP == 64, "patches of 8 x 4 or 8 x 8 pixels");
+  constexpr int STAGE = (TP + WS_NP_MAX) * WS_ROWB;        // bytes per stage: A rows then B rows
+  static_assert(2 * STAGE >= 32 * WS_NP_MAX * 4, "the S buffer of one 32-pixel half aliases the two stages");
+  extern __shared__ __attribute__((aligned(16))) char ws_smem[];   // [2][STAGE]
+  __shared__ float s_x[TP], s_y[TP];        // target coordinates
+  __shared__ int s_x0[TP], s_y0[TP];        // window origin (floor - r), or the far sentinel
+  __shared__ int s_box[4];                  // bx0, by0, bw, bh
+
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+  const int tile = blockIdx.x;
+  const int txi = tile % tiles_x, tyi = (tile / tiles_x) % tiles_y;
+  const long long b = tile / (tiles_x * tiles_y);
+  const int px0 = txi * 8, py0 = tyi * TPY;
+  const long long hw = (long long)H1 * W1;
+  const int rd = 2 * r + 1;
+  constexpr int FAR = WS_FAR;
+
+  // ---- per-pixel coordinates and the bounding box of the patch's windows (wave 0) -------------------------------------------------
+  if (wid == 0) {
+    float x, y;
+    int x0, y0, box[4];
+    patch_box<TPY>(coords, b, py0, px0, H1, W1, H2, W2, r, lane, x, y, x0, y0, box);
+    if (lane < TP) { s_x[lane] = x; s_y[lane] = y; s_x0[lane] = x0; s_y0[lane] = y0; }
+    if (lane < 4) s_box[lane] = box[lane];
+  }
+  __syncthreads();
+  const int bx0 = s_box[0], by0 = s_box[1], bw = s_box[2], bh = s_box[3];
+  const long long np_ll = (long long)bw * bh;
+  if (np_ll > WS_NP_MAX) return;      // strongly divergent flow: altcorr_fwd_overflow_kernel (launched behind this one) takes the patch
+  const int NP = (int)np_ll;
+  const int NCB = (NP + 31) >> 5;                       // column blocks of 32 box points
+
+  f32x16 acc[MT][4];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mt][q][e] = 0.f;
+
+  if (NP > 0) {
+    // ---- staging plan: thread t owns 16-byte chunk (t & 3) of A row t >> 2 (TP == 64) and of B rows (t >> 2) + 64 i -------------
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(f1), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(f2), 0, 0x7fffffff, 0x00020000);
+    const int ch = t & 3, r0 = t >> 2;
+    const unsigned sw = (unsigned)(((ch ^ ((r0 >> 2) & 3)) << 4));      // swizzled chunk byte offset (rows r0 + 64 i share the key)
+    unsigned aoff = WS_OOB;
+    if (r0 < TP) {
+      const int yy = py0 + (r0 >> 3), xx = px0 + (r0 & 7);
+      if (yy < H1 && xx < W1) aoff = (unsigned)(((b * hw + (long long)yy * W1 + xx) * C + ch * 4) * 4);
+    }
+    unsigned boff[WS_NP_MAX / 64];
+#pragma unroll
+    for (int i = 0; i < WS_NP_MAX / 64; ++i) {
+      const int j = r0 + 64 * i;
+      boff[i] = WS_OOB;
+      if (j < NP) {
+        const int jy = j / bw, jx = j - jy * bw;           // inside the clipped box => inside the map
+        boff[i] = (unsigned)((((b * H2 + by0 + jy) * (long long)W2 + bx0 + jx) * C + ch * 4) * 4);
+      }
+    }
+    const int nrow_b = (NCB * 32 + 63) >> 6;               // B passes of 64 rows that hold live column blocks
+    ws_u32x4 ra, rb[WS_NP_MAX / 64];
+    auto load = [&](int k0) {
+      const bool cok = k0 + ch * 4 < C;                    // C is a multiple of 4
+      ra = __builtin_amdgcn_raw_buffer_load_b128(rs1, (cok && r0 < TP) ? aoff : WS_OOB, k0 * 4, 0);
+#pragma unroll
+      for (int i = 0; i < WS_NP_MAX / 64; ++i)
+        if (i < nrow_b) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rs2, cok ? boff[i] : WS_OOB, k0 * 4, 0);
+    };
+    auto store = [&](char* stage) {
+      if (r0 < TP) *reinterpret_cast<ws_u32x4*>(stage + r0 * WS_ROWB + sw) = ra;
+#pragma unroll
+      for (int i = 0; i < WS_NP_MAX / 64; ++i)
+        if (i < nrow_b) *reinterpret_cast<ws_u32x4*>(stage + (TP + r0 + 64 * i) * WS_ROWB + sw) = rb[i];
+    };
+    // fragment addressing: lane l feeds row l & 31 and the k half l >> 5; per 8 channels one ds_read_b128 (chunk 2 q + (l >> 5))
+    const int frow = lane & 31, hl = lane >> 5;
+    const int key = (frow >> 2) & 3;                       // rows 32 m + frow share it
+    const int ko0 = ((0 + hl) ^ key) << 4, ko1 = ((2 + hl) ^ key) << 4;
+
+    const int nsteps = (C + WS_BK - 1) / WS_BK;
+    char* st0 = ws_smem;
+    char* st1 = ws_smem + STAGE;
+    load(0);
+    store(st0);
+    __syncthreads();
+    for (int k = 0; k < nsteps; ++k) {
+      char* cur = (k & 1) ? st1 : st0;
+      char* nxt = (k & 1) ? st0 : st1;
+      if (k + 1 < nsteps) load((k + 1) * WS_BK);
+      f32x4 fa[MT][2];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        fa[mt][0] = *reinterpret_cast<const f32x4*>(cur + (mt * 32 + frow) * WS_ROWB + ko0);
+        fa[mt][1] = *reinterpret_cast<const f32x4*>(cur + (mt * 32 + frow) * WS_ROWB + ko1);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int cb = wid + 4 * q;                        // wave-uniform
+        if (cb < NCB) {
+          const char* brow = cur + (TP + cb * 32 + frow) * WS_ROWB;
+          const f32x4 fb0 = *reinterpret_cast<const f32x4*>(brow + ko0);
+          const f32x4 fb1 = *reinterpret_cast<const f32x4*>(brow + ko1);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[mt][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mt][0][e], fb0[e], acc[mt][q], 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[mt][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mt][1][e], fb1[e], acc[mt][q], 0, 0, 0);
+          }
+        }
+      }
+      if (k + 1 < nsteps) store(nxt);
+      __syncthreads();
+    }
+  }
+
+  // ---- S of one 32-pixel half through LDS, then every pixel's (2r+1)^2 cells from its own taps ------------------------------------
+  float* S = reinterpret_cast<float*>(ws_smem);            // [32][SLD]
+  const int SLD = NCB * 32 + 1;                            // odd row stride: the tap gathers below spread over the banks
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    if (NP > 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int cb = wid + 4 * q;
+        if (cb < NCB) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            S[((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * SLD + cb * 32 + (lane & 31)] = acc[mt][q][e];
+        }
+      }
+    }
+    __syncthreads();
+    for (int idx = t; idx < 32 * rd * rd; idx += 256) {
+      const int i = idx / (rd * rd), kc = idx - i * (rd * rd);
+      const int q = mt * 32 + i;
+      const int yy = py0 + (q >> 3), xx = px0 + (q & 7);
+      if (yy >= H1 || xx >= W1) continue;
+      const int ox = kc / rd, oy = kc - ox * rd;
+      const float x = s_x[q], y = s_y[q];
+      const float dx = x - floorf(x), dy = y - floorf(y), ex = 1.0f - dx, ey = 1.0f - dy;
+      const int wx = s_x0[q] - bx0 + ox, wy = s_y0[q] - by0 + oy;       // tap (oy, ox) in box coordinates (garbage for FAR: filtered)
+      const bool far = s_x0[q] == FAR || s_y0[q] == FAR;
+      const bool cx0 = !far && (unsigned)wx < (unsigned)bw, cx1 = !far && (unsigned)(wx + 1) < (unsigned)bw;
+      const bool cy0 = !far && (unsigned)wy < (unsigned)bh, cy1 = !far && (unsigned)(wy + 1) < (unsigned)bh;
+      const float* Si = S + i * SLD;
+      const float s00 = (cy0 && cx0) ? Si[wy * bw + wx] : 0.f, s01 = (cy0 && cx1) ? Si[wy * bw + wx + 1] : 0.f;
+      const float s10 = (cy1 && cx0) ? Si[(wy + 1) * bw + wx] : 0.f, s11 = (cy1 && cx1) ? Si[(wy + 1) * bw + wx + 1] : 0.f;
+      out[(b * rd * rd + kc) * hw + (long long)yy * W1 + xx] = s00 * ey * ex + s01 * ey * dx + s10 * dy * ex + s11 * dy * dx;
+    }
+    __syncthreads();
+  }
+}
+
 // Backward of the above w.r.t. both feature maps (correlation_kernel.cu:122-256): per pixel, the gradient of the
 // (2r+1)^2 cells is folded back onto the (2r+2)^2 taps (transpose of the bilinear combine), then
 //   fmap1_grad[p]   = sum_t gs[t] * fmap2[tap t]          (wave-local, one butterfly across the 4 tap groups)
@@ -178,7 +477,11 @@ __global__ __launch_bounds__(256) void altcorr_bwd_kernel(const float* __restric
 
 }  // namespace
 
+int g_altcorr_mode = 0;   // tuning / test knob (pfk_debug_set_altcorr): 0 heuristic, 1 per-pixel kernel, 2 / 3 window-sharing 8x4 / 8x8, 4 = the overflow kernel alone on every patch (timing)
+
 extern "C" {
+
+void pfk_debug_set_altcorr(int mode) { g_altcorr_mode = mode; }
 
 int pfk_altcorr_backward_f32(const float* fmap1, const float* fmap2, const float* coords, const float* corr_grad,
                              float* fmap1_grad, float* fmap2_grad, int B, int H1, int W1, int H2, int W2, int C,
@@ -209,7 +512,40 @@ int pfk_altcorr_forward_f32(const float* fmap1, const float* fmap2, const float*
   const long long M = (long long)B * H1 * W1;
   const long long blocks = (M + 3) / 4;
   if (blocks > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(altcorr_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), fmap1,
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  // Window-sharing MFMA kernel on 8 x 4 patches once the patch grid fills the chip (a block lives ~30 us: 16 K-steps of exposed L2
+  // latency), the per-pixel kernel below that and for maps whose byte offsets do not fit the 32-bit buffer addressing of the staging
+  // loads.  MI355X, C = 256, r = 4 (scripts/lookup_bench.py, gpurun_out/r3_altcorr.log): 55x128 batch 8 with a smooth flow field
+  // 271 -> 133 us (2.0x; 22 TFLOP/s of useful window work), 110x256 (1/4 resolution) 142 -> 74 us; a field with +-4 px of
+  // low-frequency variation per 8 px 272 -> 192 us; iid noise of sigma 6 px on every pixel (no two windows share anything: every box
+  // overflows and the patch is handed to altcorr_fwd_overflow_kernel) 333 -> 435 us.  8 x 8 patches never beat 8 x 4.
+  const int tx = (W1 + 7) / 8;
+  const long long t8 = (long long)B * ((H1 + 7) / 8) * tx, t4 = (long long)B * ((H1 + 3) / 4) * tx;
+  const bool fits32 = (long long)B * H1 * W1 * C * 4 < 0x7fffffffLL && (long long)B * H2 * W2 * C * 4 < 0x7fffffffLL && t8 * 16 < 0x7fffffffLL && t4 * 8 < 0x7fffffffLL;
+  const int mode = g_altcorr_mode;
+  if (fits32 && mode != 1 && (mode >= 2 || t4 >= 256)) {
+    const bool big = mode == 3;
+    if (big) {
+      constexpr size_t smem = 2 * (64 + WS_NP_MAX) * WS_ROWB;
+      static pfk_device_once once;
+      once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(altcorr_fwd_ws_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); });
+      hipLaunchKernelGGL(altcorr_fwd_ws_kernel<8>, dim3((unsigned)t8), dim3(256), smem, st, fmap1, fmap2, coords, out, B, H1, W1, H2, W2, C,
+                         radius, tx, (H1 + 7) / 8);
+      hipLaunchKernelGGL(altcorr_fwd_overflow_kernel<8>, dim3((unsigned)(t8 * 16)), dim3(256), 0, st, fmap1, fmap2, coords, out, H1, W1, H2,
+                         W2, C, radius, tx, (H1 + 7) / 8, 0);
+    } else {
+      constexpr size_t smem = 2 * (32 + WS_NP_MAX) * WS_ROWB;
+      static pfk_device_once once;
+      once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(altcorr_fwd_ws_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); });
+      if (mode != 4)
+        hipLaunchKernelGGL(altcorr_fwd_ws_kernel<4>, dim3((unsigned)t4), dim3(256), smem, st, fmap1, fmap2, coords, out, B, H1, W1, H2, W2,
+                           C, radius, tx, (H1 + 3) / 4);
+      hipLaunchKernelGGL(altcorr_fwd_overflow_kernel<4>, dim3((unsigned)(t4 * 8)), dim3(256), 0, st, fmap1, fmap2, coords, out, H1, W1, H2,
+                         W2, C, radius, tx, (H1 + 3) / 4, mode == 4);
+    }
+    return pfk_launch_status();
+  }
+  hipLaunchKernelGGL(altcorr_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, fmap1,
                      fmap2, coords, out, M, H1, W1, H2, W2, C, radius);
   return pfk_launch_status();
 }

@@ -596,6 +596,7 @@ int64_t conv_workspace_fault_offset() { return pfk_conv_workspace_fault_offset()
 void debug_set_tile(int64_t cfg) { pfk_debug_set_tile((int)cfg); }
 void debug_set_lookup_pix(int64_t pix) { pfk_debug_set_lookup_pix((int)pix); }
 void debug_set_wgrad(int64_t v) { pfk_debug_set_wgrad((int)v); }
+void debug_set_altcorr(int64_t v) { pfk_debug_set_altcorr((int)v); }
 
 }  // namespace
 
@@ -619,6 +620,7 @@ TORCH_LIBRARY(pfk, m) {
   m.def("debug_set_tile(int cfg) -> ()", &debug_set_tile);
   m.def("debug_set_lookup_pix(int pix) -> ()", &debug_set_lookup_pix);
   m.def("debug_set_wgrad(int variant) -> ()", &debug_set_wgrad);
+  m.def("debug_set_altcorr(int mode) -> ()", &debug_set_altcorr);
   m.def("corr_volume(Tensor f1, Tensor f2, float scale, Tensor(a!) out) -> ()");
   m.def("corr_pool2x2(Tensor inp, Tensor(a!) out) -> ()");
   m.def("corr_volume_bf16(Tensor f1, Tensor f2, float scale, Tensor(a!) out) -> ()");

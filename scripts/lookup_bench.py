@@ -31,13 +31,36 @@ for B in (1, 8):
         same = True if ref is None else bool(torch.equal(ref, out))
         ref = out.clone() if ref is None else ref
         print(f"lookup B={B} variant {variant}: {us:.1f} us, algorithmic {alg/1e6:.1f} MB -> {alg/us/1e6:.2f} TB/s ({100*alg/us/1e6/8:.1f}% of 8 TB/s) same={same}")
-    f1 = torch.randn(B, h, w, 256, device=dev); f2 = torch.randn(B, h, w, 256, device=dev)
-    c5 = coords.permute(0, 2, 3, 1).reshape(B, 1, h, w, 2).contiguous()
-    for _ in range(3):
-        ops.altcorr_forward(f1, f2, c5, r)
-    e0.record()
-    for _ in range(20):
-        ops.altcorr_forward(f1, f2, c5, r)
-    e1.record(); torch.cuda.synchronize()
-    us = 1e3 * e0.elapsed_time(e1) / 20
-    print(f"altcorr level-0 B={B}: {us:.1f} us ({B*N*100*256*2/us/1e6:.2f} TFLOP/s, {B*N*100*1024/us/1e6:.2f} TB/s of L2 gathers)")
+    # K7 on-demand correlation: the per-pixel kernel (mode 1) against the window-sharing MFMA kernel on 8x4 / 8x8 patches (2 / 3)
+    # and the library's choice (0), for a smooth flow field (bicubic-upsampled low-resolution noise, +-20 px: what a flow network
+    # produces) and for the iid sigma = 6 px field above (every patch's box overflows: the window-sharing kernel's fallback)
+    for (hh2, ww2) in ((h, w), (2 * h, 2 * w)):
+        if hh2 != h and B > 1:
+            continue
+        Nn = hh2 * ww2
+        f1 = torch.randn(B, hh2, ww2, 256, device=dev); f2 = torch.randn(B, hh2, ww2, 256, device=dev)
+        ys2, xs2 = torch.meshgrid(torch.arange(hh2, device=dev, dtype=torch.float32), torch.arange(ww2, device=dev, dtype=torch.float32), indexing="ij")
+        grid = torch.stack([xs2, ys2], 0)[None]
+        for amp in (1.5, 4.0):
+          smooth = torch.nn.functional.interpolate(torch.randn(B, 2, hh2 // 8 + 2, ww2 // 8 + 2, device=dev) * amp, size=(hh2, ww2), mode="bicubic", align_corners=True)
+          fields = {f"smooth{amp}": grid + smooth} if amp < 2 else {f"smooth{amp}": grid + smooth, "iid-6px": grid + torch.randn(B, 2, hh2, ww2, device=dev) * 6}
+          for fname, cc in fields.items():
+              c5 = cc.permute(0, 2, 3, 1).reshape(B, 1, hh2, ww2, 2).contiguous()
+              base = None
+              line = f"altcorr {hh2}x{ww2} B={B} {fname:8s}:"
+              for mode in (1, 2, 3, 4, 0):
+                  ops.debug_set_altcorr(mode)
+                  for _ in range(3):
+                      o = ops.altcorr_forward(f1, f2, c5, r)
+                  e0.record()
+                  for _ in range(20):
+                      o = ops.altcorr_forward(f1, f2, c5, r)
+                  e1.record(); torch.cuda.synchronize()
+                  us = 1e3 * e0.elapsed_time(e1) / 20
+                  o = o[0] if isinstance(o, (list, tuple)) else o
+                  if base is None:
+                      base = o.clone()
+                  err = float((o - base).abs().max() / base.abs().max())
+                  line += f" mode {mode}: {us:7.1f} us ({B*Nn*100*256*2/us/1e6:5.1f} TF useful, diff {err:.1e}) |"
+              ops.debug_set_altcorr(0)
+              print(line)

@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--torch-encoders", action="store_true")
     ap.add_argument("--corr-tile", type=int, default=-1, help="force a GEMM tile configuration while timing the correlation volume")
+    ap.add_argument("--enc-tiles", default="-1", help="comma list of GEMM tile configurations to force while timing the encoders")
     args = ap.parse_args()
     dev = torch.device("cuda")
     m = RAFT(conv_precision=args.conv_precision, native_encoders=not args.torch_encoders).load_synthetic(1234).eval().to(dev)
@@ -42,8 +43,12 @@ def main():
         both = torch.cat([i1, i2], 0)
         t_pre, _ = timed(lambda: m.preprocess(x), args.reps)
         fnet, cnet = m.encoders(dev)      # the libpfk engines (or the torch modules with native_encoders=False)
-        t_f, fm = timed(lambda: fnet(both), args.reps)
-        t_c, _ = timed(lambda: cnet(i1), args.reps)
+        for tile in [int(t) for t in args.enc_tiles.split(",")][::-1]:      # the library's own choice (-1) last: its numbers go on
+            torch.ops.pfk.debug_set_tile(tile)
+            t_f, fm = timed(lambda: fnet(both), args.reps)
+            t_c, _ = timed(lambda: cnet(i1), args.reps)
+            print(f"encoders with tile configuration {tile}: fnet {t_f:.2f} ms, cnet {t_c:.2f} ms")
+        torch.ops.pfk.debug_set_tile(-1)
         B = args.batch
         torch.ops.pfk.debug_set_tile(args.corr_tile)
         t_corr, _ = timed(lambda: CorrBlock(fm[:B], fm[B:], num_levels=4, radius=4), args.reps)

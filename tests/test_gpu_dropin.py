@@ -136,6 +136,40 @@ def test_alt_cuda_corr_abi(gpu, B, H1, W1, H2, W2, C, r):
         mod.forward(f1.cuda().permute(0, 2, 1, 3), f2.cuda(), coords.cuda(), r)   # CHECK_CONTIGUOUS
 
 
+@pytest.mark.parametrize("mode", [1, 2, 3])
+@pytest.mark.parametrize("B,H1,W1,H2,W2,C,r,sigma", [
+    (2, 27, 45, 27, 45, 256, 4, 0.6),     # smooth flow: every patch goes through the shared box (ragged patch grid)
+    (1, 16, 24, 16, 24, 256, 4, 3.0),     # rough flow: most boxes overflow -> per-pixel fallback inside the kernel
+    (2, 22, 13, 11, 6, 128, 3, 0.8),      # coarser fmap2 (pyramid level), r = 3, windows hanging over every border
+    (1, 9, 10, 9, 10, 36, 4, 0.5),        # C = 36: two K-steps of 16 and one of 4
+])
+def test_altcorr_forward_kernels(gpu, mode, B, H1, W1, H2, W2, C, r, sigma):
+    """K7 forward, each kernel forced (`debug_set_altcorr`): 1 = one wave per pixel, 2 / 3 = the window-sharing MFMA kernel on
+    8x4 / 8x8 patches (shared bounding box, per-pixel fallback for overflowing boxes), against the oracle's restatement of
+    correlation_kernel.cu:18-119; NaN / far-away coordinates keep their pattern."""
+    g = torch.Generator().manual_seed(31 + mode)
+    f1 = torch.randn(B, H1, W1, C, generator=g)
+    f2 = torch.randn(B, H2, W2, C, generator=g)
+    base = torch.stack(torch.meshgrid(torch.arange(H1, dtype=torch.float32), torch.arange(W1, dtype=torch.float32),
+                                      indexing="ij")[::-1], -1)[None, None].repeat(B, 1, 1, 1, 1)
+    smooth = torch.nn.functional.interpolate(torch.randn(B, 2, 4, 5, generator=g) * 4, size=(H1, W1), mode="bicubic", align_corners=True)
+    coords = (base + smooth.permute(0, 2, 3, 1)[:, None]) * (W2 / W1) + torch.randn(B, 1, H1, W1, 2, generator=g) * sigma
+    coords[0, 0, 0, 0, 0] = float("nan")
+    coords[0, 0, 0, 1, 1] = 1e12
+    coords[0, 0, H1 - 1, W1 - 1] = torch.tensor([-30.0, 2.5])       # a window entirely left of the map
+    ref = O.alt_corr_forward(f1, f2, coords, r)
+    torch.ops.pfk.debug_set_altcorr(mode)
+    try:
+        out = torch.ops.pfk.altcorr_forward(f1.cuda(), f2.cuda(), coords.cuda(), r)
+    finally:
+        torch.ops.pfk.debug_set_altcorr(0)
+    got = (out[0] if isinstance(out, (list, tuple)) else out).cpu()
+    assert got.shape == ref.shape
+    assert bool((torch.isnan(got) == torch.isnan(ref)).all())
+    err = torch.where(torch.isnan(ref), torch.zeros_like(ref), (got - ref).abs())
+    assert err.max().item() < 2e-4 * max(1.0, ref.nan_to_num().abs().max().item())
+
+
 @pytest.mark.parametrize("B,C,H,W,L,r", [(1, 256, 16, 24, 4, 4), (2, 128, 24, 40, 2, 4), (1, 64, 18, 22, 3, 3)])
 def test_alternate_corr_block(gpu, B, C, H, W, L, r):
     """`get_corr_block(alternate_corr=True)` (raft/corr.py:67-101, the default of ccmr / ms_raft_p): pooled fmap2 per level,
