@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256, 2) void altcorr_fwd_ws_kernel(const float* __r
     }
     __syncthreads();
     for (int idx = t; idx < 32 * rd * rd; idx += 256) {
-      const int i = idx / (rd * rd), kc = idx - i * (rd * rd);
+      const int kc = idx >> 5, i = idx & 31;               // pixel fastest: a row of the patch is one 32-byte run of an output plane
       const int q = mt * 32 + i;
       const int yy = py0 + (q >> 3), xx = px0 + (q & 7);
       if (yy >= H1 || xx >= W1) continue;
@@ -516,8 +516,8 @@ int pfk_altcorr_forward_f32(const float* fmap1, const float* fmap2, const float*
   // Window-sharing MFMA kernel on 8 x 4 patches once the patch grid fills the chip (a block lives ~30 us: 16 K-steps of exposed L2
   // latency), the per-pixel kernel below that and for maps whose byte offsets do not fit the 32-bit buffer addressing of the staging
   // loads.  MI355X, C = 256, r = 4 (scripts/lookup_bench.py, gpurun_out/r3_altcorr.log): 55x128 batch 8 with a smooth flow field
-  // 271 -> 133 us (2.0x; 22 TFLOP/s of useful window work), 110x256 (1/4 resolution) 142 -> 74 us; a field with +-4 px of
-  // low-frequency variation per 8 px 272 -> 192 us; iid noise of sigma 6 px on every pixel (no two windows share anything: every box
+  // 270 -> 129 us (2.1x; 22 TFLOP/s of useful window work), 110x256 (1/4 resolution) 141 -> 73 us; a field with +-4 px of
+  // low-frequency variation per 8 px 271 -> 186 us; iid noise of sigma 6 px on every pixel (no two windows share anything: every box
   // overflows and the patch is handed to altcorr_fwd_overflow_kernel) 333 -> 435 us.  8 x 8 patches never beat 8 x 4.
   const int tx = (W1 + 7) / 8;
   const long long t8 = (long long)B * ((H1 + 7) / 8) * tx, t4 = (long long)B * ((H1 + 3) / 4) * tx;
