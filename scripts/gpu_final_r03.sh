@@ -10,12 +10,14 @@ timeout 200 python scripts/corr_bench.py > $O/z_corr.log 2>&1
 timeout 200 python scripts/lookup_bench.py > $O/z_lookup.log 2>&1
 timeout 200 python scripts/conv_bench.py --batch 1 --cfgs=-1,4 --reps 40 > $O/z_conv_b1.log 2>&1
 timeout 200 python scripts/conv_bench.py --batch 8 --cfgs=-1,10 --reps 10 --rounds 3 > $O/z_conv_b8.log 2>&1
+timeout 200 python scripts/conv_bench.py --batch 8 --cfgs=300,302,200,203,100,103 --reps 10 --rounds 3 > $O/z_conv_bf_b8.log 2>&1
 timeout 200 python scripts/wgrad_bench.py --variants=0,4 > $O/z_wgrad.log 2>&1
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py --no-cpu-baseline --no-roofline --no-split-modes --no-extra-legs --no-batch1"
 tr() { name=$1; shift; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$name -o r -- "$@" > $O/$name.log 2>&1; }
 tr z_tr_f32 $B --steps 3 --warmup 2
 tr z_tr_b1 $B --batch 1 --steps 10 --warmup 3
+tr z_tr_x6 $B --conv-precision bf16x6 --steps 3 --warmup 2
 tr z_tr_seam python $R/scripts/seam_prof.py
 tr z_tr_seam_torch python $R/scripts/seam_prof.py --unpatched
 tr z_tr_train python $R/scripts/train_prof.py

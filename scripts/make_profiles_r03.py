@@ -22,6 +22,10 @@ def bench_line():
     raise SystemExit("no JSON line in z_bench.log")
 
 
+def cut(text, n):
+    return "\n".join(l[:n] for l in text.splitlines())
+
+
 def tail(name, n=3):
     try:
         return "\n".join(open(os.path.join(O, name)).read().strip().splitlines()[-n:])
@@ -75,7 +79,7 @@ Micro-benches of the same run — correlation path (z_corr.log):
 ```
 lookup / on-demand correlation (z_lookup.log):
 ```
-{tail('z_lookup.log', 6)}
+{cut(tail('z_lookup.log', 13), 420)}
 ```
 update-block convolutions, batch 8, 3 rounds round-robin, heuristic vs 64x64 x3 everywhere (z_conv_b8.log):
 ```
@@ -84,6 +88,10 @@ update-block convolutions, batch 8, 3 rounds round-robin, heuristic vs 64x64 x3 
 batch 1 (z_conv_b1.log):
 ```
 {tail('z_conv_b1.log', 13)}
+```
+the same launches on the split-bf16 kernels: heuristic vs round 2's tiles, three / two / one plane (z_conv_bf_b8.log):
+```
+{cut(tail('z_conv_bf_b8.log', 13), 460)}
 ```
 weight gradient (z_wgrad.log):
 ```
@@ -96,6 +104,7 @@ weight gradient (z_wgrad.log):
     for name, fw, top, title in (
             ("z_tr_f32", 5, 24, "raft fp32 (default bench command), batch 8, 5 forwards"),
             ("z_tr_b1", 13, 18, "raft fp32, batch 1, 13 forwards"),
+            ("z_tr_x6", 5, 14, "raft with conv_precision=bf16x6 (split-bf16 kernels K8, profiles/r03_d), batch 8, 5 forwards"),
             ("z_tr_seam", 8, 24, "drop-in seam path: SeamRAFT + patch.accelerate (B1/B3/B4/B5), batch 1, 8 forwards"),
             ("z_tr_seam_torch", 3, 24, "the same object un-patched: stock PyTorch-ROCm ops (MIOpen / rocBLAS / grid_sample), batch 1, the FIRST 3 forwards of the process — MIOpen still runs its naive fallback convolution for the 7x7 / 1x5 / 5x1 shapes while it searches; warmed up the same forward takes 41 ms (bench.py --torch-baseline: 24.3 pairs/s)"),
             ("z_tr_train", 4, 30, "training step (BASELINE config 5 shape: batch 10, 368x496, 12 iterations), 4 steps incl. backward + AdamW")):
