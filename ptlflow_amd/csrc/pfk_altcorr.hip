@@ -163,7 +163,7 @@ __device__ __forceinline__ void altcorr_pixel(const float* __restrict__ f1, cons
 constexpr int WS_FAR = -(1 << 30);
 template <int TPY>
 __device__ __forceinline__ void patch_box(const float* __restrict__ coords, long long b, int py0, int px0, int H1, int W1, int H2,
-                                          int W2, int r, int lane, float& x, float& y, int& x0, int& y0, int (&box)[4]) {
+                                          int W2, int r, int lane, float& x, float& y, int& x0, int& y0, int (&box)[5]) {
   constexpr int TP = 8 * TPY;
   const int n = 2 * r + 2;
   const int yy = py0 + (lane >> 3), xx = px0 + (lane & 7);
@@ -185,49 +185,63 @@ __device__ __forceinline__ void patch_box(const float* __restrict__ coords, long
     lo_x = min(lo_x, __shfl_xor(lo_x, off, 64)); hi_x = max(hi_x, __shfl_xor(hi_x, off, 64));
     lo_y = min(lo_y, __shfl_xor(lo_y, off, 64)); hi_y = max(hi_y, __shfl_xor(hi_y, off, 64));
   }
+  // taps of the patch that lie inside the map: what the per-pixel algorithm would have to compute
+  int work = use ? (min(x0 + n, W2) - max(x0, 0)) * (min(y0 + n, H2) - max(y0, 0)) : 0;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) work += __shfl_xor(work, off, 64);
   const bool any = hi_x > lo_x && hi_y > lo_y;
   box[0] = any ? lo_x : 0; box[1] = any ? lo_y : 0; box[2] = any ? hi_x - lo_x : 0; box[3] = any ? hi_y - lo_y : 0;
+  box[4] = work;
 }
 
-// The patches the window-sharing kernel skipped (box of more than WS_NP_MAX points): the per-pixel algorithm, one pixel per wave
-// as in altcorr_fwd_kernel (four consecutive pixels of a patch row per block); a wave whose patch fits leaves after the box test.
+// The shared GEMM computes TP x NP dot products where the per-pixel algorithm computes `work` of them, about ten times more slowly
+// each: the patch takes the GEMM when its box fits the LDS budget and is not mostly other pixels' (or out-of-map) points.
+template <int TPY>
+__device__ __forceinline__ bool patch_takes_gemm(const int (&box)[5], int ratio) {
+  const long long np = (long long)box[2] * box[3];
+  return np <= WS_NP_MAX && np * (8 * TPY) <= (long long)ratio * box[4];
+}
+
+// The patches the window-sharing kernel skipped: the per-pixel algorithm, one pixel per wave, blocks in the per-pixel kernel's own
+// row-major order (four consecutive pixels of an image row — they always lie in one patch); a block whose patch took the GEMM
+// leaves after the box test (one per block, wave 0).
 template <int TPY>
 __global__ __launch_bounds__(256) void altcorr_fwd_overflow_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
                                                                    const float* __restrict__ coords, float* __restrict__ out,
-                                                                   int H1, int W1, int H2, int W2, int C, int r, int tiles_x,
-                                                                   int tiles_y, int force) {
-  constexpr int TP = 8 * TPY, SUBS = TP / 4;
+                                                                   int H1, int W1, int H2, int W2, int C, int r, int groups_x,
+                                                                   int force, int ratio) {
   __shared__ float s_tap[4][104];
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int tile = blockIdx.x / SUBS, sub = blockIdx.x % SUBS;
-  const int txi = tile % tiles_x, tyi = (tile / tiles_x) % tiles_y;
-  const long long b = tile / (tiles_x * tiles_y);
-  const int px0 = txi * 8, py0 = tyi * TPY;
   __shared__ float s_xy[4][2];
   __shared__ int s_over;
-  if (wid == 0) {                                       // one box test per block
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int gx = blockIdx.x % groups_x;                 // group of four pixels in its row
+  const long long rowid = blockIdx.x / groups_x;        // b * H1 + y
+  const long long b = rowid / H1;
+  const int yy = (int)(rowid - b * H1);
+  const int xg = gx * 4;
+  const int px0 = xg & ~7, py0 = yy - yy % TPY;
+  if (wid == 0) {
     float x, y;
-    int x0, y0, box[4];
+    int x0, y0, box[5];
     patch_box<TPY>(coords, b, py0, px0, H1, W1, H2, W2, r, lane, x, y, x0, y0, box);
-    if (lane >= sub * 4 && lane < sub * 4 + 4) { s_xy[lane - sub * 4][0] = x; s_xy[lane - sub * 4][1] = y; }
-    if (lane == 0) s_over = force || (long long)box[2] * box[3] > WS_NP_MAX;
+    const int q0 = (yy - py0) * 8 + (xg - px0);         // first of this block's pixels inside the patch
+    if (lane >= q0 && lane < q0 + 4) { s_xy[lane - q0][0] = x; s_xy[lane - q0][1] = y; }
+    if (lane == 0) s_over = force || !patch_takes_gemm<TPY>(box, ratio);
   }
   __syncthreads();
   if (!s_over) return;
   const long long hw = (long long)H1 * W1;
-  const int q = sub * 4 + wid;                          // pixel of the patch
-  const float xq = s_xy[wid][0], yq = s_xy[wid][1];
-  const int yy = py0 + (q >> 3), xx = px0 + (q & 7);
-  const bool live = yy < H1 && xx < W1;
+  const int xx = xg + wid;
+  const bool live = xx < W1;
   const int pix = yy * W1 + xx;
-  altcorr_pixel(f1, f2, out, live, b * hw + pix, b, pix, xq, yq, hw, H2, W2, C, r, s_tap[wid], lane);
+  altcorr_pixel(f1, f2, out, live, b * hw + pix, b, pix, s_xy[wid][0], s_xy[wid][1], hw, H2, W2, C, r, s_tap[wid], lane);
 }
 
 template <int TPY>
 __global__ __launch_bounds__(256, 2) void altcorr_fwd_ws_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
                                                                 const float* __restrict__ coords, float* __restrict__ out,
                                                                 int B, int H1, int W1, int H2, int W2, int C, int r,
-                                                                int tiles_x, int tiles_y) {
+                                                                int tiles_x, int tiles_y, int ratio) {
   constexpr int TP = 8 * TPY, MT = TP / 32;
   static_assert(TP == 32 || TP == 64, "patches of 8 x 4 or 8 x 8 pixels");
   constexpr int STAGE = (TP + WS_NP_MAX) * WS_ROWB;        // bytes per stage: A rows then B rows
@@ -235,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void altcorr_fwd_ws_kernel(const float* __r
   extern __shared__ __attribute__((aligned(16))) char ws_smem[];   // [2][STAGE]
   __shared__ float s_x[TP], s_y[TP];        // target coordinates
   __shared__ int s_x0[TP], s_y0[TP];        // window origin (floor - r), or the far sentinel
-  __shared__ int s_box[4];                  // bx0, by0, bw, bh
+  __shared__ int s_box[5];                  // bx0, by0, bw, bh, takes-the-GEMM flag
 
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
   const int tile = blockIdx.x;
@@ -249,15 +263,16 @@ __global__ __launch_bounds__(256, 2) void altcorr_fwd_ws_kernel(const float* __r
   // ---- per-pixel coordinates and the bounding box of the patch's windows (wave 0) -------------------------------------------------
   if (wid == 0) {
     float x, y;
-    int x0, y0, box[4];
+    int x0, y0, box[5];
     patch_box<TPY>(coords, b, py0, px0, H1, W1, H2, W2, r, lane, x, y, x0, y0, box);
     if (lane < TP) { s_x[lane] = x; s_y[lane] = y; s_x0[lane] = x0; s_y0[lane] = y0; }
     if (lane < 4) s_box[lane] = box[lane];
+    if (lane == 4) s_box[4] = patch_takes_gemm<TPY>(box, ratio) || box[4] == 0;   // nothing inside the map: zeros / NaNs from here
   }
   __syncthreads();
   const int bx0 = s_box[0], by0 = s_box[1], bw = s_box[2], bh = s_box[3];
   const long long np_ll = (long long)bw * bh;
-  if (np_ll > WS_NP_MAX) return;      // strongly divergent flow: altcorr_fwd_overflow_kernel (launched behind this one) takes the patch
+  if (!s_box[4]) return;              // strongly divergent flow: altcorr_fwd_overflow_kernel (launched behind this one) takes the patch
   const int NP = (int)np_ll;
   const int NCB = (NP + 31) >> 5;                       // column blocks of 32 box points
 
@@ -513,35 +528,42 @@ int pfk_altcorr_forward_f32(const float* fmap1, const float* fmap2, const float*
   const long long blocks = (M + 3) / 4;
   if (blocks > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  // Window-sharing MFMA kernel on 8 x 4 patches once the patch grid fills the chip (a block lives ~30 us: 16 K-steps of exposed L2
-  // latency), the per-pixel kernel below that and for maps whose byte offsets do not fit the 32-bit buffer addressing of the staging
+  // Window-sharing MFMA kernel on 8 x 4 patches once the patch grid fills the chip (a block lives ~30 us), the per-pixel kernel below that and for maps whose byte offsets do not fit the 32-bit buffer addressing of the staging
   // loads.  MI355X, C = 256, r = 4 (scripts/lookup_bench.py, gpurun_out/r3_altcorr.log): 55x128 batch 8 with a smooth flow field
   // 270 -> 129 us (2.1x; 22 TFLOP/s of useful window work), 110x256 (1/4 resolution) 141 -> 73 us; a field with +-4 px of
   // low-frequency variation per 8 px 271 -> 186 us; iid noise of sigma 6 px on every pixel (no two windows share anything: every box
-  // overflows and the patch is handed to altcorr_fwd_overflow_kernel) 333 -> 435 us.  8 x 8 patches never beat 8 x 4.
+  // overflows and the patch is handed to altcorr_fwd_overflow_kernel) 333 -> 400 us (the overflow kernel alone, in the per-pixel
+  // kernel's row-major block order, 333; the rest is the border patches' GEMMs in front of it).  8 x 8 patches never beat 8 x 4.
   const int tx = (W1 + 7) / 8;
   const long long t8 = (long long)B * ((H1 + 7) / 8) * tx, t4 = (long long)B * ((H1 + 3) / 4) * tx;
-  const bool fits32 = (long long)B * H1 * W1 * C * 4 < 0x7fffffffLL && (long long)B * H2 * W2 * C * 4 < 0x7fffffffLL && t8 * 16 < 0x7fffffffLL && t4 * 8 < 0x7fffffffLL;
+  const bool fits32 = (long long)B * H1 * W1 * C * 4 < 0x7fffffffLL && (long long)B * H2 * W2 * C * 4 < 0x7fffffffLL ;
   const int mode = g_altcorr_mode;
   if (fits32 && mode != 1 && (mode >= 2 || t4 >= 256)) {
     const bool big = mode == 3;
+    // (a cost rule — GEMM only while TP x NP <= ratio x the taps the per-pixel algorithm would compute — was measured: it trims the
+    // all-noise case, 400 -> 360 us at ratio 6, and costs smooth fields 72 -> 88 us at 110x256, because a rejected border patch
+    // then runs alone in the second launch; off = a huge ratio)
+    const int ratio = 1 << 20;
+    const int gxn = (W1 + 3) / 4;
+    const long long ogrid = (long long)B * H1 * gxn;
+    if (ogrid > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
     if (big) {
       constexpr size_t smem = 2 * (64 + WS_NP_MAX) * WS_ROWB;
       static pfk_device_once once;
       once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(altcorr_fwd_ws_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); });
       hipLaunchKernelGGL(altcorr_fwd_ws_kernel<8>, dim3((unsigned)t8), dim3(256), smem, st, fmap1, fmap2, coords, out, B, H1, W1, H2, W2, C,
-                         radius, tx, (H1 + 7) / 8);
-      hipLaunchKernelGGL(altcorr_fwd_overflow_kernel<8>, dim3((unsigned)(t8 * 16)), dim3(256), 0, st, fmap1, fmap2, coords, out, H1, W1, H2,
-                         W2, C, radius, tx, (H1 + 7) / 8, 0);
+                         radius, tx, (H1 + 7) / 8, ratio);
+      hipLaunchKernelGGL(altcorr_fwd_overflow_kernel<8>, dim3((unsigned)ogrid), dim3(256), 0, st, fmap1, fmap2, coords, out, H1, W1, H2, W2,
+                         C, radius, gxn, 0, ratio);
     } else {
       constexpr size_t smem = 2 * (32 + WS_NP_MAX) * WS_ROWB;
       static pfk_device_once once;
       once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(altcorr_fwd_ws_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); });
       if (mode != 4)
         hipLaunchKernelGGL(altcorr_fwd_ws_kernel<4>, dim3((unsigned)t4), dim3(256), smem, st, fmap1, fmap2, coords, out, B, H1, W1, H2, W2,
-                           C, radius, tx, (H1 + 3) / 4);
-      hipLaunchKernelGGL(altcorr_fwd_overflow_kernel<4>, dim3((unsigned)(t4 * 8)), dim3(256), 0, st, fmap1, fmap2, coords, out, H1, W1, H2,
-                         W2, C, radius, tx, (H1 + 3) / 4, mode == 4);
+                           C, radius, tx, (H1 + 3) / 4, ratio);
+      hipLaunchKernelGGL(altcorr_fwd_overflow_kernel<4>, dim3((unsigned)ogrid), dim3(256), 0, st, fmap1, fmap2, coords, out, H1, W1, H2, W2,
+                         C, radius, gxn, mode == 4, ratio);
     }
     return pfk_launch_status();
   }
