@@ -348,12 +348,14 @@ struct KStep {
 
 // two resident blocks per CU (=> <= 256 registers) whenever two of them fit in the 160 KB of LDS; an eight-wave block stays alone
 // (two of them would cap a lane at 128 registers)
-constexpr int bf_blocks_per_cu(int ns, int bm, int bn, int sub, int waves) {
+constexpr int bf_blocks_per_cu(int ns, int bm, int bn, int sub, int waves, int nsets) {
+  // (two resident eight-wave blocks of the two-plane 128x128 tile would need <= 128 registers: 32 bytes of scratch, not built)
   return (waves <= 4 && 2 * (2 * sub * ns * (bm + bn) * ROWB) <= 160 * 1024) ? 2 : 1;
 }
 
 template <int EPI, int NS, int BM, int BN, int SUB, int WM = 2, int WN = 2, int NSETS = 2>
-__global__ __launch_bounds__(64 * WM * WN, bf_blocks_per_cu(NS, BM, BN, SUB, WM * WN)) void conv_gemm_bf_kernel(const GemmArgs a) {
+// (hipcc reads the second launch-bounds argument as waves per SIMD: resident blocks x waves per block / 4)
+__global__ __launch_bounds__(64 * WM * WN, bf_blocks_per_cu(NS, BM, BN, SUB, WM * WN, NSETS) * WM * WN / 4) void conv_gemm_bf_kernel(const GemmArgs a) {
   using St = StagerBF<NS, BM, BN, SUB, 64 * WM * WN, NSETS>;
   constexpr int MT = BM / (32 * WM), NT = BN / (32 * WN);
   constexpr int A_PLANE = St::A_PLANE, STAGE = SUB * St::SUBSTAGE;
