@@ -45,7 +45,7 @@ struct GemmArgs {
   int pp_whole;            // 1: blocks get whole tiles only (no partial-tile hand-off, no workspace)
   const void* wbf;         // split-bf16 path: weight planes [nsplit][cout][ktot] bf16, same k order as `weight`
   long long wbf_plane_bytes;
-  int dbg;                 // split-bf16 timing ablations (results are garbage): 1 no global loads, 2 no split + LDS stores, 4 no fragment reads + MFMAs
+  int m_tile_base;         // split-bf16 path: a launch may cover a range of row tiles only (launch_bf's tail split); first row tile, in units of BM
 };
 
 // Tile id -> (tile_m, tile_n).  Row-major by default (tile_n fastest: the column tiles of one row panel run together and share

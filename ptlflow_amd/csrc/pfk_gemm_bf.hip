@@ -369,7 +369,7 @@ __global__ __launch_bounds__(64 * WM * WN, bf_blocks_per_cu(NS, BM, BN, SUB, WM 
 
   const int bid = pfk_xcd_remap(blockIdx.x, gridDim.x);
   const int tile_n = bid % a.tiles_n;
-  const int tile_m = bid / a.tiles_n;
+  const int tile_m = bid / a.tiles_n + a.m_tile_base;
   const long long m0 = (long long)tile_m * BM;
   const int n0 = tile_n * BN;
 
@@ -417,12 +417,16 @@ __global__ __launch_bounds__(64 * WM * WN, bf_blocks_per_cu(NS, BM, BN, SUB, WM 
 }
 
 template <int EPI, int NS, int BM, int BN, int SUB, int WM = 2, int WN = 2, int NSETS = 2>
-int launch_bf_one(const GemmArgs& a, hipStream_t st) {
+int launch_bf_one(const GemmArgs& a, hipStream_t st, long long row0, long long row1) {
   GemmArgs g = a;
   if (a.M >= 0x7fffffffLL || a.Wo <= 0 || a.Ho <= 0) return PFK_ERR_UNSUPPORTED;   // 32-bit pixel arithmetic in the stager
   fastdiv_make((unsigned)a.Wo, g.wo_mul, g.wo_sh);
   fastdiv_make((unsigned)a.Ho, g.ho_mul, g.ho_sh);
-  const long long tiles_m = (a.M + BM - 1) / BM;
+  // output rows [row0, row1) of M (row0 a multiple of BM; row1 < 0: to the end)
+  if (row1 < 0 || row1 > a.M) row1 = a.M;
+  if (row0 % BM || row0 >= row1) return row0 >= row1 && row0 <= a.M ? PFK_OK : PFK_ERR_BAD_ARG;
+  g.m_tile_base = (int)(row0 / BM);
+  const long long tiles_m = (row1 - row0 + BM - 1) / BM;
   g.tiles_n = (a.b_rows + BN - 1) / BN;
   const long long nblk = tiles_m * g.tiles_n;
   if (nblk <= 0 || nblk > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
@@ -439,11 +443,11 @@ int launch_bf_one(const GemmArgs& a, hipStream_t st) {
 }
 
 template <int NS, int BM, int BN, int SUB, int WM = 2, int WN = 2, int NSETS = 2>
-int launch_bf_epi(const GemmArgs& g, int epi, hipStream_t st) {
+int launch_bf_epi(const GemmArgs& g, int epi, hipStream_t st, long long row0, long long row1) {
   switch (epi) {
-    case PFK_EPI_LINEAR: return launch_bf_one<PFK_EPI_LINEAR, NS, BM, BN, SUB, WM, WN, NSETS>(g, st);
-    case PFK_EPI_GRU_ZR: return launch_bf_one<PFK_EPI_GRU_ZR, NS, BM, BN, SUB, WM, WN, NSETS>(g, st);
-    case PFK_EPI_GRU_Q:  return launch_bf_one<PFK_EPI_GRU_Q, NS, BM, BN, SUB, WM, WN, NSETS>(g, st);
+    case PFK_EPI_LINEAR: return launch_bf_one<PFK_EPI_LINEAR, NS, BM, BN, SUB, WM, WN, NSETS>(g, st, row0, row1);
+    case PFK_EPI_GRU_ZR: return launch_bf_one<PFK_EPI_GRU_ZR, NS, BM, BN, SUB, WM, WN, NSETS>(g, st, row0, row1);
+    case PFK_EPI_GRU_Q:  return launch_bf_one<PFK_EPI_GRU_Q, NS, BM, BN, SUB, WM, WN, NSETS>(g, st, row0, row1);
     default: return PFK_ERR_BAD_ARG;
   }
 }
@@ -451,15 +455,15 @@ int launch_bf_epi(const GemmArgs& g, int epi, hipStream_t st) {
 // tile configurations: 1 = 64x64 (two sub-steps per barrier), 2 = 128x64, 3 = 128x128, 4 = 128x128 with eight waves (2 x 4: every
 // thread splits and stages half as much per MFMA)
 template <int NS>
-int launch_bf_ns(const GemmArgs& g, int epi, int cfg, hipStream_t st) {
+int launch_bf_ns(const GemmArgs& g, int epi, int cfg, hipStream_t st, long long row0 = 0, long long row1 = -1) {
   switch (cfg) {
-    case 1: return launch_bf_epi<NS, 64, 64, 2>(g, epi, st);
-    case 2: return launch_bf_epi<NS, 128, 64, 1>(g, epi, st);
-    case 3: return launch_bf_epi<NS, 128, 128, 1>(g, epi, st);
-    case 4: return launch_bf_epi<NS, 128, 128, 1, 2, 4>(g, epi, st);
+    case 1: return launch_bf_epi<NS, 64, 64, 2>(g, epi, st, row0, row1);
+    case 2: return launch_bf_epi<NS, 128, 64, 1>(g, epi, st, row0, row1);
+    case 3: return launch_bf_epi<NS, 128, 128, 1>(g, epi, st, row0, row1);
+    case 4: return launch_bf_epi<NS, 128, 128, 1, 2, 4>(g, epi, st, row0, row1);
     // 64x64 wave tiles (half the fragment bytes per MFMA of the configurations above) with eight waves: 256x128 / 128x256
-    case 5: return launch_bf_epi<NS, 256, 128, 1, 4, 2, 1>(g, epi, st);
-    case 6: return launch_bf_epi<NS, 128, 256, 1, 2, 4, 1>(g, epi, st);
+    case 5: return launch_bf_epi<NS, 256, 128, 1, 4, 2, 1>(g, epi, st, row0, row1);
+    case 6: return launch_bf_epi<NS, 128, 256, 1, 2, 4, 1>(g, epi, st, row0, row1);
     default: return PFK_ERR_BAD_ARG;
   }
 }
@@ -474,7 +478,7 @@ int launch_bf(const GemmArgs& a0, int epi, int nsplit, hipStream_t st) {
   GemmArgs a = a0;
   a.vec_flags = gemm_vec_flags(a);
   int cfg = g_bf_cfg % 10;
-  a.dbg = g_bf_cfg / 10;
+  a.m_tile_base = 0;
   if (cfg == 0) {
     // Measured on MI355X (scripts/conv_bench.py, batch 1 and 8, RAFT update-block shapes).  The kernels are bound by LDS
     // traffic (ds_write_b128 moves ~80 B/clk/CU), so the biggest tile that still fills the chip wins; three planes only
@@ -506,12 +510,33 @@ int launch_bf(const GemmArgs& a0, int epi, int nsplit, hipStream_t st) {
       else if (!skip && nsplit >= 2 && (pad128 - a.b_rows) * 3 <= a.b_rows && nb5 >= 220) cfg = 5;
     }
   }
-  switch (nsplit) {
-    case 1: return launch_bf_ns<1>(a, epi, cfg, st);
-    case 2: return launch_bf_ns<2>(a, epi, cfg, st);
-    case 3: return launch_bf_ns<3>(a, epi, cfg, st);
-    default: return PFK_ERR_BAD_ARG;
+  // Tail split (round 3): the 64x64-wave-tile configurations run ONE block per CU, so a grid of 3.44 rounds of 256 blocks costs 4
+  // (fh|mask conv1 at batch 8: 880 blocks: 344 -> 329 us with the split).  When the last round is at most 60 % full (at 72 % — the
+  // z|r convolutions' 440 blocks — the second launch's own ramp and tail cost more than the round they save: 293 -> 326 us), the big tiles take the whole rounds and the
+  // remaining rows go to the eight-wave 128x128 tile (half the work per block, twice the blocks) in a second launch on disjoint rows.
+  long long split_row = -1;
+  if ((cfg == 5 || cfg == 6) && g_bf_cfg / 10 != 9) {       // pfk_debug_set_tile(190 + t): tail split off (A/B timing)
+    const int bm = cfg == 5 ? 256 : 128, bn = cfg == 5 ? 128 : 256;
+    const long long tn = (a.b_rows + bn - 1) / bn, tmr = (a.M + bm - 1) / bm, nblk = tmr * tn;
+    const long long full = nblk / 256 * 256, rem = nblk - full;
+    if (full > 0 && rem > 0 && rem * 10 <= 256 * 6) {
+      const long long rows = full / tn * bm;              // whole row tiles inside the full rounds
+      if (rows > 0 && rows < a.M) split_row = rows;
+    }
   }
+  auto run = [&](int c, long long r0, long long r1) {
+    switch (nsplit) {
+      case 1: return launch_bf_ns<1>(a, epi, c, st, r0, r1);
+      case 2: return launch_bf_ns<2>(a, epi, c, st, r0, r1);
+      case 3: return launch_bf_ns<3>(a, epi, c, st, r0, r1);
+      default: return (int)PFK_ERR_BAD_ARG;
+    }
+  };
+  if (split_row > 0) {
+    const int rc = run(cfg, 0, split_row);
+    return rc != PFK_OK ? rc : run(4, split_row, -1);
+  }
+  return run(cfg, 0, -1);
 }
 
 }  // namespace pfkg

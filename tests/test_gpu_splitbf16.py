@@ -154,6 +154,36 @@ def test_split_conv_every_tile_configuration(gpu, tile):
         torch.ops.pfk.debug_set_tile(100)
 
 
+@pytest.mark.parametrize("nsplit", [2, 3])
+def test_split_conv_tail_split(gpu, nsplit):
+    """A grid of 2.15 rounds of one-block-per-CU tiles (275 row tiles x 2 column tiles of 128x256): `launch_bf` gives the two whole
+    rounds to the big tiles and rows 32768.. to the eight-wave 128x128 tile in a second launch.  Checked against float64 on the
+    first image (first launch only) and on the last one (which holds the split row), and against the un-split launch."""
+    torch.manual_seed(17)
+    B, H, W, cin, cout = 5, 55, 128, 64, 512
+    x = torch.randn(B, cin, H, W)
+    wt = torch.randn(cout, cin, 3, 3) / math.sqrt(cin * 9)
+    bias = torch.randn(cout)
+    w = planes(wt, [(0, cin, cin)], nsplit)
+    xp = pm(x)
+    outs = []
+    for knob in (100, 190):                    # heuristic with / without the tail split
+        torch.ops.pfk.debug_set_tile(knob)
+        try:
+            out = torch.zeros(B * H * W, cout, device=gpu)
+            torch.ops.pfk.conv2d([xp], B, H, W, 3, 3, w, bias.cuda(), cout, EPI_LINEAR, True, 1.0, out, None, None, None)
+            outs.append(out)
+        finally:
+            torch.ops.pfk.debug_set_tile(100)
+    for b in (0, B - 1):
+        ref = F.relu(F.conv2d(x[b:b + 1].double(), wt.double(), bias.double(), padding=1)).float()
+        got = unpm(outs[0][b * H * W:(b + 1) * H * W], 1, H, W)
+        close(got, ref, rtol=TOL[nsplit], atol=TOL[nsplit])
+    # the two schedules differ only in the term order of the 2^-16 products on the rows that changed kernel
+    assert (outs[0] - outs[1]).abs().max().item() <= TOL[nsplit]
+    assert torch.equal(outs[0][:32768], outs[1][:32768]), "the rows of the whole rounds run the same kernel either way"
+
+
 def _epe(precisions, H, W, iters, small=False, seed=1234):
     from ptlflow_amd.raft import RAFT
     base = RAFT(small=small, iters=iters).load_synthetic(seed).eval()
