@@ -209,6 +209,26 @@ def golden_sea_raft_model():
     torch.save(rec, os.path.join(OUT, "sea_raft_model.pt"))
 
 
+def golden_alt_corr():
+    """The on-demand correlation path as the reference computes it WITHOUT its CUDA extension: `IterativeCorrBlock`
+    (ptlflow/utils/correlation.py:539-615, what raft/corr.py:111-113 builds for `alternate_corr=True` when `alt_cuda_corr` is
+    missing) on a 64x136 grid — 272 patches of 8x4 pixels, enough for libpfk's window-sharing kernel to be the one that runs —
+    with a smooth flow field plus 0.6 px of per-pixel noise (+0.013: away from exact integers, where grid_sample's index round trip
+    and a raw floor() disagree).  Output rows 0, 4, 8, ... are stored (1.4 MB instead of 5.6)."""
+    corr_mod = ref_loader.ref_module("ptlflow.models.raft.corr")
+    g = torch.Generator().manual_seed(77)
+    B, C, H, W, L, r = 1, 32, 64, 136, 2, 4
+    f1, f2 = torch.randn(B, C, H, W, generator=g), torch.randn(B, C, H, W, generator=g)
+    smooth = torch.nn.functional.interpolate(torch.randn(B, 2, H // 8 + 2, W // 8 + 2, generator=g) * 2.5, size=(H, W), mode="bicubic",
+                                             align_corners=True)
+    coords = O.coords_grid(B, H, W) + smooth + torch.randn(B, 2, H, W, generator=g) * 0.6 + 0.013
+    with torch.no_grad():
+        out = corr_mod.IterativeCorrBlock(fmap1=f1, fmap2=f2, radius=r, num_levels=L)(coords)
+    assert tuple(out.shape) == (B, L * (2 * r + 1) ** 2, H, W)
+    torch.save({"fmap1": f1, "fmap2": f2, "coords": coords, "levels": L, "radius": r, "row_step": 4,
+                "out_rows": out[:, :, ::4].clone()}, os.path.join(OUT, "alt_corr.pt"))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(4)
@@ -218,6 +238,7 @@ def main():
     golden_gma()
     golden_warm_start()
     golden_sea_raft_model()
+    golden_alt_corr()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
 

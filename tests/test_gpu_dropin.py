@@ -186,6 +186,26 @@ def test_alternate_corr_block(gpu, B, C, H, W, L, r):
     assert (got - ref).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_alternate_corr_block_vs_reference_golden(gpu, mode):
+    """`get_corr_block(alternate_corr=True)` on libpfk against what the REFERENCE computes for it without its CUDA extension
+    (`IterativeCorrBlock`, recorded by oracle/make_golden.py::golden_alt_corr; 64x136 grid: the library's own choice for level 0
+    is the window-sharing kernel), with the library's choice and with each forward kernel forced."""
+    import os
+    from ptlflow_amd.corr import get_corr_block
+    gold = torch.load(os.path.join(os.path.dirname(__file__), "golden", "alt_corr.pt"))
+    torch.ops.pfk.debug_set_altcorr(mode)
+    try:
+        blk = get_corr_block(fmap1=gold["fmap1"].cuda(), fmap2=gold["fmap2"].cuda(), num_levels=gold["levels"], radius=gold["radius"],
+                             alternate_corr=True)
+        got = blk(gold["coords"].cuda()).cpu()[:, :, ::gold["row_step"]]
+    finally:
+        torch.ops.pfk.debug_set_altcorr(0)
+    ref = gold["out_rows"]
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item())
+
+
 def test_gma_update_block_dropin(gpu):
     """Seam B3 with GMA's five-argument forward(net, inp, corr, flow, attention) (gma/update.py:148)."""
     from ptlflow_amd.raft import _param_tree
