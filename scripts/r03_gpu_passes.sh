@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 3: the GPU passes behind profiles/r03_a / r03_b (each was one `gpurun -- bash scripts/r03_gpu_passes.sh <pass>` call;
-# logs under gpurun_out/r3<pass>_*).  Usage: bash scripts/r03_gpu_passes.sh b|c|d|e|f|g|h|i|j|k|l|m|n|o|p|q
+# logs under gpurun_out/r3<pass>_*).  Usage: bash scripts/r03_gpu_passes.sh b|c|d|e|f|g|h|i|j|k|l|m|n|o|p|q|r|s
 O=$GRAFT_REPO_ROOT/gpurun_out; mkdir -p $O
 case "$1" in
 b)
@@ -142,6 +142,29 @@ q)
     tail -3 $O/r3q_pmc_$i.log | cut -c1-200
   done
   python $GRAFT_REPO_ROOT/scripts/pmc_by_kernel.py $O/r3q_pmc_* --match=conv_gemm > $O/r3q_counters.txt; cat $O/r3q_counters.txt
+  ;;
+r)
+  # round 3: counters of fm on the split-bf16 kernels AFTER the eight-wave tiles (heuristic: 128x256 + tail split; two planes: 128x128 x2)
+  cd /tmp && export TMPDIR=/tmp
+  i=0
+  for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS" "SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_ANY SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE"; do
+    i=$((i+1))
+    timeout 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $O/r3r_pmc_$i -- python $GRAFT_REPO_ROOT/scripts/conv_bench.py --batch 8 --cfgs=300,200,100 --only fm,zr1 --reps 3 > $O/r3r_pmc_$i.log 2>&1
+    tail -3 $O/r3r_pmc_$i.log | cut -c1-200
+  done
+  python $GRAFT_REPO_ROOT/scripts/pmc_by_kernel.py $O/r3r_pmc_* --match=conv_gemm > $O/r3r_counters.txt; cat $O/r3r_counters.txt
+  ;;
+s)
+  # round 3: shader clock and socket power under each kernel family (rocm-smi polled every 50 ms while one fm convolution loops ~2 s)
+  for cfg in 10 300 200 100; do
+    ( for i in $(seq 1 70); do rocm-smi --showclocks --showpower 2>/dev/null | grep -E "sclk|Socket Power" | tr -s ' ' | tr '\n' ';'; echo; sleep 0.05; done ) > $O/r3s_smi_$cfg.log 2>&1 &
+    SMI=$!
+    timeout 120 python scripts/conv_bench.py --batch 8 --cfgs=$cfg --reps 3000 --only fm > $O/r3s_conv_$cfg.log 2>&1
+    wait $SMI
+    echo "cfg $cfg: $(grep -v amdgpu $O/r3s_conv_$cfg.log | head -1 | cut -c1-110)"
+    grep -o "sclk clock level: [0-9S]*: ([0-9]*Mhz)" $O/r3s_smi_$cfg.log | sort | uniq -c | sort -rn | head -4
+    grep -o "Socket Graphics Package Power (W): [0-9.]*" $O/r3s_smi_$cfg.log | sort -t: -k2 -n | tail -2
+  done
   ;;
 *) echo "unknown pass $1"; exit 2;;
 esac
