@@ -163,7 +163,7 @@ __device__ __forceinline__ void altcorr_pixel(const float* __restrict__ f1, cons
 constexpr int WS_FAR = -(1 << 30);
 template <int TPY>
 __device__ __forceinline__ void patch_box(const float* __restrict__ coords, long long b, int py0, int px0, int H1, int W1, int H2,
-                                          int W2, int r, int lane, float& x, float& y, int& x0, int& y0, int (&box)[5]) {
+                                          int W2, int r, int lane, float& x, float& y, int& x0, int& y0, int (&box)[4]) {
   constexpr int TP = 8 * TPY;
   const int n = 2 * r + 2;
   const int yy = py0 + (lane >> 3), xx = px0 + (lane & 7);
@@ -185,22 +185,14 @@ __device__ __forceinline__ void patch_box(const float* __restrict__ coords, long
     lo_x = min(lo_x, __shfl_xor(lo_x, off, 64)); hi_x = max(hi_x, __shfl_xor(hi_x, off, 64));
     lo_y = min(lo_y, __shfl_xor(lo_y, off, 64)); hi_y = max(hi_y, __shfl_xor(hi_y, off, 64));
   }
-  // taps of the patch that lie inside the map: what the per-pixel algorithm would have to compute
-  int work = use ? (min(x0 + n, W2) - max(x0, 0)) * (min(y0 + n, H2) - max(y0, 0)) : 0;
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) work += __shfl_xor(work, off, 64);
   const bool any = hi_x > lo_x && hi_y > lo_y;
   box[0] = any ? lo_x : 0; box[1] = any ? lo_y : 0; box[2] = any ? hi_x - lo_x : 0; box[3] = any ? hi_y - lo_y : 0;
-  box[4] = work;
 }
 
-// The shared GEMM computes TP x NP dot products where the per-pixel algorithm computes `work` of them, about ten times more slowly
-// each: the patch takes the GEMM when its box fits the LDS budget and is not mostly other pixels' (or out-of-map) points.
-template <int TPY>
-__device__ __forceinline__ bool patch_takes_gemm(const int (&box)[5], int ratio) {
-  const long long np = (long long)box[2] * box[3];
-  return np <= WS_NP_MAX && np * (8 * TPY) <= (long long)ratio * box[4];
-}
+// The patch takes the shared GEMM when its box fits the LDS budget.  (A cost rule on top — GEMM only while TP x NP <= 6 x the taps
+// the per-pixel algorithm would compute — was measured: it trims the all-noise case, 400 -> 360 us, and costs smooth fields
+// 72 -> 88 us at 110x256, because a rejected border patch then runs alone in the second launch.  Not kept.)
+__device__ __forceinline__ bool patch_takes_gemm(const int (&box)[4]) { return (long long)box[2] * box[3] <= WS_NP_MAX; }
 
 // The patches the window-sharing kernel skipped: the per-pixel algorithm, one pixel per wave, blocks in the per-pixel kernel's own
 // row-major order (four consecutive pixels of an image row — they always lie in one patch); a block whose patch took the GEMM
@@ -209,7 +201,7 @@ template <int TPY>
 __global__ __launch_bounds__(256) void altcorr_fwd_overflow_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
                                                                    const float* __restrict__ coords, float* __restrict__ out,
                                                                    int H1, int W1, int H2, int W2, int C, int r, int groups_x,
-                                                                   int force, int ratio) {
+                                                                   int force) {
   __shared__ float s_tap[4][104];
   __shared__ float s_xy[4][2];
   __shared__ int s_over;
@@ -222,11 +214,11 @@ __global__ __launch_bounds__(256) void altcorr_fwd_overflow_kernel(const float* 
   const int px0 = xg & ~7, py0 = yy - yy % TPY;
   if (wid == 0) {
     float x, y;
-    int x0, y0, box[5];
+    int x0, y0, box[4];
     patch_box<TPY>(coords, b, py0, px0, H1, W1, H2, W2, r, lane, x, y, x0, y0, box);
     const int q0 = (yy - py0) * 8 + (xg - px0);         // first of this block's pixels inside the patch
     if (lane >= q0 && lane < q0 + 4) { s_xy[lane - q0][0] = x; s_xy[lane - q0][1] = y; }
-    if (lane == 0) s_over = force || !patch_takes_gemm<TPY>(box, ratio);
+    if (lane == 0) s_over = force || !patch_takes_gemm(box);
   }
   __syncthreads();
   if (!s_over) return;
@@ -241,7 +233,7 @@ template <int TPY>
 __global__ __launch_bounds__(256, 2) void altcorr_fwd_ws_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
                                                                 const float* __restrict__ coords, float* __restrict__ out,
                                                                 int B, int H1, int W1, int H2, int W2, int C, int r,
-                                                                int tiles_x, int tiles_y, int ratio) {
+                                                                int tiles_x, int tiles_y) {
   constexpr int TP = 8 * TPY, MT = TP / 32;
   static_assert(TP == 32 || TP == 64, "patches of 8 x 4 or 8 x 8 pixels");
   constexpr int STAGE = (TP + WS_NP_MAX) * WS_ROWB;        // bytes per stage: A rows then B rows
@@ -263,11 +255,11 @@ __global__ __launch_bounds__(256, 2) void altcorr_fwd_ws_kernel(const float* __r
   // ---- per-pixel coordinates and the bounding box of the patch's windows (wave 0) -------------------------------------------------
   if (wid == 0) {
     float x, y;
-    int x0, y0, box[5];
+    int x0, y0, box[4];
     patch_box<TPY>(coords, b, py0, px0, H1, W1, H2, W2, r, lane, x, y, x0, y0, box);
     if (lane < TP) { s_x[lane] = x; s_y[lane] = y; s_x0[lane] = x0; s_y0[lane] = y0; }
     if (lane < 4) s_box[lane] = box[lane];
-    if (lane == 4) s_box[4] = patch_takes_gemm<TPY>(box, ratio) || box[4] == 0;   // nothing inside the map: zeros / NaNs from here
+    if (lane == 4) s_box[4] = patch_takes_gemm(box);
   }
   __syncthreads();
   const int bx0 = s_box[0], by0 = s_box[1], bw = s_box[2], bh = s_box[3];
@@ -540,10 +532,6 @@ int pfk_altcorr_forward_f32(const float* fmap1, const float* fmap2, const float*
   const int mode = g_altcorr_mode;
   if (fits32 && mode != 1 && (mode >= 2 || t4 >= 256)) {
     const bool big = mode == 3;
-    // (a cost rule — GEMM only while TP x NP <= ratio x the taps the per-pixel algorithm would compute — was measured: it trims the
-    // all-noise case, 400 -> 360 us at ratio 6, and costs smooth fields 72 -> 88 us at 110x256, because a rejected border patch
-    // then runs alone in the second launch; off = a huge ratio)
-    const int ratio = 1 << 20;
     const int gxn = (W1 + 3) / 4;
     const long long ogrid = (long long)B * H1 * gxn;
     if (ogrid > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
@@ -552,18 +540,18 @@ int pfk_altcorr_forward_f32(const float* fmap1, const float* fmap2, const float*
       static pfk_device_once once;
       once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(altcorr_fwd_ws_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); });
       hipLaunchKernelGGL(altcorr_fwd_ws_kernel<8>, dim3((unsigned)t8), dim3(256), smem, st, fmap1, fmap2, coords, out, B, H1, W1, H2, W2, C,
-                         radius, tx, (H1 + 7) / 8, ratio);
+                         radius, tx, (H1 + 7) / 8);
       hipLaunchKernelGGL(altcorr_fwd_overflow_kernel<8>, dim3((unsigned)ogrid), dim3(256), 0, st, fmap1, fmap2, coords, out, H1, W1, H2, W2,
-                         C, radius, gxn, 0, ratio);
+                         C, radius, gxn, 0);
     } else {
       constexpr size_t smem = 2 * (32 + WS_NP_MAX) * WS_ROWB;
       static pfk_device_once once;
       once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(altcorr_fwd_ws_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); });
       if (mode != 4)
         hipLaunchKernelGGL(altcorr_fwd_ws_kernel<4>, dim3((unsigned)t4), dim3(256), smem, st, fmap1, fmap2, coords, out, B, H1, W1, H2, W2,
-                           C, radius, tx, (H1 + 3) / 4, ratio);
+                           C, radius, tx, (H1 + 3) / 4);
       hipLaunchKernelGGL(altcorr_fwd_overflow_kernel<4>, dim3((unsigned)ogrid), dim3(256), 0, st, fmap1, fmap2, coords, out, H1, W1, H2, W2,
-                         C, radius, gxn, mode == 4, ratio);
+                         C, radius, gxn, mode == 4);
     }
     return pfk_launch_status();
   }
