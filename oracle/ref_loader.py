@@ -1,9 +1,9 @@
 """TEST INFRASTRUCTURE — loads the *real* reference (hmorimitsu/ptlflow at /root/reference)
 in this container so the oracle restatement can be pinned against it.
 
-Only `oracle/make_golden.py` and `tests/test_oracle_vs_reference.py` use this module; nothing
-in `ptlflow_amd/`, `bench.py` or the `-m gpu` tests may import it (the GPU box has no
-/root/reference).
+Used by `oracle/make_golden.py`, the `reference`-marked tests and bench.py's `dropin` / `cpu_baseline`
+legs (the reference as the thing being accelerated / the baseline being timed); nothing under
+`ptlflow_amd/` may import it.
 
 `import ptlflow` does not work here (lightning, jsonargparse, loguru, torchmetrics, cv2,
 torchvision, timm are absent and there is no network) -- SURVEY.md §8(c).  The hot-path
@@ -16,7 +16,9 @@ files themselves only need torch + scipy + einops, so:
      raft/update.py, raft/raft.py, utils/correlation.py ...) is the reference's own file,
      imported unmodified from where it lies.
 
-Nothing is copied: the reference code runs from /root/reference.
+Nothing is copied into the history: the reference code runs from /root/reference where that exists (the build
+container) and otherwise from the archive `oracle/stage_ref.py` packed there (`oracle/_ref/`, git-ignored, shipped to the GPU
+box with the working tree like the built `.so` files) — the same unmodified files either way.
 """
 from __future__ import annotations
 
@@ -25,11 +27,31 @@ import os
 import sys
 import types
 
-REFERENCE_ROOT = os.environ.get("PTLFLOW_REFERENCE_ROOT", "/root/reference")
+def _has_tree(root) -> bool:
+    return bool(root) and os.path.isdir(os.path.join(root, "ptlflow", "models", "raft"))
+
+
+def _resolve_root():
+    """$PTLFLOW_REFERENCE_ROOT, else /root/reference, else the archive staged by oracle/stage_ref.py (unpacked once per
+    content hash into the temp dir).  Returns (root, kind) with kind in {"env", "tree", "staged", None}."""
+    env = os.environ.get("PTLFLOW_REFERENCE_ROOT")
+    if env:
+        return (env, "env") if _has_tree(env) else (env, None)
+    if _has_tree("/root/reference") and not os.environ.get("PFK_REFERENCE_FORCE_STAGED"):   # (the flag: test the staged path here)
+        return "/root/reference", "tree"
+    try:
+        from oracle import stage_ref
+        root = stage_ref.unpack()
+    except Exception:                                   # a damaged archive is "no reference", loudly visible in the skips
+        root = None
+    return (root, "staged") if _has_tree(root) else ("/root/reference", None)
+
+
+REFERENCE_ROOT, REFERENCE_KIND = _resolve_root()
 
 
 def reference_available() -> bool:
-    return os.path.isdir(os.path.join(REFERENCE_ROOT, "ptlflow", "models", "raft"))
+    return REFERENCE_KIND is not None
 
 
 def _install_stubs() -> None:
@@ -73,6 +95,17 @@ def _install_stubs() -> None:
 
             def add_state(self, name, default, dist_reduce_fx=None):
                 self.register_buffer(name, default)
+                self.__dict__.setdefault("_pfk_defaults", {})[name] = default.clone()
+
+            def reset(self):
+                for name, default in self.__dict__.get("_pfk_defaults", {}).items():
+                    getattr(self, name).copy_(default)
+
+            def forward(self, *a, **k):
+                # torchmetrics.Metric.forward: the metric of THIS batch (update on cleared states, compute)
+                self.reset()
+                self.update(*a, **k)
+                return self.compute()
 
         tm.Metric = Metric
         sys.modules["torchmetrics"] = tm
@@ -120,6 +153,15 @@ def _install_stubs() -> None:
         tvt = types.ModuleType("torchvision.transforms")
         tvf = types.ModuleType("torchvision.transforms.functional")
         tv.transforms, tvt.functional = tvt, tvf
+
+        def resize(img, size, *a, **k):
+            # ccmr|ms_raft_plus/extractor.py call TF.resize(feature_map, (h, w)) on tensors: torchvision's tensor path is
+            # bilinear interpolate, align_corners=False, antialias on.  The accelerated GPU run and the CPU run it is
+            # compared with both go through this stand-in, so it cannot create or hide a difference between them.
+            import torch.nn.functional as F
+            return F.interpolate(img, size=tuple(size), mode="bilinear", align_corners=False, antialias=True)
+
+        tvf.resize = resize
         sys.modules.update({"torchvision": tv, "torchvision.transforms": tvt, "torchvision.transforms.functional": tvf})
 
 

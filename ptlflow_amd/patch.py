@@ -218,17 +218,31 @@ class _UpsampleSeam:
             with torch.no_grad():
                 want = self.original(flow, mask)
             got = self._kernel(flow, mask)
-            return tuple(want.shape) == tuple(got.shape) and float((want.float() - got).abs().max()) <= 1e-5
+            ok = tuple(want.shape) == tuple(got.shape) and \
+                float((want.float() - got).abs().max()) <= 1e-5 * max(1.0, float(want.float().abs().max()))
         except Exception:
-            return False
+            ok = False
+        if not ok:
+            import warnings
+            warnings.warn("ptlflow_amd: this model's upsample_flow is not RAFT's 8x convex upsampling; seam B5 keeps the "
+                          "model's own method", RuntimeWarning, stacklevel=3)
+        return ok
 
-    def __call__(self, flow, mask):
+    def __call__(self, *args, **kwargs):
+        # Other families give `upsample_flow` more arguments — ccmr.py:213 / ms_raft_plus.py:199 pass `scale=`, dip a `rate`,
+        # rapidflow / dpflow a `factor`, gmflow (feature, bilinear, upsample_factor): anything but the plain two-tensor
+        # positional call is the model's own business and goes to its own method exactly as it was written.
+        if kwargs or len(args) != 2 or not (torch.is_tensor(args[0]) and torch.is_tensor(args[1])):
+            return self.original(*args, **kwargs)
+        flow, mask = args
         eligible = (flow.is_cuda and flow.dtype == torch.float32 and mask.dtype == torch.float32 and mask.dim() == 4 and
                     mask.shape[1] == 576 and flow.dim() == 4 and flow.shape[1] == 2 and
                     not (torch.is_grad_enabled() and (flow.requires_grad or mask.requires_grad)))
         if not eligible:
             return self.original(flow, mask)
         if self.ok is None:
+            if torch.cuda.is_current_stream_capturing():     # the probe copies host data: illegal inside a graph capture
+                return self.original(flow, mask)
             self.ok = self._probe(flow.device)
         return self._kernel(flow, mask) if self.ok else self.original(flow, mask)
 

@@ -108,7 +108,13 @@ class _Flush(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):
-        acc, ctx.packs.acc = ctx.packs.acc, None
+        packs = ctx.packs
+        acc, packs.acc = packs.acc, None
+        # break the cycle ConvPacks -> alias (this node's outputs) -> grad_fn -> ctx -> ConvPacks, and drop the step's
+        # accumulators: a later backward through the same graph returns its gradients the ordinary way (g below)
+        packs.alias = None
+        packs.extra.pop("dwzr", None)
+        packs.extra.pop("dbzr", None)
         out = []
         for i, g in enumerate(grads):          # accumulated total, plus whatever a use returned the ordinary way
             a = None if acc is None else acc.get(i)
@@ -388,7 +394,7 @@ def update_block_train_pm(P: Dict[str, torch.Tensor], spec, h, i, c, f, B: int, 
         names = [f"gru.conv{k}{sfx}" for k in "zrq"]
         wz, wr, wq = (P[n + ".weight"] for n in names)
         bz, br, bq = (P[n + ".bias"] for n in names)
-        pk_zr = packs_for(cache, "zr" + sfx, [wz, wr], acc)
+        pk_zr = packs_for(cache, "zr" + sfx, [wz, wr, bz, br], acc)      # the cached z|r concatenation includes the biases
         pk_q = packs_for(cache, "q" + sfx, [wq], acc)
         wz, wr, bz, br = step_params(pk_zr, wz, wr, bz, br)
         wq, bq = step_params(pk_q, wq, bq)
