@@ -89,6 +89,7 @@ def parse():
                          "or split-bf16 MFMA (include/pfk.h, pfk_conv2d_bf16s)")
     ap.add_argument("--no-split-modes", action="store_true", help="skip the extra split-bf16 legs (`split_bf16` in the output)")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the model_benchmark-protocol, gma, bf16 and training legs")
+    ap.add_argument("--no-whole-models", action="store_true", help="skip the whole-model legs on the reference's SEARAFT / CCMR / MSRAFTPlus classes")
     ap.add_argument("--torch-baseline", action="store_true",
                     help="dropin leg: also time the un-patched torch / MIOpen forward of the same model (first call compiles MIOpen kernels)")
     ap.add_argument("--cpu-forwards", type=int, default=3)
@@ -152,33 +153,128 @@ def _epe(flow_gpu, flow_ref):
     return float(d.mean()), float(d.max())
 
 
-def dropin_leg(cpu_state, dev, H, W, iters, pair_cpu, ref_flows, torch_baseline=False):
-    """Throughput of the drop-in SEAM path (what `ptlflow.get_model("raft")` + `patch.accelerate(model)` runs): the reference's
-    caller loop — raft.py:125-194 — in torch, seams B1 / B3 / B4 on libpfk.  Batch 1, model_benchmark.py's protocol.  The
-    caller keeps NCHW tensors between the seams, computes `coords1 + delta_flow`, `coords1 - coords0` and the convex upsampling
-    (softmax + unfold + weighted sum, raft.py:112-123) in torch ops every iteration, exactly like the reference."""
+def reference_raft(cpu_state, iters):
+    """The reference's own `ptlflow.models.raft.raft.RAFT` (oracle/ref_loader.py: /root/reference, or the archive staged for the
+    GPU box by oracle/stage_ref.py) carrying the bench's weights — or None where no reference is importable."""
+    try:
+        from oracle import ref_loader          # the reference as the thing being accelerated / timed as the baseline
+        if not ref_loader.reference_available():
+            return None, None
+        m = ref_loader.build_raft(iters=iters)
+        missing, unexpected = m.load_state_dict(cpu_state, strict=False)
+        if missing or unexpected:
+            raise RuntimeError(f"state_dict mismatch with the reference class: missing {missing[:3]}, unexpected {unexpected[:3]}")
+        return m.eval(), ref_loader.REFERENCE_KIND
+    except Exception as e:
+        return None, repr(e)[:200]
+
+
+def dropin_leg(cpu_state, dev, H, W, iters, pair_cpu, ref_flows, torch_baseline=False, batch8=None):
+    """Throughput of the drop-in SEAM path — what `ptlflow.get_model("raft")` + `patch.accelerate(model)` runs: the REFERENCE'S
+    OWN `RAFT` class (its `forward`, raft.py:125-194, its `preprocess_images` / `InputPadder` / `postprocess_predictions`) with
+    seams B1 / B3 / B4 / B5 on libpfk.  Batch 1 under model_benchmark.py's protocol, plus the batch-8 throughput setting.  Where
+    no reference is importable the torch-only stand-in (`ptlflow_amd.seam_model.SeamRAFT`, the same caller loop) takes its place
+    and `what` says so."""
     from ptlflow_amd import patch
-    from ptlflow_amd.seam_model import SeamRAFT
-    m = SeamRAFT(iters=iters).eval()
-    m.load_state_dict(cpu_state, strict=True)
-    m = m.to(dev)
+    m, kind = reference_raft(cpu_state, iters)
     leg = {}
+    if m is not None:
+        leg["what"] = (f"ptlflow.models.raft.raft.RAFT — the reference's own class ({kind}: "
+                       f"{'/root/reference' if kind == 'tree' else 'oracle/_ref archive staged by oracle/stage_ref.py'}) "
+                       "+ ptlflow_amd.patch.accelerate: seams B1/B3/B4/B5 on libpfk")
+        leg["model_class"] = f"{type(m).__module__}.{type(m).__name__}"
+    else:
+        from ptlflow_amd.seam_model import SeamRAFT
+        m = SeamRAFT(iters=iters).eval()
+        m.load_state_dict(cpu_state, strict=True)
+        leg["what"] = ("ptlflow_amd.seam_model.SeamRAFT (torch-only stand-in for the reference's caller loop; no reference importable"
+                       + (f": {kind}" if kind else "") + ") + ptlflow_amd.patch.accelerate: seams B1/B3/B4/B5 on libpfk")
+        leg["model_class"] = "ptlflow_amd.seam_model.SeamRAFT"
+    m = m.to(dev)
     if torch_baseline:      # stock PyTorch-ROCm ops (MIOpen convolutions, matmul / avg_pool2d / grid_sample): today's ptlflow on this GPU
-        t = protocol_leg(m, dev, H, W, n=5)
+        with torch.no_grad():
+            t = protocol_leg(m, dev, H, W, n=5)
         leg["torch_rocm_unpatched"] = {"value": t["value"], "unit": "frame-pairs/s", "ms_median": t["ms_median"],
                                        "what": "the same model object before patch.accelerate: stock PyTorch-ROCm ops"}
     patch.accelerate(m)
     try:
-        out = m({"images": pair_cpu.to(dev)})
-        if ref_flows is not None:
-            mean, mx = _epe(out["flows"][:1, 0], ref_flows)
-            leg["epe_vs_cpu"] = {"mean": mean, "max": mx, "gate": 1e-3}
-        leg.update(protocol_leg(m, dev, H, W))
+        with torch.no_grad():
+            out = m({"images": pair_cpu.to(dev)})
+            if ref_flows is not None:
+                mean, mx = _epe(out["flows"][:1, 0], ref_flows)
+                leg["epe_vs_cpu"] = {"mean": mean, "max": mx, "gate": 1e-3}
+            leg.update(protocol_leg(m, dev, H, W))
+            if batch8 is not None:
+                sec = timed(lambda: m(batch8), 2, 5)
+                leg["batch8"] = {"value": batch8["images"].shape[0] / sec, "unit": "frame-pairs/s", "ms_per_step": 1e3 * sec,
+                                 "note": "the same accelerated object on the headline's batch (8 smooth pairs per forward)"}
     finally:
         patch.restore(m)
-    leg["what"] = ("ptlflow_amd.seam_model.SeamRAFT (torch-only RAFT, the reference's caller loop: module-global get_corr_block, "
-                   "update_block(net, inp, corr, flow), torch upsample_flow) + ptlflow_amd.patch.accelerate: seams B1/B3/B4 on libpfk")
     return leg
+
+
+def whole_model_legs(dev, H, W, check: bool):
+    """The other §8 families as WHOLE reference models on the GPU (BASELINE config 3's sea_raft side, SURVEY §8 f1's ccmr /
+    ms_raft_p): the reference's own classes with the seams that apply —
+      sea_raft_s_full   `SEARAFT` (ResNet-FPN + ConvNeXt block on torch / MIOpen; `get_corr_block` = seam B1 on K1-K3 with the
+                        bilinear-1/2 pyramid), fp32 and under bf16 autocast, with and without the seam;
+      ccmr / ms_raft_p  constructed with their defaults (`alternate_corr=True`): their `AlternateCorrBlock` calls this repo's
+                        `alt_cuda_corr` plug-in (seam B2, K7) with zero patching; `accelerate` adds seam B3.
+    pairs/s by model_benchmark.py's protocol (batch 1); EPE of sea_raft against the model's own CPU forward on the smooth pair
+    (ccmr / ms_raft_p are checked against their CPU forwards in tests/test_gpu_reference_models.py at sizes whose materialised
+    volume fits the CPU run)."""
+    from oracle import ref_loader
+    from ptlflow_amd import patch
+    from ptlflow_amd.synth import smooth_pair
+    if not ref_loader.reference_available():
+        return {"skipped": "no reference importable (oracle/_ref not staged)"}
+    legs = {}
+    x1 = smooth_pair(1, H, W, seed=1234)
+
+    def run(name, build, unpatched=True, autocast=False, epe=False):
+        leg = {}
+        try:
+            torch.manual_seed(1234)
+            m = build().eval()
+            ref = None
+            if epe and check:
+                with torch.no_grad():
+                    ref = m({"images": x1.clone()})["flows"][:, 0]
+            m = m.to(dev)
+            with torch.no_grad():
+                if unpatched:
+                    t = protocol_leg(m, dev, H, W, n=5)
+                    leg["unpatched_torch_rocm"] = {"value": t["value"], "ms_median": t["ms_median"]}
+                patch.accelerate(m)
+                try:
+                    t = protocol_leg(m, dev, H, W)
+                    leg.update({"value": t["value"], "unit": "frame-pairs/s", "ms_median": t["ms_median"], "protocol": t["protocol"]})
+                    if ref is not None:
+                        mean, mx = _epe(m({"images": x1.to(dev)})["flows"][:1, 0], ref)
+                        leg["epe_vs_cpu"] = {"mean": mean, "max": mx, "gate": 1e-3}
+                    if autocast:
+                        with torch.autocast("cuda", dtype=torch.bfloat16):
+                            t = protocol_leg(m, dev, H, W)
+                            leg["bf16_autocast"] = {"value": t["value"], "ms_median": t["ms_median"]}
+                            if ref is not None:
+                                mean, mx = _epe(m({"images": x1.to(dev)})["flows"][:1, 0], ref)
+                                leg["bf16_autocast"]["epe_vs_cpu_fp32"] = {"mean": mean, "max": mx}
+                finally:
+                    patch.restore(m)
+            leg["model_class"] = f"{type(m).__module__}.{type(m).__name__}"
+            del m
+        except Exception as e:
+            leg["error"] = repr(e)[:300]
+        torch.cuda.empty_cache()
+        legs[name] = leg
+
+    S = ref_loader.ref_module("ptlflow.models.sea_raft.sea_raft")
+    run("sea_raft_s_full", lambda: S.SEARAFT(block_dims=[64, 128, 256]), autocast=True, epe=True)
+    C = ref_loader.ref_module("ptlflow.models.ccmr.ccmr")
+    run("ccmr_full", lambda: C.CCMR(), unpatched=False)          # un-patched it cannot run at all: no alt_cuda_corr without this repo
+    M = ref_loader.ref_module("ptlflow.models.ms_raft_plus.ms_raft_plus")
+    run("ms_raft_p_full", lambda: M.MSRAFTPlus(), unpatched=False)
+    return legs
 
 
 def sea_raft_corr_leg(dev, bf16: bool, batch=8, h=55, w=128, D=256, check=True):
@@ -273,12 +369,40 @@ def train_leg(dev, batch=10, H=368, W=496, iters=12, steps=4, warmup=2):
                       "encoders, correlation / lookup, update block and upsampling forward+backward on libpfk autograd nodes"}
 
 
+def self_launch(args) -> None:
+    """`python bench.py --gpus N` (N > 1) started WITHOUT a launcher: start the N ranks ourselves — one process per GPU under
+    `torch.distributed.run` on 127.0.0.1, the invocation the docstring shows — and exit with their status.  What this replaces
+    in the reference is Lightning's own process launch (ptlflow/utils/lightning/ptlflow_trainer.py:71, :281).  Refuses loudly
+    when the box has fewer than N devices (unless PFK_BENCH_SHARED_DEVICE=1 asks for the one-device code-path smoke): a line
+    that says `n_gpus: 1` for a `--gpus 8` request would be a wrong SCALE record."""
+    import socket
+    import subprocess
+    shared = os.environ.get("PFK_BENCH_SHARED_DEVICE") == "1"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus and not shared:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {n_dev} GPU(s) visible on this node; refusing to report fewer ranks "
+                         "than requested (PFK_BENCH_SHARED_DEVICE=1 runs all ranks on cuda:0 as a code-path smoke)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // args.gpus)))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        self_launch(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
@@ -289,7 +413,7 @@ def main():
     dev_index = 0 if shared else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    dist = None
+    dist, ranks_seen = None, 1
     # under torch.distributed.run (RANK set) the process group is created even for one rank, so that a single-GPU box can
     # exercise the RCCL branch (init, barrier, max-reduce) that the N > 1 runs rely on
     if world > 1 or "RANK" in os.environ:
@@ -299,6 +423,11 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)                                 # every rank contributes 1: the job size as the collective sees it
+        ranks_seen = int(ones.item())
+        if ranks_seen != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but the all-reduce counted {ranks_seen} rank(s)")
 
     import ptlflow_amd
     from ptlflow_amd.raft import GMA, RAFT
@@ -348,6 +477,7 @@ def main():
         "value": pairs / elapsed,
         "unit": "frame-pairs/s",
         "n_gpus": world,
+        "rccl_ranks": ranks_seen if dist is not None else None,   # all-reduce of ones over the process group (None: no group, plain 1-GPU run)
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
@@ -430,30 +560,28 @@ def main():
                 times.sort()
                 return times, res
 
-            if args.model == "gma":
-                times, ref = cpu_times(lambda: O.gma_forward(cpu_state, images_cpu[:1], iters=args.iters))
+            # The baseline is the REFERENCE'S OWN forward wherever it is importable (/root/reference, or the archive
+            # oracle/stage_ref.py staged for the GPU box): kind "reference".  Only without it the port is timed (kind "port").
+            rm, ref_kind = (reference_raft(cpu_state, args.iters) if args.model == "raft" else (None, None))
+            if rm is not None:
+                with torch.no_grad():
+                    times, ref = cpu_times(lambda: rm({"images": images_cpu[:1]}))
+                ref = {"flows": ref["flows"].float()}
+                kind = "reference"
+                sample = (f"{len(times)} forward(s) of the reference's own ptlflow.models.raft.raft.RAFT.forward (oracle/ref_loader.py, "
+                          f"source: {ref_kind}) on the first frame pair of the batch, median; torch {torch.__version__} CPU, {cores} threads")
+                del rm
             else:
-                times, ref = cpu_times(lambda: O.raft_forward(cpu_state, images_cpu[:1], iters=args.iters, small=small))
+                if args.model == "gma":
+                    times, ref = cpu_times(lambda: O.gma_forward(cpu_state, images_cpu[:1], iters=args.iters))
+                else:
+                    times, ref = cpu_times(lambda: O.raft_forward(cpu_state, images_cpu[:1], iters=args.iters, small=small))
+                kind = "port"
+                sample = (f"{len(times)} full forward(s) of oracle/raft_oracle.py (bit-identical restatement of the reference forward, ~12 % "
+                          f"slower: explicit gather lookup vs grid_sample) on the first frame pair of the batch, median; "
+                          f"torch {torch.__version__} CPU, {cores} threads" + (f"; reference not importable: {ref_kind}" if ref_kind else ""))
             med = times[len(times) // 2]
-            result["cpu_baseline"] = {"value": 1.0 / med, "unit": "frame-pairs/s", "cores": cores,
-                                      "kind": "port",
-                                      "sample": f"{len(times)} full forward(s) on the first frame pair of the batch, median; "
-                                                f"torch {torch.__version__} CPU, {cores} threads",
-                                      "note": "the port (oracle/raft_oracle.py) is bit-identical to the reference forward and ~12 % slower "
-                                              "(its explicit gather lookup vs grid_sample; 2.46 s vs 2.20 s on 8 cores in the build container)"}
-            # where the reference tree itself is present (the build container; never the GPU box) time IT: kind "reference"
-            try:
-                from oracle import ref_loader
-                if ref_loader.reference_available() and args.model in ("raft", "raft_small"):
-                    rm = ref_loader.build_raft(small=small, iters=args.iters)
-                    rm.load_state_dict(cpu_state, strict=False)
-                    with torch.no_grad():
-                        rt, _ = cpu_times(lambda: rm({"images": images_cpu[:1]}))
-                    result["cpu_baseline"].update({"value": 1.0 / rt[len(rt) // 2], "kind": "reference", "port_value": 1.0 / med,
-                                                   "sample": f"{len(rt)} forward(s) of the reference's own RAFT.forward "
-                                                             f"(/root/reference through oracle/ref_loader.py), median; {cores} threads"})
-            except Exception:
-                pass
+            result["cpu_baseline"] = {"value": 1.0 / med, "unit": "frame-pairs/s", "cores": cores, "kind": kind, "sample": sample}
             mean, mx = O.epe(out["flows"][:1, 0].float().cpu(), ref["flows"][:, 0])
             result["epe_vs_cpu"] = {"mean": mean, "max": mx, "gate": 1e-3}
         else:
@@ -518,7 +646,7 @@ def main():
             # ... and on the drop-in seam path (the reference's caller loop, seams B1 / B3 / B4 patched)
             try:
                 result["dropin"] = dropin_leg(cpu_state, dev, args.height, args.width, args.iters, images_cpu[:1], ref_raft,
-                                              args.torch_baseline)
+                                              args.torch_baseline, batch8=inputs)
             except Exception as e:  # a leg must never take the headline line down with it
                 result["dropin"] = {"error": repr(e)[:300]}
             torch.cuda.empty_cache()
@@ -551,6 +679,11 @@ def main():
                 except Exception as e:
                     legs[name] = {"error": repr(e)[:300]}
                 torch.cuda.empty_cache()
+            if not args.no_whole_models:
+                try:
+                    legs.update(whole_model_legs(dev, args.height, args.width, check))
+                except Exception as e:
+                    legs["whole_models"] = {"error": repr(e)[:300]}
             result["config3"] = legs
             # (c) BASELINE config 4 on one GPU: KITTI-sized pairs (375x1242 -> padded 376x1248, 47x156 grid), batch 8 per GPU
             try:

@@ -197,6 +197,109 @@ def test_encoder_backward_ops_exact_on_their_inputs(gpu):
     assert worst[1] < 5e-6, worst
 
 
+def test_update_block_backward_ops_exact_on_their_inputs(gpu):
+    """The update block's backward nodes — every `_ConvPM` (motion encoder, heads: multi-source, padded channels, cout = 2,
+    7x7 on the 2-channel flow) and every `_GruPass` (gate derivatives, four data-gradient convolutions, two weight-gradient
+    launches) — against float64 arithmetic ON THE NODE'S OWN INPUTS (saved activations, incoming gradient), inside a RAFT
+    training step.  With the encoder check above this covers every libpfk backward node: the op-level gate (5e-6 relative L2)
+    the whole-step bounds of `compare_gradients` derive from."""
+    import torch.nn.functional as F
+    import ptlflow_amd.train as TR
+    from ptlflow_amd.raft import RAFT
+    from ptlflow_amd.train import sequence_loss
+    recs = []
+    conv_bwd0, gru_bwd0, ubt0 = TR._ConvPM.backward, TR._GruPass.backward, TR.update_block_train_pm
+
+    def nchw(t, gm, n=None):
+        t = t.detach().double().cpu()
+        t = t if n is None else t[:, :n]
+        return t.view(gm.B, -1, t.shape[1]).view(gm.B, gm.H, gm.W, t.shape[1]).permute(0, 3, 1, 2).contiguous()
+
+    def rel(a, b):
+        return float((a.double().cpu() - b).norm() / b.norm().clamp_min(1e-300))
+
+    def conv_ref(gm, srcs, reals, w, dy):
+        xin = torch.cat([nchw(s_, gm, n) for s_, n in zip(srcs, reals)], 1).requires_grad_(True)
+        w64 = w.detach().double().cpu().requires_grad_(True)
+        with torch.enable_grad():
+            y = F.conv2d(xin, w64, None, gm.stride, (gm.kh // 2, gm.kw // 2))
+        d = dy.detach().double().cpu()[:, :w.shape[0]]
+        gx, gw = torch.autograd.grad(y, [xin, w64], d.view(gm.B, y.shape[2], y.shape[3], -1).permute(0, 3, 1, 2))
+        return gx.permute(0, 2, 3, 1).reshape(-1, gx.shape[1]), gw, d.sum(0)
+
+    def conv_bwd(ctx, dY):
+        res = conv_bwd0(ctx, dY)
+        weight, outp, *srcs = ctx.saved_tensors
+        gm = ctx.g
+        if gm.stride != 1 or gm.B * gm.H * gm.W > 4000:      # the update block's convolutions only (1/8-resolution grid)
+            return res
+        d = dY.detach().float()
+        if ctx.relu:
+            d = d * (outp > 0)
+        gx, gw, gb = conv_ref(gm, srcs, ctx.real, weight, d)
+        name = "conv %dx%d %s->%d" % (gm.kh, gm.kw, "+".join(map(str, ctx.real)), weight.shape[0])
+        if res[0] is not None:
+            recs.append((name + " wgrad", rel(res[0], gw)))
+        if res[1] is not None:
+            recs.append((name + " bgrad", rel(res[1], gb)))
+        first = 0
+        for i, n in enumerate(ctx.real):
+            if res[6 + i] is not None:
+                recs.append((name + " dgrad src%d" % i, rel(res[6 + i][:, :n], gx[:, first:first + n])))
+                if res[6 + i].shape[1] > n:
+                    assert float(res[6 + i][:, n:].abs().max()) == 0.0, "gradient in a padding channel"
+            first += n
+        return res
+
+    def gru_bwd(ctx, dhn):
+        res = gru_bwd0(ctx, dhn)
+        h, x, z, r, q, rh, wq = (t.detach() for t in ctx.saved_tensors)
+        gm, xr, wzr = ctx.g, ctx.x_real, ctx.wzr
+        C = h.shape[1]
+        D = lambda t: t.double().cpu()
+        dh_n, z64, r64, q64, h64 = D(dhn), D(z), D(r), D(q), D(h)
+        da_q = dh_n * z64 * (1 - q64 * q64)
+        dz = dh_n * (q64 - h64)
+        dh = dh_n * (1 - z64)
+        gq, gwq, gbq = conv_ref(gm, [rh, x], [C, xr], wq, da_q)
+        d_rh, dx = gq[:, :C], gq[:, C:]
+        dh = dh + d_rh * r64
+        da_zr = torch.cat([dz * z64 * (1 - z64), d_rh * h64 * r64 * (1 - r64)], 1)
+        gzr, gwzr, gbzr = conv_ref(gm, [h, x], [C, xr], wzr, da_zr)
+        dh = dh + gzr[:, :C]
+        dx = dx + gzr[:, C:]
+        name = "gru %dx%d C=%d x=%d" % (gm.kh, gm.kw, C, xr)
+        recs.append((name + " dh", rel(res[0], dh)))
+        recs.append((name + " dx", rel(res[1][:, :xr], dx)))
+        assert res[2] is not None, "this test runs the non-accumulating path so that every node returns its weight gradients"
+        recs.append((name + " dWz", rel(res[2], gwzr[:C])))
+        recs.append((name + " dWr", rel(res[3], gwzr[C:])))
+        recs.append((name + " dWq", rel(res[4], gwq)))
+        recs.append((name + " dbz", rel(res[5], gbzr[:C])))
+        recs.append((name + " dbr", rel(res[6], gbzr[C:])))
+        recs.append((name + " dbq", rel(res[7], gbq)))
+        return res
+
+    def ubt(*a, **k):
+        k["accumulate_wgrad"] = False                     # per-node weight gradients (the accumulating path adds the same launches' results)
+        return ubt0(*a, **k)
+
+    model = RAFT(iters=2).load_synthetic(21).to(gpu).train()
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(2, 2, 3, 184, 248, generator=g)
+    gt = torch.randn(2, 2, 184, 248, generator=g) * 4
+    TR._ConvPM.backward, TR._GruPass.backward, TR.update_block_train_pm = staticmethod(conv_bwd), staticmethod(gru_bwd), ubt
+    try:
+        out = model({"images": x.to(gpu)})
+        sequence_loss(out["flow_preds"], gt.to(gpu), torch.ones(2, 1, 184, 248, device=gpu)).backward()
+    finally:
+        TR._ConvPM.backward, TR._GruPass.backward, TR.update_block_train_pm = staticmethod(conv_bwd0), staticmethod(gru_bwd0), ubt0
+    assert sum(r[0].startswith("gru") for r in recs) == 2 * 2 * 8 and len(recs) > 80, len(recs)
+    worst = max(recs, key=lambda r: r[1])
+    print("update-block backward checks: %d, worst %s relL2 %.2e" % (len(recs), worst[0], worst[1]))
+    assert worst[1] < 5e-6, worst
+
+
 @pytest.mark.parametrize("kind,small,B,H,W", [("instance", False, 2, 96, 136), ("batch", False, 2, 96, 136), ("instance", True, 1, 104, 72),
                                               ("none", True, 2, 64, 96)])
 def test_encoder_train_gradients(gpu, kind, small, B, H, W):
