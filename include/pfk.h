@@ -52,22 +52,29 @@ enum pfk_status {
   PFK_ERR_BAD_ARG = -1,      /* null pointer, non-positive size, unsupported combination */
   PFK_ERR_ALIGNMENT = -2,    /* pointer not 16-byte aligned or ld/channels not a multiple of 4 */
   PFK_ERR_UNSUPPORTED = -3,  /* shape outside what the kernels were built for */
-  PFK_ERR_LAUNCH = -4        /* hipLaunchKernel reported an error */
+  PFK_ERR_LAUNCH = -4,       /* hipLaunchKernel reported an error */
+  PFK_ERR_DISABLED = -5      /* a pfk_debug_set_* knob called in a process that did not opt in with PFK_DEBUG_KNOBS=1 */
 };
 
 #define PFK_MAX_LEVELS 8
-#define PFK_ABI_VERSION 4
+#define PFK_ABI_VERSION 5
 
 int pfk_abi_version(void);
 const char* pfk_status_string(int status);
-/* tuning/debug knob: force the implicit-GEMM tile configuration (-1 = heuristic). Not thread-safe. */
-void pfk_debug_set_tile(int cfg);
+/* sha256 (first 16 hex digits) of the sources this library was built from (every file of csrc/, include/pfk.h, the compiler flags), stamped by
+ * ptlflow_amd/_build.py; ptlflow_amd.load_native() refuses a library whose stamp differs from the tree it sits in. */
+const char* pfk_source_hash(void);
+/* The pfk_debug_set_* knobs change PROCESS-GLOBAL kernel selection (tests and tuning scripts force every tile shape / kernel
+ * variant through them).  They are inert — return PFK_ERR_DISABLED and change nothing — unless the process environment has
+ * PFK_DEBUG_KNOBS=1 at the first call, so a production caller cannot flip tile state by accident.  Not thread-safe.
+ * tuning/debug knob: force the implicit-GEMM tile configuration (-1 = heuristic). */
+int pfk_debug_set_tile(int cfg);
 /* test hook: n / d through the multiplier arithmetic the persistent convolution kernel decodes its tiles with (n < 2^31, d >= 1) */
 unsigned pfk_debug_fastdiv(unsigned n, unsigned d);
-/* tuning knob of the pyramid lookup: source pixels per workgroup, 4 (default) or 8. Not thread-safe. */
-void pfk_debug_set_lookup_pix(int pix);
-void pfk_debug_set_altcorr(int mode);       /* on-demand correlation forward: 0 = heuristic, 1 = per-pixel kernel, 2 / 3 = window-sharing MFMA kernel on 8x4 / 8x8 patches */
-void pfk_debug_set_wgrad(int variant);      /* weight-gradient tile height: 0 = by padding waste, 1 / 2 / 4 = forced 32 / 64 / 128 rows (tuning knob) */
+/* tuning knob of the pyramid lookup: source pixels per workgroup, 4 (default) or 8. */
+int pfk_debug_set_lookup_pix(int pix);
+int pfk_debug_set_altcorr(int mode);       /* on-demand correlation forward: 0 = heuristic, 1 = per-pixel kernel, 2 / 3 = window-sharing MFMA kernel on 8x4 / 8x8 patches */
+int pfk_debug_set_wgrad(int variant);      /* weight-gradient tile height: 0 = by padding waste, 1 / 2 / 4 = forced 32 / 64 / 128 rows (tuning knob) */
 
 /* ---- K1: all-pairs correlation --------------------------------------------------------------
  * out[b][i][j] = scale * sum_d f1[b][i][d] * f2[b][j][d]        (fp32 MFMA, exact fp32 products)

@@ -32,6 +32,25 @@ class NativeLibraryMissing(RuntimeError):
     pass
 
 
+class NativeLibraryStale(RuntimeError):
+    pass
+
+
+def _check_stamp() -> None:
+    """The libraries carry the content hash of the sources they were built from (ptlflow_amd/_build.py).  Where the sources
+    lie next to them (this tree: csrc/, include/pfk.h) a library built from OTHER sources is refused — the `.so` files travel
+    with the working tree and a checkout resets the mtimes a time-stamp check would rely on.  PFK_ALLOW_STALE=1 overrides."""
+    if os.environ.get("PFK_ALLOW_STALE") == "1" or not (_PKG / "csrc" / "pfk_gemm.hip").exists():
+        return
+    from . import _build
+    want = _build.source_hash()
+    got = torch.ops.pfk.source_hash()          # "<extension stamp>:<libpfk.so stamp>"
+    if got != f"{want}:{want}":
+        raise NativeLibraryStale(
+            f"native libraries were built from other sources (stamps {got}, tree {want}); run `python -m ptlflow_amd._build` "
+            "(or __graft_entry__.build()).  PFK_ALLOW_STALE=1 loads them anyway.")
+
+
 def load_native(build_if_missing: bool = False) -> None:
     """Load ``_pfk_torch.so`` (which pulls in ``libpfk.so``) and register ``torch.ops.pfk``.
 
@@ -51,6 +70,13 @@ def load_native(build_if_missing: bool = False) -> None:
                 "`python -m ptlflow_amd._build` (or __graft_entry__.build()). There is no fallback path."
             )
     torch.ops.load_library(str(TORCH_EXT_PATH))
+    try:
+        _check_stamp()
+    except NativeLibraryStale:
+        if not (build_if_missing or os.environ.get("PFK_AUTOBUILD") == "1"):
+            raise
+        raise NativeLibraryStale("stale native libraries are already loaded into this process; rebuild "
+                                 "(`python -m ptlflow_amd._build`) and restart")
     _loaded = True
 
 

@@ -9,6 +9,11 @@
   ~/.cache) so the .so travels with the tree.
 
 hipcc cross-compiles without a GPU; nothing here needs one.
+
+Staleness is decided by CONTENT, not by mtime: `source_hash()` — sha256 over every file of csrc/ (sources and headers),
+include/pfk.h and the compiler flags — is compiled into both libraries (`pfk_source_hash()`, `torch.ops.pfk.source_hash()`).
+A library whose stamp differs from the tree's hash is rebuilt here and REFUSED by `ptlflow_amd.load_native()`: the `.so`
+files travel with the working tree (git-ignored, not gpurun-ignored), and a `git checkout` or a fresh push resets mtimes.
 """
 from __future__ import annotations
 
@@ -39,16 +44,51 @@ HIP_SOURCES = [
     ("pfk_wgrad.hip", []),
     ("pfk_corr_bf16.hip", []),
     ("pfk_bwd.hip", ["-ffp-contract=off"]),   # same coordinate arithmetic as pfk_corr.hip (pfk_lookup.h)
+    ("pfk_stamp.hip", []),                    # pfk_source_hash(): compiled with -DPFK_SOURCE_HASH=<tree hash>
 ]
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
              f"-I{INCLUDE}", f"-I{CSRC}", "-Wall", "-Wno-unused-function"]
 
 
-def _stale(target: Path, deps) -> bool:
-    if not target.exists():
-        return True
-    t = target.stat().st_mtime
-    return any(Path(d).stat().st_mtime > t for d in deps)
+def _sha(paths, extra: str = "") -> str:
+    import hashlib
+    h = hashlib.sha256(extra.encode())
+    for p in sorted(map(Path, paths), key=lambda q: q.name):
+        h.update(p.name.encode())
+        h.update(p.read_bytes())
+    return h.hexdigest()[:16]
+
+
+def source_files():
+    return sorted([p for p in CSRC.iterdir() if p.suffix in (".hip", ".h", ".cpp")] + [INCLUDE / "pfk.h"])
+
+
+def source_hash() -> str:
+    """Stamp of the tree: every kernel / binding source, the public header, the flags."""
+    return _sha(source_files(), " ".join(HIP_FLAGS) + repr(HIP_SOURCES))
+
+
+def _stale(target: Path, key: str) -> bool:
+    """True unless `target` exists and was built for `key` (a content hash kept next to it)."""
+    stamp = target.with_name(target.name + ".stamp")
+    return not (target.exists() and stamp.exists() and stamp.read_text() == key)
+
+
+def _mark(target: Path, key: str) -> None:
+    target.with_name(target.name + ".stamp").write_text(key)
+
+
+def embedded_hash(lib: Path):
+    """The stamp compiled into a built libpfk.so (ctypes, no GPU needed), or None."""
+    if not lib.exists():
+        return None
+    import ctypes
+    try:
+        f = ctypes.CDLL(str(lib)).pfk_source_hash
+        f.restype = ctypes.c_char_p
+        return f().decode()
+    except (OSError, AttributeError):
+        return None
 
 
 def _run(cmd) -> None:
@@ -59,15 +99,25 @@ def _run(cmd) -> None:
 def build_libpfk(force: bool = False) -> Path:
     OBJ.mkdir(exist_ok=True)
     headers = [INCLUDE / "pfk.h", CSRC / "pfk_common.h", CSRC / "pfk_gemm.h", CSRC / "pfk_lookup.h"]
-    objs = []
+    tree = source_hash()
+    objs, jobs = [], []
     for src, extra in HIP_SOURCES:
         s = CSRC / src
         o = OBJ / (s.stem + ".o")
-        if force or _stale(o, [s, *headers]):
-            _run([HIPCC, *HIP_FLAGS, *extra, "-c", s, "-o", o])
+        define = [f'-DPFK_SOURCE_HASH="{tree}"'] if src == "pfk_stamp.hip" else []      # the TU that defines pfk_source_hash()
+        key = _sha([s, *headers], " ".join(HIP_FLAGS + extra + define))
+        if force or _stale(o, key):
+            jobs.append(([HIPCC, *HIP_FLAGS, *extra, *define, "-c", s, "-o", o], o, key))
         objs.append(o)
-    if force or _stale(LIBPFK, objs):
+    rebuilt = bool(jobs)
+    if jobs:       # independent translation units: compile them side by side
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as pool:
+            for (cmd, o, key), _ in zip(jobs, pool.map(lambda j: _run(j[0]), jobs)):
+                _mark(o, key)
+    if force or rebuilt or embedded_hash(LIBPFK) != tree:
         _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIBPFK])
+    assert embedded_hash(LIBPFK) == tree, (embedded_hash(LIBPFK), tree)
     return LIBPFK
 
 
@@ -76,18 +126,21 @@ def build_torch_ext(force: bool = False) -> Path:
     from torch.utils import cpp_extension as ce
 
     src = CSRC / "pfk_torch.cpp"
-    if not (force or _stale(LIBTORCH_EXT, [src, INCLUDE / "pfk.h", LIBPFK])):
+    tree = source_hash()
+    key = tree + ":" + torch.__version__
+    if not (force or _stale(LIBTORCH_EXT, key)):
         return LIBTORCH_EXT
     tlib = Path(torch.__file__).parent / "lib"
     inc = [f"-I{p}" for p in ce.include_paths()] + [f"-I{INCLUDE}", f"-I{ROCM / 'include'}"]
     abi = int(torch._C._GLIBCXX_USE_CXX11_ABI)
     cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1",
-           "-DUSE_ROCM=1", f"-D_GLIBCXX_USE_CXX11_ABI={abi}", "-DTORCH_EXTENSION_NAME=_pfk_torch",
+           "-DUSE_ROCM=1", f"-D_GLIBCXX_USE_CXX11_ABI={abi}", "-DTORCH_EXTENSION_NAME=_pfk_torch", f'-DPFK_SOURCE_HASH="{tree}"',
            *inc, str(src), "-o", str(LIBTORCH_EXT),
            f"-L{tlib}", "-lc10", "-ltorch_cpu", "-ltorch", "-lc10_hip", "-ltorch_hip",
            f"-L{PKG}", "-lpfk", f"-L{ROCM / 'lib'}", "-lamdhip64",
            f"-Wl,-rpath,{tlib}", "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{ROCM / 'lib'}"]
     _run(cmd)
+    _mark(LIBTORCH_EXT, key)
     return LIBTORCH_EXT
 
 

@@ -488,7 +488,7 @@ int g_altcorr_mode = 0;   // tuning / test knob (pfk_debug_set_altcorr): 0 heuri
 
 extern "C" {
 
-void pfk_debug_set_altcorr(int mode) { g_altcorr_mode = mode; }
+int pfk_debug_set_altcorr(int mode) { if (!pfk_debug_knobs_enabled()) return PFK_ERR_DISABLED; g_altcorr_mode = mode; return PFK_OK; }
 
 int pfk_altcorr_backward_f32(const float* fmap1, const float* fmap2, const float* coords, const float* corr_grad,
                              float* fmap1_grad, float* fmap2_grad, int B, int H1, int W1, int H2, int W2, int C,

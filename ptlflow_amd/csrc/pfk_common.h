@@ -28,6 +28,13 @@ struct pfk_device_once {
   }
 };
 
+// pfk_debug_set_* are inert unless the process opted in (include/pfk.h)
+#include <stdlib.h>
+static inline bool pfk_debug_knobs_enabled() {
+  const char* e = getenv("PFK_DEBUG_KNOBS");
+  return e && e[0] == '1' && e[1] == 0;
+}
+
 static inline int pfk_launch_status() {
   return hipGetLastError() == hipSuccess ? PFK_OK : PFK_ERR_LAUNCH;
 }

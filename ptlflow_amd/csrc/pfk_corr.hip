@@ -247,7 +247,7 @@ int pool_launch(const T* in, T* out, int64_t M, int H, int W, pfk_stream_t strea
 
 extern "C" {
 
-void pfk_debug_set_lookup_pix(int pix) { g_lookup_pix = pix == 8 ? 8 : 4; }
+int pfk_debug_set_lookup_pix(int pix) { if (!pfk_debug_knobs_enabled()) return PFK_ERR_DISABLED; g_lookup_pix = pix == 8 ? 8 : 4; return PFK_OK; }
 
 int pfk_corr_lookup_f32(const pfk_lookup_desc* d, pfk_stream_t stream) { return lookup_launch<float>(d, stream); }
 

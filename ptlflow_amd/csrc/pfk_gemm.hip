@@ -1219,12 +1219,15 @@ int desc_to_args(const pfk_conv_desc* d, GemmArgs& a, int kpad) {
 
 extern "C" {
 
-void pfk_debug_set_tile(int cfg) {
-  if (cfg >= 300) { g_small_swizzled = cfg - 300; return; }      // 301: small grids on the swizzled layout, 300: off
-  if (cfg >= 200) { g_sk_variant = cfg - 200; return; }          // 200 + v: stream-K schedule variant (launch_sk)
+int pfk_debug_set_tile(int cfg) {
+  if (!pfk_debug_knobs_enabled()) return PFK_ERR_DISABLED;
+  if (cfg >= 300) { g_small_swizzled = cfg - 300; return PFK_OK; }      // 301: small grids on the swizzled layout, 300: off
+  if (cfg >= 200) { g_sk_variant = cfg - 200; return PFK_OK; }          // 200 + v: stream-K schedule variant (launch_sk)
   if (cfg >= 100) g_bf_cfg = cfg - 100;   // split-bf16 tile configuration (0 = heuristic)
   else { g_force_tile = cfg; if (cfg < 0) g_bf_cfg = 0; }
+  return PFK_OK;
 }
+
 
 unsigned pfk_debug_fastdiv(unsigned n, unsigned d) {
   unsigned mul; int sh;

@@ -503,6 +503,7 @@ const char* pfk_status_string(int status) {
     case PFK_ERR_ALIGNMENT: return "pointer/stride alignment";
     case PFK_ERR_UNSUPPORTED: return "unsupported shape";
     case PFK_ERR_LAUNCH: return "kernel launch failed";
+    case PFK_ERR_DISABLED: return "debug knob disabled (set PFK_DEBUG_KNOBS=1 in the process environment to use pfk_debug_set_*)";
     default: return "unknown status";
   }
 }

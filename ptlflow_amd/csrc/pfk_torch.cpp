@@ -593,15 +593,21 @@ void gru_backward_zr(const Tensor& d_rh, const Tensor& h, const Tensor& r, Tenso
 int64_t abi_version() { return pfk_abi_version(); }
 int64_t conv_workspace_bytes() { return pfk_conv_workspace_bytes(); }
 int64_t conv_workspace_fault_offset() { return pfk_conv_workspace_fault_offset(); }
-void debug_set_tile(int64_t cfg) { pfk_debug_set_tile((int)cfg); }
-void debug_set_lookup_pix(int64_t pix) { pfk_debug_set_lookup_pix((int)pix); }
-void debug_set_wgrad(int64_t v) { pfk_debug_set_wgrad((int)v); }
-void debug_set_altcorr(int64_t v) { pfk_debug_set_altcorr((int)v); }
+// inert (RuntimeError) unless the process opted in with PFK_DEBUG_KNOBS=1: process-global kernel selection (include/pfk.h)
+void debug_set_tile(int64_t cfg) { check_ok(pfk_debug_set_tile((int)cfg), "debug_set_tile"); }
+void debug_set_lookup_pix(int64_t pix) { check_ok(pfk_debug_set_lookup_pix((int)pix), "debug_set_lookup_pix"); }
+void debug_set_wgrad(int64_t v) { check_ok(pfk_debug_set_wgrad((int)v), "debug_set_wgrad"); }
+void debug_set_altcorr(int64_t v) { check_ok(pfk_debug_set_altcorr((int)v), "debug_set_altcorr"); }
+#ifndef PFK_SOURCE_HASH
+#define PFK_SOURCE_HASH "unstamped"
+#endif
+std::string source_hash() { return std::string(PFK_SOURCE_HASH) + ":" + pfk_source_hash(); }   // "<this extension's stamp>:<libpfk.so's stamp>"
 
 }  // namespace
 
 TORCH_LIBRARY(pfk, m) {
   m.def("abi_version() -> int", &abi_version);
+  m.def("source_hash() -> str", &source_hash);
   m.def("gru_gates_zr(Tensor a_zr, Tensor h, Tensor(a!) z, Tensor(b!) r, Tensor(c!) rh) -> ()");
   m.def("gru_gates_q(Tensor a_q, Tensor z, Tensor h, Tensor(a!) q, Tensor(b!) h_new) -> ()");
   m.def("gru_backward_q(Tensor dh_new, Tensor z, Tensor q, Tensor h, Tensor(a!) da_q, Tensor(b!) da_zr, Tensor(c!) dh) -> ()");

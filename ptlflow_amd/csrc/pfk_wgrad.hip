@@ -307,7 +307,7 @@ inline int ktot_of(const pfk_conv_desc* d) {
 
 extern "C" {
 
-void pfk_debug_set_wgrad(int variant) { g_wgrad_variant = variant; }
+int pfk_debug_set_wgrad(int variant) { if (!pfk_debug_knobs_enabled()) return PFK_ERR_DISABLED; g_wgrad_variant = variant; return PFK_OK; }
 
 long long pfk_conv_wgrad_workspace_bytes(const pfk_conv_desc* d, int with_bias) {
   if (!d || d->num_src < 1 || d->num_src > 3 || d->cout <= 0) return 0;

@@ -9,6 +9,7 @@ proper is tests/ against the CPU oracle."""
 import argparse
 import math
 import os
+os.environ.setdefault("PFK_DEBUG_KNOBS", "1")   # tuning script: uses the pfk_debug_set_* knobs
 import sys
 
 import torch

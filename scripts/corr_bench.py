@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Time the correlation path's kernels on the north-star shape (55x128 grid, D=256, L=4, r=4; GPU box): K1 fp32 (tile walk:
 row-major vs 16x16 supertiles), K1 bf16, K2, K3 on fp32 / bf16 pyramids, lookup backward, volume backward."""
+import os
+os.environ.setdefault("PFK_DEBUG_KNOBS", "1")   # tuning script: uses the pfk_debug_set_* knobs
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

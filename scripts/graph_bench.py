@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
 """Eager vs hipGraph-replayed iteration loop (GPU box).  python scripts/graph_bench.py [--height 436 --width 1024 --batch 1]"""
+import os
+os.environ.setdefault("PFK_DEBUG_KNOBS", "1")   # tuning script: uses the pfk_debug_set_* knobs
 import argparse, os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
 """Time the pyramid lookup (K3) and the on-demand correlation (K7) on the north-star shape (GPU box)."""
+import os
+os.environ.setdefault("PFK_DEBUG_KNOBS", "1")   # tuning script: uses the pfk_debug_set_* knobs
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -3,6 +3,7 @@
     python scripts/stage_time.py [--batch 8] [--conv-precision fp32]"""
 import argparse
 import os
+os.environ.setdefault("PFK_DEBUG_KNOBS", "1")   # tuning script: uses the pfk_debug_set_* knobs
 import sys
 
 import torch

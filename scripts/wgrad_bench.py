@@ -7,6 +7,7 @@ torch matmul of the unfolded input on the small shapes, and variant-vs-variant e
 differ in the last bits; the gate is relative to the gradient's scale); the parity gate proper is tests/test_gpu_train.py."""
 import argparse
 import os
+os.environ.setdefault("PFK_DEBUG_KNOBS", "1")   # tuning script: uses the pfk_debug_set_* knobs
 import sys
 
 import torch

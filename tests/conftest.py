@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# the tests force every tile shape / kernel variant through the pfk_debug_set_* knobs, which are inert in a process that did
+# not opt in (include/pfk.h)
+os.environ.setdefault("PFK_DEBUG_KNOBS", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

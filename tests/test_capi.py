@@ -34,7 +34,7 @@ def test_exports_every_declared_symbol(lib):
 
 
 def test_abi_version_and_status_strings(lib):
-    assert lib.pfk_abi_version() == 4
+    assert lib.pfk_abi_version() == 5
     lib.pfk_status_string.restype = ctypes.c_char_p
     assert lib.pfk_status_string(0) == b"ok"
     assert b"alignment" in lib.pfk_status_string(-2)
@@ -63,6 +63,51 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".h")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", txt, flags=re.M), f"{f} imports the oracle"
+
+
+def test_product_never_touches_the_staged_reference():
+    """oracle/_ref (the reference staged for the GPU box) is test infrastructure like the rest of oracle/."""
+    pkg = os.path.join(ROOT, "ptlflow_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle/_ref" not in txt and "stage_ref" not in txt and "ref_loader" not in txt, f"{f} refers to the staged reference"
+
+
+def test_libraries_carry_the_tree_stamp():
+    """Both libraries are stamped with the content hash of csrc/ + include/pfk.h (ptlflow_amd/_build.py); load_native()
+    refuses any other stamp, so a stale `.so` travelling with the tree cannot be loaded silently."""
+    import torch
+    import ptlflow_amd
+    from ptlflow_amd import _build
+    want = _build.source_hash()
+    assert _build.embedded_hash(ptlflow_amd.LIBPFK_PATH) == want
+    ptlflow_amd.load_native()
+    assert torch.ops.pfk.source_hash() == f"{want}:{want}"
+    # a different tree hash must be refused
+    real = _build.source_hash
+    _build.source_hash = lambda: "0" * 16
+    try:
+        with pytest.raises(ptlflow_amd.NativeLibraryStale):
+            ptlflow_amd._check_stamp()
+    finally:
+        _build.source_hash = real
+
+
+def test_debug_knobs_are_inert_without_opt_in():
+    """pfk_debug_set_* flip process-global kernel selection: PFK_ERR_DISABLED (-5) unless the process has PFK_DEBUG_KNOBS=1."""
+    import subprocess
+    import sys
+    import ptlflow_amd
+    code = ("import ctypes,sys; lib=ctypes.CDLL(sys.argv[1]); "
+            "print(lib.pfk_debug_set_tile(3), lib.pfk_debug_set_lookup_pix(8), lib.pfk_debug_set_altcorr(1), lib.pfk_debug_set_wgrad(2))")
+    env = {k: v for k, v in os.environ.items() if k != "PFK_DEBUG_KNOBS"}
+    off = subprocess.run([sys.executable, "-c", code, str(ptlflow_amd.LIBPFK_PATH)], env=env, capture_output=True, text=True)
+    assert off.stdout.split() == ["-5"] * 4, off.stdout + off.stderr
+    on = subprocess.run([sys.executable, "-c", code, str(ptlflow_amd.LIBPFK_PATH)], env=dict(env, PFK_DEBUG_KNOBS="1"),
+                        capture_output=True, text=True)
+    assert on.stdout.split() == ["0"] * 4, on.stdout + on.stderr
 
 
 def test_fastdiv_multipliers_are_exact():

@@ -109,3 +109,34 @@ def test_bench_two_ranks_shared_device(gpu):
     # whole-job value: both ranks' pairs over the max-over-ranks time
     assert r["value"] == pytest.approx(2 * 2 * 2 / (r["ms_per_step"] * 2 / 1e3), rel=1e-6)
     assert r["streamk_faults"] == 0
+
+
+_SMALL = ["--steps", "2", "--warmup", "1", "--batch", "2", "--iters", "4", "--height", "184", "--width", "320", "--no-cpu-baseline",
+          "--no-roofline", "--no-split-modes", "--no-extra-legs", "--no-batch1"]
+
+
+def test_bench_gpus_2_self_launches_two_ranks(gpu):
+    """`python bench.py --gpus 2` with NO launcher (how a driver may invoke it): bench.py starts the two ranks itself and the
+    one JSON line says n_gpus == 2, rccl_ranks == 2 (an all-reduce of ones over the process group)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(PFK_BENCH_SHARED_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", *_SMALL], env=env, cwd=ROOT,
+                         capture_output=True, text=True, timeout=900)
+    assert run.returncode == 0, run.stderr[-2000:]
+    lines = [l for l in run.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, run.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["rccl_ranks"] == 2 and r["config"]["global_batch"] == 4
+
+
+def test_bench_refuses_more_ranks_than_devices(gpu):
+    """Without the shared-device flag a one-GPU box must FAIL `--gpus 2` loudly, never print an `n_gpus: 1` line."""
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box has two GPUs: the refusal cannot be provoked")
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "PFK_BENCH_SHARED_DEVICE")}
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", *_SMALL], env=env, cwd=ROOT,
+                         capture_output=True, text=True, timeout=600)
+    assert run.returncode != 0
+    assert not [l for l in run.stdout.splitlines() if l.startswith("{")], run.stdout[-1000:]
+    assert "only 1 GPU" in run.stderr

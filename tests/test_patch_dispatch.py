@@ -155,3 +155,24 @@ def test_hook_envelope():
     assert not _supported_envelope(f, torch.empty(1, 128, 55, 128), 4, 4)
     big = torch.empty(1, 256, 1, 1).expand(1, 256, 1500, 1500)
     assert not _supported_envelope(big, big, 4, 4)        # > 2 GiB feature matrix: 32-bit offsets
+
+
+def test_upsample_seam_passes_other_signatures_through():
+    """Seam B5 shadows `model.upsample_flow` on every model that has one; families whose method takes more than
+    (flow, mask) — ccmr.py:213 / ms_raft_plus.py:199 call it with `scale=2` — must reach their own method untouched
+    (round-3 advisor finding: the seam raised TypeError on them)."""
+    import torch
+    from ptlflow_amd.patch import _UpsampleSeam
+    calls = []
+
+    def original(flow, mask, scale=8, *extra, **kw):
+        calls.append((scale, extra, kw))
+        return flow * scale
+
+    seam = _UpsampleSeam(original)
+    f, m = torch.ones(1, 2, 3, 4), torch.zeros(1, 36, 3, 4)
+    assert torch.equal(seam(f, m, scale=2), f * 2)
+    assert torch.equal(seam(f, m, 4), f * 4)
+    assert torch.equal(seam(flow=f, mask=m), f * 8)
+    assert torch.equal(seam(f, m), f * 8)                  # CPU tensors: not eligible, original
+    assert [c[0] for c in calls] == [2, 4, 8, 8] and seam.ok is None      # never probed
