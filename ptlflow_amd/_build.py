@@ -63,9 +63,15 @@ def source_files():
     return sorted([p for p in CSRC.iterdir() if p.suffix in (".hip", ".h", ".cpp")] + [INCLUDE / "pfk.h"])
 
 
+def _flag_signature(flags) -> str:
+    """The flags that change code generation — without the -I paths, which name wherever this tree happens to lie (the GPU box
+    runs a copy under a scratch path; the stamp must be the same there)."""
+    return " ".join(f for f in flags if not f.startswith("-I"))
+
+
 def source_hash() -> str:
     """Stamp of the tree: every kernel / binding source, the public header, the flags."""
-    return _sha(source_files(), " ".join(HIP_FLAGS) + repr(HIP_SOURCES))
+    return _sha(source_files(), _flag_signature(HIP_FLAGS) + repr(HIP_SOURCES))
 
 
 def _stale(target: Path, key: str) -> bool:
@@ -105,7 +111,7 @@ def build_libpfk(force: bool = False) -> Path:
         s = CSRC / src
         o = OBJ / (s.stem + ".o")
         define = [f'-DPFK_SOURCE_HASH="{tree}"'] if src == "pfk_stamp.hip" else []      # the TU that defines pfk_source_hash()
-        key = _sha([s, *headers], " ".join(HIP_FLAGS + extra + define))
+        key = _sha([s, *headers], _flag_signature(HIP_FLAGS + extra + define))
         if force or _stale(o, key):
             jobs.append(([HIPCC, *HIP_FLAGS, *extra, *define, "-c", s, "-o", o], o, key))
         objs.append(o)

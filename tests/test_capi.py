@@ -95,6 +95,21 @@ def test_libraries_carry_the_tree_stamp():
         _build.source_hash = real
 
 
+def test_stamp_does_not_depend_on_where_the_tree_lies(tmp_path):
+    """The GPU box runs a COPY of this tree under a scratch path: the stamp must be the same there (round 4: absolute -I
+    paths in the hashed flags made every load on the box fail as stale)."""
+    import shutil
+    import subprocess
+    import sys
+    shutil.copytree(os.path.join(ROOT, "ptlflow_amd"), tmp_path / "ptlflow_amd", ignore=shutil.ignore_patterns("_obj", "__pycache__"))
+    shutil.copytree(os.path.join(ROOT, "include"), tmp_path / "include")
+    run = subprocess.run([sys.executable, "-c", "import ptlflow_amd, torch; ptlflow_amd.load_native(); print(torch.ops.pfk.source_hash())"],
+                         cwd=tmp_path, env={k: v for k, v in os.environ.items() if k != "PYTHONPATH"}, capture_output=True, text=True)
+    assert run.returncode == 0, run.stderr[-1500:]
+    from ptlflow_amd import _build
+    assert run.stdout.strip().endswith(f"{_build.source_hash()}:{_build.source_hash()}")
+
+
 def test_debug_knobs_are_inert_without_opt_in():
     """pfk_debug_set_* flip process-global kernel selection: PFK_ERR_DISABLED (-5) unless the process has PFK_DEBUG_KNOBS=1."""
     import subprocess
