@@ -162,6 +162,8 @@ def reference_raft(cpu_state, iters):
             return None, None
         m = ref_loader.build_raft(iters=iters)
         missing, unexpected = m.load_state_dict(cpu_state, strict=False)
+        # (the metric accumulators BaseModel registers — `train_metrics.*`, `val_metrics.*` — are not weights)
+        missing = [k for k in missing if not k.startswith(("train_metrics.", "val_metrics."))]
         if missing or unexpected:
             raise RuntimeError(f"state_dict mismatch with the reference class: missing {missing[:3]}, unexpected {unexpected[:3]}")
         return m.eval(), ref_loader.REFERENCE_KIND
@@ -242,9 +244,13 @@ def whole_model_legs(dev, H, W, check: bool):
                     ref = m({"images": x1.clone()})["flows"][:, 0]
             m = m.to(dev)
             with torch.no_grad():
+                stock_bf16 = None
                 if unpatched:
                     t = protocol_leg(m, dev, H, W, n=5)
                     leg["unpatched_torch_rocm"] = {"value": t["value"], "ms_median": t["ms_median"]}
+                    if autocast and ref is not None:     # what bf16 autocast costs the SAME model on stock PyTorch-ROCm ops
+                        with torch.autocast("cuda", dtype=torch.bfloat16):
+                            stock_bf16 = _epe(m({"images": x1.to(dev)})["flows"][:1, 0], ref)
                 patch.accelerate(m)
                 try:
                     t = protocol_leg(m, dev, H, W)
@@ -259,6 +265,8 @@ def whole_model_legs(dev, H, W, check: bool):
                             if ref is not None:
                                 mean, mx = _epe(m({"images": x1.to(dev)})["flows"][:1, 0], ref)
                                 leg["bf16_autocast"]["epe_vs_cpu_fp32"] = {"mean": mean, "max": mx}
+                                if stock_bf16 is not None:
+                                    leg["bf16_autocast"]["epe_of_stock_torch_rocm_autocast_vs_cpu_fp32"] = {"mean": stock_bf16[0], "max": stock_bf16[1]}
                 finally:
                     patch.restore(m)
             leg["model_class"] = f"{type(m).__module__}.{type(m).__name__}"
