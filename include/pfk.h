@@ -273,10 +273,22 @@ int pfk_convex_upsample_pm_f32(const float* flow_pm, int flow_ld, const float* m
  * replaces corr_cuda_forward (ptlflow/utils/external/alt_cuda_corr/correlation_kernel.cu:258-285; pybind
  * `alt_cuda_corr.forward`, correlation.cpp:23-37, called from AlternateCorrBlock, raft/corr.py:76-101):
  * fmap1 [B][H1][W1][C], fmap2 [B][H2][W2][C] (NHWC fp32 contiguous), coords [B][H1][W1][2] (x, y) ->
- * out [B][(2r+1)^2][H1][W1], cell = oy + (2r+1)*ox, UNSCALED (the caller divides by sqrt(C)). */
+ * out [B][(2r+1)^2][H1][W1], cell = oy + (2r+1)*ox, UNSCALED (the caller divides by sqrt(C)).
+ * `workspace`: pfk_altcorr_workspace_bytes(B, H1, W1) bytes of device memory (4-byte aligned, no initialisation needed), or NULL.
+ * With it the launch counts the 8x4-pixel patches whose windows share a bounding box small enough for the window-sharing MFMA
+ * kernel and runs that kernel only when at least a quarter of them qualify; otherwise (noise-like coordinate fields) every pixel
+ * takes the per-pixel kernel.  NULL: the decision is per patch only. */
+long long pfk_altcorr_workspace_bytes(int B, int H1, int W1);
 int pfk_altcorr_forward_f32(const float* fmap1, const float* fmap2, const float* coords, float* out,
                             int B, int H1, int W1, int H2, int W2, int C, int radius,
-                            pfk_stream_t stream);
+                            void* workspace, pfk_stream_t stream);
+
+/* The same with bf16 feature maps (NHWC bf16 contiguous; coords and out fp32): the maps are widened exactly, products and
+ * accumulation are fp32 — the on-demand counterpart of the bf16 volume for bf16 / autocast callers, half the
+ * gather bytes of an L2-bound kernel.  The reference's extension is float-only (correlation_kernel.cu:275) and its callers
+ * up-cast half inputs (raft/corr.py:90-96); IterativeCorrBlock under autocast (ptlflow/utils/correlation.py:539-615) is the oracle. */
+int pfk_altcorr_forward_bf16(const void* fmap1_bf16, const void* fmap2_bf16, const float* coords, float* out,
+                             int B, int H1, int W1, int H2, int W2, int C, int radius, void* workspace, pfk_stream_t stream);
 
 /* backward of the above w.r.t. the feature maps: corr_cuda_backward (correlation_kernel.cu:288-324, pybind
  * `alt_cuda_corr.backward`).  corr_grad [B][(2r+1)^2][H1][W1] -> fmap1_grad [B][H1][W1][C] (overwritten),

@@ -229,6 +229,22 @@ def golden_alt_corr():
                 "out_rows": out[:, :, ::4].clone()}, os.path.join(OUT, "alt_corr.pt"))
 
 
+def golden_alt_corr_bf16():
+    """The same path for bf16 callers: `IterativeCorrBlock` on bf16 feature maps under `torch.autocast("cpu", bfloat16)` (the
+    reference has no bf16 mode of its own; autocast is how BASELINE config 3's precision reaches it) on golden_alt_corr's
+    inputs.  Stored: rows 0, 4, 8, ... of the autocast output and the largest difference of that output from the fp32 one —
+    the reference's own bf16 gap, which `pfk_altcorr_forward_bf16` (exact products of the bf16 values) must stay inside."""
+    corr_mod = ref_loader.ref_module("ptlflow.models.raft.corr")
+    gold = torch.load(os.path.join(OUT, "alt_corr.pt"))
+    f1, f2, coords, L, r = gold["fmap1"], gold["fmap2"], gold["coords"], gold["levels"], gold["radius"]
+    with torch.no_grad():
+        ref32 = corr_mod.IterativeCorrBlock(fmap1=f1, fmap2=f2, radius=r, num_levels=L)(coords)
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            out = corr_mod.IterativeCorrBlock(fmap1=f1.bfloat16(), fmap2=f2.bfloat16(), radius=r, num_levels=L)(coords).float()
+    torch.save({"row_step": 4, "out_rows_autocast": out[:, :, ::4].clone(), "autocast_gap_max": float((out - ref32).abs().max()),
+                "autocast_gap_mean": float((out - ref32).abs().mean())}, os.path.join(OUT, "alt_corr_bf16.pt"))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(4)
@@ -239,6 +255,7 @@ def main():
     golden_warm_start()
     golden_sea_raft_model()
     golden_alt_corr()
+    golden_alt_corr_bf16()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
 

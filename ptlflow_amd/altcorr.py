@@ -30,6 +30,11 @@ def forward(fmap1: torch.Tensor, fmap2: torch.Tensor, coords: torch.Tensor, radi
             raise RuntimeError(f"{name} must be a CUDA tensor")
         if not t.is_contiguous():               # CHECK_CONTIGUOUS, correlation.cpp:20
             raise RuntimeError(f"{name} must be contiguous")
+    if fmap1.dtype == torch.bfloat16 and fmap2.dtype == torch.bfloat16:
+        # bf16 maps go to the kernel as they are (pfk_altcorr_forward_bf16: exact widening, fp32 products and accumulation): half
+        # the gather traffic, no fp32 copies of the maps; the result takes the maps' dtype like the half path below
+        out = torch.ops.pfk.altcorr_forward(fmap1, fmap2, coords.float(), int(radius))
+        return [out.to(fmap1.dtype)]
     if fmap1.dtype != torch.float32:
         # the reference's extension is float-only (correlation_kernel.cu:275: corr_forward_kernel<float>); its callers up-cast
         # half inputs and cast the result back (raft/corr.py:90-96).  Accepting them here saves the caller that dance.

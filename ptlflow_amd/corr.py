@@ -285,35 +285,52 @@ class AlternateCorrBlock:
     per pyramid level of ``fmap2`` (avg-pooled), the (2r+1)^2 window around ``coords / 2^l`` with the gfx950 kernel behind
     the ``alt_cuda_corr`` ABI (``pfk_altcorr_forward_f32``).  Same channel layout and ``/ sqrt(dim)`` as the reference."""
 
-    def __init__(self, fmap1: torch.Tensor, fmap2: torch.Tensor, num_levels: int = 4, radius: int = 4):
+    def __init__(self, fmap1: torch.Tensor, fmap2: torch.Tensor, num_levels: int = 4, radius: int = 4,
+                 map_dtype: Optional[torch.dtype] = None):
+        """``map_dtype``: element type of the feature maps the kernel gathers — ``torch.float32`` (default for fp32 / fp16 maps:
+        the reference up-casts half inputs, raft/corr.py:90-96) or ``torch.bfloat16`` (default for bf16 maps, i.e. autocast
+        callers; `RAFT(conv_precision="bf16", alternate_corr=True)` asks for it explicitly): `pfk_altcorr_forward_bf16`, bf16
+        maps pooled in bf16 like the reference's own `F.avg_pool2d` on them, fp32 products / accumulation / output."""
         if not fmap1.is_cuda:
             raise RuntimeError("ptlflow_amd.AlternateCorrBlock needs GPU tensors (no CPU fallback)")
         _ops()
         self.num_levels, self.radius = num_levels, radius
         self.out_dtype = fmap1.dtype
         self.dim = fmap1.shape[1]
-        self.f1 = fmap1.float().permute(0, 2, 3, 1).contiguous()                 # NHWC, what the kernel reads
+        if map_dtype is None:
+            map_dtype = torch.bfloat16 if fmap1.dtype == torch.bfloat16 else torch.float32
+        if map_dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("map_dtype must be torch.float32 or torch.bfloat16")
+        self.map_dtype = map_dtype
+        self.f1 = fmap1.to(map_dtype).permute(0, 2, 3, 1).contiguous()            # NHWC, what the kernel reads
         self.f2 = []
-        f2 = fmap2.float()
+        f2 = fmap2.to(map_dtype)
         for _ in range(num_levels):
             self.f2.append(f2.permute(0, 2, 3, 1).contiguous())
             f2 = F.avg_pool2d(f2, 2, stride=2)
 
     def __call__(self, coords: torch.Tensor) -> torch.Tensor:
+        corr = self._windows(coords)
+        return corr if self.out_dtype == torch.float32 else corr.to(self.out_dtype)
+
+    def _windows(self, coords: torch.Tensor) -> torch.Tensor:
+        """[B, L (2r+1)^2, H, W] in fp32 (the kernels' output type whatever the maps' type)."""
         from . import altcorr
         c = coords.float().permute(0, 2, 3, 1)
         B, H, W, _ = c.shape
         out = []
         for l in range(self.num_levels):
             ci = (c / 2 ** l).reshape(B, 1, H, W, 2).contiguous()
-            (corr,) = altcorr.forward(self.f1, self.f2[l], ci, self.radius)
+            if self.map_dtype == torch.bfloat16:       # the op itself returns fp32 (altcorr.forward would round it to the maps' dtype)
+                corr = torch.ops.pfk.altcorr_forward(self.f1, self.f2[l], ci, self.radius)
+            else:
+                (corr,) = altcorr.forward(self.f1, self.f2[l], ci, self.radius)
             out.append(corr.squeeze(1))
-        corr = torch.stack(out, dim=1).reshape(B, -1, H, W) / math.sqrt(self.dim)
-        return corr if self.out_dtype == torch.float32 else corr.to(self.out_dtype)
+        return torch.stack(out, dim=1).reshape(B, -1, H, W) / math.sqrt(self.dim)
 
     def lookup_pm(self, coords: torch.Tensor) -> torch.Tensor:
         """Pixel-major ``[B*h*w, C]`` form for the update engine (same contract as ``CorrBlock.lookup_pm``)."""
-        corr = self(coords).float()
+        corr = self._windows(coords)
         B, C, H, W = corr.shape
         return corr.permute(0, 2, 3, 1).reshape(B * H * W, C).contiguous()
 

@@ -18,7 +18,18 @@ namespace {
 
 constexpr int MAX_C4 = 8;   // channels <= 16 lanes * 4 floats * MAX_C4 = 512
 
-__global__ __launch_bounds__(256) void altcorr_fwd_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+// Feature-map element: float, or bf16 (pfk_altcorr_forward_bf16: bf16 maps, exact widening, fp32 products and accumulation —
+// half the gather bytes of an L2-bound kernel).  load4: four consecutive channels as floats.
+typedef unsigned short bf16_t;
+typedef unsigned int ac_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 widen4(ac_u32x2 u) {
+  return f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+}
+__device__ __forceinline__ f32x4 load4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 load4(const bf16_t* p) { return widen4(*reinterpret_cast<const ac_u32x2*>(p)); }
+
+template <class T>
+__global__ __launch_bounds__(256) void altcorr_fwd_kernel(const T* __restrict__ f1, const T* __restrict__ f2,
                                                           const float* __restrict__ coords, float* __restrict__ out,
                                                           long long M, int H1, int W1, int H2, int W2, int C, int r) {
   __shared__ float s_tap[4][104];
@@ -49,7 +60,7 @@ __global__ __launch_bounds__(256) void altcorr_fwd_kernel(const float* __restric
 #pragma unroll
   for (int i = 0; i < MAX_C4; ++i) {
     const int c = cl * 4 + i * 64;
-    a[i] = (live && c < C) ? *reinterpret_cast<const f32x4*>(f1 + p * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    a[i] = (live && c < C) ? load4(f1 + p * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
   for (int t0 = 0; t0 < ntaps; t0 += 4) {
@@ -59,12 +70,12 @@ __global__ __launch_bounds__(256) void altcorr_fwd_kernel(const float* __restric
     const bool ok = live && t < ntaps && (unsigned)yy < (unsigned)H2 && (unsigned)xx < (unsigned)W2;
     float acc = 0.f;
     if (ok) {
-      const float* row = f2 + ((b * H2 + yy) * (long long)W2 + xx) * C;
+      const T* row = f2 + ((b * H2 + yy) * (long long)W2 + xx) * C;
 #pragma unroll
       for (int i = 0; i < MAX_C4; ++i) {
         const int c = cl * 4 + i * 64;
         if (c < C) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(row + c);
+          const f32x4 v = load4(row + c);
           acc = fmaf(a[i].x, v.x, fmaf(a[i].y, v.y, fmaf(a[i].z, v.z, fmaf(a[i].w, v.w, acc))));
         }
       }
@@ -107,7 +118,8 @@ typedef unsigned int ws_u32x4 __attribute__((ext_vector_type(4)));
 constexpr unsigned WS_OOB = 0x80000000u;
 
 // per-pixel algorithm of altcorr_fwd_kernel for one pixel per wave (wave-local: no workgroup barrier)
-__device__ __forceinline__ void altcorr_pixel(const float* __restrict__ f1, const float* __restrict__ f2, float* __restrict__ out,
+template <class T>
+__device__ __forceinline__ void altcorr_pixel(const T* __restrict__ f1, const T* __restrict__ f2, float* __restrict__ out,
                                               bool live, long long p, long long b, int pix, float x, float y, long long hw, int H2,
                                               int W2, int C, int r, float* s_tap_w, int lane) {
   const int g = lane >> 4, cl = lane & 15;
@@ -120,7 +132,7 @@ __device__ __forceinline__ void altcorr_pixel(const float* __restrict__ f1, cons
 #pragma unroll
   for (int i = 0; i < MAX_C4; ++i) {
     const int c = cl * 4 + i * 64;
-    a[i] = (live && c < C) ? *reinterpret_cast<const f32x4*>(f1 + p * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    a[i] = (live && c < C) ? load4(f1 + p * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
   for (int t0 = 0; t0 < ntaps; t0 += 4) {
     const int t = t0 + g;
@@ -129,12 +141,12 @@ __device__ __forceinline__ void altcorr_pixel(const float* __restrict__ f1, cons
     const bool ok = live && t < ntaps && (unsigned)yy < (unsigned)H2 && (unsigned)xx < (unsigned)W2;
     float acc = 0.f;
     if (ok) {
-      const float* row = f2 + ((b * H2 + yy) * (long long)W2 + xx) * C;
+      const T* row = f2 + ((b * H2 + yy) * (long long)W2 + xx) * C;
 #pragma unroll
       for (int i = 0; i < MAX_C4; ++i) {
         const int c = cl * 4 + i * 64;
         if (c < C) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(row + c);
+          const f32x4 v = load4(row + c);
           acc = fmaf(a[i].x, v.x, fmaf(a[i].y, v.y, fmaf(a[i].z, v.z, fmaf(a[i].w, v.w, acc))));
         }
       }
@@ -194,14 +206,74 @@ __device__ __forceinline__ void patch_box(const float* __restrict__ coords, long
 // 72 -> 88 us at 110x256, because a rejected border patch then runs alone in the second launch.  Not kept.)
 __device__ __forceinline__ bool patch_takes_gemm(const int (&box)[4]) { return (long long)box[2] * box[3] <= WS_NP_MAX; }
 
+// ---- launch-wide gate (round 4) --------------------------------------------------------------------------------------------------
+// The window-sharing GEMM pays when MANY patches take it.  When almost every box overflows (iid-noise coordinate fields), the few
+// border patches that still fit ran their ~30 us GEMM blocks on an otherwise idle chip in FRONT of the per-pixel pass: 400 us
+// against the per-pixel kernel's 333 (0.83x).  altcorr_plan_kernel counts the patches that would take the GEMM (64 patches per
+// block, two per wave-iteration, per-block counts: no atomics, no zero-fill, deterministic); both passes read the counts and, when
+// fewer than a quarter of the patches qualify, the GEMM pass leaves and the per-pixel pass takes EVERY patch.
+constexpr int PLAN_PATCHES = 64;      // patches per plan block
+template <int TPY>
+__global__ __launch_bounds__(256) void altcorr_plan_kernel(const float* __restrict__ coords, int* __restrict__ counts, int B, int H1,
+                                                           int W1, int H2, int W2, int r, int tiles_x, int tiles_y) {
+  static_assert(TPY == 4, "two 8x4 patches per wave");
+  __shared__ int s_cnt[4];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, half = lane >> 5, hl = lane & 31;
+  const int n = 2 * r + 2;
+  const long long npatch = (long long)B * tiles_x * tiles_y;
+  int mine = 0;
+#pragma unroll
+  for (int it = 0; it < PLAN_PATCHES / 8; ++it) {
+    const long long tile = (long long)blockIdx.x * PLAN_PATCHES + (it * 4 + wid) * 2 + half;
+    const bool tl = tile < npatch;
+    const int txi = (int)(tile % tiles_x), tyi = (int)((tile / tiles_x) % tiles_y);
+    const long long b = tile / ((long long)tiles_x * tiles_y);
+    const int yy = tyi * TPY + (hl >> 3), xx = txi * 8 + (hl & 7);
+    const bool inside = tl && yy < H1 && xx < W1;
+    int x0 = WS_FAR, y0 = WS_FAR;
+    if (inside) {
+      const long long p = b * ((long long)H1 * W1) + (long long)yy * W1 + xx;
+      const float fx = floorf(coords[p * 2 + 0]), fy = floorf(coords[p * 2 + 1]);
+      x0 = (fabsf(fx) < 1.0e9f) ? (int)fx - r : WS_FAR;
+      y0 = (fabsf(fy) < 1.0e9f) ? (int)fy - r : WS_FAR;
+    }
+    const bool use = inside && x0 != WS_FAR && y0 != WS_FAR && x0 < W2 && y0 < H2 && x0 + n > 0 && y0 + n > 0;   // as patch_box()
+    int lo_x = use ? max(x0, 0) : (1 << 30), hi_x = use ? min(x0 + n, W2) : -(1 << 30);
+    int lo_y = use ? max(y0, 0) : (1 << 30), hi_y = use ? min(y0 + n, H2) : -(1 << 30);
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) {       // within the 32-lane half
+      lo_x = min(lo_x, __shfl_xor(lo_x, off, 64)); hi_x = max(hi_x, __shfl_xor(hi_x, off, 64));
+      lo_y = min(lo_y, __shfl_xor(lo_y, off, 64)); hi_y = max(hi_y, __shfl_xor(hi_y, off, 64));
+    }
+    const bool any = hi_x > lo_x && hi_y > lo_y;
+    const int box[4] = {0, 0, any ? hi_x - lo_x : 0, any ? hi_y - lo_y : 0};
+    if (tl && hl == 0 && patch_takes_gemm(box)) ++mine;
+  }
+  mine += __shfl_xor(mine, 32, 64);                 // the two halves' leaders
+  if (lane == 0) s_cnt[wid] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) counts[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+
+// one wave: do enough patches take the GEMM for the window-sharing pass to run at all?  (counts == nullptr: always)
+__device__ __forceinline__ bool gemm_pass_enabled(const int* __restrict__ counts, int nplan, long long npatch, int lane) {
+  if (counts == nullptr) return true;
+  int s = 0;
+  for (int i = lane; i < nplan; i += 64) s += counts[i];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+  return 4LL * s >= npatch;
+}
+
 // The patches the window-sharing kernel skipped: the per-pixel algorithm, one pixel per wave, blocks in the per-pixel kernel's own
 // row-major order (four consecutive pixels of an image row — they always lie in one patch); a block whose patch took the GEMM
 // leaves after the box test (one per block, wave 0).
-template <int TPY>
-__global__ __launch_bounds__(256) void altcorr_fwd_overflow_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+template <int TPY, class T>
+__global__ __launch_bounds__(256) void altcorr_fwd_overflow_kernel(const T* __restrict__ f1, const T* __restrict__ f2,
                                                                    const float* __restrict__ coords, float* __restrict__ out,
                                                                    int H1, int W1, int H2, int W2, int C, int r, int groups_x,
-                                                                   int force) {
+                                                                   int force, const int* __restrict__ counts, int nplan,
+                                                                   long long npatch) {
   __shared__ float s_tap[4][104];
   __shared__ float s_xy[4][2];
   __shared__ int s_over;
@@ -218,7 +290,8 @@ __global__ __launch_bounds__(256) void altcorr_fwd_overflow_kernel(const float* 
     patch_box<TPY>(coords, b, py0, px0, H1, W1, H2, W2, r, lane, x, y, x0, y0, box);
     const int q0 = (yy - py0) * 8 + (xg - px0);         // first of this block's pixels inside the patch
     if (lane >= q0 && lane < q0 + 4) { s_xy[lane - q0][0] = x; s_xy[lane - q0][1] = y; }
-    if (lane == 0) s_over = force || !patch_takes_gemm(box);
+    const bool gemm_on = gemm_pass_enabled(counts, nplan, npatch, lane);
+    if (lane == 0) s_over = force || !gemm_on || !patch_takes_gemm(box);
   }
   __syncthreads();
   if (!s_over) return;
@@ -229,11 +302,11 @@ __global__ __launch_bounds__(256) void altcorr_fwd_overflow_kernel(const float* 
   altcorr_pixel(f1, f2, out, live, b * hw + pix, b, pix, s_xy[wid][0], s_xy[wid][1], hw, H2, W2, C, r, s_tap[wid], lane);
 }
 
-template <int TPY>
-__global__ __launch_bounds__(256, 2) void altcorr_fwd_ws_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+template <int TPY, class T>
+__global__ __launch_bounds__(256, 2) void altcorr_fwd_ws_kernel(const T* __restrict__ f1, const T* __restrict__ f2,
                                                                 const float* __restrict__ coords, float* __restrict__ out,
                                                                 int B, int H1, int W1, int H2, int W2, int C, int r,
-                                                                int tiles_x, int tiles_y) {
+                                                                int tiles_x, int tiles_y, const int* __restrict__ counts, int nplan) {
   constexpr int TP = 8 * TPY, MT = TP / 32;
   static_assert(TP == 32 || TP == 64, "patches of 8 x 4 or 8 x 8 pixels");
   constexpr int STAGE = (TP + WS_NP_MAX) * WS_ROWB;        // bytes per stage: A rows then B rows
@@ -259,7 +332,8 @@ __global__ __launch_bounds__(256, 2) void altcorr_fwd_ws_kernel(const float* __r
     patch_box<TPY>(coords, b, py0, px0, H1, W1, H2, W2, r, lane, x, y, x0, y0, box);
     if (lane < TP) { s_x[lane] = x; s_y[lane] = y; s_x0[lane] = x0; s_y0[lane] = y0; }
     if (lane < 4) s_box[lane] = box[lane];
-    if (lane == 4) s_box[4] = patch_takes_gemm(box);
+    const bool gemm_on = gemm_pass_enabled(counts, nplan, (long long)B * tiles_x * tiles_y, lane);
+    if (lane == 4) s_box[4] = gemm_on && patch_takes_gemm(box);
   }
   __syncthreads();
   const int bx0 = s_box[0], by0 = s_box[1], bw = s_box[2], bh = s_box[3];
@@ -278,14 +352,15 @@ __global__ __launch_bounds__(256, 2) void altcorr_fwd_ws_kernel(const float* __r
 
   if (NP > 0) {
     // ---- staging plan: thread t owns 16-byte chunk (t & 3) of A row t >> 2 (TP == 64) and of B rows (t >> 2) + 64 i -------------
-    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(f1), 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(f2), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(f1), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(f2), 0, 0x7fffffff, 0x00020000);
+    constexpr int ES = (int)sizeof(T);                      // bytes per feature-map element
     const int ch = t & 3, r0 = t >> 2;
     const unsigned sw = (unsigned)(((ch ^ ((r0 >> 2) & 3)) << 4));      // swizzled chunk byte offset (rows r0 + 64 i share the key)
     unsigned aoff = WS_OOB;
     if (r0 < TP) {
       const int yy = py0 + (r0 >> 3), xx = px0 + (r0 & 7);
-      if (yy < H1 && xx < W1) aoff = (unsigned)(((b * hw + (long long)yy * W1 + xx) * C + ch * 4) * 4);
+      if (yy < H1 && xx < W1) aoff = (unsigned)(((b * hw + (long long)yy * W1 + xx) * C + ch * 4) * ES);
     }
     unsigned boff[WS_NP_MAX / 64];
 #pragma unroll
@@ -294,17 +369,25 @@ __global__ __launch_bounds__(256, 2) void altcorr_fwd_ws_kernel(const float* __r
       boff[i] = WS_OOB;
       if (j < NP) {
         const int jy = j / bw, jx = j - jy * bw;           // inside the clipped box => inside the map
-        boff[i] = (unsigned)((((b * H2 + by0 + jy) * (long long)W2 + bx0 + jx) * C + ch * 4) * 4);
+        boff[i] = (unsigned)((((b * H2 + by0 + jy) * (long long)W2 + bx0 + jx) * C + ch * 4) * ES);
       }
     }
     const int nrow_b = (NCB * 32 + 63) >> 6;               // B passes of 64 rows that hold live column blocks
     ws_u32x4 ra, rb[WS_NP_MAX / 64];
     auto load = [&](int k0) {
       const bool cok = k0 + ch * 4 < C;                    // C is a multiple of 4
-      ra = __builtin_amdgcn_raw_buffer_load_b128(rs1, (cok && r0 < TP) ? aoff : WS_OOB, k0 * 4, 0);
+      // four channels per thread: one 16-byte (fp32) or 8-byte (bf16, widened on the way into LDS: the GEMM stays fp32) load
+      if constexpr (ES == 4) {
+        ra = __builtin_amdgcn_raw_buffer_load_b128(rs1, (cok && r0 < TP) ? aoff : WS_OOB, k0 * 4, 0);
 #pragma unroll
-      for (int i = 0; i < WS_NP_MAX / 64; ++i)
-        if (i < nrow_b) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rs2, cok ? boff[i] : WS_OOB, k0 * 4, 0);
+        for (int i = 0; i < WS_NP_MAX / 64; ++i)
+          if (i < nrow_b) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rs2, cok ? boff[i] : WS_OOB, k0 * 4, 0);
+      } else {
+        ra = __builtin_bit_cast(ws_u32x4, widen4(__builtin_amdgcn_raw_buffer_load_b64(rs1, (cok && r0 < TP) ? aoff : WS_OOB, k0 * 2, 0)));
+#pragma unroll
+        for (int i = 0; i < WS_NP_MAX / 64; ++i)
+          if (i < nrow_b) rb[i] = __builtin_bit_cast(ws_u32x4, widen4(__builtin_amdgcn_raw_buffer_load_b64(rs2, cok ? boff[i] : WS_OOB, k0 * 2, 0)));
+      }
     };
     auto store = [&](char* stage) {
       if (r0 < TP) *reinterpret_cast<ws_u32x4*>(stage + r0 * WS_ROWB + sw) = ra;
@@ -486,6 +569,67 @@ __global__ __launch_bounds__(256) void altcorr_bwd_kernel(const float* __restric
 
 int g_altcorr_mode = 0;   // tuning / test knob (pfk_debug_set_altcorr): 0 heuristic, 1 per-pixel kernel, 2 / 3 window-sharing 8x4 / 8x8, 4 = the overflow kernel alone on every patch (timing)
 
+namespace {
+// forward for float or bf16 feature maps (coords / out fp32 either way)
+template <class T>
+int altcorr_forward_launch(const T* fmap1, const T* fmap2, const float* coords, float* out, int B, int H1,
+                           int W1, int H2, int W2, int C, int radius, void* workspace, pfk_stream_t stream) {
+  if (!fmap1 || !fmap2 || !coords || !out) return PFK_ERR_BAD_ARG;
+  if (B <= 0 || H1 <= 0 || W1 <= 0 || H2 <= 0 || W2 <= 0 || C <= 0) return PFK_ERR_BAD_ARG;
+  if (radius < 1 || radius > 4) return PFK_ERR_UNSUPPORTED;
+  if ((C & 3) || !pfk_aligned16(fmap1) || !pfk_aligned16(fmap2)) return PFK_ERR_ALIGNMENT;
+  if (C > 64 * MAX_C4) return PFK_ERR_UNSUPPORTED;
+  const long long M = (long long)B * H1 * W1;
+  const long long blocks = (M + 3) / 4;
+  if (blocks > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  // Window-sharing MFMA kernel on 8 x 4 patches once the patch grid fills the chip (a block lives ~30 us), the per-pixel kernel below that and for maps whose byte offsets do not fit the 32-bit buffer addressing of the staging
+  // loads.  MI355X, C = 256, r = 4 (scripts/lookup_bench.py, gpurun_out/r3_altcorr.log): 55x128 batch 8 with a smooth flow field
+  // 270 -> 129 us (2.1x; 22 TFLOP/s of useful window work), 110x256 (1/4 resolution) 141 -> 73 us; a field with +-4 px of
+  // low-frequency variation per 8 px 271 -> 186 us; iid noise of sigma 6 px on every pixel (no two windows share anything: every box
+  // overflows and the patch is handed to altcorr_fwd_overflow_kernel) 333 -> 400 us (the overflow kernel alone, in the per-pixel
+  // kernel's row-major block order, 333; the rest is the border patches' GEMMs in front of it).  8 x 8 patches never beat 8 x 4.
+  const int tx = (W1 + 7) / 8;
+  const long long t8 = (long long)B * ((H1 + 7) / 8) * tx, t4 = (long long)B * ((H1 + 3) / 4) * tx;
+  const bool fits32 = (long long)B * H1 * W1 * C * (long long)sizeof(T) < 0x7fffffffLL && (long long)B * H2 * W2 * C * (long long)sizeof(T) < 0x7fffffffLL;
+  const int mode = g_altcorr_mode;
+  if (fits32 && mode != 1 && (mode >= 2 || t4 >= 256)) {
+    const bool big = mode == 3;
+    const int gxn = (W1 + 3) / 4;
+    const long long ogrid = (long long)B * H1 * gxn;
+    if (ogrid > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
+    // launch-wide gate (8 x 4 patches, when the caller lent a workspace): per-block counts of the patches that take the GEMM
+    int* counts = (!big && mode == 0) ? static_cast<int*>(workspace) : nullptr;
+    const int nplan = (int)((t4 + PLAN_PATCHES - 1) / PLAN_PATCHES);
+    if (counts)
+      hipLaunchKernelGGL((altcorr_plan_kernel<4>), dim3((unsigned)nplan), dim3(256), 0, st, coords, counts, B, H1, W1, H2, W2, radius, tx,
+                         (H1 + 3) / 4);
+    if (big) {
+      constexpr size_t smem = 2 * (64 + WS_NP_MAX) * WS_ROWB;
+      static pfk_device_once once;
+      once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(altcorr_fwd_ws_kernel<8, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); });
+      hipLaunchKernelGGL((altcorr_fwd_ws_kernel<8, T>), dim3((unsigned)t8), dim3(256), smem, st, fmap1, fmap2, coords, out, B, H1, W1, H2, W2, C,
+                         radius, tx, (H1 + 7) / 8, (const int*)nullptr, 0);
+      hipLaunchKernelGGL((altcorr_fwd_overflow_kernel<8, T>), dim3((unsigned)ogrid), dim3(256), 0, st, fmap1, fmap2, coords, out, H1, W1, H2, W2,
+                         C, radius, gxn, 0, (const int*)nullptr, 0, t8);
+    } else {
+      constexpr size_t smem = 2 * (32 + WS_NP_MAX) * WS_ROWB;
+      static pfk_device_once once;
+      once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(altcorr_fwd_ws_kernel<4, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); });
+      if (mode != 4)
+        hipLaunchKernelGGL((altcorr_fwd_ws_kernel<4, T>), dim3((unsigned)t4), dim3(256), smem, st, fmap1, fmap2, coords, out, B, H1, W1, H2, W2,
+                           C, radius, tx, (H1 + 3) / 4, (const int*)counts, nplan);
+      hipLaunchKernelGGL((altcorr_fwd_overflow_kernel<4, T>), dim3((unsigned)ogrid), dim3(256), 0, st, fmap1, fmap2, coords, out, H1, W1, H2, W2,
+                         C, radius, gxn, mode == 4, (const int*)counts, nplan, t4);
+    }
+    return pfk_launch_status();
+  }
+  hipLaunchKernelGGL((altcorr_fwd_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st, fmap1,
+                     fmap2, coords, out, M, H1, W1, H2, W2, C, radius);
+  return pfk_launch_status();
+}
+}  // namespace
+
 extern "C" {
 
 int pfk_debug_set_altcorr(int mode) { if (!pfk_debug_knobs_enabled()) return PFK_ERR_DISABLED; g_altcorr_mode = mode; return PFK_OK; }
@@ -509,55 +653,21 @@ int pfk_altcorr_backward_f32(const float* fmap1, const float* fmap2, const float
 }
 
 
+long long pfk_altcorr_workspace_bytes(int B, int H1, int W1) {
+  if (B <= 0 || H1 <= 0 || W1 <= 0) return 0;
+  const long long t4 = (long long)B * ((H1 + 3) / 4) * ((W1 + 7) / 8);
+  return ((t4 + PLAN_PATCHES - 1) / PLAN_PATCHES) * (long long)sizeof(int);
+}
+
 int pfk_altcorr_forward_f32(const float* fmap1, const float* fmap2, const float* coords, float* out, int B, int H1,
-                            int W1, int H2, int W2, int C, int radius, pfk_stream_t stream) {
-  if (!fmap1 || !fmap2 || !coords || !out) return PFK_ERR_BAD_ARG;
-  if (B <= 0 || H1 <= 0 || W1 <= 0 || H2 <= 0 || W2 <= 0 || C <= 0) return PFK_ERR_BAD_ARG;
-  if (radius < 1 || radius > 4) return PFK_ERR_UNSUPPORTED;
-  if ((C & 3) || !pfk_aligned16(fmap1) || !pfk_aligned16(fmap2)) return PFK_ERR_ALIGNMENT;
-  if (C > 64 * MAX_C4) return PFK_ERR_UNSUPPORTED;
-  const long long M = (long long)B * H1 * W1;
-  const long long blocks = (M + 3) / 4;
-  if (blocks > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  // Window-sharing MFMA kernel on 8 x 4 patches once the patch grid fills the chip (a block lives ~30 us), the per-pixel kernel below that and for maps whose byte offsets do not fit the 32-bit buffer addressing of the staging
-  // loads.  MI355X, C = 256, r = 4 (scripts/lookup_bench.py, gpurun_out/r3_altcorr.log): 55x128 batch 8 with a smooth flow field
-  // 270 -> 129 us (2.1x; 22 TFLOP/s of useful window work), 110x256 (1/4 resolution) 141 -> 73 us; a field with +-4 px of
-  // low-frequency variation per 8 px 271 -> 186 us; iid noise of sigma 6 px on every pixel (no two windows share anything: every box
-  // overflows and the patch is handed to altcorr_fwd_overflow_kernel) 333 -> 400 us (the overflow kernel alone, in the per-pixel
-  // kernel's row-major block order, 333; the rest is the border patches' GEMMs in front of it).  8 x 8 patches never beat 8 x 4.
-  const int tx = (W1 + 7) / 8;
-  const long long t8 = (long long)B * ((H1 + 7) / 8) * tx, t4 = (long long)B * ((H1 + 3) / 4) * tx;
-  const bool fits32 = (long long)B * H1 * W1 * C * 4 < 0x7fffffffLL && (long long)B * H2 * W2 * C * 4 < 0x7fffffffLL ;
-  const int mode = g_altcorr_mode;
-  if (fits32 && mode != 1 && (mode >= 2 || t4 >= 256)) {
-    const bool big = mode == 3;
-    const int gxn = (W1 + 3) / 4;
-    const long long ogrid = (long long)B * H1 * gxn;
-    if (ogrid > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
-    if (big) {
-      constexpr size_t smem = 2 * (64 + WS_NP_MAX) * WS_ROWB;
-      static pfk_device_once once;
-      once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(altcorr_fwd_ws_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); });
-      hipLaunchKernelGGL(altcorr_fwd_ws_kernel<8>, dim3((unsigned)t8), dim3(256), smem, st, fmap1, fmap2, coords, out, B, H1, W1, H2, W2, C,
-                         radius, tx, (H1 + 7) / 8);
-      hipLaunchKernelGGL(altcorr_fwd_overflow_kernel<8>, dim3((unsigned)ogrid), dim3(256), 0, st, fmap1, fmap2, coords, out, H1, W1, H2, W2,
-                         C, radius, gxn, 0);
-    } else {
-      constexpr size_t smem = 2 * (32 + WS_NP_MAX) * WS_ROWB;
-      static pfk_device_once once;
-      once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(altcorr_fwd_ws_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); });
-      if (mode != 4)
-        hipLaunchKernelGGL(altcorr_fwd_ws_kernel<4>, dim3((unsigned)t4), dim3(256), smem, st, fmap1, fmap2, coords, out, B, H1, W1, H2, W2,
-                           C, radius, tx, (H1 + 3) / 4);
-      hipLaunchKernelGGL(altcorr_fwd_overflow_kernel<4>, dim3((unsigned)ogrid), dim3(256), 0, st, fmap1, fmap2, coords, out, H1, W1, H2, W2,
-                         C, radius, gxn, mode == 4);
-    }
-    return pfk_launch_status();
-  }
-  hipLaunchKernelGGL(altcorr_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, fmap1,
-                     fmap2, coords, out, M, H1, W1, H2, W2, C, radius);
-  return pfk_launch_status();
+                            int W1, int H2, int W2, int C, int radius, void* workspace, pfk_stream_t stream) {
+  return altcorr_forward_launch<float>(fmap1, fmap2, coords, out, B, H1, W1, H2, W2, C, radius, workspace, stream);
+}
+
+int pfk_altcorr_forward_bf16(const void* fmap1_bf16, const void* fmap2_bf16, const float* coords, float* out, int B, int H1,
+                             int W1, int H2, int W2, int C, int radius, void* workspace, pfk_stream_t stream) {
+  return altcorr_forward_launch<bf16_t>(static_cast<const bf16_t*>(fmap1_bf16), static_cast<const bf16_t*>(fmap2_bf16), coords, out,
+                                        B, H1, W1, H2, W2, C, radius, workspace, stream);
 }
 
 }  // extern "C"

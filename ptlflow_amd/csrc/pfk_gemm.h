@@ -45,10 +45,6 @@ struct GemmArgs {
   int pp_whole;            // 1: blocks get whole tiles only (no partial-tile hand-off, no workspace)
   const void* wbf;         // split-bf16 path: weight planes [nsplit][cout][ktot] bf16, same k order as `weight`
   long long wbf_plane_bytes;
-  int stagger;             // > 0: phase stagger of the initially resident blocks (conv_gemm_v3_kernel): dispatch round r = blockIdx.x / 256
-                           // of the first `stagger_rounds` rounds sleeps r * stagger * 8128 cycles before its first tile
-  int stagger_rounds;
-  int prio_mode;           // 1: s_setprio(1) for waves in odd hardware wave slots (static, whole kernel)
   int m_tile_base;         // split-bf16 path: a launch may cover a range of row tiles only (launch_bf's tail split); first row tile, in units of BM
 };
 

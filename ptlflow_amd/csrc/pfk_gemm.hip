@@ -481,20 +481,6 @@ __global__ __launch_bounds__(256 * GROUPS) void conv_gemm_v3_kernel(const GemmAr
   const int n0 = tile_n * BN;
   const long long batch = blockIdx.y;
 
-  // Phase stagger (experiment, round 4): equal tiles keep the co-resident blocks of a CU in lockstep — they reach their
-  // prologues / epilogues together and the matrix pipe idles through both.  Delaying the k-th initially resident block of a CU by
-  // k / BPC of a tile time once, at the start, keeps them out of phase for the whole launch (every later block inherits the
-  // phase of the one it replaces).
-  if (a.stagger > 0) {
-    const int round = (int)(blockIdx.x >> 8);
-    if (round > 0 && round < a.stagger_rounds)
-      for (int i = 0; i < round * a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-  }
-  if (a.prio_mode == 1) {
-    const unsigned hwid = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);   // HW_REG_HW_ID[3:0] = wave slot on the SIMD
-    if (hwid & 1) __builtin_amdgcn_s_setprio(1);
-  }
-
   Stager<BM, BN, LD> st(a, m0, n0, gtid, batch);
   const int S = st.total_steps();
   const int my_steps = (S - grp + GROUPS - 1) / GROUPS;
@@ -1002,7 +988,6 @@ int launch_pp(const GemmArgs& a, int epi, int batches, hipStream_t st, int varia
 }
 
 // variant bits: 1 = swizzled 48 KB LDS layout, 2 = per-XCD tile groups, blocks per CU = 1 + (variant >> 2)  (1..3)
-int g_stagger = 0, g_prio_mode = 0;   // experiment knobs: pfk_debug_set_tile(400 + s) / (500 + p)
 int g_sk_variant = 6;     // padded layout, two blocks per CU, per-XCD groups: the best of the sweep (scripts/conv_bench.py cfg 30 + v at
                           // batch 1: z|r conv 69.8 us with one group -> 63.7 us with XCD groups; swizzled / three per CU: 65.6 / 70.3)
 
@@ -1062,10 +1047,7 @@ int launch_one(const GemmArgs& g, dim3 grid, hipStream_t st) {
     attr_once.run([&] {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     });
-    GemmArgs gs = g;
-    gs.stagger_rounds = (int)((160 * 1024) / smem);     // resident blocks per CU by LDS (the binding limit of these kernels)
-    if (gs.stagger_rounds > 8 / G) gs.stagger_rounds = 8 / G;
-    hipLaunchKernelGGL(kern, grid, dim3(256 * G), smem, st, gs);
+    hipLaunchKernelGGL(kern, grid, dim3(256 * G), smem, st, g);
   }
   return pfk_launch_status();
 }
@@ -1097,7 +1079,6 @@ int g_small_swizzled = 0;   // tuning knob (pfk_debug_set_tile(301)): small grid
 int launch(const GemmArgs& a0, int epi, int batches, hipStream_t st) {
   GemmArgs a = a0;
   a.vec_flags = gemm_vec_flags(a);
-  a.stagger = g_stagger; a.prio_mode = g_prio_mode;
   if (a.M >= 0x7fffffffLL || a.Wo <= 0 || a.Ho <= 0) return PFK_ERR_UNSUPPORTED;   // 32-bit pixel arithmetic in the kernels
   fastdiv_make((unsigned)a.Wo, a.wo_mul, a.wo_sh);
   fastdiv_make((unsigned)a.Ho, a.ho_mul, a.ho_sh);
@@ -1241,8 +1222,6 @@ extern "C" {
 int pfk_debug_set_tile(int cfg) {
   if (!pfk_debug_knobs_enabled()) return PFK_ERR_DISABLED;
   if (cfg >= 300) { g_small_swizzled = cfg - 300; return PFK_OK; }      // 301: small grids on the swizzled layout, 300: off
-  if (cfg >= 500) { g_prio_mode = cfg - 500; return PFK_OK; }
-  if (cfg >= 400) { g_stagger = cfg - 400; return PFK_OK; }
   if (cfg >= 200) { g_sk_variant = cfg - 200; return PFK_OK; }          // 200 + v: stream-K schedule variant (launch_sk)
   if (cfg >= 100) g_bf_cfg = cfg - 100;   // split-bf16 tile configuration (0 = heuristic)
   else { g_force_tile = cfg; if (cfg < 0) g_bf_cfg = 0; }

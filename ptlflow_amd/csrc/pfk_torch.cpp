@@ -262,19 +262,33 @@ void convex_upsample_pm(const Tensor& flow_pm, const Tensor& mask, Tensor out) {
 // alt_cuda_corr.forward semantics (correlation.cpp:23-37): returns [B, N, (2r+1)^2, H1, W1], unscaled
 Tensor altcorr_forward(const Tensor& fmap1, const Tensor& fmap2, const Tensor& coords, int64_t radius) {
   OpScope scope(fmap1);
-  check_dev_f32(fmap1, "fmap1"); check_dev_f32(fmap2, "fmap2"); check_dev_f32(coords, "coords");
+  // fp32 maps (the reference extension's only type, correlation_kernel.cu:275) or bf16 maps (pfk_altcorr_forward_bf16: exact widening,
+  // fp32 products and accumulation; the result is fp32 either way — coords stay fp32)
+  const bool bf = fmap1.scalar_type() == at::kBFloat16;
+  if (bf) {
+    TORCH_CHECK(fmap1.is_cuda() && fmap2.is_cuda() && fmap2.scalar_type() == at::kBFloat16, "altcorr_forward: both feature maps bf16 on the GPU");
+  } else {
+    check_dev_f32(fmap1, "fmap1"); check_dev_f32(fmap2, "fmap2");
+  }
+  check_dev_f32(coords, "coords");
   TORCH_CHECK(fmap1.dim() == 4 && fmap2.dim() == 4 && coords.dim() == 5 && coords.size(4) == 2, "altcorr_forward: fmap [B,H,W,C], coords [B,N,H1,W1,2]");
   TORCH_CHECK(fmap1.is_contiguous() && fmap2.is_contiguous() && coords.is_contiguous(), "altcorr_forward: contiguous inputs");  // CHECK_CONTIGUOUS in the reference
   const int B = fmap1.size(0), H1 = fmap1.size(1), W1 = fmap1.size(2), C = fmap1.size(3);
   const int H2 = fmap2.size(1), W2 = fmap2.size(2), N = coords.size(1);
   TORCH_CHECK(fmap2.size(0) == B && fmap2.size(3) == C && coords.size(0) == B && coords.size(2) == H1 && coords.size(3) == W1);
   const int rd = 2 * radius + 1;
-  Tensor out = at::empty({B, N, rd * rd, H1, W1}, fmap1.options());
+  Tensor out = at::empty({B, N, rd * rd, H1, W1}, coords.options());
+  // the launch-wide gate's per-block counts (pfk.h): a few hundred bytes from the caching allocator, written before they are read
+  Tensor ws = at::empty({std::max<int64_t>(1, pfk_altcorr_workspace_bytes(B, H1, W1) / 4)}, coords.options().dtype(at::kInt));
   for (int n = 0; n < N; ++n) {
     Tensor cn = coords.select(1, n).contiguous();
-    Tensor on = N == 1 ? out.view({B, rd * rd, H1, W1}) : at::empty({B, rd * rd, H1, W1}, fmap1.options());
-    check_ok(pfk_altcorr_forward_f32(fptr(fmap1), fptr(fmap2), fptr(cn), fptr(on), B, H1, W1, H2, W2, C, radius, cur_stream()),
-             "altcorr_forward");
+    Tensor on = N == 1 ? out.view({B, rd * rd, H1, W1}) : at::empty({B, rd * rd, H1, W1}, coords.options());
+    if (bf)
+      check_ok(pfk_altcorr_forward_bf16(fmap1.data_ptr(), fmap2.data_ptr(), fptr(cn), fptr(on), B, H1, W1, H2, W2, C, radius, ws.data_ptr(), cur_stream()),
+               "altcorr_forward (bf16 maps)");
+    else
+      check_ok(pfk_altcorr_forward_f32(fptr(fmap1), fptr(fmap2), fptr(cn), fptr(on), B, H1, W1, H2, W2, C, radius, ws.data_ptr(), cur_stream()),
+               "altcorr_forward");
     if (N != 1) out.select(1, n).copy_(on);
   }
   return out;

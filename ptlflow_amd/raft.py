@@ -337,7 +337,8 @@ class RAFT(nn.Module):
             st = None      # a new engine, or its buffers were re-bound for another shape in between: the recorded addresses are stale
         if st is None:
             if self.alternate_corr:
-                corr_fn = AlternateCorrBlock(fm[:B], fm[B:], num_levels=self.corr_levels, radius=self.corr_radius)
+                corr_fn = AlternateCorrBlock(fm[:B], fm[B:], num_levels=self.corr_levels, radius=self.corr_radius,
+                                             map_dtype=torch.bfloat16 if self.conv_precision == "bf16" else None)
             else:   # conv_precision "bf16" = BASELINE config 3's precision: bf16 operands everywhere autocast would put them
                 vt = torch.bfloat16 if self.conv_precision == "bf16" else torch.float32
                 corr_fn = CorrBlock(fm[:B], fm[B:], num_levels=self.corr_levels, radius=self.corr_radius, volume_dtype=vt)

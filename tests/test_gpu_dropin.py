@@ -357,3 +357,56 @@ def test_alt_cuda_corr_backward_multi_set_and_half_inputs(gpu):
     ref16 = torch.cat([O.alt_corr_forward(f1.detach().half().float(), f2.detach().half().float(), coords.half().float()[:, n:n + 1], r)
                        for n in range(N)], 1)
     assert (h.float().cpu() - ref16).abs().max().item() < 2e-2 * max(1.0, ref16.abs().max().item())
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3])
+def test_altcorr_forward_bf16_kernels(gpu, mode):
+    """`pfk_altcorr_forward_bf16` (SURVEY §8 f1 "fp32 + bf16"): bf16 feature maps widened exactly, fp32 products and
+    accumulation — each forward kernel forced, against the oracle's fp32 restatement run on the SAME bf16-rounded values
+    (so the only difference left is summation order), with NaN / far-away coordinates and a coarser fmap2."""
+    for (B, H1, W1, H2, W2, C, r, sigma) in [(2, 27, 45, 27, 45, 256, 4, 0.6), (1, 16, 24, 16, 24, 256, 4, 3.0),
+                                             (2, 22, 13, 11, 6, 128, 3, 0.8), (1, 9, 10, 9, 10, 36, 4, 0.5)]:
+        g = torch.Generator().manual_seed(131 + mode)
+        f1 = torch.randn(B, H1, W1, C, generator=g).bfloat16()
+        f2 = torch.randn(B, H2, W2, C, generator=g).bfloat16()
+        base = torch.stack(torch.meshgrid(torch.arange(H1, dtype=torch.float32), torch.arange(W1, dtype=torch.float32),
+                                          indexing="ij")[::-1], -1)[None, None].repeat(B, 1, 1, 1, 1)
+        smooth = torch.nn.functional.interpolate(torch.randn(B, 2, 4, 5, generator=g) * 4, size=(H1, W1), mode="bicubic", align_corners=True)
+        coords = (base + smooth.permute(0, 2, 3, 1)[:, None]) * (W2 / W1) + torch.randn(B, 1, H1, W1, 2, generator=g) * sigma
+        coords[0, 0, 0, 0, 0] = float("nan")
+        coords[0, 0, 0, 1, 1] = 1e12
+        ref = O.alt_corr_forward(f1.float(), f2.float(), coords, r)
+        torch.ops.pfk.debug_set_altcorr(mode)
+        try:
+            got = torch.ops.pfk.altcorr_forward(f1.cuda(), f2.cuda(), coords.cuda(), r).cpu()
+        finally:
+            torch.ops.pfk.debug_set_altcorr(0)
+        assert got.dtype == torch.float32 and got.shape == ref.shape
+        assert bool((torch.isnan(got) == torch.isnan(ref)).all())
+        err = torch.where(torch.isnan(ref), torch.zeros_like(ref), (got - ref).abs())
+        assert err.max().item() < 2e-4 * max(1.0, ref.nan_to_num().abs().max().item()), (mode, C, err.max().item())
+
+
+def test_alternate_corr_block_bf16_vs_reference_autocast(gpu):
+    """`AlternateCorrBlock` on bf16 feature maps (what autocast callers and `RAFT(conv_precision="bf16", alternate_corr=True)`
+    hand it) against the REFERENCE's `IterativeCorrBlock` under `torch.autocast("cpu", bfloat16)` on the same maps
+    (tests/golden/alt_corr_bf16.pt, oracle/make_golden.py::golden_alt_corr_bf16) and against the reference's fp32 output:
+    the kernel multiplies the bf16 values exactly, so it must sit INSIDE the reference's own bf16 gap on both counts."""
+    import os
+    from ptlflow_amd.corr import AlternateCorrBlock, get_corr_block
+    gd = os.path.join(os.path.dirname(__file__), "golden")
+    gold, gbf = torch.load(os.path.join(gd, "alt_corr.pt")), torch.load(os.path.join(gd, "alt_corr_bf16.pt"))
+    blk = get_corr_block(fmap1=gold["fmap1"].cuda().bfloat16(), fmap2=gold["fmap2"].cuda().bfloat16(), num_levels=gold["levels"],
+                         radius=gold["radius"], alternate_corr=True)
+    assert isinstance(blk, AlternateCorrBlock) and blk.map_dtype == torch.bfloat16
+    out = blk(gold["coords"].cuda())
+    assert out.dtype == torch.bfloat16                       # the caller's dtype, like the reference's half path (raft/corr.py:96)
+    got = blk.lookup_pm(gold["coords"].cuda())               # fp32 values before that last rounding
+    B, C, H, W = out.shape
+    got = got.view(B, H, W, C).permute(0, 3, 1, 2).cpu()[:, :, ::gold["row_step"]]
+    gap = gbf["autocast_gap_max"]
+    e32 = (got - gold["out_rows"]).abs().max().item()
+    eac = (got - gbf["out_rows_autocast"]).abs().max().item()
+    print(f"bf16 on-demand correlation: max |err| vs the reference's fp32 output {e32:.3e}, vs its autocast output {eac:.3e} "
+          f"(the reference's own autocast-vs-fp32 gap: {gap:.3e})")
+    assert e32 <= gap and eac <= 2.0 * gap
