@@ -276,7 +276,7 @@ int pfk_convex_upsample_pm_f32(const float* flow_pm, int flow_ld, const float* m
  * out [B][(2r+1)^2][H1][W1], cell = oy + (2r+1)*ox, UNSCALED (the caller divides by sqrt(C)).
  * `workspace`: pfk_altcorr_workspace_bytes(B, H1, W1) bytes of device memory (4-byte aligned, no initialisation needed), or NULL.
  * With it the launch counts the 8x4-pixel patches whose windows share a bounding box small enough for the window-sharing MFMA
- * kernel and runs that kernel only when at least a quarter of them qualify; otherwise (noise-like coordinate fields) every pixel
+ * kernel and runs that kernel only when at least 5/8 of them qualify; otherwise (noise-like coordinate fields) every pixel
  * takes the per-pixel kernel.  NULL: the decision is per patch only. */
 long long pfk_altcorr_workspace_bytes(int B, int H1, int W1);
 int pfk_altcorr_forward_f32(const float* fmap1, const float* fmap2, const float* coords, float* out,

@@ -209,10 +209,13 @@ __device__ __forceinline__ bool patch_takes_gemm(const int (&box)[4]) { return (
 // ---- launch-wide gate (round 4) --------------------------------------------------------------------------------------------------
 // The window-sharing GEMM pays when MANY patches take it.  When almost every box overflows (iid-noise coordinate fields), the few
 // border patches that still fit ran their ~30 us GEMM blocks on an otherwise idle chip in FRONT of the per-pixel pass: 400 us
-// against the per-pixel kernel's 333 (0.83x).  altcorr_plan_kernel counts the patches that would take the GEMM (64 patches per
-// block, two per wave-iteration, per-block counts: no atomics, no zero-fill, deterministic); both passes read the counts and, when
-// fewer than a quarter of the patches qualify, the GEMM pass leaves and the per-pixel pass takes EVERY patch.
-constexpr int PLAN_PATCHES = 64;      // patches per plan block
+// against the per-pixel kernel's 333 (0.83x).  altcorr_plan_kernel counts the patches that would take the GEMM (8 patches per
+// block — two per wave, one coordinate load deep — per-block counts: no atomics, no zero-fill, deterministic); both passes read
+// the counts and, when fewer than 5/8 of the patches qualify, the GEMM pass leaves and the per-pixel pass takes EVERY patch.
+// Measured (MI355X, 55x128, batch 8, C = 256, r = 4; gpurun_out/r4c_lookup.log, r4d): every patch qualifies 129 us vs 272
+// per-pixel; ~3/4 qualify (smooth field of +-4 px per 8 px) 186 vs 276; half qualify 346 vs 313 — the two passes run one after
+// the other and each leaves the chip half empty — so the gate sits between: 5/8.
+constexpr int PLAN_PATCHES = 8;       // patches per plan block
 template <int TPY>
 __global__ __launch_bounds__(256) void altcorr_plan_kernel(const float* __restrict__ coords, int* __restrict__ counts, int B, int H1,
                                                            int W1, int H2, int W2, int r, int tiles_x, int tiles_y) {
@@ -222,9 +225,8 @@ __global__ __launch_bounds__(256) void altcorr_plan_kernel(const float* __restri
   const int n = 2 * r + 2;
   const long long npatch = (long long)B * tiles_x * tiles_y;
   int mine = 0;
-#pragma unroll
-  for (int it = 0; it < PLAN_PATCHES / 8; ++it) {
-    const long long tile = (long long)blockIdx.x * PLAN_PATCHES + (it * 4 + wid) * 2 + half;
+  {
+    const long long tile = (long long)blockIdx.x * PLAN_PATCHES + wid * 2 + half;
     const bool tl = tile < npatch;
     const int txi = (int)(tile % tiles_x), tyi = (int)((tile / tiles_x) % tiles_y);
     const long long b = tile / ((long long)tiles_x * tiles_y);
@@ -262,7 +264,7 @@ __device__ __forceinline__ bool gemm_pass_enabled(const int* __restrict__ counts
   for (int i = lane; i < nplan; i += 64) s += counts[i];
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
-  return 4LL * s >= npatch;
+  return 8LL * s >= 5LL * npatch;
 }
 
 // The patches the window-sharing kernel skipped: the per-pixel algorithm, one pixel per wave, blocks in the per-pixel kernel's own

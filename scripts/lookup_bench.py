@@ -45,7 +45,10 @@ for B in (1, 8):
         grid = torch.stack([xs2, ys2], 0)[None]
         for amp in (1.5, 4.0):
           smooth = torch.nn.functional.interpolate(torch.randn(B, 2, hh2 // 8 + 2, ww2 // 8 + 2, device=dev) * amp, size=(hh2, ww2), mode="bicubic", align_corners=True)
-          fields = {f"smooth{amp}": grid + smooth} if amp < 2 else {f"smooth{amp}": grid + smooth, "iid-6px": grid + torch.randn(B, 2, hh2, ww2, device=dev) * 6}
+          noise = torch.randn(B, 2, hh2, ww2, device=dev) * 6
+          half = (torch.rand(B, 1, hh2 // 8 + 1, ww2 // 8 + 1, device=dev) < 0.5).float().repeat_interleave(8, 2).repeat_interleave(8, 3)[:, :, :hh2, :ww2]
+          fields = {f"smooth{amp}": grid + smooth} if amp < 2 else {f"smooth{amp}": grid + smooth, "iid-6px": grid + noise,
+                                                                     "half-iid": grid + smooth + noise * half}
           for fname, cc in fields.items():
               c5 = cc.permute(0, 2, 3, 1).reshape(B, 1, hh2, ww2, 2).contiguous()
               base = None
@@ -64,5 +67,20 @@ for B in (1, 8):
                       base = o.clone()
                   err = float((o - base).abs().max() / base.abs().max())
                   line += f" mode {mode}: {us:7.1f} us ({B*Nn*100*256*2/us/1e6:5.1f} TF useful, diff {err:.1e}) |"
+              ops.debug_set_altcorr(0)
+              print(line)
+              # bf16 feature maps (pfk_altcorr_forward_bf16): per-pixel kernel and the library's choice
+              f1b, f2b = f1.bfloat16(), f2.bfloat16()
+              line = f"altcorr {hh2}x{ww2} B={B} {fname:8s} bf16 maps:"
+              for mode in (1, 0):
+                  ops.debug_set_altcorr(mode)
+                  for _ in range(3):
+                      o = ops.altcorr_forward(f1b, f2b, c5, r)
+                  e0.record()
+                  for _ in range(20):
+                      o = ops.altcorr_forward(f1b, f2b, c5, r)
+                  e1.record(); torch.cuda.synchronize()
+                  us = 1e3 * e0.elapsed_time(e1) / 20
+                  line += f" mode {mode}: {us:7.1f} us |"
               ops.debug_set_altcorr(0)
               print(line)
