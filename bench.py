@@ -639,6 +639,25 @@ def main():
             result["skip_dead_upsample"] = {"value": args.batch * 1e3 / ms, "unit": "frame-pairs/s", "ms_per_step": ms,
                                             "identical_output": bool(torch.equal(o3["flows"], out["flows"]))}
             del m3, o3
+        if world == 1 and args.conv_precision == "fp32" and not args.no_split_modes and args.model == "raft":
+            # A/B of the loop-invariant hoist (ptlflow_amd/update.py, UpdateEngine): the same forward with the GRU convolutions in
+            # the reference's single-chain form — conv over cat([h, inp, motion]) every iteration — beside `value`, which computes
+            # the context features' part of them once per forward
+            m4 = RAFT(small=small, iters=args.iters, upsample_every_iter=not args.skip_dead_upsample, hoist_context=False).eval()
+            m4.load_state_dict(cpu_state)
+            m4 = m4.to(dev)
+            sec = timed(lambda: m4(inputs), 2, 5)
+            o4 = m4(inputs)
+            d = (o4["flows"][:1, 0].float() - out["flows"][:1, 0].float()).pow(2).sum(1).sqrt()
+            result["single_chain_gru"] = {"value": args.batch / sec, "unit": "frame-pairs/s", "ms_per_step": 1e3 * sec,
+                                          "epe_vs_value_mean": float(d.mean()), "epe_vs_value_max": float(d.max()),
+                                          "what": "hoist_context=False: every GRU convolution over all of cat([h, inp, motion]) in every "
+                                                  "iteration, as round 3 ran it"}
+            if ref is not None:
+                mean, mx = _epe(o4["flows"][:1, 0], ref["flows"][:, 0])
+                result["single_chain_gru"]["epe_vs_cpu"] = {"mean": mean, "max": mx}
+            del m4, o4
+            torch.cuda.empty_cache()
         default_cfg = args.model == "raft" and (args.height, args.width, args.iters) == (436, 1024, 32) and args.conv_precision == "fp32"
         if world == 1 and default_cfg and not args.no_extra_legs:
             del out

@@ -174,9 +174,9 @@ int pfk_convex_upsample_bwd_f32(const float* flow, int flow_ld, const float* mas
 enum pfk_epilogue {
   PFK_EPI_LINEAR = 0,  /* v = (acc+bias) ; relu? ; v *= scale ; [v = residual[p*residual_ld+co] + v] ;
                           out[p*out_ld + out_coff + co] = v */
-  PFK_EPI_GRU_ZR = 1,  /* cout = 2*Ch: co<Ch: z=sigmoid -> aux_z[p*Ch+co];
-                          co>=Ch: r=sigmoid -> aux_rh[p*Ch + co-Ch] = r * h[p*h_ld + co-Ch] */
-  PFK_EPI_GRU_Q = 2    /* cout = Ch: q=tanh; h[p*h_ld+co] = (1-z)*h + z*q, z = aux_z[p*Ch+co] */
+  PFK_EPI_GRU_ZR = 1,  /* cout = 2*Ch: v = acc + bias [+ residual[p*residual_ld+co]]; co<Ch: z=sigmoid(v) -> aux_z[p*Ch+co];
+                          co>=Ch: r=sigmoid(v) -> aux_rh[p*Ch + co-Ch] = r * h[p*h_ld + co-Ch] */
+  PFK_EPI_GRU_Q = 2    /* cout = Ch: q=tanh(acc + bias [+ residual]); h[p*h_ld+co] = (1-z)*h + z*q, z = aux_z[p*Ch+co] */
 };
 
 typedef struct {
@@ -202,7 +202,12 @@ typedef struct {
   int h_ld;
   float* aux_z;          /* [M][Ch] */
   float* aux_rh;         /* [M][Ch] */
-  const float* residual; /* LINEAR only, optional: added after relu/scale (GMA's `fmap + gamma*out`, gma_utils.py:111) */
+  const float* residual; /* optional [M][cout] rows.  LINEAR: added after relu/scale (GMA's `fmap + gamma*out`, gma_utils.py:111).
+                            GRU_ZR / GRU_Q (ABI 5): added to the gate PRE-activation — the loop-invariant part of a gate's
+                            convolution: in raft/update.py:60-71 the GRU input is cat([h, inp, motion]) and `inp` (the context
+                            features, raft.py:158-160) does not change over the iterations, so conv(W[:, inp slice], inp) + bias is
+                            computed once per forward and handed in here while the per-iteration convolution covers the h and
+                            motion channels only (16-byte aligned, residual_ld % 4 == 0) */
   int residual_ld;
   int stride;            /* 0 or 1: "same" convolution; s > 1: output (yo, xo) reads input (yo*s + ky - kh/2, xo*s + kx - kw/2),
                             Ho = (H-1)/s + 1, Wo = (W-1)/s + 1 (= PyTorch's Conv2d(k, stride=s, padding=k/2)); H, W are the

@@ -126,6 +126,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& a, const f32x16 (&acc)[
           else outp[p * a.out_ld + a.out_coff + n] = v;
         } else if constexpr (EPI == PFK_EPI_GRU_ZR) {
           const int ch = a.ch_hidden;
+          if (a.residual != nullptr) v += a.residual[p * a.residual_ld + n];   // loop-invariant part of the pre-activation (pfk.h)
           const float g = sigmoid_f(v);
           if (n < ch) {
             a.aux_z[p * ch + n] = g;
@@ -135,6 +136,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& a, const f32x16 (&acc)[
           }
         } else {  // PFK_EPI_GRU_Q
           const int ch = a.ch_hidden;
+          if (a.residual != nullptr) v += a.residual[p * a.residual_ld + n];
           const float q = tanhf(v);
           const float z = a.aux_z[p * ch + n];
           const float hv = a.h[p * a.h_ld + n];
@@ -244,6 +246,9 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs& a, const f32x16 (&a
         } else if constexpr (EPI == PFK_EPI_GRU_ZR) {     // cout = 2 * ch, ch % 4 == 0: a float4 never straddles z | r
           if (n >= a.b_rows) continue;
           const int ch = a.ch_hidden;
+          // the loop-invariant part of the gate pre-activations (context features x their weight slice + bias, computed once per
+          // forward — pfk.h, `residual` on the GRU epilogues): [M][cout] rows, 16-byte aligned (desc_to_args checks)
+          if (a.residual != nullptr) v += *reinterpret_cast<const f32x4*>(a.residual + p * a.residual_ld + n);
           f32x4 g;
 #pragma unroll
           for (int e = 0; e < 4; ++e) g[e] = sigmoid_f(v[e]);
@@ -257,6 +262,7 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs& a, const f32x16 (&a
         } else {  // PFK_EPI_GRU_Q
           if (n >= a.b_rows) continue;
           const int ch = a.ch_hidden;
+          if (a.residual != nullptr) v += *reinterpret_cast<const f32x4*>(a.residual + p * a.residual_ld + n);
           const f32x4 z = *reinterpret_cast<const f32x4*>(a.aux_z + p * ch + n);
           const f32x4 hv = *reinterpret_cast<const f32x4*>(a.h + p * a.h_ld + n);
           f32x4 o;

@@ -1212,6 +1212,12 @@ int desc_to_args(const pfk_conv_desc* d, GemmArgs& a, int kpad) {
     default:
       return PFK_ERR_BAD_ARG;
   }
+  if (d->epilogue != PFK_EPI_LINEAR && d->residual) {
+    // GRU epilogues: an additive pre-activation term [M][cout] (the loop-invariant context part), float4 accesses
+    if (d->residual_ld < d->cout) return PFK_ERR_BAD_ARG;
+    if (!pfk_aligned16(d->residual) || (d->residual_ld & 3)) return PFK_ERR_ALIGNMENT;
+    a.residual = d->residual; a.residual_ld = d->residual_ld;
+  }
   return PFK_OK;
 }
 

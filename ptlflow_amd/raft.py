@@ -123,9 +123,13 @@ class RAFT(nn.Module):
     def __init__(self, corr_levels: int = 4, corr_radius: Optional[int] = None, iters: int = 32, small: bool = False,
                  upsample_every_iter: bool = True, conv_precision: str = "fp32", native_encoders: bool = True,
                  alternate_corr: bool = False, use_graph: bool = False, overlap_mask_head: bool = True,
-                 fork_branches: Optional[bool] = None):
+                 fork_branches: Optional[bool] = None, hoist_context: bool = True):
         super().__init__()
         self.small = small
+        # True (default): the context features' part of the GRU convolutions — loop-invariant, `inp` is the same tensor in every
+        # iteration (raft.py:158-160, update.py:60-71) — is computed once per forward instead of once per iteration
+        # (UpdateEngine's docstring); False: the single-chain launches (A/B, tests)
+        self.hoist_context = hoist_context
         # True: the mask head's second convolution and the convex upsampling of iteration i — off the recurrent critical path:
         # nothing of iteration i+1 reads their results — run on a second HIP stream next to iteration i+1's lookup / motion
         # encoder / GRU, filling the idle CUs of those launches' tails (same kernels, same operands: bit-identical output).
@@ -196,7 +200,7 @@ class RAFT(nn.Module):
         params = dict(self.update_block.named_parameters())
         v = tuple((p.data_ptr(), p._version) for p in params.values())
         if self._engine is None or self._engine.device != device:
-            self._engine = UpdateEngine(params, self.spec, device, self.conv_precision)
+            self._engine = UpdateEngine(params, self.spec, device, self.conv_precision, self.hoist_context)
         elif v != self._versions:
             # re-packing allocates new weight tensors: every captured graph still points at the old (freed) ones
             self._engine.pack(params)

@@ -11,6 +11,8 @@ fixed chain of launches on torch's current stream:
     conv   3x3 (+relu)            MFMA                           -> hx     [M, Ch+Ci : Ch+Ci+co]
     GRU pass(es): z|r conv (+sigmoid, r*h)  MFMA, one GEMM for both gates -> z, rh
                   q conv (+tanh, blend)      MFMA                 -> hx[:, :Ch] (in place)
+                  (the context part of both convolutions — `inp` x its weight slice + bias — is loop-invariant:
+                   computed once per forward by `prepare_context`, added in the gate epilogues)
     flow-head conv1 | mask conv1 3x3 (+relu)  MFMA, one GEMM      -> fm     [M, 2*fh]
     flow-head conv2 3x3 -> delta; coords1 += delta; flow = coords1 - coords0   direct, fused
     mask conv2 1x1, *0.25         MFMA                           -> mask   [M, 576]
@@ -103,9 +105,23 @@ CONV_PRECISIONS = {"fp32": 0, "bf16": 1, "bf16x3": 2, "bf16x6": 3}
 
 
 class UpdateEngine:
+    """``hoist_context`` (default on): the GRU convolutions of raft/update.py:60-71 / :27-30 run over
+    ``cat([h, inp, motion...])``, and ``inp`` — the context features, raft.py:158-160 — is the same tensor in every one of
+    the 12 / 32 iterations.  A convolution is linear in its input channels, so
+
+        conv(W, cat([h, inp, m])) + b  =  conv(W[:, h | m slices], cat([h, m]))  +  ( conv(W[:, inp slice], inp) + b )
+
+    and the second term is loop-invariant: `prepare_context()` computes it ONCE per forward (one launch per gate convolution,
+    a third of one iteration's GRU work) and the per-iteration launches cover the h and motion channels only, adding the
+    stored term to the gate pre-activation in their epilogue (`residual` of PFK_EPI_GRU_ZR / _Q, include/pfk.h).  A third of
+    the SepConvGRU's multiply-adds (128 of 384 input channels; 15.8 % of the update block's) leave the loop.  Same sum, other
+    association: results differ from the single-chain form by fp32 rounding only (the tests' per-convolution and EPE gates
+    are unchanged).  ``hoist_context=False`` keeps the single-chain launches (A/B, tests)."""
+
     def __init__(self, params: Dict[str, torch.Tensor], spec: UpdateSpec, device: torch.device,
-                 conv_precision: str = "fp32"):
+                 conv_precision: str = "fp32", hoist_context: bool = True):
         load_native()
+        self.hoist_context = bool(hoist_context)
         if conv_precision not in CONV_PRECISIONS:
             raise ValueError(f"conv_precision must be one of {sorted(CONV_PRECISIONS)}, got {conv_precision!r}")
         self.conv_precision = conv_precision
@@ -143,8 +159,11 @@ class UpdateEngine:
         self._real_cin = {"c1": s.corr_channels, "c2": s.c1, "f2": s.f1, "cv": (s.c2 if s.c2 else s.c1) + s.f2,
                           "fm": s.hidden, "mk": s.fh_hidden}
         for _, _, sfx in s.gru_passes:
-            self._real_cin["zr" + sfx] = real
-            self._real_cin["q" + sfx] = real
+            # the launches' own multiply-adds: with the context term hoisted they cover the h and motion channels only
+            self._real_cin["zr" + sfx] = real - (s.context if self.hoist_context else 0)
+            self._real_cin["q" + sfx] = real - (s.context if self.hoist_context else 0)
+            self._real_cin["zrc" + sfx] = s.context
+            self._real_cin["qc" + sfx] = s.context
         w["c1.w"] = pk(g("encoder.convc1.weight"), seg1(s.corr_channels))
         w["c1.b"] = g("encoder.convc1.bias").contiguous()
         if s.c2:
@@ -163,6 +182,19 @@ class UpdateEngine:
         for kh, kw, sfx in s.gru_passes:
             wz, wr, wq = (g(f"gru.conv{k}{sfx}.weight") for k in "zrq")
             bz, br, bq = (g(f"gru.conv{k}{sfx}.bias") for k in "zrq")
+            if self.hoist_context:
+                # per iteration: sources h (hx[:, :Ch]) / r*h and the rest of x behind the context slice (motion features ...);
+                # once per forward: the context slice with the biases (prepare_context)
+                Ci = s.context
+                rest = [(0, Ch, Ch), (Ch + Ci, real - Ch - Ci, hxc - Ch - Ci)]
+                wzr = torch.cat([wz, wr], 0)
+                w[f"zr{sfx}.w"] = pk(wzr, rest)
+                w[f"q{sfx}.w"] = pk(wq, rest)
+                w[f"zrc{sfx}.w"] = pk(wzr, [(Ch, Ci, Ci)])
+                w[f"zrc{sfx}.b"] = torch.cat([bz, br]).contiguous()
+                w[f"qc{sfx}.w"] = pk(wq, [(Ch, Ci, Ci)])
+                w[f"qc{sfx}.b"] = bq.contiguous()
+                continue
             # z|r: one source = the whole hx row (h | x), padded channels get zero weights
             w[f"zr{sfx}.w"] = pk(torch.cat([wz, wr], 0), [(0, real, hxc)])
             w[f"zr{sfx}.b"] = torch.cat([bz, br]).contiguous()
@@ -203,6 +235,10 @@ class UpdateEngine:
         self.flo1 = z(s.f1)
         self.zbuf = z(s.hidden)
         self.rh = z(s.hidden)
+        # loop-invariant gate pre-activations (prepare_context): per GRU pass [M, 2 Ch] for z|r and [M, Ch] for q
+        self.ctx = {("zr" + sfx): z(2 * s.hidden) for _, _, sfx in s.gru_passes} if self.hoist_context else {}
+        if self.hoist_context:
+            self.ctx.update({("q" + sfx): z(s.hidden) for _, _, sfx in s.gru_passes})
         self.fm = z(s.fh_hidden * (2 if s.has_mask else 1))
         self.mask = z(s.mask_channels) if s.has_mask else None
         self._scratch_c0 = torch.zeros(B, 2, H, W, device=dev, dtype=torch.float32)
@@ -314,7 +350,7 @@ class UpdateEngine:
                 self.flops["ag"] = 2.0 * N * N * mc
 
     def load_state(self, net: torch.Tensor, inp: torch.Tensor) -> None:
-        """NCHW ``net`` / ``inp`` -> their hx slices (once per forward)."""
+        """NCHW ``net`` / ``inp`` -> their hx slices (once per forward), then the loop-invariant context terms."""
         B, H, W = self._shape
         for src, dst in ((net, self.h_view), (inp, self.inp_view)):
             src = src.float()
@@ -322,10 +358,21 @@ class UpdateEngine:
                 self.ops.nchw_to_pm(src, dst)
             else:                         # channels-last producer (the native encoders): rows are already pixel-major
                 dst.view(B, H, W, dst.shape[1]).copy_(src.permute(0, 2, 3, 1))
+        self.prepare_context()
+
+    def prepare_context(self) -> None:
+        """Once per forward, after `inp` is in its hx slice: conv(W[:, inp slice], inp) + bias of every gate convolution
+        (class docstring) into `self.ctx` — what the per-iteration launches add to their pre-activations."""
+        if not self.hoist_context:
+            return
+        Ch = self.spec.hidden
+        for kh, kw, sfx in self.spec.gru_passes:
+            self._conv([self.inp_view], kh, kw, "zrc" + sfx, 2 * Ch, relu=False, out=self.ctx["zr" + sfx])
+            self._conv([self.inp_view], kh, kw, "qc" + sfx, Ch, relu=False, out=self.ctx["q" + sfx])
 
     # ------------------------------------------------------------------ one iteration
     def _conv(self, srcs: List[torch.Tensor], kh, kw, key, cout, relu=True, scale=1.0, out=None,
-              epi=EPI_LINEAR, h=None, z=None, rh=None, workspace=True):
+              epi=EPI_LINEAR, h=None, z=None, rh=None, workspace=True, residual=None):
         B, H, W = self._shape
         prof = self.profile
         if prof is not None:
@@ -335,7 +382,7 @@ class UpdateEngine:
         # (none: plain tile grid)
         ws = self.workspace if workspace is True else (workspace if isinstance(workspace, torch.Tensor) else None)
         self.ops.conv2d(srcs, B, H, W, kh, kw, self.w[key + ".w"], self.w.get(key + ".b"), cout, epi, relu, scale,
-                        out, h, z, rh, ws)
+                        out, h, z, rh, ws, residual)
         if prof is not None:
             e1.record()
             prof.setdefault(key, []).append((e0, e1))
@@ -393,6 +440,14 @@ class UpdateEngine:
         """SepConvGRU / ConvGRU passes (update.py:58-73 / :24-32) over hx = [h | x], h updated in place."""
         s = self.spec
         Ch = s.hidden
+        if self.hoist_context:
+            rest = self.hx[:, Ch + s.context:]          # x without the context slice: motion features [| aggregated ones] | pad
+            for kh, kw, sfx in s.gru_passes:
+                self._conv([self.h_view, rest], kh, kw, "zr" + sfx, 2 * Ch, epi=EPI_GRU_ZR, h=self.h_view, z=self.zbuf, rh=self.rh,
+                           residual=self.ctx["zr" + sfx])
+                self._conv([self.rh, rest], kh, kw, "q" + sfx, Ch, epi=EPI_GRU_Q, h=self.h_view, z=self.zbuf,
+                           residual=self.ctx["q" + sfx])
+            return
         for kh, kw, sfx in s.gru_passes:
             self._conv([self.hx], kh, kw, "zr" + sfx, 2 * Ch, epi=EPI_GRU_ZR, h=self.h_view, z=self.zbuf, rh=self.rh)
             self._conv([self.rh, self.x_view], kh, kw, "q" + sfx, Ch, epi=EPI_GRU_Q, h=self.h_view, z=self.zbuf)
@@ -546,6 +601,7 @@ class PfkUpdateBlock(torch.nn.Module):
         if new_forward or inp is not self._inp_ref or inp._version != self._inp_version:
             ops.nchw_to_pm(inp.float().contiguous(), eng.inp_view)
             self._inp_ref, self._inp_version = inp, inp._version
+            eng.prepare_context()      # the loop-invariant part of the GRU pre-activations, once per (forward, scale)
         # corr: a channels-last view of a [M, C] buffer (what ptlflow_amd.CorrBlock returns) is used as is
         cpm = corr.permute(0, 2, 3, 1)
         C = corr.shape[1]

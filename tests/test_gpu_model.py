@@ -219,3 +219,31 @@ def test_side_stream_mask_head_is_bit_identical(gpu, kind):
             x = O.smooth_pair(8, 480, 640, seed=seed).cuda()      # 8 x 60 x 80 = 38 400 pixels: above the side-stream threshold
             fa, fb = a({"images": x}), b({"images": x})
             assert torch.equal(fa["flows"], fb["flows"]) and torch.equal(fa["flow_small"], fb["flow_small"]), (every, seed)
+
+
+@pytest.mark.parametrize("kind,H,W,iters", [("raft", 436, 1024, 32), ("raft_small", 184, 320, 12), ("gma", 184, 320, 12)])
+def test_hoisted_context_term_equals_the_single_chain_form(gpu, kind, H, W, iters):
+    """The loop-invariant hoist (UpdateEngine: conv over cat([h, inp, m]) = conv over [h, m] + (conv over inp + bias), the second
+    term once per forward) is the SAME sum in another association: against the single-chain launches (`hoist_context=False`)
+    the flow may differ by fp32 rounding only — held here to 1e-4 px mean, a tenth of the north-star gate — and both stay
+    inside the EPE gate against the CPU oracle.  One update-block step is also compared state by state (net, delta)."""
+    from ptlflow_amd.raft import GMA, RAFT
+    small = kind == "raft_small"
+    outs = {}
+    for hoist in (True, False):
+        model = (GMA(iters=iters) if kind == "gma" else RAFT(small=small, iters=iters, hoist_context=hoist))
+        if kind == "gma":
+            model.hoist_context = hoist
+        model = model.load_synthetic(1234).eval()
+        P = {k: v.clone() for k, v in model.state_dict().items()}
+        x = O.smooth_pair(1, H, W, 1234)
+        model = model.cuda()
+        outs[hoist] = model({"images": x.cuda()})
+        assert model.engine(torch.device("cuda", 0)).hoist_context is hoist
+    ref = O.gma_forward(P, x, iters=iters) if kind == "gma" else O.raft_forward(P, x, iters=iters, small=small)
+    d_mean, d_max = O.epe(outs[True]["flows"][:, 0].cpu(), outs[False]["flows"][:, 0].cpu())
+    m1, x1 = O.epe(outs[True]["flows"][:, 0].cpu(), ref["flows"][:, 0])
+    m0, x0 = O.epe(outs[False]["flows"][:, 0].cpu(), ref["flows"][:, 0])
+    print(f"{kind}: hoisted vs single-chain EPE mean {d_mean:.2e} max {d_max:.2e}; vs the CPU oracle: hoisted {m1:.2e} / {x1:.2e}, "
+          f"single-chain {m0:.2e} / {x0:.2e}")
+    assert d_mean <= 1e-4 and m1 <= 1e-3 and m0 <= 1e-3
