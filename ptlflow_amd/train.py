@@ -243,7 +243,11 @@ class _GruPass(torch.autograd.Function):
     weight-gradient launches."""
 
     @staticmethod
-    def forward(ctx, h, x, wz, wr, wq, bz, br, bq, g: _Geometry, x_real: int, pk_zr: ConvPacks, pk_q: ConvPacks):
+    def forward(ctx, h, x, wz, wr, wq, bz, br, bq, g: _Geometry, x_real: int, pk_zr: ConvPacks, pk_q: ConvPacks,
+                pzr: Optional[torch.Tensor] = None, pq: Optional[torch.Tensor] = None):
+        """``pzr`` [M, 2C] / ``pq`` [M, C]: additive terms of the z|r and q pre-activations — the loop-invariant context part of
+        the gate convolutions, computed once per step by the caller (`update_block_train_pm`); ``x`` / the weights then cover
+        the remaining input channels only.  Their gradient is the pre-activation gradient itself."""
         ops = torch.ops.pfk
         h = h.float().contiguous()
         x = x.float().contiguous()
@@ -257,15 +261,16 @@ class _GruPass(torch.autograd.Function):
         segs = [(0, C, C), (C, x_real, x.shape[1])]
         a_zr = torch.empty(M, 2 * C, device=dev, dtype=torch.float32)
         ops.conv2d([h, x], g.B, g.H, g.W, g.kh, g.kw, _fwd_pack(pk_zr, wzr, segs), bzr, 2 * C, EPI_LINEAR, False, 1.0, a_zr,
-                   None, None, None, ws)
+                   None, None, None, ws, None if pzr is None else pzr.detach().float().contiguous())
         z, r, rh = (torch.empty(M, C, device=dev, dtype=torch.float32) for _ in range(3))
         ops.gru_gates_zr(a_zr, h, z, r, rh)
         a_q = torch.empty(M, C, device=dev, dtype=torch.float32)
         ops.conv2d([rh, x], g.B, g.H, g.W, g.kh, g.kw, _fwd_pack(pk_q, wq, segs), bq.detach().float().contiguous(), C, EPI_LINEAR,
-                   False, 1.0, a_q, None, None, None, ws)
+                   False, 1.0, a_q, None, None, None, ws, None if pq is None else pq.detach().float().contiguous())
         q, hn = torch.empty_like(a_q), torch.empty_like(a_q)
         ops.gru_gates_q(a_q, z, h, q, hn)
         ctx.g, ctx.x_real, ctx.pk_zr, ctx.pk_q, ctx.wzr = g, x_real, pk_zr, pk_q, wzr
+        ctx.has_p = (pzr is not None, pq is not None)
         ctx.save_for_backward(h, x, z, r, q, rh, wq)
         return hn
 
@@ -310,12 +315,14 @@ class _GruPass(torch.autograd.Function):
                 pk_zr.acc = {0: dwzr[:C], 1: dwzr[C:], 2: dbzr[:C], 3: dbzr[C:]}      # (wz, wr, bz, br) as given to _Flush
             ops.conv_wgrad_unpacked([rh, x], da_q, g.B, g.H, g.W, g.kh, g.kw, pk_q.acc[0], pk_q.acc[1], reals, 1, not first)
             ops.conv_wgrad_unpacked([h, x], da_zr, g.B, g.H, g.W, g.kh, g.kw, pk_zr.extra["dwzr"], pk_zr.extra["dbzr"], reals, 1, not first)
-            return (dh, dx, None, None, None, None, None, None, None, None, None, None)
+            return (dh, dx, None, None, None, None, None, None, None, None, None, None,
+                    da_zr if ctx.has_p[0] else None, da_q if ctx.has_p[1] else None)
         dwq, dbq = torch.empty(wq.shape, device=dev, dtype=torch.float32), torch.empty(C, device=dev, dtype=torch.float32)
         ops.conv_wgrad_unpacked([rh, x], da_q, g.B, g.H, g.W, g.kh, g.kw, dwq, dbq, reals, 1)
         dwzr, dbzr = torch.empty(wzr.shape, device=dev, dtype=torch.float32), torch.empty(2 * C, device=dev, dtype=torch.float32)
         ops.conv_wgrad_unpacked([h, x], da_zr, g.B, g.H, g.W, g.kh, g.kw, dwzr, dbzr, reals, 1)
-        return (dh, dx, dwzr[:C], dwzr[C:], dwq, dbzr[:C], dbzr[C:], dbq, None, None, None, None)
+        return (dh, dx, dwzr[:C], dwzr[C:], dwq, dbzr[:C], dbzr[C:], dbq, None, None, None, None,
+                da_zr if ctx.has_p[0] else None, da_q if ctx.has_p[1] else None)
 
 
 def conv_pm(srcs: Sequence[torch.Tensor], weight: torch.Tensor, bias: Optional[torch.Tensor], B: int, H: int, W: int,
@@ -351,8 +358,35 @@ def _pad4(x: torch.Tensor) -> torch.Tensor:
     return x if c % 4 == 0 else F.pad(x, (0, round_up(c, 4) - c))
 
 
+def _context_terms(P: Dict[str, torch.Tensor], spec, i: torch.Tensor, B: int, H: int, W: int, cache: dict, owner: torch.Tensor,
+                   acc: bool):
+    """The loop-invariant part of the GRU (raft/update.py:60-71 / :27-30): the gate convolutions run over cat([h, inp, motion])
+    and `inp` — the context features — is the same tensor in every iteration, so conv(W[:, inp slice], inp) is computed ONCE per
+    training step (forward, data and weight gradient alike: autograd sums the twelve pre-activation gradients and runs one
+    backward convolution) and the per-iteration nodes work on W without that slice.  Returns, per GRU pass,
+    (wz_rest, wr_rest, wq_rest, pzr, pq); cached in `cache` for as long as `owner` (the caller's context tensor) is the same
+    object at the same version — a new forward brings a new one."""
+    import weakref
+    ent = cache.get("ctx")
+    if ent is not None and ent[0]() is owner and ent[1] == owner._version:
+        return ent[2]
+    Ch, Ci = spec.hidden, spec.context
+    out = {}
+    for kh, kw, sfx in spec.gru_passes:
+        ws = [P[f"gru.conv{k}{sfx}.weight"] for k in "zrq"]
+        rest = [torch.cat([w[:, :Ch], w[:, Ch + Ci:]], 1).contiguous() for w in ws]       # autograd routes the gradients back
+        wc = [w[:, Ch:Ch + Ci].contiguous() for w in ws]
+        wzr_c = torch.cat([wc[0], wc[1]], 0)
+        pzr = conv_pm([i], wzr_c, None, B, H, W, False, None, packs_for(cache, "zrc" + sfx, [wzr_c], acc))
+        pq = conv_pm([i], wc[2], None, B, H, W, False, None, packs_for(cache, "qc" + sfx, [wc[2]], acc))
+        out[sfx] = (rest[0], rest[1], rest[2], pzr, pq)
+    cache["ctx"] = (weakref.ref(owner), owner._version, out)
+    return out
+
+
 def update_block_train_pm(P: Dict[str, torch.Tensor], spec, h, i, c, f, B: int, H: int, W: int, cache: Optional[dict] = None,
-                          accumulate_wgrad: bool = False, attention: Optional[torch.Tensor] = None):
+                          accumulate_wgrad: bool = False, attention: Optional[torch.Tensor] = None, hoist_context: bool = True,
+                          context_owner: Optional[torch.Tensor] = None):
     """BasicUpdateBlock.forward / SmallUpdateBlock.forward (update.py:144-153 / :122-128) with every convolution on
     ``conv_pm``, on pixel-major tensors: ``h`` [M, Ch], ``i`` [M, Ci], ``c`` [M, corr channels], ``f`` [M, 2] ->
     ``(h', mask [M, 576] | None, delta [M, 2])``.  ``P``: the block's named parameters; ``cache``: a dict that keeps the packed
@@ -371,15 +405,20 @@ def update_block_train_pm(P: Dict[str, torch.Tensor], spec, h, i, c, f, B: int, 
     flo = conv([_pad4(f)], "encoder.convf1", True, [2])
     flo = conv([flo], "encoder.convf2", True)
     out = conv([cor, flo], "encoder.conv", True)
-    # x = [inp | motion features (encoder out | flow) | zero pad to a multiple of 4] in ONE concatenation (update.py:112 + :146)
-    x_real = spec.x_channels
-    parts = [i, out, f]
+    # x = [inp | motion features (encoder out | flow) | zero pad to a multiple of 4] in ONE concatenation (update.py:112 + :146);
+    # with the context term hoisted (`_context_terms`, needs a cache to live in) `inp` stays out of it
+    # (step-scoped caches only — `accumulate_wgrad`, the mirror's training forward: a cache that outlives the step would hand the
+    #  next forward derived tensors whose autograd graph the previous backward has already freed)
+    hoist = hoist_context and acc
+    ctx_terms = _context_terms(P, spec, i, B, H, W, cache, i if context_owner is None else context_owner, acc) if hoist else None
+    x_real = spec.x_channels - (spec.context if hoist else 0)
+    parts = [out, f] if hoist else [i, out, f]
     if spec.aggregate:
         mf = torch.cat([out, f], 1)
         v = conv([mf], "aggregator.to_v")                                        # 1x1, no bias
         N = H * W
         agg = torch.bmm(attention.reshape(B, N, N).float(), v.view(B, N, v.shape[1])).reshape(B * N, v.shape[1])
-        parts = [i, mf, mf + P["aggregator.gamma"] * agg]
+        parts = [mf, mf + P["aggregator.gamma"] * agg] if hoist else [i, mf, mf + P["aggregator.gamma"] * agg]
     if x_real % 4:
         zkey = ("zpad", i.shape[0], round_up(x_real, 4) - x_real, i.device)
         z = cache.get(zkey) if cache is not None else None
@@ -394,11 +433,14 @@ def update_block_train_pm(P: Dict[str, torch.Tensor], spec, h, i, c, f, B: int, 
         names = [f"gru.conv{k}{sfx}" for k in "zrq"]
         wz, wr, wq = (P[n + ".weight"] for n in names)
         bz, br, bq = (P[n + ".bias"] for n in names)
+        pzr = pq = None
+        if hoist:
+            wz, wr, wq, pzr, pq = ctx_terms[sfx]      # the weights without their context slice; that slice's products, once per step
         pk_zr = packs_for(cache, "zr" + sfx, [wz, wr, bz, br], acc)      # the cached z|r concatenation includes the biases
         pk_q = packs_for(cache, "q" + sfx, [wq], acc)
         wz, wr, bz, br = step_params(pk_zr, wz, wr, bz, br)
         wq, bq = step_params(pk_q, wq, bq)
-        h = _GruPass.apply(h, x, wz, wr, wq, bz, br, bq, _Geometry(B, H, W, kh, kw), x_real, pk_zr, pk_q)
+        h = _GruPass.apply(h, x, wz, wr, wq, bz, br, bq, _Geometry(B, H, W, kh, kw), x_real, pk_zr, pk_q, pzr, pq)
     # heads (update.py:6-14, 138-142, 152)
     delta = conv([conv([h], "flow_head.conv1", True)], "flow_head.conv2")
     mask = None
@@ -411,7 +453,7 @@ def update_block_train(P: Dict[str, torch.Tensor], spec, net, inp, corr, flow, c
     """NCHW face of `update_block_train_pm` (what `PfkUpdateBlock` calls from the reference's loop):
     NCHW in, NCHW out: ``(net, mask | None, delta_flow)``."""
     B, _, H, W = net.shape
-    h, mask, delta = update_block_train_pm(P, spec, _pm(net), _pm(inp), _pm(corr), _pm(flow), B, H, W, cache)
+    h, mask, delta = update_block_train_pm(P, spec, _pm(net), _pm(inp), _pm(corr), _pm(flow), B, H, W, cache, context_owner=inp)
     return _nchw(h, B, H, W), (None if mask is None else _nchw(mask, B, H, W)), _nchw(delta, B, H, W)
 
 

@@ -27,6 +27,8 @@ SHAPES = [
     ("c1", [324], 256, 1, 1, 0), ("c2", [256], 192, 3, 3, 0), ("f2", [128], 64, 3, 3, 0), ("cv", [256], 126, 3, 3, 0),
     ("zr1", [384], 256, 1, 5, 1), ("q1", [128, 256], 128, 1, 5, 2), ("zr2", [384], 256, 5, 1, 1), ("q2", [128, 256], 128, 5, 1, 2),
     ("fm", [128], 512, 3, 3, 0), ("mk", [256], 576, 1, 1, 0),
+    # round 4: the GRU launches with the context slice hoisted out of the loop (h | motion features: 128 + 128 input channels)
+    ("zr1h", [128, 128], 256, 1, 5, 1), ("q1h", [128, 128], 128, 1, 5, 2), ("zr2h", [128, 128], 256, 5, 1, 1), ("q2h", [128, 128], 128, 5, 1, 2),
 ]
 
 
