@@ -528,15 +528,12 @@ def main():
                 pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
                 rec = pmc["entries"].get(f"{dom.rstrip('12')}@b{args.batch}")
                 if rec and (args.height, args.width, small) == (436, 1024, False):
-                    import hashlib
-                    h = hashlib.sha256()
-                    for f in ("pfk_gemm.hip", "pfk_gemm.h"):
-                        h.update(open(os.path.join(ROOT, "ptlflow_amd", "csrc", f), "rb").read())
+                    from ptlflow_amd import _build      # the stamp both libraries carry: every file of csrc/ + include/pfk.h + flags
                     # MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports half the bytes of the 128-byte requests these kernels
                     # cause (calibrated in profiles/r03_b) -> doubled; WRITE_SIZE taken as reported (KB)
                     traffic = {"bytes": (2 * rec["fetch_kb"] + rec["write_kb"]) * 1024,
                                "algorithmic_bytes": int(s["bytes_per_launch"]) if s.get("bytes_per_launch") else None,
-                               "stale": h.hexdigest()[:16] != pmc.get("kernel_source_sha16"),
+                               "stale": _build.source_hash() != pmc.get("kernel_source_sha16"),
                                "source": "profiles/pmc_traffic.json (rocprofv3 TCC_EA0_RDREQ x 128 B / FETCH_SIZE x2 + WRITE_SIZE, separate "
                                          "--pmc passes; `stale`: the kernel sources changed since that measurement)"}
             except Exception:

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""A few forwards of the drop-in seam path — SeamRAFT (the reference's caller loop in torch) + patch.accelerate — for
+"""A few forwards of the drop-in seam path — the reference's own `ptlflow.models.raft.raft.RAFT` (oracle/ref_loader.py: /root/reference
+or the archive staged for the GPU box; `SeamRAFT`, the torch-only stand-in, where neither exists) + patch.accelerate — for
 rocprofv3 --kernel-trace; `--unpatched` traces the same object on stock PyTorch-ROCm ops instead."""
 import os, sys
 import torch
@@ -11,15 +12,27 @@ from ptlflow_amd.seam_model import SeamRAFT
 ptlflow_amd.load_native()
 dev = torch.device("cuda:0")
 state = RAFT(iters=32).load_synthetic(1234).state_dict()
-m = SeamRAFT(iters=32).eval()
-m.load_state_dict(state, strict=True)
+try:
+    from oracle import ref_loader
+    real = ref_loader.reference_available()
+except Exception:
+    real = False
+if real:
+    m = ref_loader.build_raft(iters=32)
+    m.load_state_dict(state, strict=False)
+    m = m.eval()
+else:
+    m = SeamRAFT(iters=32).eval()
+    m.load_state_dict(state, strict=True)
+print("model class:", type(m).__module__ + "." + type(m).__name__)
 m = m.to(dev)
 if "--unpatched" not in sys.argv:
     patch.accelerate(m)
 g = torch.Generator().manual_seed(1234)
 x = {"images": torch.rand(1, 2, 3, 436, 1024, generator=g).to(dev)}
 n = 3 if "--unpatched" in sys.argv else 8
-for _ in range(n):
-    out = m(x)
+with torch.no_grad():
+    for _ in range(n):
+        out = m(x)
 torch.cuda.synchronize()
 print("forwards", n, "flows", tuple(out["flows"].shape))
