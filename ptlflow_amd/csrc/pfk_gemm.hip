@@ -1105,17 +1105,15 @@ int launch(const GemmArgs& a0, int epi, int batches, hipStream_t st) {
                     a.sk_steps >= 24;
     // a handful of output tiles with a very long K (GEMM-shaped callers with a tall reduction): only stream-K fills the chip
     const bool sk_long = sk_fits && a.sk_ws != nullptr && batches == 1 && blocks64 <= 64 && a.sk_steps >= 128;
-    // Round 4, batch 8 (scripts/conv_bench.py --batch 8, gpurun_out/r4i_conv_b8.log, 3 rounds): with 64 or more K-steps per tile the
-    // stream-K schedule also wins on grids of 1000..4000 tiles whose output is too narrow for the 64x128 tiles — convc2 (cout 192,
-    // 2640 tiles x 72 steps) 415 -> 390 us, conv (cout 126, 1760 x 72) 275 -> 267 us: the last, partly filled round of 64x64
-    // tiles is spread over all CUs.  It loses for 36..40 steps (fm 513 -> 542, z|r 304 -> 317, q 161 -> 165) and short K.
-    const bool sk_wide = sk_fits && a.sk_ws != nullptr && batches == 1 && blocks64 >= 4 * 256 && blocks64 <= 16 * 256 &&
-                         a.sk_steps >= 64 && !(a.b_rows >= 256 && (a.b_rows & 127) == 0);
+    // (Round 4: stream-K on the 1000..4000-tile grids of batch 8 was measured and NOT taken — convc2 (2640 tiles x 72 K-steps)
+    //  415 -> 390 us on one box, 412 -> 404 on another; conv (1760 x 72) 275 -> 267 / 273 -> 278; slower wherever K is 36..40 steps
+    //  (fm, z|r, q) — while its HBM-side fetch is 10x the tile grid's (508 vs 54 MB per convc2 launch: an XCD's resident blocks
+    //  work on distant tiles of its range at once).  profiles/r04_a section 2.)
     // Tile grids: >= 3 tiles per CU: the swizzled 48 KB layout (cfg 10) keeps three blocks resident — also for short K since the
     // LDS epilogue (c1 111 -> 104 us, mask conv2 163 -> 158 us at batch 8).  Below that the padded rows' immediate-offset fragment
     // reads are a few % faster (cfg 4), down to one tile per CU for short K too (convc1 at batch 1: 18.7 vs 19.9 us on the
     // 2-stage kernel); smaller short-K grids keep the 2-stage kernel's cheaper prologue (cfg 0).
-    cfg = (sk || sk_long || sk_wide) ? 9 : (blocks64 >= 3 * 256 ? 10 : ((a.sk_steps < 16 && blocks64 < 256) ? 0 : 4));
+    cfg = (sk || sk_long) ? 9 : (blocks64 >= 3 * 256 ? 10 : ((a.sk_steps < 16 && blocks64 < 256) ? 0 : 4));
     // Round 3, batch 8 (scripts/conv_bench.py, three boxes): 64x128 tiles on the swizzled layout (72 KB: two blocks per CU, two
     // accumulators and 32 MFMAs per wave and barrier, 12 instead of 16 B/clk/CU of operand traffic) beat 64x64 x3 where the
     // output width is a multiple of 128 and the grid still has >= 3 rounds of them: fh|mask conv1 526 -> 513 us (129 TFLOP/s),
