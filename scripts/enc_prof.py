@@ -16,7 +16,9 @@ from ptlflow_amd.synth import smooth_pair  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--tile", type=int, default=-1, help="force a GEMM tile configuration (pfk_debug_set_tile)")
     args = ap.parse_args()
+    os.environ.setdefault("PFK_DEBUG_KNOBS", "1")
     dev = torch.device("cuda")
     m = RAFT().load_synthetic(1234).eval().to(dev)
     x = smooth_pair(args.batch, 436, 1024, seed=1).to(dev)
@@ -26,6 +28,7 @@ def main():
         i1, i2 = xp[:, 0].contiguous(), xp[:, 1].contiguous()
         both = torch.cat([i1, i2], 0)
         fnet, cnet = m.encoders(dev)
+        torch.ops.pfk.debug_set_tile(args.tile)
         for _ in range(2):
             fnet(both); cnet(i1)
         torch.cuda.synchronize()

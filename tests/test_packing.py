@@ -89,3 +89,33 @@ def test_unpack_wgrad_is_the_inverse_of_pack():
     padded = F.pad(packed, (0, 0, 0, 2))                       # the kernel's output has cout rounded up to a multiple of 4
     back = _unpack_wgrad(padded, w.shape, segs, _Geometry(1, 4, 4, kh, kw))
     assert torch.equal(back, w)
+
+
+def test_hoisted_gru_packing_equals_the_single_chain_convolution():
+    """The loop-invariant hoist of UpdateEngine (ptlflow_amd/update.py): with hx = [h | inp | motion | pad] the engine packs, per
+    GRU pass, (a) the weight over the h and motion channels for the per-iteration launch — sources hx[:, :Ch] and hx[:, Ch+Ci:] —
+    and (b) the weight over the context channels + the bias for the once-per-forward launch.  Emulating both launches' K loops
+    on the CPU, (a) + (b) must equal F.conv2d over cat([h, inp, motion]) with the full weight and bias (raft/update.py:60-62),
+    for the SepConvGRU's 1x5 / 5x1 kernels and raft_small's 3x3 ConvGRU (hx padded to a multiple of 4)."""
+    from ptlflow_amd.update import UpdateEngine, basic_spec, small_spec
+    from ptlflow_amd.synth import synth_state_dict, update_block_shapes
+    torch.manual_seed(3)
+    H, W = 5, 6
+    M = H * W
+    for spec in (basic_spec(), small_spec()):
+        P = synth_state_dict(update_block_shapes(spec), 5)
+        eng = UpdateEngine(P, spec, torch.device("cpu"), "fp32", hoist_context=True)
+        Ch, Ci, real, hxc = spec.hidden, spec.context, spec.hidden + spec.x_channels, spec.hx_channels
+        hx = torch.randn(M, hxc)
+        hx[:, real:] = 0.0                                                  # the pad channels are zero in the engine's buffer
+        x_nchw = hx[:, :real].view(1, H, W, real).permute(0, 3, 1, 2)
+        for kh, kw, sfx in spec.gru_passes:
+            wz, wr, wq = (P[f"gru.conv{k}{sfx}.weight"] for k in "zrq")
+            bz, br, bq = (P[f"gru.conv{k}{sfx}.bias"] for k in "zrq")
+            for key, wfull, bfull in (("zr", torch.cat([wz, wr], 0), torch.cat([bz, br])), ("q", wq, bq)):
+                ref = F.conv2d(x_nchw, wfull, bfull, padding=(kh // 2, kw // 2)).permute(0, 2, 3, 1).reshape(M, -1)
+                rest = hx[:, Ch + Ci:]
+                per_iter = emulate([hx[:, :Ch], rest], [Ch, rest.shape[1]], eng.w[f"{key}{sfx}.w"], kh, kw, H, W)
+                ctx = emulate([hx[:, Ch:Ch + Ci]], [Ci], eng.w[f"{key}c{sfx}.w"], kh, kw, H, W) + eng.w[f"{key}c{sfx}.b"]
+                assert eng.w.get(f"{key}{sfx}.b") is None                  # the bias lives in the context term
+                assert torch.allclose(per_iter + ctx, ref, atol=2e-4), (key, sfx, float((per_iter + ctx - ref).abs().max()))
