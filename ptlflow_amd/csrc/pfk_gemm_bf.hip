@@ -33,7 +33,11 @@ constexpr int ROWB = 64;           // bytes per LDS row: 32 bf16
 // TH threads (256 or 512) stage SUB K-sub-steps per barrier: thread t owns channels (t & 3)*8 .. +7 of rows (t >> 2) + RP*i
 // (RP = TH / 4 rows per pass) of both operands.  LDS rows are 64 bytes = four 16-byte chunks; chunk' = chunk ^ ((row >> 2) & 3) makes both the
 // ds_write_b128 (8 lanes = 2 rows) and the fragment ds_read_b128 (MI355X_MICROARCH.md lane groups) conflict-free.
-template <int NS, int BM, int BN, int SUB, int TH = 256, int NSETS = 2>
+// BDMA (round 4, experiment behind pfk_debug_set_tile(180 + t)): the weight planes — three quarters of a K sub-step's bytes, and no
+// split to do on them — go global -> LDS by `buffer_load_dwordx4 ... lds` (LDS-DMA: no VGPR round trip, no ds_write_b128) straight
+// into the stage the NEXT step reads; a wave's 64 lanes land on 1 KiB of consecutive LDS (16 rows x 64 B), so the XOR swizzle is
+// applied to WHICH global chunk a lane fetches instead of where it stores it.
+template <int NS, int BM, int BN, int SUB, int TH = 256, int NSETS = 2, bool BDMA = false>
 struct StagerBF {
   static constexpr int RP = TH / 4;
   static_assert(BM % RP == 0 && BN % RP == 0, "tile rows must be a multiple of the rows staged per pass");
@@ -54,7 +58,9 @@ struct StagerBF {
   // NSETS = 2: two register sets, the loads of step j+2 are issued while step j+1's wait to be split; NSETS = 1 (the 64x64-wave-tile
   // configurations, which have no registers to spare): a register is split + stored and then reloaded within the same step
   f32x4 ra[NSETS][SUB][A_PT][2];
-  u32x4 rb[NSETS][SUB][NS][B_PT];
+  u32x4 rb[BDMA ? 1 : NSETS][BDMA ? 1 : SUB][BDMA ? 1 : NS][BDMA ? 1 : B_PT];
+  int posb = 0, pb_koff = 0;      // BDMA: the weight stream's own K position (one step ahead of the MFMAs, one behind the A loads)
+  unsigned bwave = 0;             // BDMA: byte offset of this wave's 16 rows inside a 64-row... pass of a plane (wave-uniform)
 
   __device__ __forceinline__ StagerBF(const GemmArgs& a, long long m0, int n0, int t) {
     H = a.H; W = a.W; kh = a.kh; kw = a.kw; ph = a.kh >> 1; pw = a.kw >> 1; nsrc = a.nsrc;
@@ -79,10 +85,13 @@ struct StagerBF {
       py[i] = (int)(prow_o - bimg * (unsigned)a.Ho) * a.stride;
       prow[i] = (int)((bimg * (unsigned)a.H + (unsigned)py[i]) * (unsigned)a.W + (unsigned)px[i]);
     }
+    // BDMA: lane (row r0, physical chunk t & 3) fetches the LOGICAL chunk that belongs there
+    const int c8b = BDMA ? (((t & 3) ^ ((r0 >> 2) & 3)) * 8) : c8;
+    bwave = (unsigned)__builtin_amdgcn_readfirstlane(t >> 6) * 1024u;
 #pragma unroll
     for (int i = 0; i < B_PT; ++i) {
       const int n = n0 + r0 + RP * i;
-      wvoff[i] = n < a.b_rows ? (unsigned)(n * a.ktot + c8) * 2u : OOB;
+      wvoff[i] = n < a.b_rows ? (unsigned)(n * a.ktot + c8b) * 2u : OOB;
     }
     set_segment(0);
     set_tap();
@@ -172,6 +181,16 @@ struct StagerBF {
     pa[PL][2 * Hf] = w[0];
     pa[PL][2 * Hf + 1] = w[1];
   }
+  // BDMA: plane PL of the weight rows of pass I, K sub-step `posb`, into sub-step slot U of `stage`
+  __device__ __forceinline__ void b_setup() { pb_koff = posb < total ? posb * BKB * 2 : 0; }
+  template <int U, int PL, int I>
+  __device__ __forceinline__ void dma_b(char* stage) const {
+#if defined(__HIP_DEVICE_COMPILE__)       // (the host pass of hipcc does not know the LDS-DMA builtin)
+    char* dst = stage + U * SUBSTAGE + NS * A_PLANE + PL * B_PLANE + I * RP * ROWB + bwave;       // wave-uniform: goes to M0
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)dst, 16, wvoff[I],
+                                             pb_koff + PL * plane_bytes, 0, 0);
+#endif
+  }
   // stage layout: [sub-step][A planes 0..NS-1][B planes 0..NS-1], planes [rows][64 B]
   template <int U, int I, int PL>
   __device__ __forceinline__ void store_a(char* stage) const {
@@ -184,7 +203,8 @@ struct StagerBF {
 
   // Unit X of a step, in order per sub-step: B stores | per row chunk: split pieces, A stores | load setup, A loads,
   // B loads, iterator advance.
-  static constexpr int U_BST = NS * B_PT, U_ROW = 3 * NS, U_AST = A_PT * U_ROW, U_ALD = 2 * A_PT, U_BLD = NS * B_PT;
+  static constexpr int U_BST = NS * B_PT, U_ROW = 3 * NS, U_AST = A_PT * U_ROW, U_ALD = 2 * A_PT, U_BLD = BDMA ? 0 : NS * B_PT;
+  static constexpr int A_LOADS_PER_SUB = U_ALD;        // BDMA: the loads that may stay in flight behind the step's last DMA
   static constexpr int UNITS_PER_SUB = U_BST + U_AST + 1 + U_ALD + U_BLD + 1;
   static constexpr int UNITS = SUB * UNITS_PER_SUB;
   template <int S, int X>
@@ -192,7 +212,13 @@ struct StagerBF {
     constexpr int U = X / UNITS_PER_SUB, x = X % UNITS_PER_SUB;
     constexpr int SL = NSETS == 2 ? S : 0, SS = NSETS == 2 ? 1 - S : 0;     // set that receives the loads / set that is stored
     if constexpr (x < U_BST) {
-      store_b<SS, U, x / B_PT, x % B_PT>(other);
+      if constexpr (BDMA) {          // the step's first units: the DMA has the whole step to land
+        if constexpr (x == 0) b_setup();
+        dma_b<U, x / B_PT, x % B_PT>(other);
+        if constexpr (x == U_BST - 1) ++posb;
+      } else {
+        store_b<SS, U, x / B_PT, x % B_PT>(other);
+      }
     } else if constexpr (x < U_BST + U_AST) {
       constexpr int y = x - U_BST, I = y / U_ROW, z = y % U_ROW;
       if constexpr (z < 2 * NS) split_piece<SS, U, I, z / NS, z % NS>();
@@ -261,13 +287,13 @@ constexpr int term1_b(int t) { constexpr int v[6] = {1, 2, 0, 1, 0, 0}; return v
 // register double-buffered per K-block: the reads of block g+1 are the first fillers of block g; the staging units of
 // StagerBF::unit are spread evenly over all MFMA slots.  Only the first block's fragment reads (right after the
 // barrier) are exposed — the co-resident block's wave covers them.
-template <int EPI, int NS, int BM, int BN, int SUB, int WM = 2, int WN = 2, int NSETS = 2>
+template <int EPI, int NS, int BM, int BN, int SUB, int WM = 2, int WN = 2, int NSETS = 2, bool BDMA = false>
 struct KStep {
   // fragment registers: double-buffered per K-block, except three planes on 64x64 wave tiles (96 registers would not fit next to
   // the 64 accumulators): there the next block's fragments are read behind the block's last MFMA and the SIMD's other wave covers
   // the LDS latency
   static constexpr int FD = (NS == 3 && WM * WN == 8 && BM / (32 * WM) * (BN / (32 * WN)) >= 4) ? 1 : 2;
-  using St = StagerBF<NS, BM, BN, SUB, 64 * WM * WN, NSETS>;
+  using St = StagerBF<NS, BM, BN, SUB, 64 * WM * WN, NSETS, BDMA>;
   static constexpr int MT = BM / (32 * WM), NT = BN / (32 * WN);
   static constexpr int T = NS * (NS + 1) / 2;
   static constexpr int NB = 2 * SUB, MPB = T * MT * NT, NM = NB * MPB;
@@ -353,10 +379,22 @@ constexpr int bf_blocks_per_cu(int ns, int bm, int bn, int sub, int waves, int n
   return (waves <= 4 && 2 * (2 * sub * ns * (bm + bn) * ROWB) <= 160 * 1024) ? 2 : 1;
 }
 
-template <int EPI, int NS, int BM, int BN, int SUB, int WM = 2, int WN = 2, int NSETS = 2>
+// end of a K step.  BDMA: the weight planes of the next step were DMA'd into the other stage by the step's first units; the A loads
+// issued behind them may stay in flight (counted vmcnt), the LDS stores of the A planes and this wave's fragment reads may not.
+template <bool BDMA, int A_LOADS>
+__device__ __forceinline__ void step_barrier() {
+  if constexpr (BDMA) {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(A_LOADS) : "memory");
+  } else {
+    __syncthreads();
+  }
+}
+
+template <int EPI, int NS, int BM, int BN, int SUB, int WM = 2, int WN = 2, int NSETS = 2, bool BDMA = false>
 // (hipcc reads the second launch-bounds argument as waves per SIMD: resident blocks x waves per block / 4)
 __global__ __launch_bounds__(64 * WM * WN, bf_blocks_per_cu(NS, BM, BN, SUB, WM * WN, NSETS) * WM * WN / 4) void conv_gemm_bf_kernel(const GemmArgs a) {
-  using St = StagerBF<NS, BM, BN, SUB, 64 * WM * WN, NSETS>;
+  static_assert(!BDMA || SUB == 1, "the counted vmcnt of step_barrier assumes one K sub-step per barrier");
+  using St = StagerBF<NS, BM, BN, SUB, 64 * WM * WN, NSETS, BDMA>;
   constexpr int MT = BM / (32 * WM), NT = BN / (32 * WN);
   constexpr int A_PLANE = St::A_PLANE, STAGE = SUB * St::SUBSTAGE;
   extern __shared__ __attribute__((aligned(16))) char smem_bf[];   // [2][STAGE]
@@ -395,7 +433,7 @@ __global__ __launch_bounds__(64 * WM * WN, bf_blocks_per_cu(NS, BM, BN, SUB, WM 
   // and j+2 (issued during step j); LDS holds steps j and j+1; one barrier per step.
   char* const stage0 = smem_bf;
   char* const stage1 = smem_bf + STAGE;
-  KStep<EPI, NS, BM, BN, SUB, WM, WN, NSETS> ks{a_row, b_row, ko0, ko1};
+  KStep<EPI, NS, BM, BN, SUB, WM, WN, NSETS, BDMA> ks{a_row, b_row, ko0, ko1};
   if constexpr (NSETS == 2) {
     st.template load_all<0>();
     st.template load_all<1>();
@@ -405,18 +443,20 @@ __global__ __launch_bounds__(64 * WM * WN, bf_blocks_per_cu(NS, BM, BN, SUB, WM 
     st.template store_all<0>(stage0);
     st.template load_all<0>();
   }
+  if constexpr (BDMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // step 0's weight planes have landed in stage 0
   __syncthreads();
   for (int step = 0; step < nsteps; step += 2) {
     ks.template run<0>(acc, st, stage0, stage1);   // MFMAs on stage0, loads -> set 0, set 1 -> stage1
-    __syncthreads();
+    step_barrier<BDMA, St::A_LOADS_PER_SUB>();
     if (step + 1 >= nsteps) break;
     ks.template run<1>(acc, st, stage1, stage0);
-    __syncthreads();
+    step_barrier<BDMA, St::A_LOADS_PER_SUB>();
   }
+  if constexpr (BDMA) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }   // nothing may land in the epilogue's LDS
   epilogue_lds<MT, NT, EPI>(a, acc, m0 + wm0, n0 + wn0, lane, 0, reinterpret_cast<float*>(smem_bf), wid);   // behind the loop's final barrier
 }
 
-template <int EPI, int NS, int BM, int BN, int SUB, int WM = 2, int WN = 2, int NSETS = 2>
+template <int EPI, int NS, int BM, int BN, int SUB, int WM = 2, int WN = 2, int NSETS = 2, bool BDMA = false>
 int launch_bf_one(const GemmArgs& a, hipStream_t st, long long row0, long long row1) {
   GemmArgs g = a;
   if (a.M >= 0x7fffffffLL || a.Wo <= 0 || a.Ho <= 0) return PFK_ERR_UNSUPPORTED;   // 32-bit pixel arithmetic in the stager
@@ -433,7 +473,7 @@ int launch_bf_one(const GemmArgs& a, hipStream_t st, long long row0, long long r
   constexpr size_t smem = 2 * (size_t)SUB * NS * (BM + BN) * ROWB;
   static_assert(smem <= 160 * 1024, "LDS budget");
   static_assert(WM * WN * 4096 <= (int)smem, "the LDS epilogue needs 4 KB per wave");
-  auto kern = conv_gemm_bf_kernel<EPI, NS, BM, BN, SUB, WM, WN, NSETS>;
+  auto kern = conv_gemm_bf_kernel<EPI, NS, BM, BN, SUB, WM, WN, NSETS, BDMA>;
   static pfk_device_once attr_once;   // one per template instantiation and device; safe with several host threads
   attr_once.run([&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -442,12 +482,12 @@ int launch_bf_one(const GemmArgs& a, hipStream_t st, long long row0, long long r
   return pfk_launch_status();
 }
 
-template <int NS, int BM, int BN, int SUB, int WM = 2, int WN = 2, int NSETS = 2>
+template <int NS, int BM, int BN, int SUB, int WM = 2, int WN = 2, int NSETS = 2, bool BDMA = false>
 int launch_bf_epi(const GemmArgs& g, int epi, hipStream_t st, long long row0, long long row1) {
   switch (epi) {
-    case PFK_EPI_LINEAR: return launch_bf_one<PFK_EPI_LINEAR, NS, BM, BN, SUB, WM, WN, NSETS>(g, st, row0, row1);
-    case PFK_EPI_GRU_ZR: return launch_bf_one<PFK_EPI_GRU_ZR, NS, BM, BN, SUB, WM, WN, NSETS>(g, st, row0, row1);
-    case PFK_EPI_GRU_Q:  return launch_bf_one<PFK_EPI_GRU_Q, NS, BM, BN, SUB, WM, WN, NSETS>(g, st, row0, row1);
+    case PFK_EPI_LINEAR: return launch_bf_one<PFK_EPI_LINEAR, NS, BM, BN, SUB, WM, WN, NSETS, BDMA>(g, st, row0, row1);
+    case PFK_EPI_GRU_ZR: return launch_bf_one<PFK_EPI_GRU_ZR, NS, BM, BN, SUB, WM, WN, NSETS, BDMA>(g, st, row0, row1);
+    case PFK_EPI_GRU_Q:  return launch_bf_one<PFK_EPI_GRU_Q, NS, BM, BN, SUB, WM, WN, NSETS, BDMA>(g, st, row0, row1);
     default: return PFK_ERR_BAD_ARG;
   }
 }
@@ -464,6 +504,10 @@ int launch_bf_ns(const GemmArgs& g, int epi, int cfg, hipStream_t st, long long 
     // 64x64 wave tiles (half the fragment bytes per MFMA of the configurations above) with eight waves: 256x128 / 128x256
     case 5: return launch_bf_epi<NS, 256, 128, 1, 4, 2, 1>(g, epi, st, row0, row1);
     case 6: return launch_bf_epi<NS, 128, 256, 1, 2, 4, 1>(g, epi, st, row0, row1);
+    // the eight-wave tiles with the weight planes by LDS-DMA (two / three planes; `launch_bf` adds 10 to the tile number)
+    case 14: if constexpr (NS >= 2) return launch_bf_epi<NS, 128, 128, 1, 2, 4, 2, true>(g, epi, st, row0, row1); else return PFK_ERR_BAD_ARG;
+    case 15: if constexpr (NS >= 2) return launch_bf_epi<NS, 256, 128, 1, 4, 2, 1, true>(g, epi, st, row0, row1); else return PFK_ERR_BAD_ARG;
+    case 16: if constexpr (NS >= 2) return launch_bf_epi<NS, 128, 256, 1, 2, 4, 1, true>(g, epi, st, row0, row1); else return PFK_ERR_BAD_ARG;
     default: return PFK_ERR_BAD_ARG;
   }
 }
@@ -532,11 +576,20 @@ int launch_bf(const GemmArgs& a0, int epi, int nsplit, hipStream_t st) {
       default: return (int)PFK_ERR_BAD_ARG;
     }
   };
+  // Round 4: on the eight-wave tiles the weight planes (three quarters of a K sub-step's bytes, nothing to split) go global -> LDS
+  // by `buffer_load_dwordx4 ... lds` (StagerBF<..., BDMA>): 6 of a thread's 9 ds_write_b128 and 24 staging registers per step
+  // disappear.  Same results (the K order does not change); batch 8, three planes (gpurun_out/r4n_conv_x6.log, 3 rounds, us):
+  // fh|mask conv1 319.3 -> 312.1, z|r 200.4 -> 195.8, convc2 287.4 -> 279.7 on 128x256; 323.7 -> 318.3, mask conv2 118.7 -> 117.0
+  // on 256x128; the 128x128 tail tile 2-9 %.  Whole forward, batch 8 (gpurun_out/r4o_legs.log, interleaved): bf16x6 102.4 -> 104.8
+  // pairs/s (+2.3 %).  Two planes gain 2-8 % per launch in the micro-benchmark but the bf16x3 forward loses 0.9 % (145.0 -> 143.7),
+  // one plane is a wash: three planes only.  pfk_debug_set_tile(170 + t) keeps the register path (A/B), 180 + t forces the DMA
+  // path (two planes too).
+  const int dma = (((nsplit == 3 && g_bf_cfg / 10 != 7) || (nsplit >= 2 && g_bf_cfg / 10 == 8)) && cfg >= 4 && cfg <= 6) ? 10 : 0;
   if (split_row > 0) {
-    const int rc = run(cfg, 0, split_row);
-    return rc != PFK_OK ? rc : run(4, split_row, -1);
+    const int rc = run(cfg + dma, 0, split_row);
+    return rc != PFK_OK ? rc : run(4 + dma, split_row, -1);
   }
-  return run(cfg, 0, -1);
+  return run(cfg + dma, 0, -1);
 }
 
 }  // namespace pfkg

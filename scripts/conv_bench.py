@@ -29,6 +29,8 @@ SHAPES = [
     ("fm", [128], 512, 3, 3, 0), ("mk", [256], 576, 1, 1, 0),
     # round 4: the GRU launches with the context slice hoisted out of the loop (h | motion features: 128 + 128 input channels)
     ("zr1h", [128, 128], 256, 1, 5, 1), ("q1h", [128, 128], 128, 1, 5, 2), ("zr2h", [128, 128], 256, 5, 1, 1), ("q2h", [128, 128], 128, 5, 1, 2),
+    # the same two launches with the plain linear epilogue: what the gate arithmetic (sigmoid / tanh / blend, h and z reads) costs
+    ("zr1hL", [128, 128], 256, 1, 5, 0), ("q1hL", [128, 128], 128, 1, 5, 0),
 ]
 
 

@@ -134,11 +134,13 @@ def test_split_gru_bf16x6(gpu, B, H, W, Ch, Cx, passes):
     close(unpm(hx[:, :Ch], B, H, W), ref, rtol=2e-5, atol=3e-5)
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 74, 75, 76, 84, 85, 86])
 def test_split_conv_every_tile_configuration(gpu, tile):
-    """The four tile configurations of the split kernel forced one by one (`debug_set_tile(100 + t)`: 64x64, 128x64, 128x128 with
-    four waves, 128x128 with eight waves) through the linear cases (ragged M, cout 40 / 96 / 126, partial K-steps) at 1, 2 and 3
-    planes and through both fused GRU epilogues."""
+    """The tile configurations of the split kernel forced one by one (`debug_set_tile(100 + t)`: 64x64, 128x64, 128x128 with
+    four waves, 128x128 / 256x128 / 128x256 with eight waves) through the linear cases (ragged M, cout 40 / 96 / 126, partial
+    K-steps) at 1, 2 and 3 planes and through both fused GRU epilogues.  On the eight-wave tiles (4-6) three planes stage their
+    weight planes by LDS-DMA (round 4, the default); 70 + t forces the register-staged path of the same tile, 80 + t the DMA path
+    for two planes as well."""
     torch.ops.pfk.debug_set_tile(100 + tile)
     try:
         for nsplit in (1, 2, 3):
