@@ -42,7 +42,9 @@ def _resolve_root():
     try:
         from oracle import stage_ref
         root = stage_ref.unpack()
-    except Exception:                                   # a damaged archive is "no reference", loudly visible in the skips
+    except Exception as e:                              # a damaged archive is "no reference" — said out loud, then visible in the skips
+        import warnings
+        warnings.warn(f"oracle/_ref could not be unpacked ({e!r}): the reference-class tests / bench legs will not run", RuntimeWarning)
         root = None
     return (root, "staged") if _has_tree(root) else ("/root/reference", None)
 
