@@ -159,7 +159,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& a, const f32x16 (&acc)[
 // row segment — four store instructions per block instead of sixteen, 8 rows x 128 B per instruction.  The accumulation order of
 // the arithmetic per element is unchanged (bit-identical results).  `lds` = block-shared scratch >= 16 KB that no wave reads
 // any more (callers sit behind their K loop's final barrier).
-template <int MT, int NT, int EPI>
+template <int MT, int NT, int EPI, bool PRELOAD = false>
 __device__ __forceinline__ void epilogue_lds(const GemmArgs& a, const f32x16 (&acc)[MT][NT], long long m_base, int n_base, int lane,
                                              long long batch, float* lds, int wid) {
   float* reg = lds + wid * 1024;                       // this wave's [32][32] block
@@ -174,6 +174,37 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs& a, const f32x16 (&a
   // the training path's fresh [M, cout] outputs with cout = 126 or 2 do not comply): wave-uniform fall-back to scalar accesses
   // (decided on the host: a pointer-to-integer cast here makes the compiler lose the global address space of every store below)
   const bool vout = a.vec_flags & 1, vres = a.vec_flags & 2, vbias = a.vec_flags & 4;
+  // GRU epilogues on wave tiles of at most two 32x32 blocks (the fp32 kernels): the epilogue's global operands — the loop-invariant
+  // pre-activation term (`residual`), h for r*h, z and h for the blend — are loaded for the WHOLE wave tile up front, so their
+  // latency runs under the LDS transposes instead of being paid once per block behind each `s_waitcnt lgkmcnt(0)` (round 4: the gate
+  // epilogues cost 2.7 % / 6.7 % of a z|r / q launch, gpurun_out/r4m_conv_b8.log).  Same values, same arithmetic: same bits.
+  // (PRELOAD: only the tile-grid kernel asks for it — the stream-K / persistent kernels are held to 168 registers for three blocks
+  //  per CU and spilled with the 32-48 extra ones)
+  constexpr bool PRE = PRELOAD && EPI != PFK_EPI_LINEAR && MT * NT <= 2;
+  f32x4 pre_res[PRE ? NT : 1][PRE ? MT : 1][4], pre_a[PRE ? NT : 1][PRE ? MT : 1][4], pre_b[PRE ? NT : 1][PRE ? MT : 1][4];
+  if constexpr (PRE) {
+    const int ch = a.ch_hidden;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = n_base + nt * 32 + c4;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+          const long long p = m_base + mt * 32 + pass * 8 + rrow;
+          const bool ok = p < a.M && n < a.b_rows;
+          const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+          pre_res[nt][mt][pass] = (ok && a.residual != nullptr) ? *reinterpret_cast<const f32x4*>(a.residual + p * a.residual_ld + n) : zero;
+          if constexpr (EPI == PFK_EPI_GRU_ZR) {
+            pre_a[nt][mt][pass] = (ok && n >= ch) ? *reinterpret_cast<const f32x4*>(a.h + p * a.h_ld + (n - ch)) : zero;
+          } else {
+            pre_a[nt][mt][pass] = ok ? *reinterpret_cast<const f32x4*>(a.aux_z + p * ch + n) : zero;
+            pre_b[nt][mt][pass] = ok ? *reinterpret_cast<const f32x4*>(a.h + p * a.h_ld + n) : zero;
+          }
+        }
+      }
+    }
+  }
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int n = n_base + nt * 32 + c4;
@@ -248,7 +279,8 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs& a, const f32x16 (&a
           const int ch = a.ch_hidden;
           // the loop-invariant part of the gate pre-activations (context features x their weight slice + bias, computed once per
           // forward — pfk.h, `residual` on the GRU epilogues): [M][cout] rows, 16-byte aligned (desc_to_args checks)
-          if (a.residual != nullptr) v += *reinterpret_cast<const f32x4*>(a.residual + p * a.residual_ld + n);
+          if constexpr (PRE) { if (a.residual != nullptr) v += pre_res[nt][mt][pass]; }
+          else if (a.residual != nullptr) v += *reinterpret_cast<const f32x4*>(a.residual + p * a.residual_ld + n);
           f32x4 g;
 #pragma unroll
           for (int e = 0; e < 4; ++e) g[e] = sigmoid_f(v[e]);
@@ -256,15 +288,22 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs& a, const f32x16 (&a
             *reinterpret_cast<f32x4*>(a.aux_z + p * ch + n) = g;
           } else {
             const int c = n - ch;
-            const f32x4 hv = *reinterpret_cast<const f32x4*>(a.h + p * a.h_ld + c);
+            f32x4 hv;
+            if constexpr (PRE) hv = pre_a[nt][mt][pass];
+            else hv = *reinterpret_cast<const f32x4*>(a.h + p * a.h_ld + c);
             *reinterpret_cast<f32x4*>(a.aux_rh + p * ch + c) = g * hv;
           }
         } else {  // PFK_EPI_GRU_Q
           if (n >= a.b_rows) continue;
           const int ch = a.ch_hidden;
-          if (a.residual != nullptr) v += *reinterpret_cast<const f32x4*>(a.residual + p * a.residual_ld + n);
-          const f32x4 z = *reinterpret_cast<const f32x4*>(a.aux_z + p * ch + n);
-          const f32x4 hv = *reinterpret_cast<const f32x4*>(a.h + p * a.h_ld + n);
+          if constexpr (PRE) { if (a.residual != nullptr) v += pre_res[nt][mt][pass]; }
+          else if (a.residual != nullptr) v += *reinterpret_cast<const f32x4*>(a.residual + p * a.residual_ld + n);
+          f32x4 z, hv;
+          if constexpr (PRE) { z = pre_a[nt][mt][pass]; hv = pre_b[nt][mt][pass]; }
+          else {
+            z = *reinterpret_cast<const f32x4*>(a.aux_z + p * ch + n);
+            hv = *reinterpret_cast<const f32x4*>(a.h + p * a.h_ld + n);
+          }
           f32x4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {

@@ -527,7 +527,7 @@ __global__ __launch_bounds__(256 * GROUPS) void conv_gemm_v3_kernel(const GemmAr
   }
 
   if constexpr (GROUPS == 1) {
-    epilogue_lds<MT, NT, EPI>(a, acc, m0 + wm0, n0 + wn0, lane, batch, smem, wid);   // behind the loop's final barrier
+    epilogue_lds<MT, NT, EPI, true>(a, acc, m0 + wm0, n0 + wn0, lane, batch, smem, wid);   // behind the loop's final barrier
   } else {
     // exchange accumulator halves: group g finishes registers [8g, 8g+8).
     // red[group][wave][tile][reg8][lane]: lane-contiguous, conflict-free.  (All stage reads are
