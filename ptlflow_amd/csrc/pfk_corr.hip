@@ -44,7 +44,10 @@ struct LookupArgs {
 // (pixels per workgroup: template parameter PIX, 4 by default — lookup_launch)
 
 // R = radius (compile-time: the (2R+1)^2 sample enumeration divides by constants), PIX pixels per workgroup.
-template <int PIX, int R, typename T>
+// SHFL (measurement variant, pfk_debug_set_lookup_pix(14)): the staged patch stays in the registers it was loaded into and
+// every tap is fetched with cross-lane reads (ds_bpermute) instead of LDS stores + loads — the alternative DESIGN.md section 3
+// weighs against the LDS staging; same arithmetic, same bits.  profiles/r04_e_lookup_shuffle.md has the numbers.
+template <int PIX, int R, typename T, bool SHFL = false>
 __global__ __launch_bounds__(256) void lookup_kernel(const LookupArgs a) {
   constexpr int n = 2 * R + 1, nn = n * n;
   __shared__ float s_patch[4][PIX][PATCH * PATCH_LD];
@@ -122,6 +125,39 @@ __global__ __launch_bounds__(256) void lookup_kernel(const LookupArgs a) {
           v[q][e3] = t;
         }
       }
+      if constexpr (SHFL) {
+        // element e of a patch lives in lane e & 63, register e >> 6: a tap is three cross-lane reads (one per register) and
+        // a select, per pixel (the register file cannot be indexed by a per-lane pixel number, so the flat sample list of
+        // the LDS path is not available: 2 passes per pixel, 47 idle lanes in the second)
+        wave_lds_sync();      // the tap tables
+        float* outl = a.out + (size_t)p0 * (unsigned)a.out_ld + l * nn;
+#pragma unroll
+        for (int q = 0; q < PIX; ++q) {
+#pragma unroll
+          for (int kk = 0; kk < (nn + 63) / 64; ++kk) {
+            const int k = lane + 64 * kk;
+            const bool valid = k < nn && p0 + q < M;
+            const int kc = k < nn ? k : 0;
+            const int i = kc / n, j = kc - i * n;
+            const float wx = s_wx[wid][q][i], wy = s_wy[wid][q][j];
+            const int e00 = (s_ry[wid][q][j] / PATCH_LD) * PATCH + s_rx[wid][q][i];
+            float tap[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const int e = e00 + (c & 1) + (c >> 1) * PATCH;
+              const float r0 = __shfl(v[q][0], e & 63, 64), r1 = __shfl(v[q][1], e & 63, 64), r2 = __shfl(v[q][2], e & 63, 64);
+              tap[c] = (e >> 6) == 0 ? r0 : ((e >> 6) == 1 ? r1 : r2);
+            }
+            const float ex = 1.0f - wx, sy = 1.0f - wy;
+            const float w_nw = sy * ex, w_ne = sy * wx, w_sw = wy * ex, w_se = wy * wx;
+            float t = tap[0] * w_nw;
+            t = fmaf(tap[1], w_ne, t);
+            t = fmaf(tap[2], w_sw, t);
+            t = fmaf(tap[3], w_se, t);
+            if (valid) outl[q * a.out_ld + k] = t;
+          }
+        }
+      } else {
 #pragma unroll
       for (int q = 0; q < PIX; ++q)
 #pragma unroll
@@ -132,9 +168,10 @@ __global__ __launch_bounds__(256) void lookup_kernel(const LookupArgs a) {
             s_patch[wid][q][yy * PATCH_LD + xx] = v[q][e3];
           }
         }
+      }
     }
     wave_lds_sync();
-    if (active) {
+    if (active && !SHFL) {
       // the PIX * (2R+1)^2 samples of this level as one flat list over the lanes (324 = 5.06 wave-iterations at R = 4
       // instead of 4 x 2 with 47 idle lanes in every second one)
       float* outl = a.out + (size_t)p0 * (unsigned)a.out_ld + l * nn;
@@ -195,16 +232,16 @@ __global__ __launch_bounds__(256) void fmap_pool2x2_kernel(const float* __restri
   *reinterpret_cast<f32x4*>(out + ((b * Ho + yo) * (long long)Wo + xo) * out_ld + c) = (((a00 + a01) + a10) + a11) * 0.25f;
 }
 
-int g_lookup_pix = 4;   // pixels per workgroup: 4 or 8 (pfk_debug_set_lookup_pix; tuning knob)
+int g_lookup_pix = 4;   // pixels per workgroup: 4 or 8; 14 = 4 with cross-lane tap reads (pfk_debug_set_lookup_pix; tuning knob)
 
-template <int PX, typename T>
+template <int PX, typename T, bool SHFL = false>
 int lookup_launch_pix(const LookupArgs& a, int radius, long long M, hipStream_t st) {
   const dim3 grid((unsigned)((M + PX - 1) / PX)), block(256);
   switch (radius) {
-    case 1: hipLaunchKernelGGL((lookup_kernel<PX, 1, T>), grid, block, 0, st, a); break;
-    case 2: hipLaunchKernelGGL((lookup_kernel<PX, 2, T>), grid, block, 0, st, a); break;
-    case 3: hipLaunchKernelGGL((lookup_kernel<PX, 3, T>), grid, block, 0, st, a); break;
-    default: hipLaunchKernelGGL((lookup_kernel<PX, 4, T>), grid, block, 0, st, a); break;
+    case 1: hipLaunchKernelGGL((lookup_kernel<PX, 1, T, SHFL>), grid, block, 0, st, a); break;
+    case 2: hipLaunchKernelGGL((lookup_kernel<PX, 2, T, SHFL>), grid, block, 0, st, a); break;
+    case 3: hipLaunchKernelGGL((lookup_kernel<PX, 3, T, SHFL>), grid, block, 0, st, a); break;
+    default: hipLaunchKernelGGL((lookup_kernel<PX, 4, T, SHFL>), grid, block, 0, st, a); break;
   }
   return pfk_launch_status();
 }
@@ -227,6 +264,7 @@ int lookup_launch(const pfk_lookup_desc* d, pfk_stream_t stream) {
   const long long M = (long long)d->B * d->h * d->w;
   if (M >= 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;   // the kernel's pixel arithmetic is 32-bit
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (g_lookup_pix == 14) return lookup_launch_pix<4, T, true>(a, d->radius, M, st);
   return g_lookup_pix == 8 ? lookup_launch_pix<8, T>(a, d->radius, M, st) : lookup_launch_pix<4, T>(a, d->radius, M, st);
 }
 
@@ -247,7 +285,7 @@ int pool_launch(const T* in, T* out, int64_t M, int H, int W, pfk_stream_t strea
 
 extern "C" {
 
-int pfk_debug_set_lookup_pix(int pix) { if (!pfk_debug_knobs_enabled()) return PFK_ERR_DISABLED; g_lookup_pix = pix == 8 ? 8 : 4; return PFK_OK; }
+int pfk_debug_set_lookup_pix(int pix) { if (!pfk_debug_knobs_enabled()) return PFK_ERR_DISABLED; g_lookup_pix = (pix == 8 || pix == 14) ? pix : 4; return PFK_OK; }
 
 int pfk_corr_lookup_f32(const pfk_lookup_desc* d, pfk_stream_t stream) { return lookup_launch<float>(d, stream); }
 

@@ -21,7 +21,8 @@ for B in (1, 8):
     out = torch.empty(B * N, 324, device=dev)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ref = None
-    for variant in (0,):
+    for variant in (4, 14, 8, 4, 14):     # pixels per workgroup; 14 = 4 with cross-lane tap reads instead of the LDS patch
+        ops.debug_set_lookup_pix(variant)
         for _ in range(3):
             ops.corr_lookup(lv, coords, r, out)
         e0.record()
@@ -32,6 +33,7 @@ for B in (1, 8):
         alg = B * (N * L * (100 + 81) * 4 + 8 * N)
         same = True if ref is None else bool(torch.equal(ref, out))
         ref = out.clone() if ref is None else ref
+        ops.debug_set_lookup_pix(4)
         print(f"lookup B={B} variant {variant}: {us:.1f} us, algorithmic {alg/1e6:.1f} MB -> {alg/us/1e6:.2f} TB/s ({100*alg/us/1e6/8:.1f}% of 8 TB/s) same={same}")
     # K7 on-demand correlation: the per-pixel kernel (mode 1) against the window-sharing MFMA kernel on 8x4 / 8x8 patches (2 / 3)
     # and the library's choice (0), for a smooth flow field (bicubic-upsampled low-resolution noise, +-20 px: what a flow network

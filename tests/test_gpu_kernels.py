@@ -93,6 +93,29 @@ def test_lookup_bit_exact(gpu, B, h, w, L, r):
         assert bool(same.all()), f"{name}: {(~same).sum().item()} of {same.numel()} differ, max {(got - ref).abs().nan_to_num().max().item():.3e}"
 
 
+@pytest.mark.parametrize("variant", [8, 14])
+def test_lookup_variants_bit_exact(gpu, variant):
+    """The two measurement variants of K3 (8 pixels per workgroup; cross-lane tap reads instead of the LDS patch,
+    profiles/r04_e_lookup_shuffle.md) produce the oracle's bits too — the timing table compares equal results."""
+    torch.manual_seed(3)
+    B, h, w, L, r, D = 1, 23, 39, 4, 4, 32
+    f1, f2 = torch.randn(B, D, h, w), torch.randn(B, D, h, w)
+    pyr = O.correlation_pyramid(f1, f2, L)
+    lv = [p.view(B * h * w, p.shape[-2], p.shape[-1]).contiguous().cuda() for p in pyr]
+    n = 2 * r + 1
+    torch.ops.pfk.debug_set_lookup_pix(variant)
+    try:
+        for name, c in _coords_cases(B, h, w):
+            ref = O.lookup(pyr, c, r)
+            out = torch.full((B * h * w, L * n * n), -7.0, device=gpu)
+            torch.ops.pfk.corr_lookup(lv, c.cuda(), r, out)
+            got = unpm(out, B, h, w)
+            same = (got == ref) | (torch.isnan(got) & torch.isnan(ref))
+            assert bool(same.all()), f"{name}: {(~same).sum().item()} of {same.numel()} differ"
+    finally:
+        torch.ops.pfk.debug_set_lookup_pix(4)
+
+
 def _packed(weight, segs):
     from ptlflow_amd.packing import pack_conv_weight
     return pack_conv_weight(weight, segs).cuda()
