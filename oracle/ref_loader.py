@@ -73,6 +73,15 @@ def _install_stubs() -> None:
             def log_dict(self, *a, **k):
                 pass
 
+            # lightning's DeviceDtypeModuleMixin: several families read `self.dtype` / `self.device` in forward()
+            @property
+            def dtype(self):
+                return next((p.dtype for p in self.parameters() if p.is_floating_point()), None)
+
+            @property
+            def device(self):
+                return next((p.device for p in self.parameters()), None)
+
         pl.LightningModule = LightningModule
         lightning.pytorch = pl
         sys.modules["lightning"] = lightning
@@ -199,6 +208,18 @@ def load() -> None:
     for fam in ("raft", "gma", "sea_raft", "ccmr", "ms_raft_plus"):
         _namespace(f"ptlflow.models.{fam}", os.path.join(root, "models", fam))
     _LOADED = True
+
+
+def ensure_family(fam: str) -> bool:
+    """Make `ptlflow.models.<fam>` importable too (any family of the reference's zoo, not only the five hot-path ones).
+    Returns False where the family's directory is not there (the staged archive carries the hot-path families only)."""
+    load()
+    path = os.path.join(REFERENCE_ROOT, "ptlflow", "models", fam)
+    if not os.path.isdir(path):
+        return False
+    if f"ptlflow.models.{fam}" not in sys.modules:
+        _namespace(f"ptlflow.models.{fam}", path)
+    return True
 
 
 def ref_module(dotted: str):

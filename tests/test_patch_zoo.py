@@ -1,0 +1,110 @@
+"""`patch.accelerate` across the reference's model zoo (CPU, build container only).
+
+north_star's drop-in claim is about three seams of the RAFT family; everything else `ptlflow.get_model()` can return must be
+left exactly as it was.  Many of the zoo's families are RAFT descendants that reuse the attribute names the seams look for
+(`update_block`, `fnet` / `cnet`, `upsample_flow`, a module-level `get_corr_block`) with different shapes, arities or
+semantics — csflow, lcv, llaflow, skflow, gmflownet, memflow, dip, rapidflow, rpknet, dpflow — so "accelerate is safe to call on
+any model" is a property worth a test of its own: for every family that can be constructed here, the forward after
+`accelerate()` (CPU tensors: no seam is eligible) equals the forward before it bit for bit, no seam wraps a block whose shapes
+the kernels do not implement, and `restore()` puts the original objects back.
+The hot-path families themselves (raft, gma, ccmr, ms_raft_plus, sea_raft) are covered by tests/test_patch_dispatch.py (CPU)
+and tests/test_gpu_reference_models.py (MI355X)."""
+import importlib
+import inspect
+import os
+import warnings
+
+import pytest
+import torch
+
+from oracle import ref_loader
+
+pytestmark = [pytest.mark.reference,
+              pytest.mark.skipif(ref_loader.REFERENCE_KIND not in ("tree", "env"), reason="needs the whole reference tree")]
+
+# families that import and construct with this image's packages (the others need timm / cupy / torch_scatter / compiled
+# extensions); (family, class)
+ZOO = [("csflow", "CSFlow"), ("dip", "DIP"), ("dpflow", "DPFlow"), ("flow1d", "Flow1D"), ("gmflow", "GMFlow"),
+       ("gmflownet", "GMFlowNet"), ("lcv", "LCV_RAFT"), ("llaflow", "LLAFlow"), ("memflow", "MemFlow"),
+       ("rapidflow", "RAPIDFlow"), ("rpknet", "RPKNet"), ("skflow", "SKFlow"), ("unimatch", "UniMatch"),
+       ("fastflownet", "FastFlowNet"), ("hd3", "HD3"), ("irr", "IRRPWC"), ("liteflownet", "LiteFlowNet"),
+       ("neuflow", "NeuFlow"), ("neuflow2", "NeuFlow2"), ("pwcnet", "PWCDCNet"), ("scopeflow", "ScopeFlow"),
+       ("starflow", "StarFlow")]
+
+
+def _find_class(fam, name):
+    if not ref_loader.ensure_family(fam):
+        pytest.skip(f"{fam}: not in this reference tree")
+    root = os.path.join(ref_loader.REFERENCE_ROOT, "ptlflow", "models", fam)
+    for fn in sorted(os.listdir(root)):
+        if not fn.endswith(".py") or fn == "__init__.py":
+            continue
+        try:
+            mod = importlib.import_module(f"ptlflow.models.{fam}.{fn[:-3]}")
+        except Exception:       # a helper module with a dependency this image lacks
+            continue
+        cls = getattr(mod, name, None)
+        if inspect.isclass(cls) and cls.__module__ == mod.__name__:
+            return cls
+    pytest.skip(f"{fam}.{name}: not importable here")
+
+
+@pytest.mark.parametrize("fam,name", ZOO)
+def test_accelerate_leaves_foreign_families_unchanged(fam, name):
+    import ptlflow_amd
+    from ptlflow_amd import patch
+    from ptlflow_amd.encoder import PfkEncoder
+    try:
+        ptlflow_amd.load_native()
+    except Exception as e:
+        pytest.skip(f"native libs unavailable: {e}")
+    cls = _find_class(fam, name)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        torch.manual_seed(0)
+        model = cls().eval()
+        x = {"images": torch.rand(1, 2, 3, 128, 192)}
+        with torch.no_grad():
+            before = model(x)["flows"]
+        originals = {a: getattr(model, a, None) for a in ("update_block", "fnet", "cnet")}
+        assert patch.accelerate(model) is model
+        # no kernel implements these families' blocks: nothing may be wrapped (a wrapped block would refuse CPU tensors below,
+        # but say it here, by name)
+        assert not isinstance(getattr(model, "update_block", None), patch.PfkUpdateBlock), f"{fam}: update block wrapped"
+        for a in ("fnet", "cnet"):
+            enc = getattr(model, a, None)
+            if isinstance(enc, PfkEncoder):          # a BasicEncoder with RAFT's own layout: allowed, and inert on CPU tensors
+                assert type(enc._ref[0]).__name__ in ("BasicEncoder", "SmallEncoder")
+        with torch.no_grad():
+            after = model(x)["flows"]
+        assert torch.equal(before, after), f"{fam}: forward changed by accelerate() (max {(before - after).abs().max():.3e})"
+        patch.restore(model)
+        for a, o in originals.items():
+            assert getattr(model, a, None) is o, f"{fam}: restore() did not put {a} back"
+        assert "upsample_flow" not in model.__dict__
+        with torch.no_grad():
+            assert torch.equal(model(x)["flows"], before)
+
+
+@pytest.mark.parametrize("fam", ["rapidflow", "rpknet", "skflow", "matchflow"])
+def test_hooked_siblings_share_rafts_corrblock(fam):
+    """Seam B1 installs its hook on every model module that exposes `get_corr_block`; for families without an entry in the
+    pyramid table it assumes RAFT's all-pairs block (avg-pool pyramid, radius-r window, x-offset-major).  These four zoo
+    families get the hook: their private `CorrBlock` copies must BE that block — volume and lookup equal to the oracle, bit for
+    bit — or the hook would change their results on the GPU."""
+    from oracle import raft_oracle as O
+    if not ref_loader.ensure_family(fam):
+        pytest.skip(f"{fam}: not in this reference tree")
+    try:
+        mod = importlib.import_module(f"ptlflow.models.{fam}.corr")
+    except Exception as e:
+        pytest.skip(f"{fam}.corr not importable here: {e!r}")
+    g = torch.Generator().manual_seed(4)
+    f1, f2 = torch.randn(1, 32, 16, 24, generator=g), torch.randn(1, 32, 16, 24, generator=g)
+    cb = mod.get_corr_block(f1, f2, num_levels=4, radius=4)
+    assert type(cb).__name__ == "CorrBlock"
+    pyr = O.correlation_pyramid(f1, f2, 4)
+    for lvl, (a, b) in enumerate(zip(cb.corr_pyramid, pyr)):
+        assert torch.equal(a.reshape(b.shape), b), f"{fam}: pyramid level {lvl} differs from RAFT's"
+    c = O.coords_grid(1, 16, 24) + torch.rand(1, 2, 16, 24, generator=g) * 12 - 6
+    assert torch.equal(cb(c), O.lookup(pyr, c, 4))
