@@ -3,7 +3,7 @@
 /root/reference exists only in the build container; the MI355X box gets a snapshot of THIS tree (untracked files
 included).  `stage()` — called by `__graft_entry__.build()` wherever /root/reference is present — packs exactly the
 files `oracle/ref_loader.py` imports (the raft / gma / sea_raft / ccmr / ms_raft_plus model packages, `base_model`,
-and the five `ptlflow/utils` modules they pull in) into ONE archive, `oracle/_ref/ptlflow_ref.zip`, next to a
+the five `ptlflow/utils` modules they pull in, and the three sibling families seam B1 also engages in: rapidflow, rpknet, skflow) into ONE archive, `oracle/_ref/ptlflow_ref.zip`, next to a
 manifest of per-file sha256 sums.  `oracle/_ref/` is git-ignored (no reference source ever enters the history) but
 not gpurun-ignored, exactly like the built `.so` files.  On a machine without /root/reference,
 `ref_loader.reference_root()` unpacks the archive into a per-content temporary directory and imports the reference's
@@ -29,6 +29,10 @@ SOURCE_ROOT = "/root/reference"
 # packages whose *.py files are staged whole (they are small and import each other), and single utility modules
 PACKAGES = ["ptlflow/models/raft", "ptlflow/models/gma", "ptlflow/models/sea_raft", "ptlflow/models/ccmr",
             "ptlflow/models/ms_raft_plus", "ptlflow/models/base_model"]
+# sibling families whose model modules expose `get_corr_block` with RAFT's own CorrBlock (tests/test_patch_zoo.py): seam B1
+# engages inside them, tests/test_gpu_reference_siblings.py runs the real classes on the MI355X.  Staged with their
+# sub-packages (local_timm/).
+PACKAGES_RECURSIVE = ["ptlflow/models/rapidflow", "ptlflow/models/rpknet", "ptlflow/models/skflow"]
 MODULES = ["ptlflow/utils/correlation.py", "ptlflow/utils/external/raft.py", "ptlflow/utils/flow_metrics.py",
            "ptlflow/utils/registry.py", "ptlflow/utils/utils.py", "ptlflow/utils/timer.py", "LICENSE"]
 
@@ -38,6 +42,10 @@ def _file_list(root: str):
     for pkg in PACKAGES:
         d = os.path.join(root, pkg)
         files += [f"{pkg}/{n}" for n in sorted(os.listdir(d)) if n.endswith(".py")]
+    for pkg in PACKAGES_RECURSIVE:
+        for d, _dirs, names in sorted(os.walk(os.path.join(root, pkg))):
+            rel = os.path.relpath(d, root).replace(os.sep, "/")
+            files += [f"{rel}/{n}" for n in sorted(names) if n.endswith(".py")]
     files += [m for m in MODULES if os.path.isfile(os.path.join(root, m))]
     return files
 

@@ -1101,8 +1101,12 @@ int launch(const GemmArgs& a0, int epi, int batches, hipStream_t st) {
     // Batch 1 (7040 pixels, round-2 sweep): z|r conv 440 tiles x 60 steps 72.5 -> 63.7 us, fh|mask conv1 880 x 36 80.5 -> 75.8,
     // convc2 330 x 72 80.4 -> 62.5; it loses for 220-tile launches (q 41.8 -> 43.5, conv 47.8 -> 48.2: one tile per CU is
     // already balanced) and for short K (convc1 18.7 -> 28.7, mask conv2 25.7 -> 37.6).
+    // Round 4: the context hoist shortened the z|r launches to 440 tiles x 40 steps, where the tile grid (all 440 blocks resident
+    // at two per CU, sharing the matrix pipe) is 2-4 % ahead again — 51.9 vs 54.1, 49.9 vs 51.4 us (gpurun_out/y_conv_b1.log).
+    // What pays for a stream-K launch's segment prologues and fix-up is the work per CU: >= 80 K-steps (17 600 < 20 480 <=
+    // 23 760 of convc2, 26 400 of the un-hoisted z|r, 31 680 of fh|mask conv1).
     const bool sk = sk_fits && a.sk_ws != nullptr && batches == 1 && blocks64 > 256 && blocks64 < 4 * 256 && fill < 0.92 &&
-                    a.sk_steps >= 24;
+                    a.sk_steps >= 24 && blocks64 * (long long)a.sk_steps >= 80LL * 256;
     // a handful of output tiles with a very long K (GEMM-shaped callers with a tall reduction): only stream-K fills the chip
     const bool sk_long = sk_fits && a.sk_ws != nullptr && batches == 1 && blocks64 <= 64 && a.sk_steps >= 128;
     // (Round 4: stream-K on the 1000..4000-tile grids of batch 8 was measured and NOT taken — convc2 (2640 tiles x 72 K-steps)

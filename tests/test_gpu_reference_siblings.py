@@ -1,0 +1,89 @@
+"""Seam B1 inside the reference's sibling families — the real `RAPIDFlow`, `RPKNet` and `SKFlow` classes on the MI355X.
+
+Their model modules import a `get_corr_block` whose `CorrBlock` is RAFT's, copy for copy (tests/test_patch_zoo.py pins each
+against the oracle, bit for bit), so `patch.accelerate` installs the correlation hook in them as well — with shapes the RAFT
+tests never produce: rapidflow / rpknet build ONE-level pyramids (num_levels = 1, radius 4) on 128-channel maps at three
+scales down to 4x6 pixels (rapidflow.py:300, rpknet.py), skflow the four-level one on 256 channels.  Everything else in these
+models (NeXt1D / PKConv encoders, their own update blocks) is foreign to the kernels and must stay the reference's torch code.
+
+Checked: the hook served every correlation block of the forward; the accelerated forward equals the SAME model's stock
+PyTorch-ROCm forward on the GPU and its CPU forward to fp32 re-association noise; `restore()` gives the stock result back.
+The classes come from /root/reference or, on the GPU box, from the archive oracle/stage_ref.py staged at build time."""
+import copy
+import sys
+import warnings
+
+import pytest
+import torch
+
+from oracle import raft_oracle as O
+from oracle import ref_loader
+
+pytestmark = [pytest.mark.gpu, pytest.mark.reference,
+              pytest.mark.skipif(not ref_loader.reference_available(),
+                                 reason="no reference: run `python -c 'import __graft_entry__ as g; g.build()'` where "
+                                        "/root/reference exists; it stages oracle/_ref/ for the GPU box")]
+
+# family, module, class, correlation blocks per forward at 128x192 (rapidflow / rpknet: one per pyramid scale)
+SIBLINGS = [("rapidflow", "rapidflow", "RAPIDFlow", 3), ("rpknet", "rpknet", "RPKNet", 3), ("skflow", "skflow", "SKFlow", 1)]
+
+
+@pytest.mark.parametrize("fam,modname,clsname,blocks", SIBLINGS)
+def test_sibling_family_whole_model(gpu, fam, modname, clsname, blocks):
+    from ptlflow_amd import patch
+    assert ref_loader.ensure_family(fam), f"{fam} was not staged"
+    mod = ref_loader.ref_module(f"ptlflow.models.{fam}.{modname}")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        torch.manual_seed(1234)
+        model = getattr(mod, clsname)().eval()
+    x = O.smooth_pair(1, 128, 192, seed=11)
+    with torch.no_grad():
+        # the CPU forward runs on a copy: rapidflow / rpknet cache derived weights in plain attributes during a forward
+        # (next1d.py:135, pkconv.py:95), which `.to(device)` does not move
+        cpu = copy.deepcopy(model)({"images": x.clone()})["flows"][:, 0]
+        model.to(gpu)
+        stock = model({"images": x.to(gpu)})["flows"][:, 0].float().cpu()
+        stock2 = model({"images": x.to(gpu)})["flows"][:, 0].float().cpu()    # the stock forward's own run-to-run spread
+    update_block, fnet = model.update_block, getattr(model, "fnet", None)
+    hook_before = mod.get_corr_block
+    patch.accelerate(model)
+    assert mod.get_corr_block is not hook_before
+    served = [0]
+    orig = patch._pfk_get_corr_block
+
+    def counting(*a, **k):
+        served[0] += 1
+        return orig(*a, **k)
+
+    patch._pfk_get_corr_block = counting
+    try:
+        assert model.update_block is update_block and getattr(model, "fnet", None) is fnet, "a foreign block was wrapped"
+        with torch.no_grad():
+            got = model({"images": x.to(gpu)})["flows"][:, 0].float().cpu()
+        assert served[0] == blocks, f"seam B1 served {served[0]} correlation blocks of {clsname}.forward, expected {blocks}"
+    finally:
+        patch._pfk_get_corr_block = orig
+        patch.restore(model)
+    with torch.no_grad():
+        again = model({"images": x.to(gpu)})["flows"][:, 0].float().cpu()
+    assert torch.isfinite(got).all()
+    scale = float(cpu.abs().max()) + 1e-6
+    e_stock = O.epe(got, stock)
+    e_cpu = O.epe(got, cpu)
+    e_base = O.epe(stock, cpu)       # what stock GPU kernels (rocBLAS / MIOpen) already differ from the CPU by
+    print(f"{clsname}: |flow| max {scale:.3f}; accelerated vs stock GPU EPE mean {e_stock[0]:.3e} max {e_stock[1]:.3e}; vs CPU "
+          f"{e_cpu[0]:.3e} / {e_cpu[1]:.3e}; stock GPU vs CPU {e_base[0]:.3e} / {e_base[1]:.3e}", file=sys.stderr)
+    # random-init networks, a dozen refinement steps: fp32 re-association noise stays at the 1e-5 level relative to the flow
+    assert e_stock[0] <= 2e-5 * max(1.0, scale) and e_stock[1] <= 2e-4 * max(1.0, scale)
+    assert e_cpu[0] <= 2e-5 * max(1.0, scale) + 2 * e_base[0]
+    # restore(): the module's own function object is back, no instance attribute shadows the class's methods, and the forward
+    # is the stock one again (bit for bit where the stock forward is run-to-run deterministic; within its own spread where
+    # MIOpen's kernels are not)
+    assert mod.get_corr_block is hook_before and "upsample_flow" not in model.__dict__
+    spread = O.epe(stock2, stock)[1]
+    print(f"{clsname}: stock run-to-run max {spread:.3e}; after restore() vs stock max {O.epe(again, stock)[1]:.3e}", file=sys.stderr)
+    if spread == 0.0:
+        assert torch.equal(again, stock), "restore() did not give the stock forward back"
+    else:
+        assert O.epe(again, stock)[1] <= 4 * spread
