@@ -49,6 +49,10 @@ _UPDATE_BLOCKS: Dict[Tuple[str, str], Callable[[int], UpdateSpec]] = {
     ("ptlflow.models.ccmr.update", "BasicUpdateBlock"): lambda cc: ccmr_spec(cc),
     # ms_raft_plus/update.py:119-153 (stack_coords=False): RAFT's block with a x2 mask head
     ("ptlflow.models.ms_raft_plus.update", "BasicUpdateBlock"): lambda cc: ms_raft_plus_spec(cc),
+    # lcv/update.py is raft/update.py reformatted (LCV-RAFT swaps the cost volume for a learnable one, lcv/corr_lcv.py, and
+    # keeps RAFT's encoders, update block and loop: lcv_raft.py:143-179)
+    ("ptlflow.models.lcv.update", "BasicUpdateBlock"): lambda cc: _with_corr_channels(basic_spec(), cc),
+    ("ptlflow.models.lcv.update", "SmallUpdateBlock"): lambda cc: _with_corr_channels(small_spec(), cc),
 }
 # parameters of a matched block that belong to a sub-module the wrapper keeps calling as is (not part of the shape check)
 _FOREIGN_PREFIX = {("ptlflow.models.ccmr.update", "BasicUpdateBlock"): "aggregator."}
@@ -57,6 +61,8 @@ _ENCODERS = {
     ("ptlflow.models.raft.extractor", "BasicEncoder"),
     ("ptlflow.models.raft.extractor", "SmallEncoder"),     # raft_small: bottleneck blocks, extractor.py:197-267
     ("ptlflow.models.gma.extractor", "BasicEncoder"),
+    ("ptlflow.models.lcv.extractor", "BasicEncoder"),       # lcv/extractor.py == raft/extractor.py, byte for byte
+    ("ptlflow.models.lcv.extractor", "SmallEncoder"),
 }
 # families whose CorrBlock pyramid is not the avg-pool one (sea_raft/corr.py:71-84)
 _PYRAMID = {"ptlflow.models.sea_raft.sea_raft": "bilinear_f2"}

@@ -87,3 +87,39 @@ def test_sibling_family_whole_model(gpu, fam, modname, clsname, blocks):
         assert torch.equal(again, stock), "restore() did not give the stock forward back"
     else:
         assert O.epe(again, stock)[1] <= 4 * spread
+
+
+@pytest.mark.parametrize("clsname,small", [("LCV_RAFT", False), ("LCV_RAFTSmall", True)])
+def test_lcv_raft_whole_model(gpu, clsname, small):
+    """LCV-RAFT (lcv/lcv_raft.py:124-189): RAFT's encoders, update block and loop around a learnable cost volume — lcv/update.py
+    and lcv/extractor.py are RAFT's files, so seams B3 (update block), B4 (encoders) and B5 (`upsample_flow`) serve the real
+    class; its own `corr_block` (lcv/corr_lcv.py) stays the reference's torch code."""
+    from ptlflow_amd import patch
+    from ptlflow_amd.encoder import PfkEncoder
+    assert ref_loader.ensure_family("lcv"), "lcv was not staged"
+    mod = ref_loader.ref_module("ptlflow.models.lcv.lcv_raft")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        torch.manual_seed(1234)
+        model = getattr(mod, clsname)().eval()
+    x = O.smooth_pair(1, 256, 320, seed=12)
+    with torch.no_grad():
+        cpu = copy.deepcopy(model)({"images": x.clone()})["flows"][:, 0]
+        model.to(gpu)
+        stock = model({"images": x.to(gpu)})["flows"][:, 0].float().cpu()
+    patch.accelerate(model)
+    try:
+        assert isinstance(model.update_block, patch.PfkUpdateBlock) and isinstance(model.fnet, PfkEncoder)
+        assert isinstance(model.cnet, PfkEncoder) and model.fnet.small == small
+        with torch.no_grad():
+            got = model({"images": x.to(gpu)})["flows"][:, 0].float().cpu()
+        assert small or model.__dict__["upsample_flow"].ok is True, "seam B5 rejected LCV_RAFT.upsample_flow"
+    finally:
+        patch.restore(model)
+    assert torch.isfinite(got).all()
+    scale = float(cpu.abs().max()) + 1e-6
+    e_stock, e_cpu, e_base = O.epe(got, stock), O.epe(got, cpu), O.epe(stock, cpu)
+    print(f"{clsname}: |flow| max {scale:.3f}; accelerated vs stock GPU EPE mean {e_stock[0]:.3e} max {e_stock[1]:.3e}; vs CPU "
+          f"{e_cpu[0]:.3e} / {e_cpu[1]:.3e}; stock GPU vs CPU {e_base[0]:.3e} / {e_base[1]:.3e}", file=sys.stderr)
+    assert e_cpu[0] <= 2e-5 * max(1.0, scale) + 2 * e_base[0] and e_cpu[1] <= 2e-4 * max(1.0, scale) + 2 * e_base[1]
+    assert e_stock[0] <= 2e-5 * max(1.0, scale) + 2 * e_base[0]
