@@ -99,8 +99,14 @@ class CorrBlock:
     backward runs on libpfk too (`_PyramidToken` / `_LookupFn`) and delivers the gradients of ``fmap1`` / ``fmap2``."""
 
     def __init__(self, fmap1: torch.Tensor, fmap2: torch.Tensor, num_levels: int = 4, radius: int = 4,
-                 pyramid: str = "avgpool", volume_dtype: Optional[torch.dtype] = None):
-        """``volume_dtype``: storage type of the pyramid — ``torch.float32`` (exact fp32 products on the fp32 matrix cores, the
+                 pyramid: str = "avgpool", volume_dtype: Optional[torch.dtype] = None, channels_last: bool = True):
+        """``channels_last``: the tensor a lookup returns is a channels-last VIEW of the pixel-major buffer (what this package's
+        update block reads without a transpose).  ``False`` returns a plain contiguous NCHW tensor instead — for callers whose
+        consumer is torch's own convolutions: a channels-last input makes PyTorch run (and propagate) the channels-last memory
+        format through the caller's whole update block, which costs the reference's SKFlow 25 ms per forward on MIOpen
+        (profiles/r04_f_dropin_speedup.md); one 9 MB transpose per lookup is cheap next to that.
+
+        ``volume_dtype``: storage type of the pyramid — ``torch.float32`` (exact fp32 products on the fp32 matrix cores, the
         parity path) or ``torch.bfloat16`` (bf16 operands and a bf16 volume: what the reference's matmul yields under
         ``torch.autocast(bfloat16)``; half the HBM bytes).  Default: bf16 only when the feature maps arrive in bfloat16 (the
         caller runs under bf16 autocast), fp32 otherwise — in particular for float16 maps (the reference's own reduced-precision
@@ -114,6 +120,7 @@ class CorrBlock:
         _ops()
         self.num_levels = num_levels
         self.radius = radius
+        self.channels_last = channels_last
         self.pyramid_mode = pyramid
         if pyramid not in ("avgpool", "bilinear_f2"):
             raise ValueError(f"unknown pyramid mode {pyramid!r}")
@@ -273,6 +280,9 @@ class CorrBlock:
     def __call__(self, coords: torch.Tensor) -> torch.Tensor:
         out = self.lookup_pm(coords)
         res = out.view(self.B, self.h, self.w, out.shape[1])[..., : self.channels].permute(0, 3, 1, 2)
+        if not self.channels_last:
+            res = res.contiguous()
+            return res if self.out_dtype == torch.float32 else res.to(self.out_dtype)
         if self.out_dtype != torch.float32:
             res = res.to(self.out_dtype)
         elif out.shape[1] != self.channels:
@@ -336,8 +346,10 @@ class AlternateCorrBlock:
 
 
 def get_corr_block(fmap1: torch.Tensor, fmap2: torch.Tensor, num_levels: int = 4, radius: int = 4,
-                   alternate_corr: bool = False, pyramid: str = "avgpool", volume_dtype: Optional[torch.dtype] = None):
+                   alternate_corr: bool = False, pyramid: str = "avgpool", volume_dtype: Optional[torch.dtype] = None,
+                   channels_last: bool = True):
     """Same signature as ptlflow/models/raft/corr.py:104-118; ``alternate_corr=True`` selects the on-demand block."""
     if alternate_corr:
         return AlternateCorrBlock(fmap1, fmap2, num_levels=num_levels, radius=radius)
-    return CorrBlock(fmap1, fmap2, num_levels=num_levels, radius=radius, pyramid=pyramid, volume_dtype=volume_dtype)
+    return CorrBlock(fmap1, fmap2, num_levels=num_levels, radius=radius, pyramid=pyramid, volume_dtype=volume_dtype,
+                     channels_last=channels_last)

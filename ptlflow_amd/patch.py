@@ -183,10 +183,14 @@ def _make_corr_hook(module_name: str, original):
         # through `pfk_corr_lookup_bwd_f32` / `pfk_corr_volume_bwd_f32` — training); CPU tensors, alternate_corr, other
         # shapes stay on the reference's own implementation.
         if fmap1.is_cuda and not alternate_corr and not kw and _supported_envelope(fmap1, fmap2, num_levels, radius):
-            return _pfk_get_corr_block(fmap1, fmap2, num_levels=num_levels, radius=radius, pyramid=pyramid)
+            return _pfk_get_corr_block(fmap1, fmap2, num_levels=num_levels, radius=radius, pyramid=pyramid,
+                                       channels_last=get_corr_block.channels_last)
         return original(fmap1=fmap1, fmap2=fmap2, num_levels=num_levels, radius=radius, alternate_corr=alternate_corr, **kw)
 
     get_corr_block.pyramid = pyramid
+    # layout of the lookups handed back: a channels-last view for this package's own update block (no transpose), plain NCHW
+    # for a model whose update block stays torch code (set by `accelerate`, see CorrBlock.__init__)
+    get_corr_block.channels_last = True
     return get_corr_block
 
 
@@ -270,6 +274,9 @@ def accelerate(model: torch.nn.Module, corr: bool = True, update_block: bool = T
         spec = match_update_block(model.update_block)
         if spec is not None:
             model.update_block = PfkUpdateBlock(model.update_block, spec, conv_precision)
+    hook = getattr(mod, "get_corr_block", None)
+    if hasattr(mod, _ORIG) and hasattr(hook, "channels_last"):
+        hook.channels_last = isinstance(getattr(model, "update_block", None), PfkUpdateBlock)
     if encoders:
         # seam B4: the BasicEncoder feature / context networks (raft, gma: `self.fnet`, `self.cnet`)
         from .encoder import PfkEncoder

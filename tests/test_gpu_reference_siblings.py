@@ -54,7 +54,9 @@ def test_sibling_family_whole_model(gpu, fam, modname, clsname, blocks):
 
     def counting(*a, **k):
         served[0] += 1
-        return orig(*a, **k)
+        block = orig(*a, **k)
+        assert block.channels_last is False, "a torch consumer must get plain NCHW lookups (memory-format propagation)"
+        return block
 
     patch._pfk_get_corr_block = counting
     try:

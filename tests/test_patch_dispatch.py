@@ -46,6 +46,7 @@ def test_own_families_are_wrapped(fam, cls, kw):
         assert isinstance(model.fnet, PfkEncoder) and isinstance(model.cnet, PfkEncoder)
         assert model.fnet.small == (cls == "RAFTSmall")      # raft_small: the bottleneck SmallEncoder path of EncoderEngine
         assert mod.get_corr_block is not orig and mod.get_corr_block.pyramid == "avgpool"
+        assert mod.get_corr_block.channels_last is True        # our own update block reads the pixel-major buffer behind the view
         assert set(model.state_dict()) == keys
     finally:
         patch.restore(model)
@@ -94,6 +95,8 @@ def test_foreign_blocks_are_left_alone(fam, cls, kw, pyramid):
         assert getattr(model, "fnet", None) is fnet and getattr(model, "cnet", None) is cnet
         assert not isinstance(fnet, PfkEncoder) and not isinstance(cnet, PfkEncoder)
         assert mod.get_corr_block is not orig and mod.get_corr_block.pyramid == pyramid
+        # the consumer of the lookups is torch code here: plain NCHW tensors, not the channels-last view our own block takes
+        assert mod.get_corr_block.channels_last is False
         # CPU tensors: the hook hands the call to the family's own CorrBlock
         cb = mod.get_corr_block(fmap1=torch.randn(1, 32, 16, 16), fmap2=torch.randn(1, 32, 16, 16), num_levels=2, radius=3)
         assert type(cb).__module__ == f"ptlflow.models.{fam}.corr"
