@@ -87,8 +87,8 @@ def test_sibling_family_whole_model(gpu, fam, modname, clsname, blocks):
     print(f"{clsname}: stock run-to-run max {spread:.3e}; after restore() vs stock max {O.epe(again, stock)[1]:.3e}", file=sys.stderr)
     if spread == 0.0:
         assert torch.equal(again, stock), "restore() did not give the stock forward back"
-    else:
-        assert O.epe(again, stock)[1] <= 4 * spread
+    else:       # two samples of a run-to-run spread: leave room for a third one to land further out
+        assert O.epe(again, stock)[1] <= max(4 * spread, 2e-5 * max(1.0, scale))
 
 
 @pytest.mark.parametrize("clsname,small", [("LCV_RAFT", False), ("LCV_RAFTSmall", True)])
