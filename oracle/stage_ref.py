@@ -33,7 +33,8 @@ PACKAGES = ["ptlflow/models/raft", "ptlflow/models/gma", "ptlflow/models/sea_raf
 # engages inside them, tests/test_gpu_reference_siblings.py runs the real classes on the MI355X.  Staged with their
 # sub-packages (local_timm/).
 PACKAGES_RECURSIVE = ["ptlflow/models/rapidflow", "ptlflow/models/rpknet", "ptlflow/models/skflow",
-                      "ptlflow/models/lcv"]      # lcv: RAFT's encoders / update block / loop around a learnable cost volume (B3-B5)
+                      "ptlflow/models/lcv",      # lcv: RAFT's encoders / update block / loop around a learnable cost volume (B3-B5)
+                      "ptlflow/models/llaflow"]  # llaflow: RAFT's / GMA's update block and encoders around its own cost volume (B3-B5)
 MODULES = ["ptlflow/utils/correlation.py", "ptlflow/utils/external/raft.py", "ptlflow/utils/flow_metrics.py",
            "ptlflow/utils/registry.py", "ptlflow/utils/utils.py", "ptlflow/utils/timer.py", "LICENSE"]
 

@@ -53,6 +53,10 @@ _UPDATE_BLOCKS: Dict[Tuple[str, str], Callable[[int], UpdateSpec]] = {
     # keeps RAFT's encoders, update block and loop: lcv_raft.py:143-179)
     ("ptlflow.models.lcv.update", "BasicUpdateBlock"): lambda cc: _with_corr_channels(basic_spec(), cc),
     ("ptlflow.models.lcv.update", "SmallUpdateBlock"): lambda cc: _with_corr_channels(small_spec(), cc),
+    # llaflow/update.py: RAFT's block (`llaflow_raft`) and GMA's with heads = 1 (`llaflow`; llaflow/gma.py's Aggregate is
+    # gma/gma_utils.py's), around the family's own cost volume (llaflow/corr.py, built directly: no B1 there)
+    ("ptlflow.models.llaflow.update", "BasicUpdateBlock"): lambda cc: _with_corr_channels(basic_spec(), cc),
+    ("ptlflow.models.llaflow.update", "GMAUpdateBlock"): lambda cc: _with_corr_channels(gma_spec(), cc),
 }
 # parameters of a matched block that belong to a sub-module the wrapper keeps calling as is (not part of the shape check)
 _FOREIGN_PREFIX = {("ptlflow.models.ccmr.update", "BasicUpdateBlock"): "aggregator."}
@@ -63,6 +67,7 @@ _ENCODERS = {
     ("ptlflow.models.gma.extractor", "BasicEncoder"),
     ("ptlflow.models.lcv.extractor", "BasicEncoder"),       # lcv/extractor.py == raft/extractor.py, byte for byte
     ("ptlflow.models.lcv.extractor", "SmallEncoder"),
+    ("ptlflow.models.llaflow.extractor", "BasicEncoder"),   # likewise identical to raft/extractor.py
 }
 # families whose CorrBlock pyramid is not the avg-pool one (sea_raft/corr.py:71-84)
 _PYRAMID = {"ptlflow.models.sea_raft.sea_raft": "bilinear_f2"}

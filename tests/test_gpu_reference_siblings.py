@@ -91,15 +91,17 @@ def test_sibling_family_whole_model(gpu, fam, modname, clsname, blocks):
         assert O.epe(again, stock)[1] <= max(4 * spread, 2e-5 * max(1.0, scale))
 
 
-@pytest.mark.parametrize("clsname,small", [("LCV_RAFT", False), ("LCV_RAFTSmall", True)])
-def test_lcv_raft_whole_model(gpu, clsname, small):
+@pytest.mark.parametrize("fam,modname,clsname,small", [("lcv", "lcv_raft", "LCV_RAFT", False), ("lcv", "lcv_raft", "LCV_RAFTSmall", True),
+                                                      ("llaflow", "llaflow", "LLAFlowRAFT", False), ("llaflow", "llaflow", "LLAFlow", False)])
+def test_registered_sibling_whole_model(gpu, fam, modname, clsname, small):
     """LCV-RAFT (lcv/lcv_raft.py:124-189): RAFT's encoders, update block and loop around a learnable cost volume — lcv/update.py
-    and lcv/extractor.py are RAFT's files, so seams B3 (update block), B4 (encoders) and B5 (`upsample_flow`) serve the real
-    class; its own `corr_block` (lcv/corr_lcv.py) stays the reference's torch code."""
+    and lcv/extractor.py are RAFT's files.  LLA-Flow (llaflow/llaflow.py:150-215): RAFT's block (`LLAFlowRAFT`) or GMA's with one
+    head (`LLAFlow`, attention passed as the fifth argument) and RAFT's encoders around its own cost volume.  Seams B3 (update
+    block), B4 (encoders) and B5 (`upsample_flow`) serve the real classes; their correlation code stays the reference's."""
     from ptlflow_amd import patch
     from ptlflow_amd.encoder import PfkEncoder
-    assert ref_loader.ensure_family("lcv"), "lcv was not staged"
-    mod = ref_loader.ref_module("ptlflow.models.lcv.lcv_raft")
+    assert ref_loader.ensure_family(fam), f"{fam} was not staged"
+    mod = ref_loader.ref_module(f"ptlflow.models.{fam}.{modname}")
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         torch.manual_seed(1234)
@@ -115,7 +117,7 @@ def test_lcv_raft_whole_model(gpu, clsname, small):
         assert isinstance(model.cnet, PfkEncoder) and model.fnet.small == small
         with torch.no_grad():
             got = model({"images": x.to(gpu)})["flows"][:, 0].float().cpu()
-        assert small or model.__dict__["upsample_flow"].ok is True, "seam B5 rejected LCV_RAFT.upsample_flow"
+        assert small or model.__dict__["upsample_flow"].ok is True, f"seam B5 rejected {clsname}.upsample_flow"
     finally:
         patch.restore(model)
     assert torch.isfinite(got).all()

@@ -25,7 +25,7 @@ pytestmark = [pytest.mark.reference,
 # families that import and construct with this image's packages (the others need timm / cupy / torch_scatter / compiled
 # extensions); (family, class)
 ZOO = [("csflow", "CSFlow"), ("dip", "DIP"), ("dpflow", "DPFlow"), ("flow1d", "Flow1D"), ("gmflow", "GMFlow"),
-       ("gmflownet", "GMFlowNet"), ("llaflow", "LLAFlow"), ("memflow", "MemFlow"),
+       ("gmflownet", "GMFlowNet"), ("memflow", "MemFlow"),
        ("rapidflow", "RAPIDFlow"), ("rpknet", "RPKNet"), ("skflow", "SKFlow"), ("unimatch", "UniMatch"),
        ("fastflownet", "FastFlowNet"), ("hd3", "HD3"), ("irr", "IRRPWC"), ("liteflownet", "LiteFlowNet"),
        ("neuflow", "NeuFlow"), ("neuflow2", "NeuFlow2"), ("pwcnet", "PWCDCNet"), ("scopeflow", "ScopeFlow"),
@@ -110,10 +110,12 @@ def test_hooked_siblings_share_rafts_corrblock(fam):
     assert torch.equal(cb(c), O.lookup(pyr, c, 4))
 
 
-@pytest.mark.parametrize("name,small", [("LCV_RAFT", False), ("LCV_RAFTSmall", True)])
-def test_lcv_raft_is_wrapped(name, small):
+@pytest.mark.parametrize("fam,name,small", [("lcv", "LCV_RAFT", False), ("lcv", "LCV_RAFTSmall", True),
+                                            ("llaflow", "LLAFlowRAFT", False), ("llaflow", "LLAFlow", False)])
+def test_registered_siblings_are_wrapped(fam, name, small):
     """LCV-RAFT keeps RAFT's encoders, update block and loop (lcv/update.py and lcv/extractor.py are RAFT's files) around a
-    learnable cost volume: seams B3 / B4 / B5 apply, its own `corr_block` is not touched (no `get_corr_block` in the module)."""
+    learnable cost volume; LLA-Flow keeps RAFT's / GMA's update block and encoders around its own volume: seams B3 / B4 / B5
+    apply, their own correlation code is not touched (no `get_corr_block` in those modules)."""
     import ptlflow_amd
     from ptlflow_amd import patch
     from ptlflow_amd.encoder import PfkEncoder
@@ -121,16 +123,17 @@ def test_lcv_raft_is_wrapped(name, small):
         ptlflow_amd.load_native()
     except Exception as e:
         pytest.skip(f"native libs unavailable: {e}")
-    cls = _find_class("lcv", name)
+    cls = _find_class(fam, name)
     torch.manual_seed(0)
     model = cls().eval()
-    keys, corr_block = set(model.state_dict()), model.corr_block
+    keys, corr_block = set(model.state_dict()), getattr(model, "corr_block", None)
     patch.accelerate(model)
     try:
         assert isinstance(model.update_block, patch.PfkUpdateBlock)
-        assert model.update_block.spec.corr_channels == model.corr_levels * (2 * model.corr_radius + 1) ** 2
+        assert model.update_block.spec.aggregate == (name == "LLAFlow")
         assert isinstance(model.fnet, PfkEncoder) and isinstance(model.cnet, PfkEncoder) and model.fnet.small == small
-        assert model.corr_block is corr_block and set(model.state_dict()) == keys
+        assert getattr(model, "corr_block", None) is corr_block and set(model.state_dict()) == keys
+        assert not hasattr(__import__("sys").modules[type(model).__module__], patch._ORIG)      # no correlation hook here
         with pytest.raises(RuntimeError, match="GPU tensors"):       # no CPU fallback behind a wrapped block
             with torch.no_grad():
                 model({"images": torch.rand(1, 2, 3, 128, 192)})
