@@ -53,7 +53,7 @@ Commands (`scripts/gpu_final_r04.sh`, one gpurun call): the whole GPU suite, `__
 --no-batch1 [--batch 1] --steps K --warmup W`, `... -- python scripts/seam_prof.py` (the drop-in seam path: the reference's own `ptlflow.models.raft.raft.RAFT` out of the
 staged archive + patch.accelerate, batch 1, 8 forwards) and `... -- python scripts/train_prof.py`
 (4 training steps, batch 10, 368x496, 12 iterations).  Tables by scripts/trace_stats.py (regs = VGPRs + AGPRs per dispatch; scratch
-must read 0 everywhere — tests/test_no_scratch.py).  GPU suite of this run: `{suite()}`.
+must read 0 everywhere — tests/test_no_scratch.py).  Last whole GPU suite of the round (gpurun_out/y_pytest.log; an earlier tree of this round — the tests added after it, 325 in all now, ran in their own calls, DESIGN.md section 4): `{suite()}`.
 
 **Bench line of this run** (gpurun_out/y_bench.log): **{d['value']:.1f} frame-pairs/s** fp32 ({d['ms_per_step']:.1f} ms/step, batch 8), EPE vs
 the CPU oracle {d['epe_vs_cpu']['mean']:.2e} mean / {d['epe_vs_cpu']['max']:.2e} max, stream-K faults {d['streamk_faults']}; roofline
