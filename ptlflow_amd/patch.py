@@ -262,6 +262,66 @@ class _UpsampleSeam:
         return self._kernel(flow, mask) if self.ok else self.original(flow, mask)
 
 
+# (module, class) of correlation MODULES whose volume is a bilinear form of the two feature maps: lcv/corr_lcv.py:19-50
+_BILINEAR_VOLUMES = {("ptlflow.models.lcv.corr_lcv", "LearnableCorrBlock")}
+
+
+class _VolumeToken:
+    """What the adapted `compute_cost_volume` hands the caller's loop in place of the list of pyramid levels."""
+
+    def __init__(self, block):
+        self.block = block
+
+
+class _LearnableVolumeSeam:
+    """Seam B1 for LCV-RAFT's learnable cost volume (lcv/corr_lcv.py, called from lcv_raft.py:147,167).
+
+    The volume is `(fmap1ᵀ W) fmap2 / √D` with `W = Pᵀ D P` rebuilt from the module's parameters on every call (:20-31), its
+    pyramid and radius-r lookup are RAFT's (:44-49, :52-76).  So it IS `CorrBlock(W-transformed fmap1, fmap2)`: the transform is
+    one `[B·N, D] x [D, D]` product, K1-K3 do the rest.  Both methods of the module instance are shadowed (the module object,
+    its parameters and state_dict keys stay): `compute_cost_volume` returns a token, `forward(token, coords)` looks up.
+
+    Left to the module's own code: CPU tensors, gradient graphs (W is learnable), shapes outside the kernels' envelope, and
+    maps so small that the module stops pooling (`min(h, w) <= 2r + 1` at some level: it then repeats a level where RAFT's
+    block keeps halving)."""
+
+    def __init__(self, module: torch.nn.Module):
+        self.module = module
+        self.compute_original = module.compute_cost_volume
+        self.forward_original = module.forward
+        self.channels_last = True
+
+    def eligible(self, fmap1: torch.Tensor, fmap2: torch.Tensor) -> bool:
+        m = self.module
+        if not (fmap1.is_cuda and fmap1.dim() == 4 and fmap1.shape == fmap2.shape):
+            return False
+        if torch.is_grad_enabled() and (fmap1.requires_grad or fmap2.requires_grad or any(p.requires_grad for p in m.parameters())):
+            return False
+        h, w = fmap1.shape[-2:]
+        if any(min(h >> i, w >> i) <= 2 * m.radius + 1 for i in range(m.num_levels - 1)):
+            return False
+        return _supported_envelope(fmap1, fmap2, m.num_levels, m.radius)
+
+    def compute_cost_volume(self, fmap1, fmap2):
+        if not self.eligible(fmap1, fmap2):
+            return self.compute_original(fmap1, fmap2)
+        B, D, h, w = fmap1.shape
+        # W by the module's own arithmetic: its method on a one-pixel crop (:20-31 run in full, the volume part on 1 x 1 maps)
+        self.compute_original(fmap1[:, :, :1, :1].contiguous(), fmap2[:, :, :1, :1].contiguous())
+        f1w = torch.matmul(fmap1.float().flatten(2).transpose(1, 2), self.module.W.float())       # [B, N, D]: already pixel-major
+        block = _pfk_get_corr_block(f1w.view(B, h, w, D).permute(0, 3, 1, 2), fmap2.float(), num_levels=self.module.num_levels,
+                                    radius=self.module.radius, channels_last=self.channels_last)
+        return _VolumeToken(block)
+
+    def forward(self, corr_pyramid, coords):
+        if isinstance(corr_pyramid, _VolumeToken):
+            return corr_pyramid.block(coords)
+        return self.forward_original(corr_pyramid, coords)
+
+
+_VOLUME_SEAM = "_pfk_learnable_volume_seam"
+
+
 def accelerate(model: torch.nn.Module, corr: bool = True, update_block: bool = True,
                conv_precision: str = "fp32", encoders: bool = True, upsample: bool = True) -> torch.nn.Module:
     """Patch seams B1/B3/B4 (+ B5, the model's `upsample_flow` method) of a ptlflow model instance in place and return it.
@@ -282,6 +342,15 @@ def accelerate(model: torch.nn.Module, corr: bool = True, update_block: bool = T
     hook = getattr(mod, "get_corr_block", None)
     if hasattr(mod, _ORIG) and hasattr(hook, "channels_last"):
         hook.channels_last = isinstance(getattr(model, "update_block", None), PfkUpdateBlock)
+    cb = getattr(model, "corr_block", None)
+    if corr and isinstance(cb, torch.nn.Module) and (type(cb).__module__, type(cb).__name__) in _BILINEAR_VOLUMES \
+            and _VOLUME_SEAM not in cb.__dict__:
+        seam = _LearnableVolumeSeam(cb)
+        seam.channels_last = isinstance(getattr(model, "update_block", None), PfkUpdateBlock)
+        # instance attributes shadow the class's methods (nn.Module.__call__ looks `forward` up on the instance)
+        cb.__dict__[_VOLUME_SEAM] = seam
+        cb.__dict__["compute_cost_volume"] = seam.compute_cost_volume
+        cb.__dict__["forward"] = seam.forward
     if encoders:
         # seam B4: the BasicEncoder feature / context networks (raft, gma: `self.fnet`, `self.cnet`)
         from .encoder import PfkEncoder
@@ -304,6 +373,10 @@ def restore(model: torch.nn.Module) -> torch.nn.Module:
     if mod is not None and hasattr(mod, _ORIG):
         mod.get_corr_block = getattr(mod, _ORIG)
         delattr(mod, _ORIG)
+    cb = getattr(model, "corr_block", None)
+    if cb is not None and _VOLUME_SEAM in getattr(cb, "__dict__", {}):
+        for name in (_VOLUME_SEAM, "compute_cost_volume", "forward"):
+            cb.__dict__.pop(name, None)
     ub = getattr(model, "update_block", None)
     if isinstance(ub, PfkUpdateBlock):
         model.update_block = ub._ref[0]

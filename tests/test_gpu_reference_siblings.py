@@ -97,7 +97,8 @@ def test_registered_sibling_whole_model(gpu, fam, modname, clsname, small):
     """LCV-RAFT (lcv/lcv_raft.py:124-189): RAFT's encoders, update block and loop around a learnable cost volume — lcv/update.py
     and lcv/extractor.py are RAFT's files.  LLA-Flow (llaflow/llaflow.py:150-215): RAFT's block (`LLAFlowRAFT`) or GMA's with one
     head (`LLAFlow`, attention passed as the fifth argument) and RAFT's encoders around its own cost volume.  Seams B3 (update
-    block), B4 (encoders) and B5 (`upsample_flow`) serve the real classes; their correlation code stays the reference's."""
+    block), B4 (encoders) and B5 (`upsample_flow`) serve the real classes; lcv's learnable volume `(fmap1' W) fmap2` additionally
+    goes through B1 (`patch._LearnableVolumeSeam`: K1-K3 on the W-transformed feature map), llaflow's stays the reference's."""
     from ptlflow_amd import patch
     from ptlflow_amd.encoder import PfkEncoder
     assert ref_loader.ensure_family(fam), f"{fam} was not staged"
@@ -106,20 +107,39 @@ def test_registered_sibling_whole_model(gpu, fam, modname, clsname, small):
         warnings.simplefilter("ignore")
         torch.manual_seed(1234)
         model = getattr(mod, clsname)().eval()
-    x = O.smooth_pair(1, 256, 320, seed=12)
+    # 320 x 448: 40 x 56 maps, the smallest at which lcv's pyramid still pools three times (corr_lcv.py:46-49) — below that its
+    # levels repeat and the learnable-volume seam leaves the module alone
+    x = O.smooth_pair(1, 320, 448, seed=12)
+    if fam == "lcv":        # a W that is not the identity it is initialised to (raw_P = I, raw_D = 0)
+        g = torch.Generator().manual_seed(3)
+        with torch.no_grad():
+            model.corr_block.raw_P.add_(torch.randn(model.corr_block.raw_P.shape, generator=g) * 0.05)
+            model.corr_block.raw_D.add_(torch.randn(model.corr_block.raw_D.shape, generator=g) * 0.3)
     with torch.no_grad():
         cpu = copy.deepcopy(model)({"images": x.clone()})["flows"][:, 0]
         model.to(gpu)
         stock = model({"images": x.to(gpu)})["flows"][:, 0].float().cpu()
     patch.accelerate(model)
+    served = [0]
+    orig_block = patch._pfk_get_corr_block
+
+    def counting(*a, **k):
+        served[0] += 1
+        return orig_block(*a, **k)
+
+    patch._pfk_get_corr_block = counting
     try:
         assert isinstance(model.update_block, patch.PfkUpdateBlock) and isinstance(model.fnet, PfkEncoder)
         assert isinstance(model.cnet, PfkEncoder) and model.fnet.small == small
         with torch.no_grad():
             got = model({"images": x.to(gpu)})["flows"][:, 0].float().cpu()
         assert small or model.__dict__["upsample_flow"].ok is True, f"seam B5 rejected {clsname}.upsample_flow"
+        # lcv: the learnable volume is served by K1-K3 (one block per forward); llaflow builds its own volume directly
+        assert served[0] == (1 if fam == "lcv" else 0)
     finally:
+        patch._pfk_get_corr_block = orig_block
         patch.restore(model)
+    assert "forward" not in getattr(model, "corr_block", model).__dict__
     assert torch.isfinite(got).all()
     scale = float(cpu.abs().max()) + 1e-6
     e_stock, e_cpu, e_base = O.epe(got, stock), O.epe(got, cpu), O.epe(stock, cpu)

@@ -134,9 +134,43 @@ def test_registered_siblings_are_wrapped(fam, name, small):
         assert isinstance(model.fnet, PfkEncoder) and isinstance(model.cnet, PfkEncoder) and model.fnet.small == small
         assert getattr(model, "corr_block", None) is corr_block and set(model.state_dict()) == keys
         assert not hasattr(__import__("sys").modules[type(model).__module__], patch._ORIG)      # no correlation hook here
+        if fam == "lcv":        # the learnable volume's two methods are shadowed on the module instance, the module stays
+            assert patch._VOLUME_SEAM in corr_block.__dict__ and corr_block.__dict__[patch._VOLUME_SEAM].channels_last is True
         with pytest.raises(RuntimeError, match="GPU tensors"):       # no CPU fallback behind a wrapped block
             with torch.no_grad():
                 model({"images": torch.rand(1, 2, 3, 128, 192)})
     finally:
         patch.restore(model)
     assert not isinstance(model.update_block, patch.PfkUpdateBlock) and not isinstance(model.fnet, PfkEncoder)
+    if corr_block is not None:
+        assert not {patch._VOLUME_SEAM, "forward", "compute_cost_volume"} & set(corr_block.__dict__)
+
+
+def test_lcv_volume_is_rafts_block_on_a_transformed_map():
+    """What `patch._LearnableVolumeSeam` relies on: lcv/corr_lcv.py's volume `(fmap1' W) fmap2 / sqrt(D)`, pyramid and lookup equal
+    RAFT's block (the oracle) built from the W-transformed first feature map — bit for bit on the CPU, for a W that is not the
+    identity, at a size where the module pools three times; and the module stops pooling (its levels repeat) below that size,
+    which is where the seam must leave it alone."""
+    from oracle import raft_oracle as O
+    from ptlflow_amd import patch
+    if not ref_loader.ensure_family("lcv"):
+        pytest.skip("lcv: not in this reference tree")
+    mod = importlib.import_module("ptlflow.models.lcv.corr_lcv")
+    torch.manual_seed(1)
+    cb = mod.LearnableCorrBlock(64, 4, 4)
+    with torch.no_grad():
+        cb.raw_P.add_(torch.randn(64, 64) * 0.3)
+        cb.raw_D.add_(torch.randn(64) * 0.5)
+        f1, f2 = torch.randn(2, 64, 44, 48), torch.randn(2, 64, 44, 48)
+        pyr = cb.compute_cost_volume(f1, f2)
+        f1w = torch.matmul(f1.flatten(2).transpose(1, 2), cb.W).view(2, 44, 48, 64).permute(0, 3, 1, 2)
+        want = O.correlation_pyramid(f1w, f2, 4)
+        for a, b in zip(pyr, want):
+            assert torch.equal(a.reshape(b.shape), b)
+        c = O.coords_grid(2, 44, 48) + torch.rand(2, 2, 44, 48) * 6 - 3
+        assert torch.equal(cb(pyr, c), O.lookup(want, c, 4))
+        small = cb.compute_cost_volume(f1[..., :32, :40].contiguous(), f2[..., :32, :40].contiguous())
+    assert [tuple(p.shape[-2:]) for p in small[:4]] == [(32, 40), (16, 20), (8, 10), (8, 10)]      # no third pooling
+    seam = patch._LearnableVolumeSeam(cb)
+    assert not seam.eligible(f1, f2)                      # CPU tensors
+    assert any(min(32 >> i, 40 >> i) <= 9 for i in range(3))       # the size rule of `eligible` for the case above
