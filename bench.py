@@ -233,15 +233,31 @@ def whole_model_legs(dev, H, W, check: bool):
     legs = {}
     x1 = smooth_pair(1, H, W, seed=1234)
 
-    def run(name, build, unpatched=True, autocast=False, epe=False):
+    def run(name, build, unpatched=True, autocast=False, epe=False, cpu_corr_module=None):
         leg = {}
         try:
             torch.manual_seed(1234)
             m = build().eval()
             ref = None
             if epe and check:
-                with torch.no_grad():
-                    ref = m({"images": x1.clone()})["flows"][:, 0]
+                # CPU side of an `alternate_corr=True` family: no CPU extension exists and the materialised volume of the 1/2-resolution
+                # scale would be 50 GB, so the reference's own fallback runs — `IterativeCorrBlock`, which `get_corr_block` picks when its
+                # module-global `alt_cuda_corr` is None ({family}/corr.py:104-118)
+                import sys
+                cm = sys.modules.get(cpu_corr_module) if cpu_corr_module else None
+                saved = getattr(cm, "alt_cuda_corr", None) if cm is not None else None
+                if cm is not None:
+                    cm.alt_cuda_corr = None
+                try:
+                    t0 = time.perf_counter()
+                    with torch.no_grad():
+                        ref = m({"images": x1.clone()})["flows"][:, 0]
+                    leg["cpu_forward_s"] = time.perf_counter() - t0
+                finally:
+                    if cm is not None:
+                        cm.alt_cuda_corr = saved
+                if cm is not None:
+                    leg["cpu_side"] = "the same model object on the CPU with the reference's IterativeCorrBlock fallback (alt_cuda_corr unset)"
             m = m.to(dev)
             with torch.no_grad():
                 stock_bf16 = None
@@ -279,9 +295,10 @@ def whole_model_legs(dev, H, W, check: bool):
     S = ref_loader.ref_module("ptlflow.models.sea_raft.sea_raft")
     run("sea_raft_s_full", lambda: S.SEARAFT(block_dims=[64, 128, 256]), autocast=True, epe=True)
     C = ref_loader.ref_module("ptlflow.models.ccmr.ccmr")
-    run("ccmr_full", lambda: C.CCMR(), unpatched=False)          # un-patched it cannot run at all: no alt_cuda_corr without this repo
+    # (un-patched they cannot run on the GPU at all: no alt_cuda_corr without this repo)
+    run("ccmr_full", lambda: C.CCMR(), unpatched=False, epe=True, cpu_corr_module="ptlflow.models.ccmr.corr")
     M = ref_loader.ref_module("ptlflow.models.ms_raft_plus.ms_raft_plus")
-    run("ms_raft_p_full", lambda: M.MSRAFTPlus(), unpatched=False)
+    run("ms_raft_p_full", lambda: M.MSRAFTPlus(), unpatched=False, epe=True, cpu_corr_module="ptlflow.models.ms_raft_plus.corr")
     return legs
 
 

@@ -147,3 +147,38 @@ def test_gma_oracle_matches_reference_fp32_and_autocast():
             r, o = m({"images": x.clone()})["flows"].float(), O.gma_forward(sd, x, iters=4)["flows"].float()
     assert O.epe(o32[:, 0], r32[:, 0])[1] <= 1e-5
     assert O.epe(o[:, 0], r[:, 0])[1] <= 1e-5
+
+
+def _baseline_coords(B, h, w, seed):
+    """SURVEY §8c's coordinate families: integer (where the grid_sample round trip flips floor() the most),
+    fractional, exact halves, and far out of bounds."""
+    g = torch.Generator().manual_seed(seed)
+    c0 = O.coords_grid(B, h, w)
+    yield "integer", c0
+    yield "integer_shifted", c0 + torch.randint(-9, 10, (B, 2, h, w), generator=g).float()
+    yield "fractional", c0 + torch.rand(B, 2, h, w, generator=g) * 16 - 8
+    yield "half", c0 + 0.5
+    yield "out_of_bounds", c0 + torch.randn(B, 2, h, w, generator=g) * 80
+
+
+# 55×128 = Sintel 436×1024 (config 2), 47×156 = KITTI 375×1242 (config 4; the width with the most round-trip index flips),
+# 46×62 = FlyingChairs 368×496 (config 5)
+@pytest.mark.parametrize("h,w", [(55, 128), (47, 156), (46, 62)])
+@pytest.mark.parametrize("D,L,r", [(256, 4, 4), (128, 2, 3)])       # D ∈ {128, 256}, L ∈ {2, 4}, r ∈ {3, 4} each appear
+def test_oracle_pyramid_and_lookup_bit_exact_at_baseline_grids(h, w, D, L, r):
+    """`O.correlation_pyramid` / `O.lookup` against the LIVE `raft.corr.CorrBlock` (raft/corr.py:13-64, raft/utils.py:67-81)
+    at the three BASELINE grids: every pyramid level `torch.equal`, every lookup of every coordinate family `torch.equal`."""
+    mod = ref_loader.ref_module("ptlflow.models.raft.corr")
+    g = torch.Generator().manual_seed(1000 + h + D + 7 * L + r)
+    f1, f2 = torch.randn(1, D, h, w, generator=g), torch.randn(1, D, h, w, generator=g)
+    cb = mod.CorrBlock(f1, f2, num_levels=L, radius=r)
+    pyr = O.correlation_pyramid(f1, f2, L)
+    assert len(pyr) == len(cb.corr_pyramid) == L
+    for a, b in zip(pyr, cb.corr_pyramid):
+        assert torch.equal(a, b)
+    for name, c in _baseline_coords(1, h, w, seed=h * w + r):
+        ref = cb(c)
+        out = O.lookup(pyr, c, r)
+        assert ref.shape == out.shape == (1, L * (2 * r + 1) ** 2, h, w)
+        assert not bool(torch.isnan(ref).any()), name
+        assert torch.equal(ref, out), f"{name}: {(ref != out).sum().item()} of {ref.numel()} values differ"
