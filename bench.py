@@ -210,8 +210,33 @@ def dropin_leg(cpu_state, dev, H, W, iters, pair_cpu, ref_flows, torch_baseline=
                 sec = timed(lambda: m(batch8), 2, 5)
                 leg["batch8"] = {"value": batch8["images"].shape[0] / sec, "unit": "frame-pairs/s", "ms_per_step": 1e3 * sec,
                                  "note": "the same accelerated object on the headline's batch (8 smooth pairs per forward)"}
+            flows_every = out["flows"].clone()
     finally:
         patch.restore(m)
+    # the same object with the reference loop's dead work skipped at the seams (opt-in, eval + no_grad only): mask head
+    # + convex upsampling on the final iteration only, `flows` bit-identical — reported beside the non-skipping form, never as it
+    try:
+        import warnings
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            patch.accelerate(m, skip_dead_upsample=True)
+        try:
+            sk = {"accepted": getattr(m.update_block, "_skip", None) is not None}
+            if not sk["accepted"]:
+                sk["refused"] = [str(x.message)[:200] for x in w][:1]
+            else:
+                with torch.no_grad():
+                    o2 = m({"images": pair_cpu.to(dev)})
+                    sk["identical_flows"] = bool(torch.equal(o2["flows"], flows_every))
+                    sk.update(protocol_leg(m, dev, H, W))
+                    if batch8 is not None:
+                        sec = timed(lambda: m(batch8), 2, 5)
+                        sk["batch8"] = {"value": batch8["images"].shape[0] / sec, "unit": "frame-pairs/s", "ms_per_step": 1e3 * sec}
+            leg["skip_dead"] = sk
+        finally:
+            patch.restore(m)
+    except Exception as e:
+        leg["skip_dead"] = {"error": repr(e)[:300]}
     return leg
 
 

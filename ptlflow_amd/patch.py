@@ -215,6 +215,7 @@ class _UpsampleSeam:
     def __init__(self, original):
         self.original = original
         self.ok = None          # None: not probed yet; True / False: the probe's verdict
+        self.skip = None        # `_DeadWorkSkip` shared with seam B3 (accelerate(..., skip_dead_upsample=True)), else None
 
     @staticmethod
     def _kernel(flow: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
@@ -259,7 +260,11 @@ class _UpsampleSeam:
             if torch.cuda.is_current_stream_capturing():     # the probe copies host data: illegal inside a graph capture
                 return self.original(flow, mask)
             self.ok = self._probe(flow.device)
-        return self._kernel(flow, mask) if self.ok else self.original(flow, mask)
+        if not self.ok:
+            return self.original(flow, mask)
+        if self.skip is not None and self.skip.upsample_is_dead():
+            return self.skip.scratch(flow)      # a non-final iteration's prediction: eval drops it (raft/raft.py:186-192)
+        return self._kernel(flow, mask)
 
 
 # (module, class) of correlation MODULES whose volume is a bilinear form of the two feature maps: lcv/corr_lcv.py:19-50
@@ -322,12 +327,105 @@ class _LearnableVolumeSeam:
 _VOLUME_SEAM = "_pfk_learnable_volume_seam"
 
 
+# (module, class) whose `forward` was checked to return, in eval mode, only the LAST iteration's upsampled flow: the loop runs
+# `range(self.iters)`, `up_mask` is consumed by `self.upsample_flow` alone, and the intermediate `flow_up` tensors go into a list
+# that eval drops (raft/raft.py:169-192, gma/gma.py:189-215).  Only for these the dead mask-head + upsampling work may be skipped.
+_LAST_FLOW_ONLY_FORWARDS = {
+    ("ptlflow.models.raft.raft", "RAFT"),
+    ("ptlflow.models.gma.gma", "GMA"),
+    ("ptlflow_amd.seam_model", "SeamRAFT"),
+}
+_SKIP = "_pfk_dead_work_skip"
+
+
+def _defining_class(model: torch.nn.Module, attr: str):
+    for cls in type(model).__mro__:
+        if attr in cls.__dict__:
+            return cls
+    return None
+
+
+class _DeadWorkSkip:
+    """§8 f2 at the seams (opt-in: `accelerate(model, skip_dead_upsample=True)`).  In eval the reference's loop computes the mask
+    head and the 8x convex upsampling on every iteration and returns the last one only (raft/raft.py:180-192).  This object is shared
+    by seam B3 (`PfkUpdateBlock`) and seam B5 (`_UpsampleSeam`): the block counts its calls since the forward began and, knowing
+    `model.iters`, computes the mask half of fh|mask conv1 and mask conv2 on the final call only; `upsample_flow` returns a
+    never-handed-out scratch tensor before it.  Active per forward only when the model is in eval mode, no gradient graph is
+    recorded and `model.iters` is a positive int; any call at or beyond `iters - 1` computes everything."""
+
+    def __init__(self, model: torch.nn.Module):
+        import weakref
+        self._model = weakref.ref(model)
+        self.active = False
+        self.iters = 0
+        self.call = 0           # index of the update-block call in flight (0-based) within the current forward
+        self._dead_now = False  # the call in flight is a non-final one: its mask / upsampled flow are never read
+        self._scratch = None
+
+    def begin_forward(self) -> None:
+        m = self._model()
+        it = getattr(m, "iters", None) if m is not None else None
+        self.active = bool(m is not None and not m.training and not torch.is_grad_enabled()
+                           and isinstance(it, int) and not isinstance(it, bool) and it >= 1)
+        self.iters = it if self.active else 0
+        self.call = 0
+        self._dead_now = False
+
+    def next_call(self) -> bool:
+        """Called by the block per call (after `begin_forward` on the first); True when this call's mask is dead."""
+        dead = self.active and not torch.is_grad_enabled() and self.call < self.iters - 1
+        self._dead_now = dead
+        self.call += 1
+        return dead
+
+    def upsample_is_dead(self) -> bool:
+        m = self._model()
+        return bool(self.active and self._dead_now and m is not None and not m.training and not torch.is_grad_enabled())
+
+    def scratch(self, flow: torch.Tensor) -> torch.Tensor:
+        B, _, H, W = flow.shape
+        shape = (B, 2, 8 * H, 8 * W)
+        if self._scratch is None or tuple(self._scratch.shape) != shape or self._scratch.device != flow.device:
+            self._scratch = torch.zeros(shape, device=flow.device, dtype=torch.float32)
+        return self._scratch
+
+
+def _dead_work_skip_for(model: torch.nn.Module):
+    """The shared skip state, or None (with a warning saying why) when skipping is not provably output-preserving for this model."""
+    import warnings
+    why = None
+    fwd, ups = _defining_class(model, "forward"), _defining_class(model, "upsample_flow")
+    it = getattr(model, "iters", None)
+    if fwd is None or (fwd.__module__, fwd.__name__) not in _LAST_FLOW_ONLY_FORWARDS:
+        why = (f"`forward` is defined by {getattr(fwd, '__module__', '?')}.{getattr(fwd, '__name__', '?')}, not by one of the loops checked "
+               "to return only the last prediction in eval")
+    elif ups is None or (ups.__module__, ups.__name__) not in _LAST_FLOW_ONLY_FORWARDS:
+        why = "`upsample_flow` is overridden"
+    elif not isinstance(it, int) or isinstance(it, bool) or it < 1:
+        why = f"`model.iters` is not a positive int attribute ({it!r})"
+    elif model.training:
+        why = "the model is in train mode (every prediction enters the loss)"
+    elif not (isinstance(model.update_block, PfkUpdateBlock) and model.update_block.spec.has_mask
+              and isinstance(model.__dict__.get("upsample_flow"), _UpsampleSeam)):
+        why = "seams B3 (a mask-head update block) and B5 are not both installed"
+    if why is not None:
+        warnings.warn(f"ptlflow_amd: skip_dead_upsample refused, every iteration keeps its mask head + upsampling: {why}",
+                      RuntimeWarning, stacklevel=3)
+        return None
+    return _DeadWorkSkip(model)
+
+
 def accelerate(model: torch.nn.Module, corr: bool = True, update_block: bool = True,
-               conv_precision: str = "fp32", encoders: bool = True, upsample: bool = True) -> torch.nn.Module:
+               conv_precision: str = "fp32", encoders: bool = True, upsample: bool = True,
+               skip_dead_upsample: bool = False) -> torch.nn.Module:
     """Patch seams B1/B3/B4 (+ B5, the model's `upsample_flow` method) of a ptlflow model instance in place and return it.
 
     ``conv_precision``: "fp32" (default, the parity path) or a split-bf16 mode of the convolutions
-    ("bf16x6", "bf16x3", "bf16"), see ``UpdateEngine``."""
+    ("bf16x6", "bf16x3", "bf16"), see ``UpdateEngine``.
+    ``skip_dead_upsample`` (opt-in, eval + no_grad forwards only): compute the mask head and the convex upsampling on the LAST
+    iteration only — the reference's loop computes them 32 times and returns the last (raft/raft.py:180-192).  `flows` stays
+    bit-identical.  Refused with a warning (everything keeps running every iteration) unless the model's `forward` is one of the
+    loops checked to drop the intermediate predictions, `model.iters` is an int and the model is in eval mode (`_DeadWorkSkip`)."""
     load_native()
     mod_name = type(model).__module__
     # registered classes (`class raft(RAFT)`) live in the same module as the implementation
@@ -362,10 +460,20 @@ def accelerate(model: torch.nn.Module, corr: bool = True, update_block: bool = T
         # an instance attribute shadows the class's method; nn.Module.__setattr__ stores plain callables in __dict__
         model.__dict__[_UPSAMPLE] = model.upsample_flow
         model.__dict__["upsample_flow"] = _UpsampleSeam(model.upsample_flow)
+    if skip_dead_upsample and _SKIP not in model.__dict__:
+        skip = _dead_work_skip_for(model)
+        if skip is not None:
+            model.__dict__[_SKIP] = skip
+            model.update_block._skip = skip
+            model.__dict__["upsample_flow"].skip = skip
     return model
 
 
 def restore(model: torch.nn.Module) -> torch.nn.Module:
+    if _SKIP in model.__dict__:
+        del model.__dict__[_SKIP]
+        if isinstance(getattr(model, "update_block", None), PfkUpdateBlock):
+            model.update_block._skip = None
     if _UPSAMPLE in model.__dict__:
         del model.__dict__[_UPSAMPLE]
         model.__dict__.pop("upsample_flow", None)

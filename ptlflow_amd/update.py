@@ -540,6 +540,7 @@ class PfkUpdateBlock(torch.nn.Module):
         self._versions = None
         self._inp_ref, self._inp_version = None, -1      # strong references: the address cannot be recycled while cached
         self._attn_ref, self._attn_version = None, -1
+        self._skip = None      # patch._DeadWorkSkip when `accelerate(model, skip_dead_upsample=True)` was accepted
 
     def _param_versions(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
@@ -598,6 +599,10 @@ class PfkUpdateBlock(torch.nn.Module):
         if new_forward:
             eng.watch_faults()
             ops.nchw_to_pm(net.float().contiguous(), eng.h_view)
+            if self._skip is not None:
+                self._skip.begin_forward()
+        # §8 f2: on the non-final iterations of an eval forward nobody reads the mask (patch._DeadWorkSkip)
+        dead_mask = self._skip is not None and eng.spec.has_mask and self._skip.next_call()
         if new_forward or inp is not self._inp_ref or inp._version != self._inp_version:
             ops.nchw_to_pm(inp.float().contiguous(), eng.inp_view)
             self._inp_ref, self._inp_version = inp, inp._version
@@ -631,7 +636,7 @@ class PfkUpdateBlock(torch.nn.Module):
                     self._attn_ref, self._attn_version = attention, attention._version
             eng.motion_and_gru(corr_pm)
         eng._scratch_c1.zero_()
-        eng.heads(eng._scratch_c0, eng._scratch_c1, eng._delta, want_mask=True, write_flow=False)
+        eng.heads(eng._scratch_c0, eng._scratch_c1, eng._delta, want_mask=not dead_mask, write_flow=False)
         mask = eng.mask_nchw() if eng.spec.has_mask else None
         out_net = eng.net_nchw()
         delta = eng._delta

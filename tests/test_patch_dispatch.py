@@ -179,3 +179,93 @@ def test_upsample_seam_passes_other_signatures_through():
     assert torch.equal(seam(flow=f, mask=m), f * 8)
     assert torch.equal(seam(f, m), f * 8)                  # CPU tensors: not eligible, original
     assert [c[0] for c in calls] == [2, 4, 8, 8] and seam.ok is None      # never probed
+
+
+def test_skip_dead_upsample_is_refused_where_it_is_not_provably_dead():
+    """`accelerate(model, skip_dead_upsample=True)` (§8 f2 at the seams): accepted on the reference's own RAFT / GMA loops in eval
+    mode; a subclass whose `forward` (or `upsample_flow`) is its own — it may consume the intermediate predictions — a model in
+    train mode, and a model without an int `iters` get a warning and the every-iteration path."""
+    _native()
+    import warnings
+    from ptlflow_amd import patch
+
+    def attempt(model):
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            patch.accelerate(model, skip_dead_upsample=True)
+        try:
+            return model.update_block._skip, [str(x.message) for x in w if "skip_dead_upsample refused" in str(x.message)]
+        finally:
+            patch.restore(model)
+
+    model, mod = _build("raft", "RAFT", iters=4)
+    skip, warned = attempt(model)
+    assert skip is not None and not warned
+    assert model.__dict__.get(patch._SKIP) is None and not hasattr(model.update_block, "_skip")      # restore() removed it
+
+    gma, _ = _build("gma", "GMA", iters=4)
+    skip, warned = attempt(gma)
+    assert skip is not None and not warned
+
+    class Consumes(mod.RAFT):                      # reads every prediction of the loop: skipping would change its result
+        def forward(self, inputs):
+            out = super().forward(inputs)
+            return out
+
+    torch.manual_seed(7)
+    sub = Consumes(iters=4).eval()
+    skip, warned = attempt(sub)
+    assert skip is None and len(warned) == 1 and "forward" in warned[0]
+
+    class OwnUpsample(mod.RAFT):
+        def upsample_flow(self, flow, mask):
+            return super().upsample_flow(flow, mask)
+
+    torch.manual_seed(7)
+    skip, warned = attempt(OwnUpsample(iters=4).eval())
+    assert skip is None and len(warned) == 1 and "upsample_flow" in warned[0]
+
+    model.train()
+    skip, warned = attempt(model)
+    assert skip is None and len(warned) == 1 and "train mode" in warned[0]
+    model.eval()
+    model.iters = [2, 2]
+    skip, warned = attempt(model)
+    assert skip is None and len(warned) == 1 and "iters" in warned[0]
+
+    small, _ = _build("raft", "RAFTSmall")       # no mask head: nothing to skip
+    skip, warned = attempt(small)
+    assert skip is None and len(warned) == 1
+
+
+def test_dead_work_skip_state_machine():
+    """The shared state alone: dead on calls 0..iters-2 of an eval / no_grad forward, live on the last and on any call beyond,
+    inactive in train mode or with gradients enabled, re-armed by `begin_forward` (which re-reads `model.iters`)."""
+    from ptlflow_amd.patch import _DeadWorkSkip
+
+    class M(torch.nn.Module):
+        iters = 3
+
+    m = M().eval()
+    s = _DeadWorkSkip(m)
+    with torch.no_grad():
+        s.begin_forward()
+        seq = []
+        for _ in range(5):
+            seq.append((s.next_call(), s.upsample_is_dead()))
+        assert seq == [(True, True), (True, True), (False, False), (False, False), (False, False)]
+        m.iters = 1
+        s.begin_forward()
+        assert s.next_call() is False
+    s.begin_forward()                               # gradients enabled
+    assert s.active is False and s.next_call() is False and not s.upsample_is_dead()
+    m.iters = 3
+    with torch.no_grad():
+        m.train()
+        s.begin_forward()
+        assert s.active is False and s.next_call() is False
+        m.eval()
+        s.begin_forward()
+        assert s.next_call() is True
+        m.train()                                   # flipped mid-forward: the upsampling seam stops trusting the flag
+        assert not s.upsample_is_dead()
