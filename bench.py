@@ -153,14 +153,14 @@ def _epe(flow_gpu, flow_ref):
     return float(d.mean()), float(d.max())
 
 
-def reference_raft(cpu_state, iters):
+def reference_raft(cpu_state, iters, small=False):
     """The reference's own `ptlflow.models.raft.raft.RAFT` (oracle/ref_loader.py: /root/reference, or the archive staged for the
     GPU box by oracle/stage_ref.py) carrying the bench's weights — or None where no reference is importable."""
     try:
         from oracle import ref_loader          # the reference as the thing being accelerated / timed as the baseline
         if not ref_loader.reference_available():
             return None, None
-        m = ref_loader.build_raft(iters=iters)
+        m = ref_loader.build_raft(small=small, iters=iters)
         missing, unexpected = m.load_state_dict(cpu_state, strict=False)
         # (the metric accumulators BaseModel registers — `train_metrics.*`, `val_metrics.*` — are not weights)
         missing = [k for k in missing if not k.startswith(("train_metrics.", "val_metrics."))]
@@ -425,7 +425,6 @@ def self_launch(args) -> None:
     in the reference is Lightning's own process launch (ptlflow/utils/lightning/ptlflow_trainer.py:71, :281).  Refuses loudly
     when the box has fewer than N devices (unless PFK_BENCH_SHARED_DEVICE=1 asks for the one-device code-path smoke): a line
     that says `n_gpus: 1` for a `--gpus 8` request would be a wrong SCALE record."""
-    import socket
     import subprocess
     shared = os.environ.get("PFK_BENCH_SHARED_DEVICE") == "1"
     if not torch.cuda.is_available():
@@ -434,11 +433,10 @@ def self_launch(args) -> None:
     if n_dev < args.gpus and not shared:
         raise SystemExit(f"bench.py --gpus {args.gpus}: only {n_dev} GPU(s) visible on this node; refusing to report fewer ranks "
                          "than requested (PFK_BENCH_SHARED_DEVICE=1 runs all ranks on cuda:0 as a code-path smoke)")
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # `--standalone`: torchrun binds a free port of 127.0.0.1 ITSELF (no probe socket of ours whose port another process could
+    # take between our close and its bind) and hands MASTER_ADDR / MASTER_PORT to the ranks
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={args.gpus}", os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
     env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // args.gpus)))
@@ -527,7 +525,9 @@ def main():
         "value": pairs / elapsed,
         "unit": "frame-pairs/s",
         "n_gpus": world,
-        "rccl_ranks": ranks_seen if dist is not None else None,   # all-reduce of ones over the process group (None: no group, plain 1-GPU run)
+        # all-reduce of ones over the process group (None: no group, plain 1-GPU run) and the backend that carried it
+        "ranks_seen": ranks_seen if dist is not None else None,
+        "backend": None if dist is None else ("gloo (shared-device smoke)" if shared else "nccl (RCCL)"),
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
@@ -617,13 +617,13 @@ def main():
 
             # The baseline is the REFERENCE'S OWN forward wherever it is importable (/root/reference, or the archive
             # oracle/stage_ref.py staged for the GPU box): kind "reference".  Only without it the port is timed (kind "port").
-            rm, ref_kind = (reference_raft(cpu_state, args.iters) if args.model == "raft" else (None, None))
+            rm, ref_kind = (reference_raft(cpu_state, args.iters, small=small) if args.model in ("raft", "raft_small") else (None, None))
             if rm is not None:
                 with torch.no_grad():
                     times, ref = cpu_times(lambda: rm({"images": images_cpu[:1]}))
                 ref = {"flows": ref["flows"].float()}
                 kind = "reference"
-                sample = (f"{len(times)} forward(s) of the reference's own ptlflow.models.raft.raft.RAFT.forward (oracle/ref_loader.py, "
+                sample = (f"{len(times)} forward(s) of the reference's own ptlflow.models.raft.raft.{'RAFTSmall' if small else 'RAFT'}.forward (oracle/ref_loader.py, "
                           f"source: {ref_kind}) on the first frame pair of the batch, median; torch {torch.__version__} CPU, {cores} threads")
                 del rm
             else:

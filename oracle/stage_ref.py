@@ -83,29 +83,59 @@ def stage(source_root: str = SOURCE_ROOT, force: bool = False) -> str | None:
     return ARCHIVE
 
 
+def _verified(root: str, sums: dict) -> bool:
+    """Every manifest file exists under `root` with the manifest's hash (and the directory is ours, not group/world writable)."""
+    try:
+        st = os.stat(root)
+        if hasattr(os, "getuid") and (st.st_uid != os.getuid() or (st.st_mode & 0o022)):
+            return False
+        for rel, want in sums.items():
+            with open(os.path.join(root, rel), "rb") as fh:
+                if hashlib.sha256(fh.read()).hexdigest() != want:
+                    return False
+        return True
+    except OSError:
+        return False
+
+
 def unpack() -> str | None:
     """Extract the staged archive into a directory keyed by the archive's content; returns its root (the directory
-    that plays /root/reference), or None when nothing was staged.  Every file is checked against the manifest."""
+    that plays /root/reference), or None when nothing was staged.  Every file is checked against the manifest — also when an
+    existing directory is REUSED (the path is predictable: another user of a shared box could have put files there), and the
+    directory must be owned by this user with mode 0700.  Concurrent unpackers (torchrun ranks, xdist workers) each extract
+    into their own temporary directory and publish it with one atomic rename; the loser of the race verifies the winner's."""
     if not (os.path.isfile(ARCHIVE) and os.path.isfile(MANIFEST)):
         return None
+    import shutil
     import tempfile
     sums = json.load(open(MANIFEST))["sha256"]
     key = hashlib.sha256(json.dumps(sums, sort_keys=True).encode()).hexdigest()[:16]
-    root = os.path.join(tempfile.gettempdir(), f"pfk_staged_reference_{key}")
-    done = os.path.join(root, ".complete")
-    if not os.path.isfile(done):
-        os.makedirs(root, exist_ok=True)
+    uid = os.getuid() if hasattr(os, "getuid") else 0
+    root = os.path.join(tempfile.gettempdir(), f"pfk_staged_reference_{uid}_{key}")
+    if os.path.isdir(root):
+        if _verified(root, sums):
+            return root
+        raise RuntimeError(f"{root} exists but is not a verbatim, privately owned copy of the staged reference; remove it")
+    tmp = tempfile.mkdtemp(prefix=f"pfk_staged_reference_{key}_")          # mode 0700, unique per process
+    try:
         with zipfile.ZipFile(ARCHIVE) as z:
             for rel, want in sums.items():
                 data = z.read(rel)
                 if hashlib.sha256(data).hexdigest() != want:
                     raise RuntimeError(f"staged reference file {rel} does not match its manifest hash")
-                dst = os.path.join(root, rel)
+                dst = os.path.join(tmp, rel)
                 os.makedirs(os.path.dirname(dst), exist_ok=True)
-                with open(dst + ".part", "wb") as fh:
+                with open(dst, "wb") as fh:
                     fh.write(data)
-                os.replace(dst + ".part", dst)
-        open(done, "w").close()
+        try:
+            os.rename(tmp, root)                 # atomic publish; fails if another process got there first
+            tmp = None
+        except OSError:
+            if not _verified(root, sums):
+                raise RuntimeError(f"{root} appeared while unpacking and does not verify against the manifest")
+    finally:
+        if tmp is not None:
+            shutil.rmtree(tmp, ignore_errors=True)
     return root
 
 

@@ -44,7 +44,10 @@ def _check_stamp() -> None:
         return
     from . import _build
     want = _build.source_hash()
-    got = torch.ops.pfk.source_hash()          # "<extension stamp>:<libpfk.so stamp>"
+    try:
+        got = torch.ops.pfk.source_hash()          # "<extension stamp>:<libpfk.so stamp>"
+    except (AttributeError, RuntimeError):         # an extension from before the stamps existed: no such op
+        got = "unstamped:unstamped"
     if got != f"{want}:{want}":
         raise NativeLibraryStale(
             f"native libraries were built from other sources (stamps {got}, tree {want}); run `python -m ptlflow_amd._build` "
@@ -59,24 +62,21 @@ def load_native(build_if_missing: bool = False) -> None:
     global _loaded
     if _loaded:
         return
-    if not (LIBPFK_PATH.exists() and TORCH_EXT_PATH.exists()):
-        if build_if_missing or os.environ.get("PFK_AUTOBUILD") == "1":
-            from . import _build
+    autobuild = build_if_missing or os.environ.get("PFK_AUTOBUILD") == "1"
+    have_sources = (_PKG / "csrc" / "pfk_gemm.hip").exists()
+    if autobuild and have_sources:
+        # BEFORE anything is loaded: a no-op when both libraries carry the tree's stamp, a rebuild when they are missing OR stale
+        # (a stale library that is already mapped into the process cannot be replaced any more)
+        from . import _build
 
-            _build.build_all()
-        else:
-            raise NativeLibraryMissing(
-                f"{LIBPFK_PATH.name} / {TORCH_EXT_PATH.name} not found under {_PKG}; run "
-                "`python -m ptlflow_amd._build` (or __graft_entry__.build()). There is no fallback path."
-            )
+        _build.build_all()
+    if not (LIBPFK_PATH.exists() and TORCH_EXT_PATH.exists()):
+        raise NativeLibraryMissing(
+            f"{LIBPFK_PATH.name} / {TORCH_EXT_PATH.name} not found under {_PKG}; run "
+            "`python -m ptlflow_amd._build` (or __graft_entry__.build()). There is no fallback path."
+        )
     torch.ops.load_library(str(TORCH_EXT_PATH))
-    try:
-        _check_stamp()
-    except NativeLibraryStale:
-        if not (build_if_missing or os.environ.get("PFK_AUTOBUILD") == "1"):
-            raise
-        raise NativeLibraryStale("stale native libraries are already loaded into this process; rebuild "
-                                 "(`python -m ptlflow_amd._build`) and restart")
+    _check_stamp()
     _loaded = True
 
 

@@ -85,16 +85,21 @@ def _mark(target: Path, key: str) -> None:
 
 
 def embedded_hash(lib: Path):
-    """The stamp compiled into a built libpfk.so (ctypes, no GPU needed), or None."""
+    """The stamp compiled into a built libpfk.so, or None.  Read from the FILE (the `PFK_SOURCE_HASH=<stamp>` record of
+    pfk_stamp.hip), never through dlopen: glibc caches handles by path, so a library relinked by this process would keep
+    answering with the stamp of the mapping made before the relink."""
     if not lib.exists():
         return None
-    import ctypes
-    try:
-        f = ctypes.CDLL(str(lib)).pfk_source_hash
-        f.restype = ctypes.c_char_p
-        return f().decode()
-    except (OSError, AttributeError):
-        return None
+    marker = b"PFK_SOURCE_HASH="
+    data = lib.read_bytes()
+    i = data.find(marker)
+    while i >= 0:
+        j = data.find(b"\0", i)
+        val = data[i + len(marker): j if j >= 0 else i + len(marker) + 64]
+        if val and all(32 < c < 127 for c in val):
+            return val.decode()
+        i = data.find(marker, i + 1)
+    return None
 
 
 def _run(cmd) -> None:

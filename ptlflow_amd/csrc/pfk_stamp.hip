@@ -6,4 +6,8 @@
 #define PFK_SOURCE_HASH "unstamped"
 #endif
 
-extern "C" const char* pfk_source_hash(void) { return PFK_SOURCE_HASH; }
+// The marker in front lets the build script read the stamp out of the FILE (ptlflow_amd/_build.py embedded_hash) without
+// dlopen-ing a library it may be about to relink.
+static const char pfk_stamp_record[] = "PFK_SOURCE_HASH=" PFK_SOURCE_HASH;
+
+extern "C" const char* pfk_source_hash(void) { return pfk_stamp_record + 16; }

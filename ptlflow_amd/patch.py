@@ -188,8 +188,13 @@ def _make_corr_hook(module_name: str, original):
         # through `pfk_corr_lookup_bwd_f32` / `pfk_corr_volume_bwd_f32` — training); CPU tensors, alternate_corr, other
         # shapes stay on the reference's own implementation.
         if fmap1.is_cuda and not alternate_corr and not kw and _supported_envelope(fmap1, fmap2, num_levels, radius):
-            return _pfk_get_corr_block(fmap1, fmap2, num_levels=num_levels, radius=radius, pyramid=pyramid,
-                                       channels_last=get_corr_block.channels_last)
+            # layout per model INSTANCE (several instances of one family module may be accelerated with different `update_block=`
+            # settings): the caller is the model's `forward` (raft.py:146-152 and its siblings call `get_corr_block` directly), so its
+            # frame's `self` is the instance; anything else gets the hook's default, set by the last `accelerate` on this module
+            caller = sys._getframe(1).f_locals.get("self")
+            cl = isinstance(getattr(caller, "update_block", None), PfkUpdateBlock) if isinstance(caller, torch.nn.Module) \
+                else get_corr_block.channels_last
+            return _pfk_get_corr_block(fmap1, fmap2, num_levels=num_levels, radius=radius, pyramid=pyramid, channels_last=cl)
         return original(fmap1=fmap1, fmap2=fmap2, num_levels=num_levels, radius=radius, alternate_corr=alternate_corr, **kw)
 
     get_corr_block.pyramid = pyramid
@@ -438,7 +443,7 @@ def accelerate(model: torch.nn.Module, corr: bool = True, update_block: bool = T
         if spec is not None:
             model.update_block = PfkUpdateBlock(model.update_block, spec, conv_precision)
     hook = getattr(mod, "get_corr_block", None)
-    if hasattr(mod, _ORIG) and hasattr(hook, "channels_last"):
+    if corr and hasattr(mod, _ORIG) and hasattr(hook, "channels_last"):      # (default for callers that are not a model's forward)
         hook.channels_last = isinstance(getattr(model, "update_block", None), PfkUpdateBlock)
     cb = getattr(model, "corr_block", None)
     if corr and isinstance(cb, torch.nn.Module) and (type(cb).__module__, type(cb).__name__) in _BILINEAR_VOLUMES \

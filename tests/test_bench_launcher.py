@@ -1,7 +1,7 @@
 """bench.py's launcher logic on the CPU (no GPU, no processes started): `python bench.py --gpus N` without a launcher must re-exec
 itself under torch.distributed.run with N ranks on 127.0.0.1 and pass its own arguments through; with fewer visible devices than
 ranks it must exit non-zero instead (the one-device smoke flag aside).  The GPU side of the same contract — two real ranks, the
-`n_gpus` / `rccl_ranks` fields of the line — is tests/test_gpu_two_ranks_one_device.py."""
+`n_gpus` / `ranks_seen` fields of the line — is tests/test_gpu_two_ranks_one_device.py."""
 import importlib
 import os
 import sys
@@ -38,8 +38,9 @@ def test_self_launch_builds_the_documented_command(bench, monkeypatch):
     cmd = seen["cmd"]
     assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
     assert "--nnodes=1" in cmd and "--nproc-per-node=4" in cmd
-    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
-    assert 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    # torchrun picks the free port itself (`--standalone`), on 127.0.0.1: no probe socket of ours, no window for a port race
+    assert "--standalone" in cmd and cmd[cmd.index("--local-addr") + 1] == "127.0.0.1"
+    assert "--master-port" not in cmd
     i = cmd.index(os.path.join(ROOT, "bench.py"))
     assert cmd[i + 1:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"]           # its own arguments, unchanged
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")

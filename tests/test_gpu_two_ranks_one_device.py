@@ -117,7 +117,7 @@ _SMALL = ["--steps", "2", "--warmup", "1", "--batch", "2", "--iters", "4", "--he
 
 def test_bench_gpus_2_self_launches_two_ranks(gpu):
     """`python bench.py --gpus 2` with NO launcher (how a driver may invoke it): bench.py starts the two ranks itself and the
-    one JSON line says n_gpus == 2, rccl_ranks == 2 (an all-reduce of ones over the process group)."""
+    one JSON line says n_gpus == 2, ranks_seen == 2 (an all-reduce of ones over the process group)."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(PFK_BENCH_SHARED_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", *_SMALL], env=env, cwd=ROOT,
@@ -126,7 +126,7 @@ def test_bench_gpus_2_self_launches_two_ranks(gpu):
     lines = [l for l in run.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, run.stdout[-2000:]
     r = json.loads(lines[0])
-    assert r["n_gpus"] == 2 and r["rccl_ranks"] == 2 and r["config"]["global_batch"] == 4
+    assert r["n_gpus"] == 2 and r["ranks_seen"] == 2 and r["backend"].startswith("gloo") and r["config"]["global_batch"] == 4
 
 
 def test_bench_refuses_more_ranks_than_devices(gpu):
