@@ -57,7 +57,7 @@ enum pfk_status {
 };
 
 #define PFK_MAX_LEVELS 8
-#define PFK_ABI_VERSION 5
+#define PFK_ABI_VERSION 6
 
 int pfk_abi_version(void);
 const char* pfk_status_string(int status);
@@ -71,7 +71,8 @@ const char* pfk_source_hash(void);
 int pfk_debug_set_tile(int cfg);
 /* test hook: n / d through the multiplier arithmetic the persistent convolution kernel decodes its tiles with (n < 2^31, d >= 1) */
 unsigned pfk_debug_fastdiv(unsigned n, unsigned d);
-/* tuning knob of the pyramid lookup: source pixels per workgroup, 4 (default) or 8. */
+/* tuning knob of the pyramid lookup: source pixels per workgroup — 4 (default: 4 on the row-major layout; on the blocked layout 4
+ * below 28 160 source pixels and 8 from there up), 8, 104 (always 4), 14 (4 with cross-lane tap reads, row-major only). */
 int pfk_debug_set_lookup_pix(int pix);
 int pfk_debug_set_altcorr(int mode);       /* on-demand correlation forward: 0 = heuristic, 1 = per-pixel kernel, 2 / 3 = window-sharing MFMA kernel on 8x4 / 8x8 patches */
 int pfk_debug_set_wgrad(int variant);      /* weight-gradient tile height: 0 = by padding waste, 1 / 2 / 4 = forced 32 / 64 / 128 rows (tuning knob) */
@@ -121,6 +122,24 @@ typedef struct {
 int pfk_corr_lookup_f32(const pfk_lookup_desc* d, pfk_stream_t stream);
 /* same with `levels` pointing to bf16 maps; arithmetic and output fp32 (grid_sample is an fp32 op under autocast) */
 int pfk_corr_lookup_bf16(const pfk_lookup_desc* d, pfk_stream_t stream);
+
+/* ---- K1-K3 on the BLOCKED volume layout (round 5; inference path) -------------------------------------------------------
+ * A level's [H][W] map per source pixel stored as ceil(H/4) x ceil(W/8) tiles of 4 rows x 8 columns, 32 consecutive elements per
+ * tile (one 128-byte line in fp32): element (y, x) of a map lives at ((y/4 * ceil(W/8) + x/8) * 32 + (y%4) * 8 + x%8);
+ * pfk_blocked_map_elems(H, W) elements per source pixel (pad elements of edge tiles are zero).  The 12 x 12 window a lookup
+ * stages covers ~9 lines instead of ~16 (raft/corr.py:29-54 reads the same taps either way).
+ *   pfk_fmap_to_blocked_f32      permutes the rows of the target feature map [B][H*W][in_ld] into that order (zero rows for pad
+ *                                elements): out [B][pfk_blocked_map_elems(H, W)][out_ld].  pfk_corr_volume_f32 / _bf16 run against
+ *                                it (N2 = pfk_blocked_map_elems) write level 0 directly in the blocked layout (raft/corr.py:56-64).
+ *   pfk_corr_pool2x2_blocked_*   K2 blocked -> blocked (raft/corr.py:25-27), the same ((a00+a01)+a10)+a11)*0.25 per element.
+ *   pfk_corr_lookup_blocked_*    K3 on blocked levels: the same pfk_lookup_desc (lvl_h / lvl_w = the maps' LOGICAL sizes), the same
+ *                                arithmetic, bit-identical output to pfk_corr_lookup_* on the row-major pyramid. */
+int64_t pfk_blocked_map_elems(int H, int W);
+int pfk_fmap_to_blocked_f32(const float* in, int in_ld, float* out, int out_ld, int B, int H, int W, int C, pfk_stream_t stream);
+int pfk_corr_pool2x2_blocked_f32(const float* in, float* out, int64_t M, int H, int W, pfk_stream_t stream);
+int pfk_corr_pool2x2_blocked_bf16(const void* in, void* out, int64_t M, int H, int W, pfk_stream_t stream);
+int pfk_corr_lookup_blocked_f32(const pfk_lookup_desc* d, pfk_stream_t stream);
+int pfk_corr_lookup_blocked_bf16(const pfk_lookup_desc* d, pfk_stream_t stream);
 
 /* ---- backward of K3 (training): scatter d(out) through the forward's four bilinear weights --------------------
  * grad_out [B*N][grad_out_ld] (the layout of pfk_corr_lookup_f32's `out`); grad_levels[l] is the gradient of the level-l
@@ -269,6 +288,16 @@ int pfk_convex_upsample_f32(const float* flow, const float* mask, int mask_ld, f
 /* upflow8 (raft/utils.py:94-96, the mask-less upsampling of raft_small): out [B][2][8H][8W] = 8 * bilinear(coords1 - coords0,
  * size 8x, align_corners = True); coords NCHW [B][2][H][W].  Index / weight arithmetic as torch's upsample_bilinear2d. */
 int pfk_upflow8_f32(const float* coords0, const float* coords1, float* out, int B, int H, int W, pfk_stream_t stream);
+
+/* ---- fused mask head conv2 + softmax + convex upsampling (round 5) ------------------------------------------------------
+ * raft/update.py:138-142,152 (`0.25 * mask[2](relu(mask[0](net)))`: the 1x1 convolution to 9*64 channels) followed by
+ * raft/raft.py:112-123 (`upsample_flow`) in ONE kernel: the [M][576] mask is never written.  x [M = B*H*W][x_ld] = the mask head's
+ * hidden activation (cin channels, cin % 32 == 0), weight_perm [576][cin] / bias_perm [576] = the 1x1 convolution's weight
+ * and bias with their ROWS permuted to [half (2)][tap k (9)][32 sub-pixels]: row half*288 + k*32 + j = original channel
+ * k*64 + half*32 + j (so a block's nine taps of 32 sub-pixels are one contiguous row range); scale = 0.25; flow_pm pixel-major
+ * (flow_pm[p*flow_ld + 0..1]); out [B][2][8H][8W] NCHW.  Bit-identical to pfk_conv2d_f32 (scale 0.25) + pfk_convex_upsample_pm_f32. */
+int pfk_mask_upsample_f32(const float* x, int x_ld, int cin, const float* weight_perm, const float* bias_perm, float scale,
+                          const float* flow_pm, int flow_ld, float* out, int B, int H, int W, pfk_stream_t stream);
 
 /* same, with the flow read pixel-major (flow_pm[p*flow_ld + 0..1], e.g. the update engine's hx slice) */
 int pfk_convex_upsample_pm_f32(const float* flow_pm, int flow_ld, const float* mask, int mask_ld,

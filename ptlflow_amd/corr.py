@@ -6,15 +6,22 @@ Same call contract as the reference: built once per forward from ``fmap1, fmap2 
 called ``iters`` times with ``coords [B,2,h,w]`` (x, y in pixels) and returns
 ``[B, L*(2r+1)^2, h, w]`` with channel ``l*(2r+1)^2 + (dx+r)*(2r+1) + (dy+r)``.
 
-MI355X layout: the volume is built by one fp32-MFMA GEMM launch (K1) straight into
-``[B*N, h, w]`` maps, pooled by K2, and every lookup is ONE launch over all levels (K3) that
+MI355X layout: the volume is built by one fp32-MFMA GEMM launch (K1) straight into per-source-pixel
+maps, pooled by K2, and every lookup is ONE launch over all levels (K3) that
 writes a pixel-major ``[B*N, C]`` buffer; the tensor handed back is a channels-last *view* of that
 buffer (shape and values as the reference, strides NHWC) so the update block's first 1x1
 convolution reads it without any transpose.
+
+Inference keeps the maps in the BLOCKED layout (include/pfk.h): 4 x 8-element tiles, one 128-byte line each, so that the
+12 x 12 window a lookup stages covers ~9 lines instead of ~16.  K1 writes it for free — the target feature map's rows are
+permuted into the blocked order once per forward (`pfk_fmap_to_blocked_f32`) and a GEMM does not care in which order its B rows
+come — K2 / K3 have blocked variants with the same arithmetic (bit-identical lookups).  The training graph keeps the row-major
+maps its backward kernels address.  ``corr_pyramid`` always presents the reference's ``[B*N, h_l, w_l]`` maps.
 """
 from __future__ import annotations
 
 import math
+import os
 import weakref
 from typing import List, Optional
 
@@ -79,7 +86,7 @@ class _LookupFn(torch.autograd.Function):
     def forward(ctx, token, coords, block):
         out = torch.empty(block.B * block.h * block.w, block.channels, device=coords.device, dtype=torch.float32)
         c = coords.detach().float().contiguous()
-        _ops().corr_lookup(block.corr_pyramid, c, block.radius, out)
+        _ops().corr_lookup(block._levels, c, block.radius, out)
         ctx.block, ctx.coords = block, c
         return out
 
@@ -99,8 +106,12 @@ class CorrBlock:
     backward runs on libpfk too (`_PyramidToken` / `_LookupFn`) and delivers the gradients of ``fmap1`` / ``fmap2``."""
 
     def __init__(self, fmap1: torch.Tensor, fmap2: torch.Tensor, num_levels: int = 4, radius: int = 4,
-                 pyramid: str = "avgpool", volume_dtype: Optional[torch.dtype] = None, channels_last: bool = True):
-        """``channels_last``: the tensor a lookup returns is a channels-last VIEW of the pixel-major buffer (what this package's
+                 pyramid: str = "avgpool", volume_dtype: Optional[torch.dtype] = None, channels_last: bool = True,
+                 layout: Optional[str] = None):
+        """``layout``: ``"blocked"`` (4 x 8-element tiles, module docstring; the default without a gradient graph) or ``"rowmajor"``
+        (the reference's ``[B*N, h_l, w_l]`` maps; what the training graph's backward kernels address, forced there).
+
+        ``channels_last``: the tensor a lookup returns is a channels-last VIEW of the pixel-major buffer (what this package's
         update block reads without a transpose).  ``False`` returns a plain contiguous NCHW tensor instead — for callers whose
         consumer is torch's own convolutions: a channels-last input makes PyTorch run (and propagate) the channels-last memory
         format through the caller's whole update block, which costs the reference's SKFlow 25 ms per forward on MIOpen
@@ -130,7 +141,8 @@ class CorrBlock:
         # (L = 2 levels of radius 4 give 162 channels: ccmr / ms_raft_plus); the pad columns stay zero
         self.cpad = (self.channels + 3) // 4 * 4
         self._out: Optional[torch.Tensor] = None
-        self.corr_pyramid: List[torch.Tensor] = []
+        self._levels: List[torch.Tensor] = []      # storage of the pyramid levels in `self.layout`
+        self._lvl_hw: List[tuple] = []             # logical (h_l, w_l) of every level
         self._shape = None
         self.grad_levels: List[torch.Tensor] = []
         self._token: Optional[torch.Tensor] = None
@@ -142,6 +154,14 @@ class CorrBlock:
         if needs_graph and volume_dtype != torch.float32:
             raise RuntimeError("the training path keeps the pyramid in fp32 (the backward kernels are fp32)")
         self.volume_dtype = volume_dtype
+        if layout is None:
+            # (PFK_VOLUME_LAYOUT: A/B knob of bench.py / the tuning scripts; a gradient graph always gets row-major maps)
+            layout = "rowmajor" if needs_graph else os.environ.get("PFK_VOLUME_LAYOUT", "blocked")
+        if layout not in ("blocked", "rowmajor"):
+            raise ValueError(f"unknown volume layout {layout!r}")
+        if needs_graph and layout != "rowmajor":
+            raise RuntimeError("the training path keeps the row-major pyramid (its backward kernels address [h_l][w_l] maps)")
+        self.layout = layout
         if needs_graph:
             self._token = _PyramidToken.apply(fmap1, fmap2, self)     # calls _build
         else:
@@ -165,7 +185,7 @@ class CorrBlock:
         shape = (B, D, h, w, tuple(fmap2.shape), fmap1.device)
         fresh = shape != self._shape
         if fresh:
-            self.corr_pyramid, self._out, self._shape = [], None, shape
+            self._levels, self._lvl_hw, self._out, self._shape = [], [], None, shape
         dev = f1.device
         vt = self.volume_dtype
         bf = vt == torch.bfloat16
@@ -178,16 +198,36 @@ class CorrBlock:
             else:
                 ops.corr_volume(f1, f2_pm, scale, out)
 
+        blocked = self.layout == "blocked"
+
+        def level_storage(hl: int, wl: int) -> torch.Tensor:
+            if blocked:
+                return torch.empty(B * N, ops.blocked_map_elems(hl, wl), device=dev, dtype=vt)
+            return torch.empty(B * N, hl, wl, device=dev, dtype=vt)
+
+        def target_rows(f2_pm: torch.Tensor, h2: int, w2: int) -> torch.Tensor:
+            """[B, rows, D] B operand of K1 for a (h2, w2) target map: the map's pixels, in the blocked order when the volume is"""
+            if not blocked:
+                return f2_pm.view(B, h2 * w2, D)
+            out = torch.empty(B * ops.blocked_map_elems(h2, w2), D, device=dev, dtype=torch.float32)
+            ops.fmap_to_blocked(f2_pm.reshape(B * h2 * w2, D), out, B, h2, w2)
+            return out.view(B, -1, D)
+
         if self.pyramid_mode == "avgpool":  # raft/corr.py:19-27
-            f2 = to_pixel_major(fmap2)
+            h2, w2 = fmap2.shape[-2:]
+            f2 = target_rows(to_pixel_major(fmap2), h2, w2)
             if fresh:
-                hl, wl = h, w
+                hl, wl = h2, w2
                 for _ in range(self.num_levels):
-                    self.corr_pyramid.append(torch.empty(B * N, hl, wl, device=dev, dtype=vt))
+                    self._levels.append(level_storage(hl, wl))
+                    self._lvl_hw.append((hl, wl))
                     hl, wl = hl // 2, wl // 2
-            volume(f2, self.corr_pyramid[0].view(B, N, N))
+            volume(f2, self._levels[0].view(B, N, -1))
             for l in range(1, self.num_levels):
-                ops.corr_pool2x2(self.corr_pyramid[l - 1], self.corr_pyramid[l])
+                if blocked:
+                    ops.corr_pool2x2_blocked(self._levels[l - 1], self._levels[l], *self._lvl_hw[l - 1])
+                else:
+                    ops.corr_pool2x2(self._levels[l - 1], self._levels[l])
         else:  # sea_raft/corr.py:77-84: one GEMM per level against fmap2 halved bilinearly (== a 2x2 average, pfk_fmap_pool2x2_f32)
             f2 = to_pixel_major(fmap2).reshape(B * fmap2.shape[-2] * fmap2.shape[-1], D)
             h2, w2 = fmap2.shape[-2:]
@@ -197,19 +237,32 @@ class CorrBlock:
                     ops.fmap_pool2x2(f2, nxt, B, h2, w2)
                     f2, h2, w2 = nxt, h2 // 2, w2 // 2
                 if fresh:
-                    self.corr_pyramid.append(torch.empty(B * N, h2, w2, device=dev, dtype=vt))
-                volume(f2.view(B, h2 * w2, D), self.corr_pyramid[l].view(B, N, h2 * w2))
+                    self._levels.append(level_storage(h2, w2))
+                    self._lvl_hw.append((h2, w2))
+                volume(target_rows(f2, h2, w2), self._levels[l].view(B, N, -1))
         return self
+
+    @property
+    def corr_pyramid(self) -> List[torch.Tensor]:
+        """The pyramid as the reference holds it (raft/corr.py:21-27): ``[B*N, h_l, w_l]`` maps.  Row-major storage is returned as
+        is; blocked storage is un-tiled into fresh tensors (tests / inspection — the lookups read the blocked storage)."""
+        if self.layout != "blocked":
+            return self._levels
+        out = []
+        for lv, (hl, wl) in zip(self._levels, self._lvl_hw):
+            th, tw = (hl + 3) // 4, (wl + 7) // 8
+            out.append(lv.view(-1, th, tw, 4, 8).permute(0, 1, 3, 2, 4).reshape(-1, th * 4, tw * 8)[:, :hl, :wl].contiguous())
+        return out
 
     # ------------------------------------------------------------------ training (autograd) side
     def _zero_grad_levels(self) -> None:
         """Gradient buffers of the pyramid levels: one [h_l][w_l] map per source pixel at a row stride padded to a multiple
         of 4 floats (so a buffer is directly the A operand / dY operand of the two backward GEMMs); zeroed once per step."""
         M = self.B * self.h * self.w
-        sizes = [(int(p.shape[1]), int(p.shape[2])) for p in self.corr_pyramid]
+        sizes = list(self._lvl_hw)
         if len(self.grad_levels) != len(sizes) or any(g.shape[0] != M or g.shape[1] != (hl * wl + 3) // 4 * 4
                                                       for g, (hl, wl) in zip(self.grad_levels, sizes)):
-            dev = self.corr_pyramid[0].device
+            dev = self._levels[0].device
             self.grad_levels = [torch.zeros(M, max(4, (hl * wl + 3) // 4 * 4), device=dev, dtype=torch.float32) for hl, wl in sizes]
         else:
             for g in self.grad_levels:
@@ -274,7 +327,10 @@ class CorrBlock:
         c = coords
         if c.dtype != torch.float32 or not c.is_contiguous():
             c = c.float().contiguous()
-        _ops().corr_lookup(self.corr_pyramid, c, self.radius, out)
+        if self.layout == "blocked":
+            _ops().corr_lookup_blocked(self._levels, [s[0] for s in self._lvl_hw], [s[1] for s in self._lvl_hw], c, self.radius, out)
+        else:
+            _ops().corr_lookup(self._levels, c, self.radius, out)
         return out
 
     def __call__(self, coords: torch.Tensor) -> torch.Tensor:

@@ -34,6 +34,16 @@ struct LookupArgs {
   int out_ld;
 };
 
+// Blocked volume layout (round 5): a level's [H][W] map per source pixel is stored as ceil(H/4) x ceil(W/8) tiles of 4 rows x 8
+// columns, 32 consecutive elements each — one 128-byte line per fp32 tile.  The 12 x 12 window a lookup stages then touches
+// (12 + dy) / 4 x (12 + dx) / 8 ~ 3.75 x 2.4 = 9 lines instead of the 12 rows x 1.34 = 16 lines of the row-major map (every row
+// of the window lies in its own line there): the HBM fetch per lookup shrinks accordingly.  Element (y, x):
+__device__ __forceinline__ int blocked_index(int y, int x, int tw) {
+  return ((((y >> 2) * tw + (x >> 3)) << 5) | ((y & 3) << 3) | (x & 7));
+}
+__host__ __device__ __forceinline__ int blocked_tiles_h(int H) { return (H + 3) >> 2; }
+__host__ __device__ __forceinline__ int blocked_tiles_w(int W) { return (W + 7) >> 3; }
+
 // PIX consecutive source pixels per workgroup: the kernel is a chain of dependent latencies (coords -> patch
 // loads -> LDS -> outputs), so each wave keeps PIX independent patches in flight instead of one — 4x fewer,
 // 4x fatter workgroups, one resident round on the chip at 55x128.
@@ -47,7 +57,8 @@ struct LookupArgs {
 // SHFL (measurement variant, pfk_debug_set_lookup_pix(14)): the staged patch stays in the registers it was loaded into and
 // every tap is fetched with cross-lane reads (ds_bpermute) instead of LDS stores + loads — the alternative DESIGN.md section 3
 // weighs against the LDS staging; same arithmetic, same bits.  profiles/r04_e_lookup_shuffle.md has the numbers.
-template <int PIX, int R, typename T, bool SHFL = false>
+// BLK: the levels are in the blocked 4 x 8 layout (pfk_corr_lookup_blocked_*); only the address of a staged element changes.
+template <int PIX, int R, typename T, bool SHFL = false, bool BLK = false>
 __global__ __launch_bounds__(256) void lookup_kernel(const LookupArgs a) {
   constexpr int n = 2 * R + 1, nn = n * n;
   __shared__ float s_patch[4][PIX][PATCH * PATCH_LD];
@@ -84,7 +95,9 @@ __global__ __launch_bounds__(256) void lookup_kernel(const LookupArgs a) {
     if (active) {
       const int Hl = a.lh[l], Wl = a.lw[l];
       const float inv = 1.0f / (float)(1 << l);   // coords / 2**l is exact (corr.py:45)
-      const T* vol0 = static_cast<const T*>(a.lv[l]) + (size_t)p0 * (unsigned)(Hl * Wl);   // one 32x32->64 multiply per level
+      const int twl = blocked_tiles_w(Wl);
+      const unsigned mapsz = BLK ? (unsigned)(blocked_tiles_h(Hl) * twl * 32) : (unsigned)(Hl * Wl);   // elements per source pixel
+      const T* vol0 = static_cast<const T*>(a.lv[l]) + (size_t)p0 * mapsz;   // one 32x32->64 multiply per level
       float v[PIX][3];
       // tap tables of all PIX pixels in one pass (two for PIX = 8): entry e = q * n + i evaluates window index i of pixel q on
       // both axes (two IEEE divisions per lane; one pass over 36 lanes instead of PIX passes over 9)
@@ -113,7 +126,7 @@ __global__ __launch_bounds__(256) void lookup_kernel(const LookupArgs a) {
         const float yb = floorf(cy) - (float)(R + 1);
         const int xbi = safe_base(xb), ybi = safe_base(yb);
         const bool pl = (p0 + q) < M;
-        const T* vol = vol0 + (size_t)q * (unsigned)(Hl * Wl);
+        const T* vol = vol0 + (size_t)q * mapsz;
 #pragma unroll
         for (int e3 = 0; e3 < 3; ++e3) {          // all loads of all PIX patches are issued before any is used
           const int e = lane + 64 * e3;
@@ -121,7 +134,7 @@ __global__ __launch_bounds__(256) void lookup_kernel(const LookupArgs a) {
           const int gy = ybi + yy, gx = xbi + xx;
           float t = 0.f;
           if (pl && e < PATCH * PATCH && (unsigned)gy < (unsigned)Hl && (unsigned)gx < (unsigned)Wl)
-            t = (float)vol[gy * Wl + gx];   // 32-bit offset inside one map; bf16 volume: exact widening (grid_sample is fp32 under autocast)
+            t = (float)vol[BLK ? blocked_index(gy, gx, twl) : gy * Wl + gx];   // 32-bit offset inside one map; bf16 volume: exact widening (grid_sample is fp32 under autocast)
           v[q][e3] = t;
         }
       }
@@ -232,21 +245,65 @@ __global__ __launch_bounds__(256) void fmap_pool2x2_kernel(const float* __restri
   *reinterpret_cast<f32x4*>(out + ((b * Ho + yo) * (long long)Wo + xo) * out_ld + c) = (((a00 + a01) + a10) + a11) * 0.25f;
 }
 
+// K2 on the blocked layout: in = M maps of (H, W) as 4 x 8 tiles, out = the (H/2, W/2) maps as 4 x 8 tiles.  One thread per
+// element of the OUTPUT STORAGE (pad elements of edge tiles are written as zero, so the storage is fully defined); the 2 x 2
+// cell of an output element lies inside ONE input tile (rows 2yo & 3 in {0, 2}, columns 2xo & 7 even).  Same summation order.
+template <typename T>
+__global__ __launch_bounds__(256) void pool2x2_blocked_kernel(const T* __restrict__ in, T* __restrict__ out, long long total,
+                                                              int TH, int TW, int Ho, int Wo, int THo, int TWo) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+    const int e = (int)(idx & 31);
+    const long long t = idx >> 5;
+    const int tx = (int)(t % TWo);
+    const long long t2 = t / TWo;
+    const int ty = (int)(t2 % THo);
+    const long long m = t2 / THo;
+    const int yo = ty * 4 + (e >> 3), xo = tx * 8 + (e & 7);
+    float v = 0.f;
+    if (yo < Ho && xo < Wo) {
+      const T* src = in + m * ((long long)TH * TW * 32) + blocked_index(2 * yo, 2 * xo, TW);
+      const float a00 = (float)src[0], a01 = (float)src[1], a10 = (float)src[8], a11 = (float)src[9];
+      v = (((a00 + a01) + a10) + a11) * 0.25f;
+    }
+    out[idx] = (T)v;
+  }
+}
+
+// Rows of a pixel-major feature map [B][H*W][in_ld] permuted into the blocked order: out [B][TH*TW*32][out_ld], row
+// ((ty*TW + tx)*32 + r*8 + c) = pixel (4ty + r, 8tx + c), zero rows where that pixel lies outside the map.  K1 run against this
+// map writes the volume's rows directly in the blocked layout — a GEMM does not care which order its B rows come in.
+__global__ __launch_bounds__(256) void fmap_to_blocked_kernel(const float* __restrict__ in, int in_ld, float* __restrict__ out,
+                                                              int out_ld, long long total4, int C4, int H, int W, int TH, int TW) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total4) return;
+  const int c = (int)(idx % C4) * 4;
+  long long t = idx / C4;
+  const int e = (int)(t & 31); t >>= 5;
+  const int tx = (int)(t % TW); t /= TW;
+  const int ty = (int)(t % TH);
+  const long long b = t / TH;
+  const int y = ty * 4 + (e >> 3), x = tx * 8 + (e & 7);
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (y < H && x < W) v = *reinterpret_cast<const f32x4*>(in + ((b * H + y) * (long long)W + x) * in_ld + c);
+  *reinterpret_cast<f32x4*>(out + (((b * TH + ty) * (long long)TW + tx) * 32 + e) * out_ld + c) = v;
+}
+
 int g_lookup_pix = 4;   // pixels per workgroup: 4 or 8; 14 = 4 with cross-lane tap reads (pfk_debug_set_lookup_pix; tuning knob)
 
-template <int PX, typename T, bool SHFL = false>
+template <int PX, typename T, bool SHFL = false, bool BLK = false>
 int lookup_launch_pix(const LookupArgs& a, int radius, long long M, hipStream_t st) {
   const dim3 grid((unsigned)((M + PX - 1) / PX)), block(256);
   switch (radius) {
-    case 1: hipLaunchKernelGGL((lookup_kernel<PX, 1, T, SHFL>), grid, block, 0, st, a); break;
-    case 2: hipLaunchKernelGGL((lookup_kernel<PX, 2, T, SHFL>), grid, block, 0, st, a); break;
-    case 3: hipLaunchKernelGGL((lookup_kernel<PX, 3, T, SHFL>), grid, block, 0, st, a); break;
-    default: hipLaunchKernelGGL((lookup_kernel<PX, 4, T, SHFL>), grid, block, 0, st, a); break;
+    case 1: hipLaunchKernelGGL((lookup_kernel<PX, 1, T, SHFL, BLK>), grid, block, 0, st, a); break;
+    case 2: hipLaunchKernelGGL((lookup_kernel<PX, 2, T, SHFL, BLK>), grid, block, 0, st, a); break;
+    case 3: hipLaunchKernelGGL((lookup_kernel<PX, 3, T, SHFL, BLK>), grid, block, 0, st, a); break;
+    default: hipLaunchKernelGGL((lookup_kernel<PX, 4, T, SHFL, BLK>), grid, block, 0, st, a); break;
   }
   return pfk_launch_status();
 }
 
-template <typename T>
+template <typename T, bool BLK = false>
 int lookup_launch(const pfk_lookup_desc* d, pfk_stream_t stream) {
   if (!d || !d->coords || !d->out) return PFK_ERR_BAD_ARG;
   if (d->num_levels < 1 || d->num_levels > PFK_MAX_LEVELS) return PFK_ERR_BAD_ARG;
@@ -264,8 +321,31 @@ int lookup_launch(const pfk_lookup_desc* d, pfk_stream_t stream) {
   const long long M = (long long)d->B * d->h * d->w;
   if (M >= 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;   // the kernel's pixel arithmetic is 32-bit
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if constexpr (BLK) {
+    for (int l = 0; l < d->num_levels; ++l)     // 32-bit element offsets inside one source pixel's map
+      if ((long long)blocked_tiles_h(d->lvl_h[l]) * blocked_tiles_w(d->lvl_w[l]) * 32 >= 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
+    // 8 pixels per workgroup from 28 160 source pixels up (a pyramid far beyond the 256 MB Infinity Cache: more windows in
+    // flight per wave pay; 55x128 batch 8, iid field 60.7 -> 55.9 us, smooth 55.2 -> 54.7), 4 below (batch 1: 10.1 vs 12.2 us;
+    // gpurun_out/r5c_lookup.log).  g_lookup_pix: 4 = this rule, 8 = always 8, 104 = always 4 (tuning knob).
+    const bool eight = g_lookup_pix == 8 || (g_lookup_pix == 4 && M >= 28160);
+    return eight ? lookup_launch_pix<8, T, false, true>(a, d->radius, M, st) : lookup_launch_pix<4, T, false, true>(a, d->radius, M, st);
+  }
   if (g_lookup_pix == 14) return lookup_launch_pix<4, T, true>(a, d->radius, M, st);
   return g_lookup_pix == 8 ? lookup_launch_pix<8, T>(a, d->radius, M, st) : lookup_launch_pix<4, T>(a, d->radius, M, st);
+}
+
+template <typename T>
+int pool_blocked_launch(const T* in, T* out, int64_t M, int H, int W, pfk_stream_t stream) {
+  if (!in || !out || M <= 0 || H <= 0 || W <= 0) return PFK_ERR_BAD_ARG;
+  const int Ho = H / 2, Wo = W / 2;
+  const int THo = blocked_tiles_h(Ho), TWo = blocked_tiles_w(Wo);
+  const long long total = (long long)M * THo * TWo * 32;
+  if (total == 0) return PFK_OK;  // a 1-pixel level pools to nothing
+  long long blocks = (total + 255) / 256;
+  if (blocks > 256LL * 32) blocks = 256LL * 32;
+  hipLaunchKernelGGL(pool2x2_blocked_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), in, out, total,
+                     blocked_tiles_h(H), blocked_tiles_w(W), Ho, Wo, THo, TWo);
+  return pfk_launch_status();
 }
 
 template <typename T>
@@ -285,13 +365,38 @@ int pool_launch(const T* in, T* out, int64_t M, int H, int W, pfk_stream_t strea
 
 extern "C" {
 
-int pfk_debug_set_lookup_pix(int pix) { if (!pfk_debug_knobs_enabled()) return PFK_ERR_DISABLED; g_lookup_pix = (pix == 8 || pix == 14) ? pix : 4; return PFK_OK; }
+int pfk_debug_set_lookup_pix(int pix) { if (!pfk_debug_knobs_enabled()) return PFK_ERR_DISABLED; g_lookup_pix = (pix == 8 || pix == 14 || pix == 104) ? pix : 4; return PFK_OK; }
 
 int pfk_corr_lookup_f32(const pfk_lookup_desc* d, pfk_stream_t stream) { return lookup_launch<float>(d, stream); }
 
 // levels[] point to bf16 maps (the pyramid of pfk_corr_volume_bf16 / pfk_corr_pool2x2_bf16); coordinates, weights,
 // accumulation and the output stay fp32 — F.grid_sample is on autocast's fp32 list, so that is what the reference runs.
 int pfk_corr_lookup_bf16(const pfk_lookup_desc* d, pfk_stream_t stream) { return lookup_launch<__bf16>(d, stream); }
+
+int pfk_corr_lookup_blocked_f32(const pfk_lookup_desc* d, pfk_stream_t stream) { return lookup_launch<float, true>(d, stream); }
+
+int pfk_corr_lookup_blocked_bf16(const pfk_lookup_desc* d, pfk_stream_t stream) { return lookup_launch<__bf16, true>(d, stream); }
+
+int pfk_corr_pool2x2_blocked_f32(const float* in, float* out, int64_t M, int H, int W, pfk_stream_t stream) {
+  return pool_blocked_launch<float>(in, out, M, H, W, stream);
+}
+
+int pfk_corr_pool2x2_blocked_bf16(const void* in, void* out, int64_t M, int H, int W, pfk_stream_t stream) {
+  return pool_blocked_launch<__bf16>(static_cast<const __bf16*>(in), static_cast<__bf16*>(out), M, H, W, stream);
+}
+
+int64_t pfk_blocked_map_elems(int H, int W) { return (int64_t)blocked_tiles_h(H) * blocked_tiles_w(W) * 32; }
+
+int pfk_fmap_to_blocked_f32(const float* in, int in_ld, float* out, int out_ld, int B, int H, int W, int C, pfk_stream_t stream) {
+  if (!in || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || in_ld < C || out_ld < C) return PFK_ERR_BAD_ARG;
+  if ((C & 3) || (in_ld & 3) || (out_ld & 3) || !pfk_aligned16(in) || !pfk_aligned16(out)) return PFK_ERR_ALIGNMENT;
+  const int TH = blocked_tiles_h(H), TW = blocked_tiles_w(W);
+  const long long total4 = (long long)B * TH * TW * 32 * (C / 4);
+  if ((total4 + 255) / 256 > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(fmap_to_blocked_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), in,
+                     in_ld, out, out_ld, total4, C / 4, H, W, TH, TW);
+  return pfk_launch_status();
+}
 
 int pfk_corr_pool2x2_f32(const float* in, float* out, int64_t M, int H, int W, pfk_stream_t stream) {
   return pool_launch<float>(in, out, M, H, W, stream);

@@ -46,6 +46,8 @@ struct GemmArgs {
   const void* wbf;         // split-bf16 path: weight planes [nsplit][cout][ktot] bf16, same k order as `weight`
   long long wbf_plane_bytes;
   int m_tile_base;         // split-bf16 path: a launch may cover a range of row tiles only (launch_bf's tail split); first row tile, in units of BM
+  // fused mask head conv2 + softmax + convex upsampling (mask_upsample_kernel): flow read pixel-major, 8x output NCHW
+  const float* mu_flow; int mu_flow_ld; float* mu_out;
 };
 
 // Tile id -> (tile_m, tile_n).  Row-major by default (tile_n fastest: the column tiles of one row panel run together and share

@@ -372,6 +372,153 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------------
+// Fused mask head conv2 + softmax + 8x convex upsampling (raft/update.py:138-142,152 + raft/raft.py:112-123), round 5.
+//
+// The reference's loop writes a [B, 576, h, w] mask (mask[k*64 + sy*8 + sx] for tap k of the 3x3 neighbourhood and sub-pixel
+// (sy, sx)) and re-reads it for softmax over k + the convex combination: 16 MB per pair and iteration through HBM, 32 times.
+// Here ONE kernel does the 1x1 convolution and consumes its output in registers: a block owns 128 pixels x 32 sub-pixels and ALL
+// NINE taps — four waves stacked in M, wave tile 32 pixels x (9 x 32) columns = nine 32x32 accumulators — so the nine logits of
+// a (pixel, sub-pixel) sit in ONE lane (accumulator register r of the nine tiles): softmax and the weighted sum of the
+// neighbours' flows are lane-local, the mask never exists in memory.  The host permutes the weight / bias rows to
+// [half (2)][tap (9)][32 sub-pixels], which makes the block's B rows the plain range [half*288, half*288 + 288) of the 2-stage
+// kernel's stager.  K loop = variant 1's (same K order per output element as every other tile shape: the logits are bit-identical
+// to the unfused launch's), 8 K-steps of 144 MFMAs per wave for the 256 input channels; LDS 2 x (128 + 288) x 36 floats = 117 KB,
+// one block per CU.  Epilogue arithmetic = the unfused pair's, operation for operation (conv epilogue: + bias, x 0.25;
+// convex_upsample_kernel: max, exp, sum in tap order, one reciprocal, un-contracted multiply-adds) => bit-identical flow.
+// -------------------------------------------------------------------------------------------------
+// One (pixel, sub-pixel) of the fused epilogue: the nine logits -> softmax -> convex combination of the neighbours' flows, with the
+// arithmetic of the unfused pair operation for operation — conv epilogue (pfk_gemm.h, LINEAR): + bias, x scale; convex_upsample_kernel
+// (pfk_misc.hip, compiled with -ffp-contract=off): max, exp, sum in tap order, one reciprocal, multiply then add.  In the unfused
+// pair the mask goes through memory between the two kernels and pfk_misc.hip never contracts, so NOTHING here may be contracted
+// into an FMA either: this translation unit is compiled with contraction on and HIP's __fmul_rn / __fadd_rn are plain operators
+// (they do not stop it), hence the pragma.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void mask_upsample_combine(const float (&logit)[9], const float (&bias)[9], float sc, const f32x2* nfp,
+                                                      float& ox, float& oy) {
+#pragma clang fp contract(off)
+  float m[9];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    float v = logit[k] + bias[k];
+    v = v * sc;
+    m[k] = v;
+    mx = fmaxf(mx, v);
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { m[k] = expf(m[k] - mx); sum = sum + m[k]; }
+  const float inv = 1.0f / sum;
+  float ax = 0.f, ay = 0.f;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const f32x2 f = nfp[k];
+    const float wk = m[k] * inv;
+    const float tx = wk * f[0], ty = wk * f[1];
+    ax = ax + tx;
+    ay = ay + ty;
+  }
+  ox = ax;
+  oy = ay;
+}
+
+__global__ __launch_bounds__(256) void mask_upsample_kernel(const GemmArgs a) {
+  constexpr int BM = 128, BN = 288, MT = 1, NT = 9;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sA = smem;                          // [2][BM][LDS_LD]
+  float* sB = smem + 2 * BM * LDS_LD;        // [2][BN][LDS_LD]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = tid >> 6;
+  const int wm0 = wid * 32;
+
+  const int bid = pfk_xcd_remap(blockIdx.x, gridDim.x);   // the two halves of a pixel tile are neighbours: one A panel through one L2
+  const int half = bid & 1;
+  const long long m0 = (long long)(bid >> 1) * BM;
+  const int n0 = half * BN;
+
+  Stager<BM, BN> st(a, m0, n0, tid, 0);
+  const int total_steps = st.total_steps();
+
+  f32x16 acc[MT][NT];
+  zero_acc<MT, NT>(acc);
+
+  st.load();
+  st.advance();
+  st.store(sA, sB);
+  __syncthreads();
+
+  const int frow = lane & 31;
+  int ko[4];
+  frag_offsets<LDS_LD>(ko, lane);
+
+  for (int step = 0; step < total_steps; ++step) {
+    const int buf = step & 1;
+    const bool more = (step + 1) < total_steps;
+    const float* cA = sA + buf * BM * LDS_LD + (wm0 + frow) * LDS_LD;
+    const float* cB = sB + buf * BN * LDS_LD + frow * LDS_LD;
+    Frags<MT, NT> fr;
+    frag_read<MT, NT, LDS_LD>(fr, cA, cB, ko, 0);
+    st.load(more);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_rest<MT, NT>(acc, fr, cA, cB, ko);
+    __builtin_amdgcn_sched_barrier(0);
+    st.store(sA + (buf ^ 1) * BM * LDS_LD, sB + (buf ^ 1) * BN * LDS_LD);
+    if (more) st.advance();
+    __syncthreads();
+  }
+
+  // ---- epilogue.  8 * flow of every pixel's 3x3 neighbourhood (zero outside the image: F.unfold's padding) -> LDS
+  f32x2* nf = reinterpret_cast<f32x2*>(smem);     // [BM][9]; every stage read sits behind the loop's final barrier
+  const unsigned H = (unsigned)a.H, W = (unsigned)a.W;
+  for (int e = tid; e < BM * 9; e += 256) {
+    const int pl = e / 9, k = e - pl * 9;
+    const unsigned p = (unsigned)m0 + (unsigned)pl;
+    f32x2 v = {0.f, 0.f};
+    if ((long long)p < a.M) {
+      const unsigned prow = fastdiv_u32(p, a.wo_mul, a.wo_sh);          // b*H + y
+      const unsigned bimg = fastdiv_u32(prow, a.ho_mul, a.ho_sh);
+      const int x = (int)(p - prow * W), y = (int)(prow - bimg * H);
+      const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
+      if ((unsigned)yy < H && (unsigned)xx < W) {
+        const float* f = a.mu_flow + ((size_t)(bimg * H + (unsigned)yy) * W + (unsigned)xx) * (size_t)a.mu_flow_ld;
+        v[0] = __fmul_rn(8.0f, f[0]);
+        v[1] = __fmul_rn(8.0f, f[1]);
+      }
+    }
+    nf[e] = v;
+  }
+  __syncthreads();
+
+  const int col = lane & 31;
+  const int s = half * 32 + col, sy = s >> 3, sx = s & 7;
+  float bias[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) bias[k] = a.bias != nullptr ? a.bias[n0 + k * 32 + col] : 0.f;
+  const float sc = a.scale;
+  const size_t HW8 = (size_t)H * W * 64;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = wm0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    const unsigned p = (unsigned)m0 + (unsigned)row;
+    float logit[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) logit[k] = acc[0][k][r];
+    float ox, oy;
+    mask_upsample_combine(logit, bias, sc, nf + row * 9, ox, oy);
+    if ((long long)p < a.M) {
+      const unsigned prow = fastdiv_u32(p, a.wo_mul, a.wo_sh);
+      const unsigned bimg = fastdiv_u32(prow, a.ho_mul, a.ho_sh);
+      const unsigned x = p - prow * W, y = prow - bimg * H;
+      const size_t o = (size_t)(8 * y + (unsigned)sy) * (8 * W) + 8 * x + (unsigned)sx;
+      a.mu_out[((size_t)bimg * 2 + 0) * HW8 + o] = ox;
+      a.mu_out[((size_t)bimg * 2 + 1) * HW8 + o] = oy;
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
 // Variant 3 (the tuned path): three LDS stages per wave group, global prefetch distance 2, register
 // double-buffered MFMA fragments, one s_barrier per K-step.
 //
@@ -1070,6 +1217,19 @@ int launch_cfg(const GemmArgs& a, int epi, int batches, hipStream_t st) {
   }
 }
 
+// the same for tiles only the LINEAR epilogue is instantiated on (the encoders' widths)
+template <int BM, int BN, int WM, int WN, int VARIANT>
+int launch_cfg_linear(const GemmArgs& a, int epi, int batches, hipStream_t st) {
+  if (epi != PFK_EPI_LINEAR) return PFK_ERR_BAD_ARG;
+  GemmArgs g = a;
+  const long long tiles_m = (a.M + BM - 1) / BM;
+  g.tiles_n = (a.b_rows + BN - 1) / BN;
+  const long long nblk = tiles_m * g.tiles_n;
+  if (nblk <= 0 || nblk > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
+  g.supertile = 0;
+  return launch_one<BM, BN, WM, WN, PFK_EPI_LINEAR, VARIANT>(g, dim3((unsigned)nblk, (unsigned)batches), st);
+}
+
 int g_force_tile = -1;  // debug/tuning knob, see pfk_debug_set_tile
 int g_small_swizzled = 0;   // tuning knob (pfk_debug_set_tile(301)): small grids on the 48 KB swizzled layout too, so that a block of a
                             // concurrently running launch (forked branches) still fits next to two of them on a CU
@@ -1123,6 +1283,12 @@ int launch(const GemmArgs& a0, int epi, int batches, hipStream_t st) {
     // output width is a multiple of 128 and the grid still has >= 3 rounds of them: fh|mask conv1 526 -> 513 us (129 TFLOP/s),
     // z|r convs 457..528 -> 436 us, convc1 108 -> 101 us; they lose on cout 192 / 126 / 576 (padding) and cout 128 (one column).
     if (g_small_swizzled && (cfg == 4 || cfg == 0)) cfg = 10;
+    // Round 5: 96 output channels (BasicEncoder's layer 2, raft/extractor.py:150-151) are 1.5 column tiles of 64 — a quarter of the
+    // MFMAs multiplied zero weight rows.  A 128 x 96 tile (four waves stacked in M, wave tile 32 x 96, 2-stage kernel, 64.5 KB: two
+    // blocks per CU) covers them exactly: 96->96 3x3 at 110x256 x 16 images 793 -> 627 us (94 -> 119 TFLOP/s of real work), the
+    // stride-2 64->96 591 -> 454 us, the 1x1 downsample 132 -> 95 us; the 3-stage kernel on the same tile (84 KB, one block per CU)
+    // 680 / 513 / 134 us (gpurun_out/r5b_enc.log).  Same K order per output element: same bits.
+    if (epi == PFK_EPI_LINEAR && a.b_rows == 96 && batches == 1 && a.M >= 128 * 256 && cfg != 9) cfg = 15;
     if (cfg == 10 && batches == 1 && a.b_rows >= 256 && (a.b_rows & 127) == 0 && tiles64 * (a.b_rows / 128) >= 6 * 256 &&
         a.sk_steps >= 8)
       cfg = 11;
@@ -1149,6 +1315,13 @@ int launch(const GemmArgs& a0, int epi, int batches, hipStream_t st) {
     case 11: return launch_cfg<64, 128, 32, 64, 101>(a, epi, batches, st);
     case 12: return launch_cfg<128, 64, 64, 32, 101>(a, epi, batches, st);
     case 13: return launch_cfg<128, 128, 64, 64, 101>(a, epi, batches, st);
+    // round 5, the encoders' widths: 96 output channels are 1.5 column tiles of 64 (a quarter of the MFMAs multiply zero rows): a
+    // 128 x 96 tile — four waves stacked in M, wave tile 32 x 96 — covers them exactly (84 KB swizzled: one block per CU; 64.5 KB on
+    // the 2-stage kernel: two); 64 output channels: taller tiles with 32 x 64 / 64 x 64 wave tiles
+    case 14: return launch_cfg_linear<128, 96, 32, 96, 101>(a, epi, batches, st);
+    case 15: return launch_cfg_linear<128, 96, 32, 96, 0>(a, epi, batches, st);
+    case 16: return launch_cfg_linear<256, 64, 64, 64, 101>(a, epi, batches, st);
+    case 17: return launch_cfg_linear<128, 64, 32, 64, 101>(a, epi, batches, st);
     // MFMA-only skeletons of the bigger padded tiles (timing ablations)
     case 27: return epi == PFK_EPI_LINEAR ? launch_cfg<64, 128, 32, 64, 31>(a, epi, batches, st) : PFK_ERR_BAD_ARG;
     case 28: return epi == PFK_EPI_LINEAR ? launch_cfg<128, 128, 64, 64, 31>(a, epi, batches, st) : PFK_ERR_BAD_ARG;
@@ -1270,6 +1443,31 @@ int pfk_conv2d_f32(const pfk_conv_desc* d, pfk_stream_t stream) {
     a.sk_flags = reinterpret_cast<unsigned*>(static_cast<char*>(d->workspace) + (size_t)SK_MAX_BLOCKS * 64 * 64 * 4);
   }
   return launch(a, d->epilogue, 1, static_cast<hipStream_t>(stream));
+}
+
+int pfk_mask_upsample_f32(const float* x, int x_ld, int cin, const float* weight_perm, const float* bias_perm, float scale,
+                          const float* flow_pm, int flow_ld, float* out, int B, int H, int W, pfk_stream_t stream) {
+  if (!x || !weight_perm || !flow_pm || !out || B <= 0 || H <= 0 || W <= 0 || cin <= 0 || x_ld < cin || flow_ld < 2) return PFK_ERR_BAD_ARG;
+  if ((cin & 31) || (x_ld & 3) || !pfk_aligned16(x) || !pfk_aligned16(weight_perm)) return PFK_ERR_ALIGNMENT;
+  const long long M = (long long)B * H * W;
+  if (M >= 0x7fffffffLL || M * x_ld * 4 >= 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;     // 32-bit byte offsets / pixel arithmetic
+  GemmArgs a{};
+  a.src0 = x; a.ld0 = x_ld; a.ch0 = cin; a.nsrc = 1;
+  a.H = H; a.W = W; a.Ho = H; a.Wo = W; a.stride = 1; a.kh = 1; a.kw = 1;
+  a.weight = weight_perm; a.bias = bias_perm; a.b_rows = 576; a.ktot = cin;
+  a.scale = scale; a.M = M;
+  a.mu_flow = flow_pm; a.mu_flow_ld = flow_ld; a.mu_out = out;
+  fastdiv_make((unsigned)W, a.wo_mul, a.wo_sh);
+  fastdiv_make((unsigned)H, a.ho_mul, a.ho_sh);
+  const long long nblk = ((M + 127) / 128) * 2;
+  if (nblk > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
+  constexpr size_t smem = 2 * (128 + 288) * LDS_LD * sizeof(float);
+  static pfk_device_once attr_once;
+  attr_once.run([&] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mask_upsample_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  });
+  hipLaunchKernelGGL(mask_upsample_kernel, dim3((unsigned)nblk), dim3(256), smem, static_cast<hipStream_t>(stream), a);
+  return pfk_launch_status();
 }
 
 int pfk_conv2d_bf16s(const pfk_conv_desc* d, const void* weight_planes, int nsplit, pfk_stream_t stream) {

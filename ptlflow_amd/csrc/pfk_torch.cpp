@@ -259,6 +259,22 @@ void convex_upsample_pm(const Tensor& flow_pm, const Tensor& mask, Tensor out) {
                                       cur_stream()), "convex_upsample_pm");
 }
 
+// fused mask conv2 + softmax + convex upsampling: x [M, cin] (a view of the fh|mask hidden buffer), weight / bias row-permuted (pfk.h)
+void mask_upsample(const Tensor& x, const Tensor& weight_perm, const c10::optional<Tensor>& bias_perm, double scale,
+                   const Tensor& flow_pm, Tensor out) {
+  OpScope scope(x);
+  check_pm(x, "x"); check_pm(flow_pm, "flow_pm"); check_dev_f32(weight_perm, "weight"); check_dev_f32(out, "out");
+  TORCH_CHECK(out.dim() == 4 && out.size(1) == 2 && out.is_contiguous() && out.size(2) % 8 == 0 && out.size(3) % 8 == 0, "mask_upsample: out [B,2,8H,8W]");
+  const int B = out.size(0), H = out.size(2) / 8, W = out.size(3) / 8;
+  const int cin = x.size(1);
+  TORCH_CHECK(x.size(0) == (int64_t)B * H * W && flow_pm.size(0) == x.size(0) && flow_pm.size(1) >= 2, "mask_upsample: rows");
+  TORCH_CHECK(weight_perm.is_contiguous() && weight_perm.dim() == 2 && weight_perm.size(0) == 576 && weight_perm.size(1) == cin, "mask_upsample: weight [576, cin]");
+  const float* bp = nullptr;
+  if (bias_perm.has_value()) { check_dev_f32(*bias_perm, "bias"); TORCH_CHECK(bias_perm->numel() == 576 && bias_perm->is_contiguous()); bp = fptr(*bias_perm); }
+  check_ok(pfk_mask_upsample_f32(fptr(x), x.stride(0), cin, fptr(weight_perm), bp, (float)scale, fptr(flow_pm), flow_pm.stride(0),
+                                 fptr(out), B, H, W, cur_stream()), "mask_upsample");
+}
+
 // alt_cuda_corr.forward semantics (correlation.cpp:23-37): returns [B, N, (2r+1)^2, H1, W1], unscaled
 Tensor altcorr_forward(const Tensor& fmap1, const Tensor& fmap2, const Tensor& coords, int64_t radius) {
   OpScope scope(fmap1);
@@ -319,6 +335,59 @@ std::vector<Tensor> altcorr_backward(const Tensor& fmap1, const Tensor& fmap2, c
   }
   return {g1, g2, gc};
 }
+
+// ---- blocked volume layout (include/pfk.h "K1-K3 on the BLOCKED volume layout"): levels are [M, pfk_blocked_map_elems(h_l, w_l)]
+void fmap_to_blocked(const Tensor& in, Tensor out, int64_t B, int64_t H, int64_t W) {
+  OpScope scope(in);
+  check_pm(in, "in"); check_pm(out, "out");
+  TORCH_CHECK(in.size(0) == B * H * W && out.size(0) == B * pfk_blocked_map_elems((int)H, (int)W) && out.size(1) == in.size(1),
+              "fmap_to_blocked: in [B*H*W, C], out [B*blocked_map_elems(H, W), C]");
+  check_ok(pfk_fmap_to_blocked_f32(fptr(in), in.stride(0), fptr(out), out.stride(0), (int)B, (int)H, (int)W, (int)in.size(1), cur_stream()),
+           "fmap_to_blocked");
+}
+
+void corr_pool2x2_blocked(const Tensor& in, Tensor out, int64_t H, int64_t W) {
+  OpScope scope(in);
+  check_dev(in, "in"); check_dev(out, "out");
+  TORCH_CHECK(in.scalar_type() == out.scalar_type() && (in.scalar_type() == at::kFloat || in.scalar_type() == at::kBFloat16),
+              "corr_pool2x2_blocked: float32 or bfloat16 maps");
+  TORCH_CHECK(in.dim() == 2 && out.dim() == 2 && in.is_contiguous() && out.is_contiguous() && in.size(0) == out.size(0),
+              "corr_pool2x2_blocked: [M, elems] contiguous");
+  TORCH_CHECK(in.size(1) == pfk_blocked_map_elems((int)H, (int)W) && out.size(1) == pfk_blocked_map_elems((int)(H / 2), (int)(W / 2)),
+              "corr_pool2x2_blocked: map sizes");
+  if (out.numel() == 0) return;
+  if (in.scalar_type() == at::kFloat) check_ok(pfk_corr_pool2x2_blocked_f32(fptr(in), fptr(out), in.size(0), (int)H, (int)W, cur_stream()), "corr_pool2x2_blocked");
+  else check_ok(pfk_corr_pool2x2_blocked_bf16(in.data_ptr(), out.data_ptr(), in.size(0), (int)H, (int)W, cur_stream()), "corr_pool2x2_blocked (bf16)");
+}
+
+void corr_lookup_blocked(at::TensorList levels, at::IntArrayRef lvl_h, at::IntArrayRef lvl_w, const Tensor& coords, int64_t radius, Tensor out) {
+  OpScope scope(coords);
+  check_dev_f32(coords, "coords"); check_pm(out, "out");
+  TORCH_CHECK(coords.dim() == 4 && coords.size(1) == 2 && coords.is_contiguous(), "corr_lookup_blocked: coords [B,2,h,w] contiguous");
+  TORCH_CHECK(levels.size() >= 1 && levels.size() <= PFK_MAX_LEVELS && lvl_h.size() == levels.size() && lvl_w.size() == levels.size(),
+              "corr_lookup_blocked: 1..8 levels with their map sizes");
+  pfk_lookup_desc d{};
+  d.B = coords.size(0); d.h = coords.size(2); d.w = coords.size(3);
+  const int64_t M = (int64_t)d.B * d.h * d.w;
+  const bool bf = levels[0].scalar_type() == at::kBFloat16;
+  for (size_t l = 0; l < levels.size(); ++l) {
+    const Tensor& v = levels[l];
+    check_dev(v, "level");
+    TORCH_CHECK(v.scalar_type() == (bf ? at::kBFloat16 : at::kFloat), "corr_lookup_blocked: levels must all be float32 or all bfloat16");
+    TORCH_CHECK(lvl_h[l] > 0 && lvl_w[l] > 0 && v.dim() == 2 && v.is_contiguous() && v.size(0) == M &&
+                v.size(1) == pfk_blocked_map_elems((int)lvl_h[l], (int)lvl_w[l]),
+                "corr_lookup_blocked: level must be [B*N, blocked_map_elems(h_l, w_l)] contiguous");
+    d.levels[l] = v.data_ptr(); d.lvl_h[l] = (int)lvl_h[l]; d.lvl_w[l] = (int)lvl_w[l];
+  }
+  d.num_levels = levels.size(); d.radius = radius;
+  d.coords = fptr(coords); d.out = fptr(out); d.out_ld = out.stride(0);
+  TORCH_CHECK(out.size(0) == M, "corr_lookup_blocked: out rows");
+  const int n = 2 * radius + 1;
+  TORCH_CHECK(out.size(1) >= d.num_levels * n * n, "corr_lookup_blocked: out channels");
+  check_ok(bf ? pfk_corr_lookup_blocked_bf16(&d, cur_stream()) : pfk_corr_lookup_blocked_f32(&d, cur_stream()), "corr_lookup_blocked");
+}
+
+int64_t blocked_map_elems(int64_t H, int64_t W) { return pfk_blocked_map_elems((int)H, (int)W); }
 
 // backward of corr_lookup: accumulates into grad_levels[l] ([B*N, ld_l] buffers holding one [h_l][w_l] map per row)
 void corr_lookup_bwd(at::TensorList grad_levels, at::IntArrayRef lvl_h, at::IntArrayRef lvl_w, const Tensor& coords,
@@ -646,6 +715,10 @@ TORCH_LIBRARY(pfk, m) {
   m.def("corr_volume_bf16(Tensor f1, Tensor f2, float scale, Tensor(a!) out) -> ()");
   m.def("fmap_pool2x2(Tensor inp, Tensor(a!) out, int B, int H, int W) -> ()");
   m.def("corr_lookup(Tensor[] levels, Tensor coords, int radius, Tensor(a!) out) -> ()");
+  m.def("fmap_to_blocked(Tensor inp, Tensor(a!) out, int B, int H, int W) -> ()");
+  m.def("corr_pool2x2_blocked(Tensor inp, Tensor(a!) out, int H, int W) -> ()");
+  m.def("corr_lookup_blocked(Tensor[] levels, int[] lvl_h, int[] lvl_w, Tensor coords, int radius, Tensor(a!) out) -> ()");
+  m.def("blocked_map_elems(int H, int W) -> int", &blocked_map_elems);
   m.def("conv2d(Tensor[] srcs, int B, int H, int W, int kh, int kw, Tensor weight, Tensor? bias, int cout, "
         "int epilogue, bool relu, float scale, Tensor(a!)? out, Tensor(b!)? h, Tensor(c!)? aux_z, Tensor(d!)? aux_rh, "
         "Tensor(e!)? workspace=None, Tensor? residual=None, int stride=1, bool relu_after_residual=False) -> ()");
@@ -657,6 +730,7 @@ TORCH_LIBRARY(pfk, m) {
   m.def("flow_from_coords(Tensor coords0, Tensor coords1, Tensor(a!) flow_out) -> ()");
   m.def("convex_upsample(Tensor flow, Tensor mask, Tensor(a!) out) -> ()");
   m.def("convex_upsample_pm(Tensor flow_pm, Tensor mask, Tensor(a!) out) -> ()");
+  m.def("mask_upsample(Tensor x, Tensor weight_perm, Tensor? bias_perm, float scale, Tensor flow_pm, Tensor(a!) out) -> ()");
   m.def("upflow8(Tensor coords0, Tensor coords1, Tensor(a!) out) -> ()");
   m.def("altcorr_forward(Tensor fmap1, Tensor fmap2, Tensor coords, int radius) -> Tensor");
   m.def("altcorr_backward(Tensor fmap1, Tensor fmap2, Tensor coords, Tensor corr_grad, int radius) -> Tensor[]");
@@ -674,12 +748,16 @@ TORCH_LIBRARY_IMPL(pfk, CUDA, m) {
   m.impl("corr_volume_bf16", &corr_volume_bf16);
   m.impl("fmap_pool2x2", &fmap_pool2x2);
   m.impl("corr_lookup", &corr_lookup);
+  m.impl("fmap_to_blocked", &fmap_to_blocked);
+  m.impl("corr_pool2x2_blocked", &corr_pool2x2_blocked);
+  m.impl("corr_lookup_blocked", &corr_lookup_blocked);
   m.impl("conv2d", &conv2d);
   m.impl("conv_cin2", &conv_cin2);
   m.impl("flow_delta", &flow_delta);
   m.impl("flow_from_coords", &flow_from_coords);
   m.impl("convex_upsample", &convex_upsample);
   m.impl("convex_upsample_pm", &convex_upsample_pm);
+  m.impl("mask_upsample", &mask_upsample);
   m.impl("upflow8", &upflow8);
   m.impl("altcorr_forward", &altcorr_forward);
   m.impl("altcorr_backward", &altcorr_backward);

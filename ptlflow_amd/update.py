@@ -206,6 +206,12 @@ class UpdateEngine:
             w["fm.b"] = torch.cat([g("flow_head.conv1.bias"), g("mask.0.bias")]).contiguous()
             w["mk.w"] = pk(g("mask.2.weight"), seg1(256))
             w["mk.b"] = g("mask.2.bias").contiguous()
+            if self.nsplit == 0 and s.mask_channels == 576 and s.fh_hidden % 32 == 0:
+                # fused mask conv2 + softmax + convex upsampling (`pfk_mask_upsample_f32`): the 1x1 weight / bias with their rows in the
+                # order [half (2)][tap (9)][32 sub-pixels] — row half*288 + k*32 + j = mask channel k*64 + half*32 + j (include/pfk.h)
+                perm = torch.arange(576, device=dev).view(9, 2, 32).permute(1, 0, 2).reshape(-1)
+                w["mku.w"] = pack_conv_weight(g("mask.2.weight"), seg1(s.fh_hidden))[perm].contiguous()
+                w["mku.b"] = w["mk.b"][perm].contiguous()
             # flow-head conv1 alone: the iterations whose mask is never looked at (`upsample_every_iter=False`) skip the mask half
             w["fh.w"] = pk(g("flow_head.conv1.weight"), seg1(Ch))
             w["fh.b"] = g("flow_head.conv1.bias").contiguous()
@@ -498,6 +504,28 @@ class UpdateEngine:
         s = self.spec
         self._conv([self.fm[:, s.fh_hidden:]], 1, 1, "mk", s.mask_channels, relu=False, scale=0.25, out=self.mask,
                    workspace=self.workspace_mask if side_stream else True)
+
+    @property
+    def can_fuse_mask_upsample(self) -> bool:
+        return "mku.w" in self.w
+
+    def mask_upsample(self, flow_up: torch.Tensor) -> None:
+        """raft/update.py:152 (`0.25 * mask(net)`, its second convolution) + raft/raft.py:112-123 (`upsample_flow`) in ONE launch:
+        reads the mask half of `fm` (written by `heads_conv1`) and the flow slice of hx, writes the 8x flow; the [M, 576] mask is
+        never materialised.  Bit-identical to `mask_head()` + `convex_upsample_pm` (tests/test_gpu_kernels.py)."""
+        s = self.spec
+        key = "mku"
+        x = self.fm[:, s.fh_hidden:]
+        if self.profile is not None:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+        self.ops.mask_upsample(x, self.w["mku.w"], self.w["mku.b"], 0.25, self.flow_view, flow_up)
+        if self.profile is not None:
+            b.record()
+            self.profile.setdefault(key, []).append((a, b))
+            M = x.shape[0]
+            self.flops[key] = 2.0 * M * 576 * s.fh_hidden
+            self.bytes[key] = 4.0 * (M * s.fh_hidden + 576 * s.fh_hidden + 2 * M + 2 * 64 * M)
 
     def step(self, corr_pm: torch.Tensor, coords0: torch.Tensor, coords1: torch.Tensor, want_mask: bool = True) -> None:
         """One full RAFT iteration body after the lookup; updates hx (net, flow) and coords1 in place."""

@@ -33,6 +33,14 @@ SHAPES = [
     ("zr1hL", [128, 128], 256, 1, 5, 0), ("q1hL", [128, 128], 128, 1, 5, 0),
 ]
 
+# --shapes enc: the BasicEncoder's convolutions (raft/extractor.py:122-195) at 440x1024; (name, cin, cout, k, epi, H, W, stride)
+# with H, W the INPUT resolution; batch = images (fnet at the headline's batch 8 sees 16)
+ENC_SHAPES = [
+    ("l1", [64], 64, 3, 3, 0, 220, 512, 1), ("l2s", [64], 96, 3, 3, 0, 220, 512, 2), ("l2", [96], 96, 3, 3, 0, 110, 256, 1),
+    ("l2d", [64], 96, 1, 1, 0, 220, 512, 2), ("l3s", [96], 128, 3, 3, 0, 110, 256, 2), ("l3", [128], 128, 3, 3, 0, 55, 128, 1),
+    ("out", [128], 256, 1, 1, 0, 55, 128, 1),
+]
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -42,6 +50,7 @@ def main():
     ap.add_argument("--H", type=int, default=55)
     ap.add_argument("--W", type=int, default=128)
     ap.add_argument("--only", default="")
+    ap.add_argument("--shapes", default="update", choices=["update", "enc"])
     ap.add_argument("--rounds", type=int, default=1, help="time every cfg `rounds` times in round-robin order and report the median "
                     "(box-to-box and warm-up drift is +-5 %: only interleaved A/B numbers of one run are comparable)")
     args = ap.parse_args()
@@ -52,11 +61,17 @@ def main():
     torch.manual_seed(0)
     tot = {c: 0.0 for c in cfgs}
     ws = torch.zeros(ops.conv_workspace_bytes(), device=dev, dtype=torch.uint8)
-    for name, segs, cout, kh, kw, epi in SHAPES:
+    for shape in (ENC_SHAPES if args.shapes == "enc" else SHAPES):
+        name, segs, cout, kh, kw, epi = shape[:6]
+        stride = 1
+        if len(shape) > 6:
+            H, W, stride = shape[6:]
+        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+        Min, M = B * H * W, B * Ho * Wo
         if args.only and name not in args.only.split(","):
             continue
         cin = sum(segs)
-        xs = [torch.randn(M, c, device=dev) for c in segs]
+        xs = [torch.randn(Min, c, device=dev) for c in segs]
         wt = torch.randn(cout, cin, kh, kw, device=dev) / math.sqrt(cin * kh * kw)
         bias = torch.randn(cout, device=dev) * 0.1
         offs, o = [], 0
@@ -64,7 +79,7 @@ def main():
             offs.append((o, c, c)); o += c
         packed = pack_conv_weight(wt, offs)
         x_nchw = torch.cat(xs, 1).view(B, H, W, cin).permute(0, 3, 1, 2).contiguous()
-        ref = F.conv2d(x_nchw, wt, bias, padding=(kh // 2, kw // 2)).permute(0, 2, 3, 1).reshape(M, cout)
+        ref = F.conv2d(x_nchw, wt, bias, stride=stride, padding=(kh // 2, kw // 2)).permute(0, 2, 3, 1).reshape(M, cout)
         Ch = cout // 2 if epi == 1 else cout
         hbuf0 = torch.tanh(torch.randn(M, Ch, device=dev))
         zbuf0 = torch.rand(M, Ch, device=dev)
@@ -81,7 +96,7 @@ def main():
 
             def run(packed=packed, out=out, hbuf=hbuf, zbuf=zbuf, rh=rh):      # bound now: later rounds call it again
                 if epi == 0:
-                    ops.conv2d(xs, B, H, W, kh, kw, packed, bias, cout, 0, False, 1.0, out, None, None, None, ws)
+                    ops.conv2d(xs, B, H, W, kh, kw, packed, bias, cout, 0, False, 1.0, out, None, None, None, ws, None, stride, False)
                 elif epi == 1:
                     ops.conv2d(xs, B, H, W, kh, kw, packed, bias, cout, 1, False, 1.0, None, hbuf, zbuf, rh, ws)
                 else:

@@ -95,6 +95,91 @@ def test_lookup_bit_exact(gpu, B, h, w, L, r):
         assert bool(same.all()), f"{name}: {(~same).sum().item()} of {same.numel()} differ, max {(got - ref).abs().nan_to_num().max().item():.3e}"
 
 
+def _to_blocked(p):
+    """[M, (1,) h, w] map -> the blocked storage of include/pfk.h: ceil(h/4) x ceil(w/8) tiles of 4 x 8 elements, zero padded."""
+    p = p.reshape(p.shape[0], p.shape[-2], p.shape[-1])
+    M, h, w = p.shape
+    th, tw = (h + 3) // 4, (w + 7) // 8
+    q = torch.zeros(M, th * 4, tw * 8, dtype=p.dtype)
+    q[:, :h, :w] = p
+    return q.view(M, th, 4, tw, 8).permute(0, 1, 3, 2, 4).reshape(M, th * tw * 32).contiguous()
+
+
+@pytest.mark.parametrize("B,h,w,L,r", [(1, 16, 24, 4, 4), (2, 23, 39, 4, 3), (1, 55, 128, 4, 4), (1, 8, 16, 4, 4), (1, 13, 17, 2, 4),
+                                       (1, 47, 156, 4, 4), (1, 46, 62, 4, 4), (1, 47, 156, 4, 3)])
+def test_lookup_blocked_bit_exact(gpu, B, h, w, L, r):
+    """K3 on the blocked 4 x 8 volume layout (pfk_corr_lookup_blocked_f32): the oracle's bits on every coordinate family,
+    and with 8 pixels per workgroup too."""
+    torch.manual_seed(2)
+    D = 32
+    f1, f2 = torch.randn(B, D, h, w), torch.randn(B, D, h, w)
+    pyr = O.correlation_pyramid(f1, f2, L)
+    lv = [_to_blocked(p).cuda() for p in pyr]
+    lh, lw = [p.shape[-2] for p in pyr], [p.shape[-1] for p in pyr]
+    assert all(x.shape[1] == torch.ops.pfk.blocked_map_elems(a, b) for x, a, b in zip(lv, lh, lw))
+    n = 2 * r + 1
+    for pix in (104, 8):         # 104 = always 4 pixels per workgroup, 8 = always 8 (the default picks by the pixel count)
+        torch.ops.pfk.debug_set_lookup_pix(pix)
+        try:
+            for name, c in _coords_cases(B, h, w):
+                ref = O.lookup(pyr, c, r)
+                out = torch.full((B * h * w, L * n * n), -7.0, device=gpu)
+                torch.ops.pfk.corr_lookup_blocked(lv, lh, lw, c.cuda(), r, out)
+                got = unpm(out, B, h, w)
+                same = (got == ref) | (torch.isnan(got) & torch.isnan(ref))
+                assert bool(same.all()), f"{name} (pix {pix}): {(~same).sum().item()} of {same.numel()} differ"
+        finally:
+            torch.ops.pfk.debug_set_lookup_pix(4)
+
+
+@pytest.mark.parametrize("M,H,W", [(7, 55, 128), (64, 27, 64), (5, 13, 32), (3, 6, 16), (4, 3, 5), (2, 1, 2), (3, 47, 156), (2, 23, 78)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_pool_blocked_bit_exact(gpu, M, H, W, dtype):
+    """K2 blocked -> blocked: torch's avg_pool2d bits, and zeros in the pad elements of the edge tiles."""
+    torch.manual_seed(1)
+    x = torch.randn(M, 1, H, W).to(dtype)
+    if H // 2 == 0 or W // 2 == 0:
+        ref = x.new_zeros(M, 1, H // 2, W // 2)          # a 1-pixel level pools to nothing (F.avg_pool2d refuses the shape)
+    else:
+        ref = F.avg_pool2d(x, 2, stride=2) if dtype == torch.bfloat16 else O.pool2x2(x)
+    out = torch.full((M, torch.ops.pfk.blocked_map_elems(H // 2, W // 2)), 3.0, dtype=dtype, device=gpu)
+    torch.ops.pfk.corr_pool2x2_blocked(_to_blocked(x).cuda(), out, H, W)
+    if out.numel():
+        assert torch.equal(out.cpu(), _to_blocked(ref))
+
+
+def test_fmap_to_blocked(gpu):
+    torch.manual_seed(4)
+    for B, H, W, C in ((2, 55, 128, 256), (1, 47, 156, 128), (3, 5, 9, 32), (1, 1, 2, 64)):
+        x = torch.randn(B * H * W, C)
+        out = torch.full((B * torch.ops.pfk.blocked_map_elems(H, W), C), 9.0, device=gpu)
+        torch.ops.pfk.fmap_to_blocked(x.cuda(), out, B, H, W)
+        want = _to_blocked(x.view(B, H, W, C).permute(0, 3, 1, 2).reshape(B * C, H, W))          # [B*C, elems]
+        want = want.view(B, C, -1).permute(0, 2, 1).reshape(-1, C)
+        assert torch.equal(out.cpu(), want)
+
+
+@pytest.mark.parametrize("B,h,w,D,L,r,dtype", [(1, 55, 128, 256, 4, 4, torch.float32), (2, 47, 156, 128, 4, 4, torch.float32),
+                                                (1, 46, 62, 256, 2, 3, torch.float32), (1, 55, 128, 256, 4, 4, torch.bfloat16),
+                                                (1, 9, 13, 64, 4, 4, torch.float32)])
+@pytest.mark.parametrize("pyramid", ["avgpool", "bilinear_f2"])
+def test_corr_block_layouts_agree(gpu, B, h, w, D, L, r, dtype, pyramid):
+    """`CorrBlock(layout="blocked")` (the inference default) against `layout="rowmajor"`: the same pyramid (bit for bit: K1 against
+    the permuted target map computes the same dot products) and the same lookups; row-major fp32 is the form the oracle tests pin."""
+    from ptlflow_amd.corr import CorrBlock
+    torch.manual_seed(6)
+    f1, f2 = torch.randn(B, D, h, w, device=gpu).to(dtype), torch.randn(B, D, h, w, device=gpu).to(dtype)
+    a = CorrBlock(f1, f2, num_levels=L, radius=r, pyramid=pyramid, layout="rowmajor")
+    b = CorrBlock(f1, f2, num_levels=L, radius=r, pyramid=pyramid)
+    assert a.layout == "rowmajor" and b.layout == "blocked" and b._levels[0].dim() == 2
+    for pa, pb in zip(a.corr_pyramid, b.corr_pyramid):
+        assert pa.shape == pb.shape and torch.equal(pa, pb)
+    for name, c in _coords_cases(B, h, w):
+        ra, rb = a(c.cuda()), b(c.cuda())
+        same = (ra == rb) | (torch.isnan(ra) & torch.isnan(rb))
+        assert bool(same.all()), name
+
+
 @pytest.mark.parametrize("variant", [8, 14])
 def test_lookup_variants_bit_exact(gpu, variant):
     """The two measurement variants of K3 (8 pixels per workgroup; cross-lane tap reads instead of the LDS patch,
@@ -371,3 +456,33 @@ def test_update_engine_step(gpu, small):
     close(c1g, c1 + delta_ref, rtol=5e-5, atol=5e-5)
     if not small:
         close(eng.mask_nchw(), mask_ref, rtol=5e-5, atol=5e-5)
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 55, 128), (2, 13, 17), (1, 8, 9), (3, 47, 156)])
+def test_mask_upsample_fused(gpu, B, H, W):
+    """pfk_mask_upsample_f32 (mask conv2 + softmax + convex upsampling, no mask in memory) against the two kernels it replaces
+    (`conv2d` with scale 0.25 -> [M, 576] mask -> `convex_upsample_pm`): bit-identical; and against the oracle's
+    `convex_upsample` on the oracle's mask (raft/raft.py:112-123, raft/update.py:152) to the GEMM tolerance."""
+    from ptlflow_amd.packing import pack_conv_weight
+    torch.manual_seed(9)
+    M, cin = B * H * W, 256
+    fm = torch.randn(M, 512)                       # fh | mask hidden: the kernel reads the second half as a strided view
+    wt = torch.randn(576, cin, 1, 1) / math.sqrt(cin)
+    bias = torch.randn(576) * 0.1
+    hx = torch.randn(M, 8)
+    flow_pm = hx[:, 4:6]                           # a 2-channel slice of a wider pixel-major row, like the engine's hx
+    packed = pack_conv_weight(wt, [(0, cin, cin)])
+    perm = torch.arange(576).view(9, 2, 32).permute(1, 0, 2).reshape(-1)
+    fm_g, hx_g = fm.cuda(), hx.cuda()
+    x_g, flow_g = fm_g[:, 256:], hx_g[:, 4:6]
+    mask = torch.empty(M, 576, device=gpu)
+    torch.ops.pfk.conv2d([x_g], B, H, W, 1, 1, packed.cuda(), bias.cuda(), 576, EPI_LINEAR, False, 0.25, mask, None, None, None, None)
+    want = torch.empty(B, 2, 8 * H, 8 * W, device=gpu)
+    torch.ops.pfk.convex_upsample_pm(flow_g, mask, want)
+    got = torch.full((B, 2, 8 * H, 8 * W), 7.0, device=gpu)
+    torch.ops.pfk.mask_upsample(x_g, packed[perm].contiguous().cuda(), bias[perm].contiguous().cuda(), 0.25, flow_g, got)
+    assert torch.equal(got, want), f"max diff {(got - want).abs().max().item():.3e}"
+    x_nchw = fm[:, 256:].reshape(B, H, W, cin).permute(0, 3, 1, 2)
+    mask_ref = 0.25 * F.conv2d(x_nchw, wt, bias)
+    flow_ref = flow_pm.reshape(B, H, W, 2).permute(0, 3, 1, 2)
+    close(got, O.convex_upsample(flow_ref, mask_ref), rtol=2e-5, atol=2e-4)

@@ -221,6 +221,27 @@ def test_side_stream_mask_head_is_bit_identical(gpu, kind):
             assert torch.equal(fa["flows"], fb["flows"]) and torch.equal(fa["flow_small"], fb["flow_small"]), (every, seed)
 
 
+@pytest.mark.parametrize("kind,B,H,W", [("raft", 8, 480, 640), ("raft", 1, 184, 320), ("gma", 2, 200, 328)])
+def test_fused_mask_upsample_is_bit_identical(gpu, kind, B, H, W):
+    """`fuse_mask_upsample`: mask conv2 + softmax + convex upsampling as ONE kernel that keeps the nine logits of a sub-pixel in
+    registers (pfk_mask_upsample_f32) against the two separate launches through a [M, 576] mask in HBM — same K order in the
+    convolution, the same epilogue / upsampling arithmetic operation for operation, so not a bit of `flows` may change; on the main
+    stream and on the side stream, with per-iteration upsampling on and off, over repeated forwards."""
+    from ptlflow_amd.raft import GMA, RAFT
+    make = (lambda **kw: GMA(iters=5, **kw)) if kind == "gma" else (lambda **kw: RAFT(iters=5, **kw))
+    for every in (True, False):
+        for overlap in (True, False):
+            a = make(upsample_every_iter=every).load_synthetic(5).eval().cuda()
+            b = make(upsample_every_iter=every).load_synthetic(5).eval().cuda()
+            a.fuse_mask_upsample, b.fuse_mask_upsample = False, True
+            a.overlap_mask_head = b.overlap_mask_head = overlap
+            assert b.engine(torch.device("cuda", 0)).can_fuse_mask_upsample
+            for seed in (1, 2, 1):
+                x = O.smooth_pair(B, H, W, seed=seed).cuda()
+                fa, fb = a({"images": x}), b({"images": x})
+                assert torch.equal(fa["flows"], fb["flows"]) and torch.equal(fa["flow_small"], fb["flow_small"]), (every, overlap, seed)
+
+
 @pytest.mark.parametrize("kind,H,W,iters", [("raft", 436, 1024, 32), ("raft_small", 184, 320, 12), ("gma", 184, 320, 12)])
 def test_hoisted_context_term_equals_the_single_chain_form(gpu, kind, H, W, iters):
     """The loop-invariant hoist (UpdateEngine: conv over cat([h, inp, m]) = conv over [h, m] + (conv over inp + bias), the second
