@@ -1315,13 +1315,13 @@ int launch(const GemmArgs& a0, int epi, int batches, hipStream_t st) {
     case 11: return launch_cfg<64, 128, 32, 64, 101>(a, epi, batches, st);
     case 12: return launch_cfg<128, 64, 64, 32, 101>(a, epi, batches, st);
     case 13: return launch_cfg<128, 128, 64, 64, 101>(a, epi, batches, st);
-    // round 5, the encoders' widths: 96 output channels are 1.5 column tiles of 64 (a quarter of the MFMAs multiply zero rows): a
-    // 128 x 96 tile — four waves stacked in M, wave tile 32 x 96 — covers them exactly (84 KB swizzled: one block per CU; 64.5 KB on
-    // the 2-stage kernel: two); 64 output channels: taller tiles with 32 x 64 / 64 x 64 wave tiles
+    // round 5, the encoders' 96-channel layers: a 128 x 96 tile — four waves stacked in M, wave tile 32 x 96 — covers 96 output
+    // channels exactly (1.5 column tiles of 64 multiplied zero weight rows in a quarter of their MFMAs): 14 = the 3-stage kernel
+    // (84 KB swizzled, one block per CU), 15 = the 2-stage kernel (64.5 KB, two blocks per CU; what launch() selects for cout 96).
+    // Measured and not kept (gpurun_out/r5b_enc.log, r5c_enc.log, r5h_conv.log): 256x64 / 128x64 / 128x128 tiles with 64x64 / 32x64 /
+    // 32x128 wave tiles on either kernel — 0 .. 90 % slower than the heuristic's choice on every encoder and update-block shape.
     case 14: return launch_cfg_linear<128, 96, 32, 96, 101>(a, epi, batches, st);
     case 15: return launch_cfg_linear<128, 96, 32, 96, 0>(a, epi, batches, st);
-    case 16: return launch_cfg_linear<256, 64, 64, 64, 101>(a, epi, batches, st);
-    case 17: return launch_cfg_linear<128, 64, 32, 64, 101>(a, epi, batches, st);
     // MFMA-only skeletons of the bigger padded tiles (timing ablations)
     case 27: return epi == PFK_EPI_LINEAR ? launch_cfg<64, 128, 32, 64, 31>(a, epi, batches, st) : PFK_ERR_BAD_ARG;
     case 28: return epi == PFK_EPI_LINEAR ? launch_cfg<128, 128, 64, 64, 31>(a, epi, batches, st) : PFK_ERR_BAD_ARG;

@@ -435,7 +435,18 @@ class RAFT(nn.Module):
         fuse = has_mask and eng.can_fuse_mask_upsample and bool(self.fuse_mask_upsample)
         for it in range(self.iters):
             last = it == self.iters - 1
-            corr_pm = corr_fn.lookup_pm(coords1)
+            if eng.profile is not None:     # bench.py's instrumented forward: HIP events around the lookup too (the HBM-bound kernel)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                corr_pm = corr_fn.lookup_pm(coords1)
+                e1.record()
+                eng.profile.setdefault("lookup", []).append((e0, e1))
+                n = 2 * self.corr_radius + 1
+                eng.flops["lookup"] = 0.0
+                # N L [(2r+2)^2 + (2r+1)^2] 4 + 8 N bytes per pair and lookup
+                eng.bytes["lookup"] = float(pixels * (self.corr_levels * ((n + 1) ** 2 + n * n) * 4 + 8))
+            else:
+                corr_pm = corr_fn.lookup_pm(coords1)
             do_up = last or self.upsample_every_iter
             if side is None or not do_up:
                 if fuse and do_up:
