@@ -70,6 +70,28 @@ for B in (1, 8):
             ck = float(out.double().sum())
             print(f"K3 {name} B={B} pix={pix}: {us:.1f} us  algorithmic {alg/1e6:.1f} MB -> {alg/us/1e6:.2f} TB/s ({100*alg/us/1e6/8:.1f}% of 8 TB/s)  checksum {ck:.6e}")
         ops.debug_set_lookup_pix(4)
+    # the blocked 4 x 8 layout of the inference path (round 5): K1 against the permuted / padded target map (7168 rows for 55 x 128),
+    # K2 blocked -> blocked, K3 on the blocked levels (same values: checksum of the lookups must equal the row-major one's)
+    nb = ops.blocked_map_elems(h, w)
+    f2blk = torch.empty(B * nb, D, device=dev)
+    us_p = timeit(lambda: ops.fmap_to_blocked(f2.view(B * N, D), f2blk, B, h, w))
+    volk = torch.empty(B, N, nb, device=dev)
+    us = timeit(lambda: ops.corr_volume(f1, f2blk.view(B, nb, D), 1 / 16.0, volk))
+    print(f"K1 fp32 B={B} blocked target map ({nb} columns): {us:.1f} us  {flop/us/1e6:.1f} TFLOP/s of real work ({100*flop/us/1e6/157.3:.1f}% of 157.3); row permutation {us_p:.1f} us")
+    lb, hh, ww, dims = [volk.view(B * N, nb)], h, w, [(h, w)]
+    for l in range(1, L):
+        hh //= 2; ww //= 2
+        lb.append(torch.empty(B * N, ops.blocked_map_elems(hh, ww), device=dev)); dims.append((hh, ww))
+    def pools_b():
+        for l in range(1, L):
+            ops.corr_pool2x2_blocked(lb[l - 1], lb[l], dims[l - 1][0], dims[l - 1][1])
+    us = timeit(pools_b)
+    byt = sum(v.numel() for v in lb[:-1]) * 4 + sum(v.numel() for v in lb[1:]) * 4
+    print(f"K2 fp32 B={B} blocked: {us:.1f} us  {byt/us/1e6:.2f} TB/s")
+    out = torch.empty(B * N, 324, device=dev)
+    alg = B * (N * L * (100 * 4 + 81 * 4) + 8 * N)
+    us = timeit(lambda: ops.corr_lookup_blocked(lb, [d[0] for d in dims], [d[1] for d in dims], coords, r, out), n=50)
+    print(f"K3 fp32 B={B} blocked: {us:.1f} us  algorithmic {alg/1e6:.1f} MB -> {alg/us/1e6:.2f} TB/s ({100*alg/us/1e6/8:.1f}% of 8 TB/s)")
     # backward pieces (training shapes are smaller; here the same shape for comparability)
     if B == 1:
         sizes = [(int(v.shape[1]), int(v.shape[2])) for v in lv]
