@@ -494,6 +494,8 @@ def main():
     model = make(args.conv_precision)
     if os.environ.get("PFK_OVERLAP") == "0":          # experiment knob: mask head + upsampling on the main stream
         model.overlap_mask_head = False
+    if os.environ.get("PFK_FUSE_MASK") == "1":        # experiment knob: K13 (fused mask conv2 + softmax + upsampling) instead of the pair
+        model.fuse_mask_upsample = True
     model.load_synthetic(1234).eval()
     cpu_state = {k: v.clone() for k, v in model.state_dict().items()}
     model = model.to(dev)

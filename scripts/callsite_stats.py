@@ -76,9 +76,12 @@ def main():
                 if site:
                     e = acc[site]; e[0] += 1; e[1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
         else:
+            # a side queue: the mask branch's (mask conv2 + upsampling of iteration i next to iteration i+1) is the one that hosts the
+            # upsampling launches; the encoders' side queue (cnet next to fnet at small batches) has convolutions of its own
+            mask_q = any("convex_upsample" in r["Kernel_Name"] or "mask_upsample_kernel" in r["Kernel_Name"] for r in rs)
             for r in rs:
                 name = r["Kernel_Name"]
-                site = next((v for k, v in NAMED.items() if k in name), "mk" if "conv_gemm" in name else None)
+                site = next((v for k, v in NAMED.items() if k in name), "mk" if (mask_q and "conv_gemm" in name) else None)
                 if site:
                     e = acc[site]; e[0] += 1; e[1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     # a serial run (no side stream) has mk inside the main queue's sequence already
