@@ -292,10 +292,12 @@ int pfk_upflow8_f32(const float* coords0, const float* coords1, float* out, int 
 /* ---- fused mask head conv2 + softmax + convex upsampling (round 5) ------------------------------------------------------
  * raft/update.py:138-142,152 (`0.25 * mask[2](relu(mask[0](net)))`: the 1x1 convolution to 9*64 channels) followed by
  * raft/raft.py:112-123 (`upsample_flow`) in ONE kernel: the [M][576] mask is never written.  x [M = B*H*W][x_ld] = the mask head's
- * hidden activation (cin channels, cin % 32 == 0), weight_perm [576][cin] / bias_perm [576] = the 1x1 convolution's weight
- * and bias with their ROWS permuted to [half (2)][tap k (9)][32 sub-pixels]: row half*288 + k*32 + j = original channel
- * k*64 + half*32 + j (so a block's nine taps of 32 sub-pixels are one contiguous row range); scale = 0.25; flow_pm pixel-major
- * (flow_pm[p*flow_ld + 0..1]); out [B][2][8H][8W] NCHW.  Bit-identical to pfk_conv2d_f32 (scale 0.25) + pfk_convex_upsample_pm_f32. */
+ * hidden activation (cin channels, cin % 32 == 0); weight_perm [640][cin] / bias_perm [640] = the 1x1 convolution's weight and bias
+ * with their ROWS in the order [quarter q (4)][tile j (5)][column c (32)]: row q*160 + j*32 + c = original channel k*64 + s with tap
+ * k = 2j + (c >> 4) and sub-pixel s = q*16 + (c & 15); the rows with k == 9 (tile 4, c >= 16) are ZERO (a block's nine taps of 16
+ * sub-pixels are then one contiguous range of 160 rows; ptlflow_amd/packing.py::permute_mask_head).  scale = 0.25; flow_pm
+ * pixel-major (flow_pm[p*flow_ld + 0..1]); out [B][2][8H][8W] NCHW.  Bit-identical to pfk_conv2d_f32 (scale 0.25) +
+ * pfk_convex_upsample_pm_f32. */
 int pfk_mask_upsample_f32(const float* x, int x_ld, int cin, const float* weight_perm, const float* bias_perm, float scale,
                           const float* flow_pm, int flow_ld, float* out, int B, int H, int W, pfk_stream_t stream);
 

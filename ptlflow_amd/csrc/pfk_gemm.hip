@@ -372,19 +372,24 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------------
-// Fused mask head conv2 + softmax + 8x convex upsampling (raft/update.py:138-142,152 + raft/raft.py:112-123), round 5.
+// K13: fused mask head conv2 + softmax + 8x convex upsampling (raft/update.py:138-142,152 + raft/raft.py:112-123), round 5.
 //
 // The reference's loop writes a [B, 576, h, w] mask (mask[k*64 + sy*8 + sx] for tap k of the 3x3 neighbourhood and sub-pixel
 // (sy, sx)) and re-reads it for softmax over k + the convex combination: 16 MB per pair and iteration through HBM, 32 times.
-// Here ONE kernel does the 1x1 convolution and consumes its output in registers: a block owns 128 pixels x 32 sub-pixels and ALL
-// NINE taps — four waves stacked in M, wave tile 32 pixels x (9 x 32) columns = nine 32x32 accumulators — so the nine logits of
-// a (pixel, sub-pixel) sit in ONE lane (accumulator register r of the nine tiles): softmax and the weighted sum of the
-// neighbours' flows are lane-local, the mask never exists in memory.  The host permutes the weight / bias rows to
-// [half (2)][tap (9)][32 sub-pixels], which makes the block's B rows the plain range [half*288, half*288 + 288) of the 2-stage
-// kernel's stager.  K loop = variant 1's (same K order per output element as every other tile shape: the logits are bit-identical
-// to the unfused launch's), 8 K-steps of 144 MFMAs per wave for the 256 input channels; LDS 2 x (128 + 288) x 36 floats = 117 KB,
-// one block per CU.  Epilogue arithmetic = the unfused pair's, operation for operation (conv epilogue: + bias, x 0.25;
-// convex_upsample_kernel: max, exp, sum in tap order, one reciprocal, un-contracted multiply-adds) => bit-identical flow.
+// Here ONE kernel does the 1x1 convolution and consumes its output in registers.  A block owns 128 pixels x 16 sub-pixels and ALL
+// NINE taps: four waves stacked in M, wave tile 32 pixels x 160 columns = five 32x32 accumulators, column c of tile j holding tap
+// 2j + (c >> 4) of sub-pixel c & 15 (the tenth "tap" is a zero weight row).  The nine logits of a (pixel, sub-pixel) therefore sit
+// in TWO lanes (c and c ^ 16) of the same accumulator registers: one cross-lane exchange per register hands both lanes all nine,
+// and softmax + the weighted sum of the neighbours' flows are lane-local from there.  The mask never exists in memory.
+// (First form of this kernel: 32 sub-pixels x nine full tiles per wave — no exchange, no pad row — needed 117 KB of LDS and 144
+//  accumulator registers: ONE block per CU, so nothing ran under its prologue or under the 144 expf per lane of its epilogue, and a
+//  block could not share a CU with the other stream's 48-72 KB blocks: 0.50 of the matrix peak standalone, slower in situ.  This
+//  form is 72 KB and <= 256 registers: two blocks per CU.)
+// The host permutes the weight / bias rows to [quarter (4)][tile (5)][32] (zero rows for the pad tap), which makes the block's B
+// rows the plain range [quarter*160, quarter*160 + 160) of the 2-stage kernel's stager.  K loop = variant 1's on the swizzled
+// layout (same K order per output element as every other tile shape: the logits are bit-identical to the unfused launch's), 8
+// K-steps of 80 MFMAs per wave for the 256 input channels; LDS 2 x (128 + 160) x 32 floats = 72 KB.  Epilogue arithmetic = the
+// unfused pair's, operation for operation => bit-identical flow.
 // -------------------------------------------------------------------------------------------------
 // One (pixel, sub-pixel) of the fused epilogue: the nine logits -> softmax -> convex combination of the neighbours' flows, with the
 // arithmetic of the unfused pair operation for operation — conv epilogue (pfk_gemm.h, LINEAR): + bias, x scale; convex_upsample_kernel
@@ -393,18 +398,12 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs a) {
 // into an FMA either: this translation unit is compiled with contraction on and HIP's __fmul_rn / __fadd_rn are plain operators
 // (they do not stop it), hence the pragma.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void mask_upsample_combine(const float (&logit)[9], const float (&bias)[9], float sc, const f32x2* nfp,
-                                                      float& ox, float& oy) {
+__device__ __forceinline__ void mask_upsample_combine(const float (&m_in)[9], const f32x2* nfp, float& ox, float& oy) {
 #pragma clang fp contract(off)
   float m[9];
   float mx = -INFINITY;
 #pragma unroll
-  for (int k = 0; k < 9; ++k) {
-    float v = logit[k] + bias[k];
-    v = v * sc;
-    m[k] = v;
-    mx = fmaxf(mx, v);
-  }
+  for (int k = 0; k < 9; ++k) { m[k] = m_in[k]; mx = fmaxf(mx, m[k]); }
   float sum = 0.f;
 #pragma unroll
   for (int k = 0; k < 9; ++k) { m[k] = expf(m[k] - mx); sum = sum + m[k]; }
@@ -421,24 +420,52 @@ __device__ __forceinline__ void mask_upsample_combine(const float (&logit)[9], c
   ox = ax;
   oy = ay;
 }
+// the conv epilogue's + bias, x scale on one logit, un-contracted
+__device__ __forceinline__ float mask_logit(float acc, float bias, float sc) {
+#pragma clang fp contract(off)
+  float v = acc + bias;
+  v = v * sc;
+  return v;
+}
 
-__global__ __launch_bounds__(256) void mask_upsample_kernel(const GemmArgs a) {
-  constexpr int BM = 128, BN = 288, MT = 1, NT = 9;
+template <int MT, int NT, int LD>
+__device__ __forceinline__ void mma_rest_ld(f32x16 (&acc)[MT][NT], Frags<MT, NT>& f, const float* cA, const float* cB,
+                                            const int (&ko)[4]) {
+  Frags<MT, NT> g;
+  frag_read<MT, NT, LD>(g, cA, cB, ko, 1);
+  __builtin_amdgcn_sched_barrier(0);
+  mma_one<MT, NT>(acc, f);
+  __builtin_amdgcn_sched_barrier(0);
+  frag_read<MT, NT, LD>(f, cA, cB, ko, 2);
+  __builtin_amdgcn_sched_barrier(0);
+  mma_one<MT, NT>(acc, g);
+  __builtin_amdgcn_sched_barrier(0);
+  frag_read<MT, NT, LD>(g, cA, cB, ko, 3);
+  __builtin_amdgcn_sched_barrier(0);
+  mma_one<MT, NT>(acc, f);
+  __builtin_amdgcn_sched_barrier(0);
+  mma_one<MT, NT>(acc, g);
+}
+
+constexpr int MU_BM = 128, MU_BN = 160, MU_ROWS = 640;   // 4 quarters x 5 tiles x 32 weight rows (9 real taps + 1 zero tap per 16 sub-pixels)
+
+__global__ __launch_bounds__(256, 2) void mask_upsample_kernel(const GemmArgs a) {
+  constexpr int BM = MU_BM, BN = MU_BN, MT = 1, NT = 5, LD = LDS_LDX;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* sA = smem;                          // [2][BM][LDS_LD]
-  float* sB = smem + 2 * BM * LDS_LD;        // [2][BN][LDS_LD]
+  float* sA = smem;                      // [2][BM][LD]
+  float* sB = smem + 2 * BM * LD;        // [2][BN][LD]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wid = tid >> 6;
   const int wm0 = wid * 32;
 
-  const int bid = pfk_xcd_remap(blockIdx.x, gridDim.x);   // the two halves of a pixel tile are neighbours: one A panel through one L2
-  const int half = bid & 1;
-  const long long m0 = (long long)(bid >> 1) * BM;
-  const int n0 = half * BN;
+  const int bid = pfk_xcd_remap(blockIdx.x, gridDim.x);   // the four quarters of a pixel tile are neighbours: one A panel through one L2
+  const int quarter = bid & 3;
+  const long long m0 = (long long)(bid >> 2) * BM;
+  const int n0 = quarter * BN;
 
-  Stager<BM, BN> st(a, m0, n0, tid, 0);
+  Stager<BM, BN, LD> st(a, m0, n0, tid, 0);
   const int total_steps = st.total_steps();
 
   f32x16 acc[MT][NT];
@@ -451,20 +478,20 @@ __global__ __launch_bounds__(256) void mask_upsample_kernel(const GemmArgs a) {
 
   const int frow = lane & 31;
   int ko[4];
-  frag_offsets<LDS_LD>(ko, lane);
+  frag_offsets<LD>(ko, lane);
 
   for (int step = 0; step < total_steps; ++step) {
     const int buf = step & 1;
     const bool more = (step + 1) < total_steps;
-    const float* cA = sA + buf * BM * LDS_LD + (wm0 + frow) * LDS_LD;
-    const float* cB = sB + buf * BN * LDS_LD + frow * LDS_LD;
+    const float* cA = sA + buf * BM * LD + (wm0 + frow) * LD;
+    const float* cB = sB + buf * BN * LD + frow * LD;
     Frags<MT, NT> fr;
-    frag_read<MT, NT, LDS_LD>(fr, cA, cB, ko, 0);
+    frag_read<MT, NT, LD>(fr, cA, cB, ko, 0);
     st.load(more);
     __builtin_amdgcn_sched_barrier(0);
-    mma_rest<MT, NT>(acc, fr, cA, cB, ko);
+    mma_rest_ld<MT, NT, LD>(acc, fr, cA, cB, ko);
     __builtin_amdgcn_sched_barrier(0);
-    st.store(sA + (buf ^ 1) * BM * LDS_LD, sB + (buf ^ 1) * BN * LDS_LD);
+    st.store(sA + (buf ^ 1) * BM * LD, sB + (buf ^ 1) * BN * LD);
     if (more) st.advance();
     __syncthreads();
   }
@@ -483,8 +510,8 @@ __global__ __launch_bounds__(256) void mask_upsample_kernel(const GemmArgs a) {
       const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
       if ((unsigned)yy < H && (unsigned)xx < W) {
         const float* f = a.mu_flow + ((size_t)(bimg * H + (unsigned)yy) * W + (unsigned)xx) * (size_t)a.mu_flow_ld;
-        v[0] = __fmul_rn(8.0f, f[0]);
-        v[1] = __fmul_rn(8.0f, f[1]);
+        v[0] = 8.0f * f[0];      // exact (a power of two)
+        v[1] = 8.0f * f[1];
       }
     }
     nf[e] = v;
@@ -492,28 +519,38 @@ __global__ __launch_bounds__(256) void mask_upsample_kernel(const GemmArgs a) {
   __syncthreads();
 
   const int col = lane & 31;
-  const int s = half * 32 + col, sy = s >> 3, sx = s & 7;
-  float bias[9];
+  const int odd = col >> 4;                          // this lane's own taps are 2j + odd
+  const int s = quarter * 16 + (col & 15), sy = s >> 3, sx = s & 7;
+  float bias[NT];
 #pragma unroll
-  for (int k = 0; k < 9; ++k) bias[k] = a.bias != nullptr ? a.bias[n0 + k * 32 + col] : 0.f;
+  for (int j = 0; j < NT; ++j) bias[j] = a.bias != nullptr ? a.bias[n0 + j * 32 + col] : 0.f;
   const float sc = a.scale;
   const size_t HW8 = (size_t)H * W * 64;
+  float* outc = a.mu_out + (size_t)odd * HW8;        // lanes with the even taps store the x component, their partners y
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = wm0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
     const unsigned p = (unsigned)m0 + (unsigned)row;
-    float logit[9];
+    float own[NT], oth[NT];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) logit[k] = acc[0][k][r];
+    for (int j = 0; j < NT; ++j) {
+      own[j] = mask_logit(acc[0][j][r], bias[j], sc);
+      oth[j] = __shfl_xor(own[j], 16, 64);           // the partner lane's tap 2j + (1 - odd) of the same (pixel, sub-pixel)
+    }
+    float m[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int j = k >> 1;
+      m[k] = ((k & 1) == odd) ? own[j] : oth[j];     // (tap 9 — tile 4 of the odd lanes — is the zero pad row: never read)
+    }
     float ox, oy;
-    mask_upsample_combine(logit, bias, sc, nf + row * 9, ox, oy);
+    mask_upsample_combine(m, nf + row * 9, ox, oy);
     if ((long long)p < a.M) {
       const unsigned prow = fastdiv_u32(p, a.wo_mul, a.wo_sh);
       const unsigned bimg = fastdiv_u32(prow, a.ho_mul, a.ho_sh);
       const unsigned x = p - prow * W, y = prow - bimg * H;
       const size_t o = (size_t)(8 * y + (unsigned)sy) * (8 * W) + 8 * x + (unsigned)sx;
-      a.mu_out[((size_t)bimg * 2 + 0) * HW8 + o] = ox;
-      a.mu_out[((size_t)bimg * 2 + 1) * HW8 + o] = oy;
+      outc[(size_t)bimg * 2 * HW8 + o] = odd ? oy : ox;
     }
   }
 }
@@ -1454,14 +1491,14 @@ int pfk_mask_upsample_f32(const float* x, int x_ld, int cin, const float* weight
   GemmArgs a{};
   a.src0 = x; a.ld0 = x_ld; a.ch0 = cin; a.nsrc = 1;
   a.H = H; a.W = W; a.Ho = H; a.Wo = W; a.stride = 1; a.kh = 1; a.kw = 1;
-  a.weight = weight_perm; a.bias = bias_perm; a.b_rows = 576; a.ktot = cin;
+  a.weight = weight_perm; a.bias = bias_perm; a.b_rows = MU_ROWS; a.ktot = cin;
   a.scale = scale; a.M = M;
   a.mu_flow = flow_pm; a.mu_flow_ld = flow_ld; a.mu_out = out;
   fastdiv_make((unsigned)W, a.wo_mul, a.wo_sh);
   fastdiv_make((unsigned)H, a.ho_mul, a.ho_sh);
-  const long long nblk = ((M + 127) / 128) * 2;
+  const long long nblk = ((M + MU_BM - 1) / MU_BM) * 4;
   if (nblk > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
-  constexpr size_t smem = 2 * (128 + 288) * LDS_LD * sizeof(float);
+  constexpr size_t smem = 2 * (MU_BM + MU_BN) * LDS_LDX * sizeof(float);
   static pfk_device_once attr_once;
   attr_once.run([&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mask_upsample_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);

@@ -268,9 +268,9 @@ void mask_upsample(const Tensor& x, const Tensor& weight_perm, const c10::option
   const int B = out.size(0), H = out.size(2) / 8, W = out.size(3) / 8;
   const int cin = x.size(1);
   TORCH_CHECK(x.size(0) == (int64_t)B * H * W && flow_pm.size(0) == x.size(0) && flow_pm.size(1) >= 2, "mask_upsample: rows");
-  TORCH_CHECK(weight_perm.is_contiguous() && weight_perm.dim() == 2 && weight_perm.size(0) == 576 && weight_perm.size(1) == cin, "mask_upsample: weight [576, cin]");
+  TORCH_CHECK(weight_perm.is_contiguous() && weight_perm.dim() == 2 && weight_perm.size(0) == 640 && weight_perm.size(1) == cin, "mask_upsample: weight [640, cin] (packing.permute_mask_head)");
   const float* bp = nullptr;
-  if (bias_perm.has_value()) { check_dev_f32(*bias_perm, "bias"); TORCH_CHECK(bias_perm->numel() == 576 && bias_perm->is_contiguous()); bp = fptr(*bias_perm); }
+  if (bias_perm.has_value()) { check_dev_f32(*bias_perm, "bias"); TORCH_CHECK(bias_perm->numel() == 640 && bias_perm->is_contiguous()); bp = fptr(*bias_perm); }
   check_ok(pfk_mask_upsample_f32(fptr(x), x.stride(0), cin, fptr(weight_perm), bp, (float)scale, fptr(flow_pm), flow_pm.stride(0),
                                  fptr(out), B, H, W, cur_stream()), "mask_upsample");
 }

@@ -60,3 +60,26 @@ def pack_flow_head_weight(weight: torch.Tensor, cin_buf: int = 0) -> torch.Tenso
     if cin_buf > cin:
         w = F.pad(w, (0, cin_buf - cin))
     return w.contiguous()
+
+
+def mask_upsample_perm(device=None) -> Tuple["torch.Tensor", "torch.Tensor"]:
+    """Row order of `pfk_mask_upsample_f32`'s weight / bias (include/pfk.h): 640 rows = [quarter (4)][tile j (5)][32 columns c], row
+    `q*160 + j*32 + c` = mask channel `k*64 + s` with tap `k = 2j + (c >> 4)` and sub-pixel `s = q*16 + (c & 15)`; the rows with
+    `k == 9` (tile 4, c >= 16) are zero.  Returns `(index [640] into the 576 channels, valid [640] bool)`."""
+    q = torch.arange(4, device=device).view(4, 1, 1)
+    j = torch.arange(5, device=device).view(1, 5, 1)
+    c = torch.arange(32, device=device).view(1, 1, 32)
+    k = 2 * j + (c >> 4)
+    s = q * 16 + (c & 15)
+    valid = (k < 9).expand(4, 5, 32).reshape(-1)
+    idx = (k.clamp(max=8) * 64 + s).expand(4, 5, 32).reshape(-1)
+    return idx, valid
+
+
+def permute_mask_head(weight_packed: "torch.Tensor", bias: "torch.Tensor") -> Tuple["torch.Tensor", "torch.Tensor"]:
+    """[576, ktot] packed 1x1 weight and [576] bias of the mask head's second convolution -> the [640, ktot] / [640] operands of
+    `pfk_mask_upsample_f32`."""
+    idx, valid = mask_upsample_perm(weight_packed.device)
+    w = weight_packed[idx] * valid[:, None].to(weight_packed.dtype)
+    b = bias[idx] * valid.to(bias.dtype)
+    return w.contiguous(), b.contiguous()

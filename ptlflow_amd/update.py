@@ -33,7 +33,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from . import load_native
-from .packing import pack_cin2_weight, pack_conv_weight, pack_flow_head_weight, round_up, split_bf16_planes
+from .packing import permute_mask_head, pack_cin2_weight, pack_conv_weight, pack_flow_head_weight, round_up, split_bf16_planes
 
 EPI_LINEAR, EPI_GRU_ZR, EPI_GRU_Q = 0, 1, 2
 
@@ -207,11 +207,9 @@ class UpdateEngine:
             w["mk.w"] = pk(g("mask.2.weight"), seg1(256))
             w["mk.b"] = g("mask.2.bias").contiguous()
             if self.nsplit == 0 and s.mask_channels == 576 and s.fh_hidden % 32 == 0:
-                # fused mask conv2 + softmax + convex upsampling (`pfk_mask_upsample_f32`): the 1x1 weight / bias with their rows in the
-                # order [half (2)][tap (9)][32 sub-pixels] — row half*288 + k*32 + j = mask channel k*64 + half*32 + j (include/pfk.h)
-                perm = torch.arange(576, device=dev).view(9, 2, 32).permute(1, 0, 2).reshape(-1)
-                w["mku.w"] = pack_conv_weight(g("mask.2.weight"), seg1(s.fh_hidden))[perm].contiguous()
-                w["mku.b"] = w["mk.b"][perm].contiguous()
+                # fused mask conv2 + softmax + convex upsampling (`pfk_mask_upsample_f32`): the 1x1 weight / bias with their rows in
+                # the kernel's [quarter][tile][32] order (packing.permute_mask_head, include/pfk.h)
+                w["mku.w"], w["mku.b"] = permute_mask_head(pack_conv_weight(g("mask.2.weight"), seg1(s.fh_hidden)), w["mk.b"])
             # flow-head conv1 alone: the iterations whose mask is never looked at (`upsample_every_iter=False`) skip the mask half
             w["fh.w"] = pk(g("flow_head.conv1.weight"), seg1(Ch))
             w["fh.b"] = g("flow_head.conv1.bias").contiguous()

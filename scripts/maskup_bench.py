@@ -6,7 +6,7 @@ import sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ptlflow_amd
-from ptlflow_amd.packing import pack_conv_weight
+from ptlflow_amd.packing import pack_conv_weight, permute_mask_head
 ptlflow_amd.load_native()
 ops = torch.ops.pfk
 dev = torch.device("cuda")
@@ -32,8 +32,7 @@ for B in (1, 2, 4, 8, 16):
     wt = torch.randn(576, cin, 1, 1, device=dev) / math.sqrt(cin)
     bias = torch.randn(576, device=dev) * 0.1
     packed = pack_conv_weight(wt, [(0, cin, cin)])
-    perm = torch.arange(576, device=dev).view(9, 2, 32).permute(1, 0, 2).reshape(-1)
-    wp, bp = packed[perm].contiguous(), bias[perm].contiguous()
+    wp, bp = permute_mask_head(packed, bias)
     x, flow = fm[:, 256:], hx[:, 386:388]
     mask = torch.empty(M, 576, device=dev)
     a = torch.empty(B, 2, 8 * H, 8 * W, device=dev); b = torch.empty_like(a)

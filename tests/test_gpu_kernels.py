@@ -463,7 +463,7 @@ def test_mask_upsample_fused(gpu, B, H, W):
     """pfk_mask_upsample_f32 (mask conv2 + softmax + convex upsampling, no mask in memory) against the two kernels it replaces
     (`conv2d` with scale 0.25 -> [M, 576] mask -> `convex_upsample_pm`): bit-identical; and against the oracle's
     `convex_upsample` on the oracle's mask (raft/raft.py:112-123, raft/update.py:152) to the GEMM tolerance."""
-    from ptlflow_amd.packing import pack_conv_weight
+    from ptlflow_amd.packing import pack_conv_weight, permute_mask_head
     torch.manual_seed(9)
     M, cin = B * H * W, 256
     fm = torch.randn(M, 512)                       # fh | mask hidden: the kernel reads the second half as a strided view
@@ -472,7 +472,7 @@ def test_mask_upsample_fused(gpu, B, H, W):
     hx = torch.randn(M, 8)
     flow_pm = hx[:, 4:6]                           # a 2-channel slice of a wider pixel-major row, like the engine's hx
     packed = pack_conv_weight(wt, [(0, cin, cin)])
-    perm = torch.arange(576).view(9, 2, 32).permute(1, 0, 2).reshape(-1)
+    wp, bp = permute_mask_head(packed, bias)
     fm_g, hx_g = fm.cuda(), hx.cuda()
     x_g, flow_g = fm_g[:, 256:], hx_g[:, 4:6]
     mask = torch.empty(M, 576, device=gpu)
@@ -480,7 +480,7 @@ def test_mask_upsample_fused(gpu, B, H, W):
     want = torch.empty(B, 2, 8 * H, 8 * W, device=gpu)
     torch.ops.pfk.convex_upsample_pm(flow_g, mask, want)
     got = torch.full((B, 2, 8 * H, 8 * W), 7.0, device=gpu)
-    torch.ops.pfk.mask_upsample(x_g, packed[perm].contiguous().cuda(), bias[perm].contiguous().cuda(), 0.25, flow_g, got)
+    torch.ops.pfk.mask_upsample(x_g, wp.cuda(), bp.cuda(), 0.25, flow_g, got)
     assert torch.equal(got, want), f"max diff {(got - want).abs().max().item():.3e}"
     x_nchw = fm[:, 256:].reshape(B, H, W, cin).permute(0, 3, 1, 2)
     mask_ref = 0.25 * F.conv2d(x_nchw, wt, bias)
