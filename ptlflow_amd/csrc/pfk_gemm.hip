@@ -380,7 +380,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs a) {
 // NINE taps: four waves stacked in M, wave tile 32 pixels x 160 columns = five 32x32 accumulators, column c of tile j holding tap
 // 2j + (c >> 4) of sub-pixel c & 15 (the tenth "tap" is a zero weight row).  The nine logits of a (pixel, sub-pixel) therefore sit
 // in TWO lanes (c and c ^ 16) of the same accumulator registers: one cross-lane exchange per register hands both lanes all nine,
-// and softmax + the weighted sum of the neighbours' flows are lane-local from there.  The mask never exists in memory.
+// and softmax + the weighted sum of the neighbours' flows are lane-local from there (the two lanes split the rows between them).
+// The mask never exists in memory.
 // (First form of this kernel: 32 sub-pixels x nine full tiles per wave — no exchange, no pad row — needed 117 KB of LDS and 144
 //  accumulator registers: ONE block per CU, so nothing ran under its prologue or under the 144 expf per lane of its epilogue, and a
 //  block could not share a CU with the other stream's 48-72 KB blocks: 0.50 of the matrix peak standalone, slower in situ.  This
@@ -526,16 +527,20 @@ __global__ __launch_bounds__(256, 2) void mask_upsample_kernel(const GemmArgs a)
   for (int j = 0; j < NT; ++j) bias[j] = a.bias != nullptr ? a.bias[n0 + j * 32 + col] : 0.f;
   const float sc = a.scale;
   const size_t HW8 = (size_t)H * W * 64;
-  float* outc = a.mu_out + (size_t)odd * HW8;        // lanes with the even taps store the x component, their partners y
+  // The two lanes of a pair split the ROWS: of every row pair (r, r + 1) the lane with the even taps finishes row r, its partner
+  // row r + 1 — one exchange per tile and row pair serves both (each lane sends the logits of the row the other finishes and
+  // receives those of its own), and each lane runs the softmax (9 expf) for 8 of the wave tile's 16 rows instead of all 16.
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = wm0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+  for (int r = 0; r < 16; r += 2) {
+    const int rr = r + odd;                          // the row this lane finishes
+    const int row = wm0 + (rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5);
     const unsigned p = (unsigned)m0 + (unsigned)row;
     float own[NT], oth[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      own[j] = mask_logit(acc[0][j][r], bias[j], sc);
-      oth[j] = __shfl_xor(own[j], 16, 64);           // the partner lane's tap 2j + (1 - odd) of the same (pixel, sub-pixel)
+      const float l0 = mask_logit(acc[0][j][r], bias[j], sc), l1 = mask_logit(acc[0][j][r + 1], bias[j], sc);
+      own[j] = odd ? l1 : l0;                        // tap 2j + odd of my row
+      oth[j] = __shfl_xor(odd ? l0 : l1, 16, 64);    // send the partner's row, receive tap 2j + (1 - odd) of mine
     }
     float m[9];
 #pragma unroll
@@ -550,7 +555,8 @@ __global__ __launch_bounds__(256, 2) void mask_upsample_kernel(const GemmArgs a)
       const unsigned bimg = fastdiv_u32(prow, a.ho_mul, a.ho_sh);
       const unsigned x = p - prow * W, y = prow - bimg * H;
       const size_t o = (size_t)(8 * y + (unsigned)sy) * (8 * W) + 8 * x + (unsigned)sx;
-      outc[(size_t)bimg * 2 * HW8 + o] = odd ? oy : ox;
+      a.mu_out[((size_t)bimg * 2 + 0) * HW8 + o] = ox;
+      a.mu_out[((size_t)bimg * 2 + 1) * HW8 + o] = oy;
     }
   }
 }

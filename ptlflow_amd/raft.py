@@ -127,10 +127,10 @@ class RAFT(nn.Module):
         super().__init__()
         self.small = small
         # The mask head's second convolution, the softmax over its nine taps and the convex upsampling (raft/update.py:152,
-        # raft/raft.py:112-123) as ONE kernel that never writes the [M, 576] mask (`pfk_mask_upsample_f32`); bit-identical to the
-        # two separate launches.  Opt-in (None = False): measured on the MI355X it removes 254 MB of HBM traffic per iteration at
-        # batch 8 and no time — 214 us against 175 + 42 standalone, and the whole forward is within 0.3 ms for {pair, fused} x
-        # {side stream, main stream}.
+        # raft/raft.py:112-123) as ONE kernel that never writes the [M, 576] mask (`pfk_mask_upsample_f32`); bit-identical
+        # to the two separate launches.  None: where it pays — fp32 convolutions from 28 160 pixels up (batch 8: 196 us against
+        # 173 + 41 for the pair, 254 MB less HBM traffic per iteration; at batch 1 the two forms take the same 34 us);
+        # True / False: always (where the kernel applies) / never.
         self.fuse_mask_upsample = fuse_mask_upsample
         # True (default): the context features' part of the GRU convolutions — loop-invariant, `inp` is the same tensor in every
         # iteration (raft.py:158-160, update.py:60-71) — is computed once per forward instead of once per iteration
@@ -432,7 +432,8 @@ class RAFT(nn.Module):
             side = self._stream(dev, "mask")
         main = torch.cuda.current_stream(dev)
         side_done = None
-        fuse = has_mask and eng.can_fuse_mask_upsample and bool(self.fuse_mask_upsample)
+        fuse = has_mask and eng.can_fuse_mask_upsample and \
+            (self.fuse_mask_upsample if self.fuse_mask_upsample is not None else pixels >= 28160)
         for it in range(self.iters):
             last = it == self.iters - 1
             if eng.profile is not None:     # bench.py's instrumented forward: HIP events around the lookup too (the HBM-bound kernel)
