@@ -236,6 +236,18 @@ typedef struct {
                             the stream, ZERO-FILLED by the caller once after allocation (the kernels leave its flag region
                             zeroed); enables the stream-K schedule for small grids (deterministic).  NULL: tile grid */
   long long workspace_bytes;
+  int cout_active;       /* ABI 6, LINEAR only: 0 or >= cout = every output channel; otherwise only output channels [0, cout_active)
+                            (a multiple of 64) are computed and written, the rest of `out` is left untouched — with EXACTLY the bits
+                            the full launch gives those channels: the tile schedule (tile grid or stream-K, and the stream-K split
+                            points) is chosen for the full `cout` and the column tiles past cout_active are skipped.  The fused
+                            flow-head | mask-head convolution (raft/update.py:13, :138-139) on the iterations whose mask nobody
+                            reads (raft/raft.py:180-192 in eval). */
+  int cout_split;        /* ABI 6, LINEAR only, 0 = none: the output channels form two groups [0, cout_split) and [cout_split, cout)
+                            of equal width (a multiple of 64; 2 * cout_split == cout) and the stream-K schedule walks their column
+                            tiles INTERLEAVED (group 0's first tile, group 1's first tile, group 0's second ...), so that a launch
+                            with cout_active == cout_split still gives every block about half of its range to do.  Pass the same
+                            value in the full launch and in the cout_active launch: the schedule, hence the bits, are then the
+                            same.  Tile-grid schedules ignore it. */
 } pfk_conv_desc;
 
 long long pfk_conv_workspace_bytes(void);

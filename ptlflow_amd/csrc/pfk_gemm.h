@@ -48,6 +48,10 @@ struct GemmArgs {
   int m_tile_base;         // split-bf16 path: a launch may cover a range of row tiles only (launch_bf's tail split); first row tile, in units of BM
   // fused mask head conv2 + softmax + convex upsampling (mask_upsample_kernel): flow read pixel-major, 8x output NCHW
   const float* mu_flow; int mu_flow_ld; float* mu_out;
+  int active_tiles_n;      // > 0: only column tiles [0, active_tiles_n) of 64 output channels are computed (pfk_conv_desc.cout_active); the
+                           // schedule is the full launch's.  stream-K kernel only — tile grids just launch fewer column tiles
+  int sk_split_tiles;      // > 0 (pfk_conv_desc.cout_split / 64, tiles_n == 2 * sk_split_tiles): the stream-K tile order interleaves the
+                           // column tiles of the two output groups — position 2i is tile i, position 2i + 1 is tile sk_split_tiles + i
 };
 
 // Tile id -> (tile_m, tile_n).  Row-major by default (tile_n fastest: the column tiles of one row panel run together and share

@@ -815,7 +815,14 @@ __global__ __launch_bounds__(256, BPC) void conv_gemm_sk_kernel(const GemmArgs a
     const int tbeg = tile * S;
     const int lo = u0 > tbeg ? u0 : tbeg;
     const int s0 = lo - tbeg, s1 = hi - tbeg, nsteps = s1 - s0;
-    const int tile_n = tile % a.tiles_n;
+    int tile_n = tile % a.tiles_n;
+    if (a.sk_split_tiles > 0) tile_n = (tile_n & 1) ? a.sk_split_tiles + (tile_n >> 1) : (tile_n >> 1);   // two output groups interleaved
+    if (a.active_tiles_n > 0 && tile_n >= a.active_tiles_n) {
+      // a column tile nobody asked for (pfk_conv_desc.cout_active): every block that holds a piece of it skips it — no partial, no
+      // flag, no epilogue; the split points of the tiles that ARE computed stay those of the full launch (same bits)
+      hi = lo;
+      continue;
+    }
     const long long m0 = (long long)(tile / a.tiles_n) * BM;
     const int n0 = tile_n * BN;
 
@@ -1336,6 +1343,13 @@ int launch(const GemmArgs& a0, int epi, int batches, hipStream_t st) {
         a.sk_steps >= 8)
       cfg = 11;
   }
+  // pfk_conv_desc.cout_active: the schedule above was chosen for the FULL output width; the stream-K kernel keeps that tile space
+  // and skips the inactive column tiles (split points of the computed tiles unchanged: same bits), every other kernel simply
+  // launches fewer column tiles (a tile's K order does not depend on its neighbours)
+  if (a.active_tiles_n > 0 && !(cfg == 9 || (cfg >= 30 && cfg <= 41))) {
+    a.b_rows = a.active_tiles_n * 64;
+    a.active_tiles_n = 0;
+  }
   if (cfg >= 50 && cfg < 82) return launch_pp(a, epi, batches, st, cfg - 50);   // 50 + v: persistent pipelined stream-K, schedule variant v
   if (cfg >= 82 && cfg < 85) return launch_pp(a, epi, batches, st, 3, cfg - 81);   // timing ablations 1..3 of variant 3 (swizzled x3, XCD groups)
   if (cfg >= 85 && cfg < 88) return launch_pp(a, epi, batches, st, 2, cfg - 84);   // ... of variant 2 (padded x2, XCD groups)
@@ -1481,6 +1495,14 @@ int pfk_conv2d_f32(const pfk_conv_desc* d, pfk_stream_t stream) {
   if (rc != PFK_OK) return rc;
   a.weight = d->weight;
   if ((long long)d->cout * a.ktot * 4 >= 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
+  if (d->cout_active > 0 && d->cout_active < d->cout) {
+    if (d->epilogue != PFK_EPI_LINEAR || (d->cout_active & 63)) return PFK_ERR_BAD_ARG;
+    a.active_tiles_n = d->cout_active / 64;
+  }
+  if (d->cout_split > 0) {
+    if (d->epilogue != PFK_EPI_LINEAR || (d->cout_split & 63) || 2 * d->cout_split != d->cout) return PFK_ERR_BAD_ARG;
+    a.sk_split_tiles = d->cout_split / 64;
+  }
   if (d->workspace && d->workspace_bytes >= (long long)SK_WS_BYTES && pfk_aligned16(d->workspace)) {
     a.sk_ws = static_cast<float*>(d->workspace);
     a.sk_flags = reinterpret_cast<unsigned*>(static_cast<char*>(d->workspace) + (size_t)SK_MAX_BLOCKS * 64 * 64 * 4);
@@ -1514,6 +1536,7 @@ int pfk_mask_upsample_f32(const float* x, int x_ld, int cin, const float* weight
 }
 
 int pfk_conv2d_bf16s(const pfk_conv_desc* d, const void* weight_planes, int nsplit, pfk_stream_t stream) {
+  if (d && ((d->cout_active > 0 && d->cout_active < d->cout) || d->cout_split > 0)) return PFK_ERR_UNSUPPORTED;   // the fp32 kernels' features (pfk.h)
   GemmArgs a{};
   if (!d || !weight_planes || nsplit < 1 || nsplit > 3) return PFK_ERR_BAD_ARG;
   if (!pfk_aligned16(weight_planes)) return PFK_ERR_ALIGNMENT;

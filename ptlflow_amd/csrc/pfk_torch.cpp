@@ -138,12 +138,14 @@ void conv2d(at::TensorList srcs, int64_t B, int64_t H, int64_t W, int64_t kh, in
             bool relu, double scale, const c10::optional<Tensor>& out, const c10::optional<Tensor>& h,
             const c10::optional<Tensor>& aux_z, const c10::optional<Tensor>& aux_rh,
             const c10::optional<Tensor>& workspace, const c10::optional<Tensor>& residual, int64_t stride,
-            bool relu_after_residual) {
+            bool relu_after_residual, int64_t cout_active, int64_t cout_split) {
   OpScope scope(weight);
   TORCH_CHECK(srcs.size() >= 1 && srcs.size() <= 3, "conv2d: 1..3 sources");
   TORCH_CHECK(stride >= 1, "conv2d: stride");
   pfk_conv_desc d{};
   d.stride = (int)stride;
+  d.cout_active = (int)cout_active;
+  d.cout_split = (int)cout_split;
   d.relu_after_residual = relu_after_residual;
   const int64_t M = B * ((H - 1) / stride + 1) * ((W - 1) / stride + 1);   // output rows
   for (size_t i = 0; i < srcs.size(); ++i) {
@@ -721,7 +723,7 @@ TORCH_LIBRARY(pfk, m) {
   m.def("blocked_map_elems(int H, int W) -> int", &blocked_map_elems);
   m.def("conv2d(Tensor[] srcs, int B, int H, int W, int kh, int kw, Tensor weight, Tensor? bias, int cout, "
         "int epilogue, bool relu, float scale, Tensor(a!)? out, Tensor(b!)? h, Tensor(c!)? aux_z, Tensor(d!)? aux_rh, "
-        "Tensor(e!)? workspace=None, Tensor? residual=None, int stride=1, bool relu_after_residual=False) -> ()");
+        "Tensor(e!)? workspace=None, Tensor? residual=None, int stride=1, bool relu_after_residual=False, int cout_active=0, int cout_split=0) -> ()");
   m.def("conv_workspace_bytes() -> int", &conv_workspace_bytes);
   m.def("conv_workspace_fault_offset() -> int", &conv_workspace_fault_offset);
   m.def("conv_cin2(Tensor inp, Tensor weight, Tensor? bias, Tensor(a!) out, int B, int H, int W, int k, bool relu) -> ()");

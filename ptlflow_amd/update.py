@@ -376,7 +376,7 @@ class UpdateEngine:
 
     # ------------------------------------------------------------------ one iteration
     def _conv(self, srcs: List[torch.Tensor], kh, kw, key, cout, relu=True, scale=1.0, out=None,
-              epi=EPI_LINEAR, h=None, z=None, rh=None, workspace=True, residual=None):
+              epi=EPI_LINEAR, h=None, z=None, rh=None, workspace=True, residual=None, cout_active=0, cout_split=0):
         B, H, W = self._shape
         prof = self.profile
         if prof is not None:
@@ -386,9 +386,12 @@ class UpdateEngine:
         # (none: plain tile grid)
         ws = self.workspace if workspace is True else (workspace if isinstance(workspace, torch.Tensor) else None)
         self.ops.conv2d(srcs, B, H, W, kh, kw, self.w[key + ".w"], self.w.get(key + ".b"), cout, epi, relu, scale,
-                        out, h, z, rh, ws, residual)
+                        out, h, z, rh, ws, residual, 1, False, cout_active, cout_split)
         if prof is not None:
             e1.record()
+            if cout_active:
+                key, cout = key + "_half", cout_active
+                self._real_cin[key] = self._real_cin[key[:-5]]
             prof.setdefault(key, []).append((e0, e1))
             # algorithmic work: 2 * pixels * cout * taps * real input channels (padding is not work)
             self.flops[key] = 2.0 * B * H * W * cout * kh * kw * self._real_cin[key]
@@ -479,12 +482,17 @@ class UpdateEngine:
 
     def heads_conv1(self, want_mask: bool = True) -> None:
         """flow-head conv1 | mask conv1 as ONE GEMM over h (update.py:13, :138-139) -> fm; without `want_mask` only the flow-head
-        half (same K order per output element: the flow half's bits do not depend on whether the mask half rides along)"""
+        half is computed (`cout_active`, include/pfk.h): the launch keeps the full launch's tile schedule — at batch 1 the stream-K
+        split points of the 880-tile grid — and skips the mask half's column tiles, so the flow half has the full launch's bits
+        whatever the schedule (round 4 could only drop the mask half where neither form fell into the stream-K window)."""
         s = self.spec
-        B, H, W = self._shape
-        # (only where neither launch falls into the stream-K window of 257..1023 tiles — there the two GEMMs would cut their tiles
-        #  at different K positions and the flow half's last bits would depend on the mode)
-        if s.has_mask and not want_mask and B * H * W >= 28160:
+        if s.has_mask and self.nsplit == 0 and s.fh_hidden % 64 == 0:
+            # `cout_split`: a stream-K schedule (batch 1) walks the column tiles of the two halves interleaved — in BOTH forms of the
+            # launch, so that they share their split points (same bits) and the half launch still balances its blocks
+            self._conv([self.h_view], 3, 3, "fm", 2 * s.fh_hidden, out=self.fm, cout_active=0 if want_mask else s.fh_hidden,
+                       cout_split=s.fh_hidden)
+        elif s.has_mask and not want_mask and self._shape[0] * self._shape[1] * self._shape[2] >= 28160:
+            # split-bf16 kernels (no `cout_active`): the flow-head-only weights, where no launch is in the stream-K window
             self._conv([self.h_view], 3, 3, "fh", s.fh_hidden, out=self.fm[:, : s.fh_hidden])
         else:
             self._conv([self.h_view], 3, 3, "fm", s.fh_hidden * (2 if s.has_mask else 1), out=self.fm)

@@ -486,3 +486,32 @@ def test_mask_upsample_fused(gpu, B, H, W):
     mask_ref = 0.25 * F.conv2d(x_nchw, wt, bias)
     flow_ref = flow_pm.reshape(B, H, W, 2).permute(0, 3, 1, 2)
     close(got, O.convex_upsample(flow_ref, mask_ref), rtol=2e-5, atol=2e-4)
+
+
+@pytest.mark.parametrize("B,H,W,with_ws", [(1, 55, 128, True), (1, 55, 128, False), (8, 55, 128, True), (2, 23, 31, True), (1, 46, 62, True)])
+def test_conv_cout_active_has_the_full_launch_bits(gpu, B, H, W, with_ws):
+    """`pfk_conv_desc.cout_active`: the fused flow-head | mask-head convolution (3x3, 128 -> 512) computing only its first 256 output
+    channels.  Whatever schedule the full launch gets — at 1 x 55 x 128 with a workspace the stream-K split of the 880-tile grid,
+    otherwise tile grids of 64x64 / 64x128 tiles — the active half must carry EXACTLY the full launch's bits and the other half of
+    `out` must be left alone."""
+    torch.manual_seed(11)
+    cin, cout, act = 128, 512, 256
+    M = B * H * W
+    x = torch.randn(M, cin, device=gpu)
+    wt = torch.randn(cout, cin, 3, 3) / math.sqrt(9 * cin)
+    bias = (torch.randn(cout) * 0.1).cuda()
+    packed = _packed(wt, [(0, cin, cin)])
+    ws = torch.zeros(torch.ops.pfk.conv_workspace_bytes(), device=gpu, dtype=torch.uint8) if with_ws else None
+    full = torch.empty(M, cout, device=gpu)
+    for split in (0, act):      # `cout_split`: the two halves' column tiles interleaved in the stream-K order, in both launches
+        torch.ops.pfk.conv2d([x], B, H, W, 3, 3, packed, bias, cout, EPI_LINEAR, True, 1.0, full, None, None, None, ws, None, 1, False, 0, split)
+        half = torch.full((M, cout), -3.0, device=gpu)
+        torch.ops.pfk.conv2d([x], B, H, W, 3, 3, packed, bias, cout, EPI_LINEAR, True, 1.0, half, None, None, None, ws, None, 1, False, act, split)
+        assert torch.equal(half[:, :act], full[:, :act]), f"cout_split={split}"
+    assert bool((half[:, act:] == -3.0).all())
+    if ws is not None:      # the flag region is all zero again: skipped tiles neither publish nor consume
+        off = torch.ops.pfk.conv_workspace_fault_offset()
+        assert int(ws[off:off + 4].view(torch.int32).item()) == 0
+        assert bool((ws[torch.ops.pfk.conv_workspace_bytes() - 768 * 64:][:768 * 4] == 0).all())
+    ref = F.relu(F.conv2d(x.view(B, H, W, cin).permute(0, 3, 1, 2).cpu(), wt, bias.cpu(), padding=1))
+    close(unpm(half[:, :act].contiguous(), B, H, W), ref[:, :act])
