@@ -119,3 +119,28 @@ def test_hoisted_gru_packing_equals_the_single_chain_convolution():
                 ctx = emulate([hx[:, Ch:Ch + Ci]], [Ci], eng.w[f"{key}c{sfx}.w"], kh, kw, H, W) + eng.w[f"{key}c{sfx}.b"]
                 assert eng.w.get(f"{key}{sfx}.b") is None                  # the bias lives in the context term
                 assert torch.allclose(per_iter + ctx, ref, atol=2e-4), (key, sfx, float((per_iter + ctx - ref).abs().max()))
+
+
+def test_permute_mask_head_row_order():
+    """`packing.permute_mask_head` = the row order `pfk_mask_upsample_f32` documents (include/pfk.h): row q*160 + j*32 + c is mask
+    channel k*64 + s with tap k = 2j + (c >> 4) and sub-pixel s = q*16 + (c & 15); the tenth tap's rows are zero; every one of the
+    576 channels appears exactly once."""
+    from ptlflow_amd.packing import mask_upsample_perm, permute_mask_head
+    w = torch.arange(576, dtype=torch.float32)[:, None].repeat(1, 32) + 1.0      # row r holds the value r + 1
+    b = torch.arange(576, dtype=torch.float32) + 1.0
+    wp, bp = permute_mask_head(w, b)
+    assert wp.shape == (640, 32) and bp.shape == (640,)
+    seen = []
+    for q in range(4):
+        for j in range(5):
+            for c in range(32):
+                k, s = 2 * j + (c >> 4), q * 16 + (c & 15)
+                row = q * 160 + j * 32 + c
+                if k == 9:
+                    assert float(bp[row]) == 0.0 and bool((wp[row] == 0).all())
+                else:
+                    assert float(bp[row]) == k * 64 + s + 1.0 and bool((wp[row] == k * 64 + s + 1.0).all())
+                    seen.append(k * 64 + s)
+    assert sorted(seen) == list(range(576))
+    idx, valid = mask_upsample_perm()
+    assert int(valid.sum()) == 576 and idx.shape == (640,)
