@@ -78,7 +78,9 @@ def main():
         else:
             # a side queue: the mask branch's (mask conv2 + upsampling of iteration i next to iteration i+1) is the one that hosts the
             # upsampling launches; the encoders' side queue (cnet next to fnet at small batches) has convolutions of its own
-            mask_q = any("convex_upsample" in r["Kernel_Name"] or "mask_upsample_kernel" in r["Kernel_Name"] for r in rs)
+            # (with the fused kernel K13 the branch has no separate mask conv2: only a queue that hosts the un-fused upsampling
+            #  kernel can host `mk` launches)
+            mask_q = any("convex_upsample" in r["Kernel_Name"] for r in rs)
             for r in rs:
                 name = r["Kernel_Name"]
                 site = next((v for k, v in NAMED.items() if k in name), "mk" if (mask_q and "conv_gemm" in name) else None)
