@@ -36,6 +36,8 @@ def classify(rows, key_time="Start_Timestamp"):
     rows = sorted(rows, key=lambda r: int(r["Dispatch_Id"]))
     idx = None
     out = []
+    # with the fused kernel K13 an iteration has no separate mask conv2: nine implicit-GEMM launches per lookup, not ten
+    SEQ = [k for k in globals()["SEQ"] if k != "mk"] if any("mask_upsample_kernel" in r["Kernel_Name"] for r in rows) else globals()["SEQ"]
     for r in rows:
         name = r["Kernel_Name"]
         site = None
