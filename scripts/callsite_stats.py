@@ -31,13 +31,15 @@ def find(path, pat):
     return c[0]
 
 
-def classify(rows, key_time="Start_Timestamp"):
+def classify(rows, fused=None):
     """rows of one trace (dicts with Kernel_Name, Dispatch_Id, Queue_Id) -> list of (callsite, row) in dispatch order."""
     rows = sorted(rows, key=lambda r: int(r["Dispatch_Id"]))
     idx = None
     out = []
     # with the fused kernel K13 an iteration has no separate mask conv2: nine implicit-GEMM launches per lookup, not ten
-    SEQ = [k for k in globals()["SEQ"] if k != "mk"] if any("mask_upsample_kernel" in r["Kernel_Name"] for r in rows) else globals()["SEQ"]
+    if fused is None:
+        fused = any("mask_upsample_kernel" in r["Kernel_Name"] for r in rows)
+    SEQ = [k for k in globals()["SEQ"] if k != "mk"] if fused else globals()["SEQ"]
     for r in rows:
         name = r["Kernel_Name"]
         site = None
@@ -71,10 +73,11 @@ def main():
     for r in rows:
         queues[r.get("Queue_Id", "0")].append(r)
     main_q = max(queues, key=lambda q: sum("lookup_kernel" in r["Kernel_Name"] for r in queues[q]))
+    fused = any("mask_upsample_kernel" in r["Kernel_Name"] for r in rows)
     acc = defaultdict(lambda: [0, 0])
     for q, rs in queues.items():
         if q == main_q:
-            for site, r in classify(rs):
+            for site, r in classify(rs, fused):
                 if site:
                     e = acc[site]; e[0] += 1; e[1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
         else:
