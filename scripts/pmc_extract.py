@@ -22,6 +22,9 @@ def load(d):
     rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Dispatch_Id"]))
     acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
     idx, last = None, None
+    # round 5: with the fused mask conv2 + softmax + upsampling kernel (K13) an iteration has nine implicit-GEMM launches, not ten
+    fused = any("mask_upsample_kernel" in r["Kernel_Name"] for r in rows)
+    seq = [k for k in SEQ if k != "mk"] if fused else SEQ
     for r in rows:
         name, did = r["Kernel_Name"], r["Dispatch_Id"]
         if did != last:                       # several counters per dispatch: advance the position once per dispatch
@@ -29,8 +32,10 @@ def load(d):
             if "lookup_kernel" in name:
                 idx = 0
                 cur = "lookup"
-            elif "conv_gemm" in name and idx is not None and idx < len(SEQ):
-                cur = SEQ[idx]
+            elif "mask_upsample_kernel" in name:
+                cur = "mku"
+            elif "conv_gemm" in name and idx is not None and idx < len(seq):
+                cur = seq[idx]
                 idx += 1
             else:
                 cur = None
@@ -56,7 +61,7 @@ def main():
     fetch, write = load(a.fetch), load(a.write)
     sq = load(a.sq) if a.sq else {}
     entries = {}
-    for key in SEQ + ["lookup"]:
+    for key in SEQ + ["lookup", "mku"]:
         if key not in fetch:
             continue
         e = {"fetch_kb": round(fetch[key].get("FETCH_SIZE", 0.0)), "write_kb": round(write.get(key, {}).get("WRITE_SIZE", 0.0)),
