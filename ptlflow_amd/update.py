@@ -669,7 +669,8 @@ class PfkUpdateBlock(torch.nn.Module):
                     eng.set_attention(attention)
                     self._attn_ref, self._attn_version = attention, attention._version
             eng.motion_and_gru(corr_pm)
-        eng._scratch_c1.zero_()
+        if new_forward:
+            eng._scratch_c1.zero_()     # the kernel's `coords1 += delta` lands here; `delta` itself does not depend on it — once per forward keeps it bounded
         eng.heads(eng._scratch_c0, eng._scratch_c1, eng._delta, want_mask=not dead_mask, write_flow=False)
         mask = eng.mask_nchw() if eng.spec.has_mask else None
         out_net = eng.net_nchw()
