@@ -39,6 +39,8 @@ def classify(rows, fused=None):
     # with the fused kernel K13 an iteration has no separate mask conv2: nine implicit-GEMM launches per lookup, not ten
     if fused is None:
         fused = any("mask_upsample_kernel" in r["Kernel_Name"] for r in rows)
+    # the mask branch on a side queue (batch 8): mask conv2 is that queue's launch, the main queue has nine GEMM launches per lookup
+    side_mk = any(q != main_q and any("convex_upsample" in r["Kernel_Name"] for r in rs) for q, rs in queues.items())
     SEQ = [k for k in globals()["SEQ"] if k != "mk"] if fused else globals()["SEQ"]
     for r in rows:
         name = r["Kernel_Name"]
@@ -77,7 +79,7 @@ def main():
     acc = defaultdict(lambda: [0, 0])
     for q, rs in queues.items():
         if q == main_q:
-            for site, r in classify(rs, fused):
+            for site, r in classify(rs, fused or side_mk):
                 if site:
                     e = acc[site]; e[0] += 1; e[1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
         else:
