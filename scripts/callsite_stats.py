@@ -39,8 +39,6 @@ def classify(rows, fused=None):
     # with the fused kernel K13 an iteration has no separate mask conv2: nine implicit-GEMM launches per lookup, not ten
     if fused is None:
         fused = any("mask_upsample_kernel" in r["Kernel_Name"] for r in rows)
-    # the mask branch on a side queue (batch 8): mask conv2 is that queue's launch, the main queue has nine GEMM launches per lookup
-    side_mk = any(q != main_q and any("convex_upsample" in r["Kernel_Name"] for r in rs) for q, rs in queues.items())
     SEQ = [k for k in globals()["SEQ"] if k != "mk"] if fused else globals()["SEQ"]
     for r in rows:
         name = r["Kernel_Name"]
@@ -76,6 +74,8 @@ def main():
         queues[r.get("Queue_Id", "0")].append(r)
     main_q = max(queues, key=lambda q: sum("lookup_kernel" in r["Kernel_Name"] for r in queues[q]))
     fused = any("mask_upsample_kernel" in r["Kernel_Name"] for r in rows)
+    # the mask branch on a side queue (batch 8): mask conv2 is that queue's launch, the main queue has nine GEMM launches per lookup
+    side_mk = any(q != main_q and any("convex_upsample" in r["Kernel_Name"] for r in rs) for q, rs in queues.items())
     acc = defaultdict(lambda: [0, 0])
     for q, rs in queues.items():
         if q == main_q:
