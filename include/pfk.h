@@ -57,7 +57,7 @@ enum pfk_status {
 };
 
 #define PFK_MAX_LEVELS 8
-#define PFK_ABI_VERSION 6
+#define PFK_ABI_VERSION 7
 
 int pfk_abi_version(void);
 const char* pfk_status_string(int status);
@@ -116,8 +116,10 @@ typedef struct {
   int radius;      /* 1..4 */
   int B, h, w;     /* source grid: N = h*w pixels per batch element */
   const float* coords;
-  float* out;
-  int out_ld;      /* >= num_levels*(2r+1)^2, multiple of 4 */
+  void* out;       /* fp32 rows, or bf16 rows when out_bf16 != 0 */
+  int out_ld;      /* in elements; >= num_levels*(2r+1)^2, multiple of 4 */
+  int out_bf16;    /* ABI 7: 0 = `out` holds fp32, 1 = bf16 (each sample rounded to nearest even: what autocast hands the next
+                      convolution; columns the lookup does not write — the pad up to out_ld — are left untouched) */
 } pfk_lookup_desc;
 int pfk_corr_lookup_f32(const pfk_lookup_desc* d, pfk_stream_t stream);
 /* same with `levels` pointing to bf16 maps; arithmetic and output fp32 (grid_sample is an fp32 op under autocast) */
@@ -271,11 +273,68 @@ int pfk_conv2d_f32(const pfk_conv_desc* d, pfk_stream_t stream);
 int pfk_conv_ktot_bf16(const pfk_conv_desc* d);
 int pfk_conv2d_bf16s(const pfk_conv_desc* d, const void* weight_planes, int nsplit, pfk_stream_t stream);
 
+/* ---- K8b (ABI 7): the same convolution with bf16 ACTIVATION STORAGE on the bf16 matrix cores ---------------------------
+ * What the reference's convolutions compute under its reduced-precision switch (scripts/model_benchmark.py:317-319,
+ * validate.py:243-244 / torch.autocast(bfloat16): every nn.Conv2d of raft/update.py:6-153 reads and writes 16-bit tensors).
+ * Sources are bf16 pixel-major rows (`ld`, `channels` in ELEMENTS, multiples of 8; 16-byte aligned), the weight is bf16
+ * [cout][ktot] with the K order of pfk_conv2d_f32's packed weight but 64-channel chunks: for each source, each tap (ky major), the
+ * source's channels zero-padded to a multiple of 64 — ktot = pfk_conv_ktot_b16(d).  Both operands go global -> LDS by LDS-DMA
+ * (no register round trip, no conversion); products on v_mfma_f32_32x32x16_bf16, fp32 accumulate, fp32 bias / residual / gate
+ * arithmetic.  Outputs:
+ *   LINEAR   out = bf16 (out_bf16 != 0; the next convolution's operand) or fp32 rows, `out_ld` / `out_coff` in elements of that type
+ *   GRU_ZR   z -> aux_z BF16 [M][Ch];  r * h (h read from its bf16 copy h_b16) -> aux_rh BF16 [M][Ch] (the q convolution's operand)
+ *   GRU_Q    h fp32 updated in place (the recurrent state keeps full precision; z read from aux_z bf16) and, when h_b16 != NULL,
+ *            its bf16 rounding -> h_b16[p * h_b16_ld + co] (the next convolutions' operand)
+ * `residual`: LINEAR — fp32 rows added after relu / scale (pfk_conv_desc); GRU epilogues — BF16 rows [M][cout] added to the gate
+ * pre-activation (the loop-invariant context term: at batch 8 these launches are bound by the HBM bytes of their epilogues, and the
+ * term is a convolution output that autocast would hold in 16 bits anyway).
+ * kh * kw <= 32.  No workspace, no stream-K: tile grids only. */
+typedef struct {
+  const void* ptr;   /* bf16 rows */
+  int ld;            /* row stride in elements (multiple of 8) */
+  int channels;      /* channels read from each row (multiple of 8) */
+} pfk_conv_src_b16;
+
+typedef struct {
+  pfk_conv_src_b16 src[3];
+  int num_src;
+  int B, H, W;
+  int kh, kw;
+  const void* weight;    /* bf16 [cout][ktot] */
+  const float* bias;     /* fp32 [cout] or NULL */
+  int cout;
+  int epilogue;          /* enum pfk_epilogue */
+  int relu;
+  float scale;
+  void* out;             /* LINEAR */
+  int out_ld, out_coff;
+  int out_bf16;          /* LINEAR: 1 = `out` holds bf16 elements, 0 = fp32 */
+  float* h;              /* GRU_Q (read + write): fp32 hidden state */
+  int h_ld;
+  void* h_b16;           /* GRU_ZR (read, required): bf16 copy of the hidden state; GRU_Q (write, optional): bf16 copy of the new one */
+  int h_b16_ld;
+  void* aux_z;           /* bf16 [M][Ch]: written by GRU_ZR, read by GRU_Q */
+  void* aux_rh;          /* bf16 [M][Ch] */
+  const void* residual;  /* LINEAR: fp32 [M][cout] rows; GRU_ZR / GRU_Q: bf16 [M][cout] rows (see above) */
+  int residual_ld;       /* in elements of that type */
+  int stride;
+  int relu_after_residual;
+} pfk_conv_b16_desc;
+int pfk_conv_ktot_b16(const pfk_conv_b16_desc* d);
+int pfk_conv2d_b16(const pfk_conv_b16_desc* d, pfk_stream_t stream);
+int pfk_debug_set_b16(int cfg);            /* K8b tile configuration: 0 = heuristic, 1..5 (pfk_gemm_b16.hip::launch_b16) */
+
 /* ---- small direct kernels ------------------------------------------------------------------- */
 /* k x k conv on a 2-channel map (the flow), relu optional: out[p*out_ld + out_coff + co].
  * in [M][in_ld] (channels 0,1 used); weight packed [k*k][2][cout]; bias [cout]. */
 int pfk_conv_cin2_f32(const float* in, int in_ld, const float* weight, const float* bias,
                       float* out, int out_ld, int out_coff, int B, int H, int W, int k, int cout,
+                      int relu, pfk_stream_t stream);
+
+/* same with a bf16 output (ABI 7; k = 3, 5 or 7): `out_bf16` holds bf16 elements, out_ld / out_coff in elements — the A operand of
+ * convf2 on the K8b path (pfk_conv2d_b16) */
+int pfk_conv_cin2_b16(const float* in, int in_ld, const float* weight, const float* bias,
+                      void* out_bf16, int out_ld, int out_coff, int B, int H, int W, int k, int cout,
                       int relu, pfk_stream_t stream);
 
 /* FlowHead.conv2 (3x3, cin -> 2) fused with the coordinate update of the RAFT loop:
@@ -286,6 +345,13 @@ int pfk_conv_cin2_f32(const float* in, int in_ld, const float* weight, const flo
 int pfk_flow_delta_f32(const float* in, int in_ld, int cin, const float* weight,
                        const float* bias, const float* coords0, float* coords1, float* delta_out,
                        float* flow_out, int flow_ld, int B, int H, int W, pfk_stream_t stream);
+
+/* same with a bf16 input (ABI 7; the flow head's hidden activation as pfk_conv2d_b16 writes it: in_ld in elements, 8-byte aligned
+ * rows) and an optional second, bf16 copy of the flow at flow_out_b16[p*flow_b16_ld + 0..1] (the 16-bit twin of the hx buffer that
+ * the next iteration's convolutions read); weight / bias / coordinates fp32, fp32 accumulation. */
+int pfk_flow_delta_b16(const void* in_bf16, int in_ld, int cin, const float* weight,
+                       const float* bias, const float* coords0, float* coords1, float* delta_out,
+                       float* flow_out, int flow_ld, void* flow_out_b16, int flow_b16_ld, int B, int H, int W, pfk_stream_t stream);
 
 /* flow = coords1 - coords0 written pixel-major (2 channels) — loop prologue / drop-in mode. */
 int pfk_flow_from_coords_f32(const float* coords0, const float* coords1, float* flow_out,

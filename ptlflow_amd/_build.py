@@ -37,6 +37,7 @@ LIBTORCH_EXT = PKG / "_pfk_torch.so"
 HIP_SOURCES = [
     ("pfk_gemm.hip", []),
     ("pfk_gemm_bf.hip", []),
+    ("pfk_gemm_b16.hip", []),                 # K8b: bf16 activation storage, LDS-DMA for both operands
     ("pfk_corr.hip", ["-ffp-contract=off"]),  # index-exact coordinate arithmetic
     ("pfk_misc.hip", ["-ffp-contract=off"]),
     ("pfk_altcorr.hip", []),
@@ -46,6 +47,12 @@ HIP_SOURCES = [
     ("pfk_bwd.hip", ["-ffp-contract=off"]),   # same coordinate arithmetic as pfk_corr.hip (pfk_lookup.h)
     ("pfk_stamp.hip", []),                    # pfk_source_hash(): compiled with -DPFK_SOURCE_HASH=<tree hash>
 ]
+# PFK_BENCH_VARIANTS=1 (tuning scripts only: scripts/conv_bench.py, scripts/conv_b16_bench.py) compiles the timing ablations and the
+# experimental tile / schedule variants of the implicit-GEMM kernels in; the shipped library does not contain them.  The flag is part
+# of the source stamp, so a variants build is only accepted by a process that also runs with PFK_BENCH_VARIANTS=1.
+BENCH_VARIANTS = os.environ.get("PFK_BENCH_VARIANTS") == "1"
+if BENCH_VARIANTS:
+    HIP_SOURCES = [(s, f + ["-DPFK_BENCH_VARIANTS"]) if s.startswith("pfk_gemm") else (s, f) for s, f in HIP_SOURCES]
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
              f"-I{INCLUDE}", f"-I{CSRC}", "-Wall", "-Wno-unused-function"]
 

@@ -394,11 +394,16 @@ class AlternateCorrBlock:
             out.append(corr.squeeze(1))
         return torch.stack(out, dim=1).reshape(B, -1, H, W) / math.sqrt(self.dim)
 
-    def lookup_pm(self, coords: torch.Tensor) -> torch.Tensor:
-        """Pixel-major ``[B*h*w, C]`` form for the update engine (same contract as ``CorrBlock.lookup_pm``)."""
+    def lookup_pm(self, coords: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Pixel-major ``[B*h*w, C]`` form for the update engine (same contract as ``CorrBlock.lookup_pm``); ``out``: a
+        ``[B*h*w, >= C]`` buffer of any float dtype to fill instead (pad columns are left alone)."""
         corr = self._windows(coords)
         B, C, H, W = corr.shape
-        return corr.permute(0, 2, 3, 1).reshape(B * H * W, C).contiguous()
+        pm = corr.permute(0, 2, 3, 1).reshape(B * H * W, C)
+        if out is not None:
+            out[:, :C].copy_(pm)
+            return out
+        return pm.contiguous()
 
 
 def get_corr_block(fmap1: torch.Tensor, fmap2: torch.Tensor, num_levels: int = 4, radius: int = 4,

@@ -30,9 +30,14 @@ struct LookupArgs {
   int lw[PFK_MAX_LEVELS];
   int L, r, B, h, w;
   const float* coords;
-  float* out;
-  int out_ld;
+  void* out;
+  int out_ld, out_bf16;
 };
+
+__device__ __forceinline__ void store_sample(const LookupArgs& a, size_t idx, float t) {
+  if (a.out_bf16) static_cast<__bf16*>(a.out)[idx] = (__bf16)t;
+  else static_cast<float*>(a.out)[idx] = t;
+}
 
 // Blocked volume layout (round 5): a level's [H][W] map per source pixel is stored as ceil(H/4) x ceil(W/8) tiles of 4 rows x 8
 // columns, 32 consecutive elements each — one 128-byte line per fp32 tile.  The 12 x 12 window a lookup stages then touches
@@ -143,7 +148,7 @@ __global__ __launch_bounds__(256) void lookup_kernel(const LookupArgs a) {
         // a select, per pixel (the register file cannot be indexed by a per-lane pixel number, so the flat sample list of
         // the LDS path is not available: 2 passes per pixel, 47 idle lanes in the second)
         wave_lds_sync();      // the tap tables
-        float* outl = a.out + (size_t)p0 * (unsigned)a.out_ld + l * nn;
+        const size_t outl = (size_t)p0 * (unsigned)a.out_ld + l * nn;
 #pragma unroll
         for (int q = 0; q < PIX; ++q) {
 #pragma unroll
@@ -167,7 +172,7 @@ __global__ __launch_bounds__(256) void lookup_kernel(const LookupArgs a) {
             t = fmaf(tap[1], w_ne, t);
             t = fmaf(tap[2], w_sw, t);
             t = fmaf(tap[3], w_se, t);
-            if (valid) outl[q * a.out_ld + k] = t;
+            if (valid) store_sample(a, outl + q * a.out_ld + k, t);
           }
         }
       } else {
@@ -187,7 +192,7 @@ __global__ __launch_bounds__(256) void lookup_kernel(const LookupArgs a) {
     if (active && !SHFL) {
       // the PIX * (2R+1)^2 samples of this level as one flat list over the lanes (324 = 5.06 wave-iterations at R = 4
       // instead of 4 x 2 with 47 idle lanes in every second one)
-      float* outl = a.out + (size_t)p0 * (unsigned)a.out_ld + l * nn;
+      const size_t outl = (size_t)p0 * (unsigned)a.out_ld + l * nn;
       for (int idx = lane; idx < PIX * nn; idx += 64) {
         const int q = idx / nn, k = idx - q * nn;
         if (p0 + q >= M) continue;
@@ -201,7 +206,7 @@ __global__ __launch_bounds__(256) void lookup_kernel(const LookupArgs a) {
         t = fmaf(ne, w_ne, t);
         t = fmaf(sw, w_sw, t);
         t = fmaf(se, w_se, t);
-        outl[q * a.out_ld + k] = t;
+        store_sample(a, outl + q * a.out_ld + k, t);
       }
     }
     wave_lds_sync();   // the next round restages this wave's region
@@ -317,7 +322,7 @@ int lookup_launch(const pfk_lookup_desc* d, pfk_stream_t stream) {
     a.lv[l] = d->levels[l]; a.lh[l] = d->lvl_h[l]; a.lw[l] = d->lvl_w[l];
   }
   a.L = d->num_levels; a.r = d->radius; a.B = d->B; a.h = d->h; a.w = d->w;
-  a.coords = d->coords; a.out = d->out; a.out_ld = d->out_ld;
+  a.coords = d->coords; a.out = d->out; a.out_ld = d->out_ld; a.out_bf16 = d->out_bf16;
   const long long M = (long long)d->B * d->h * d->w;
   if (M >= 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;   // the kernel's pixel arithmetic is 32-bit
   hipStream_t st = static_cast<hipStream_t>(stream);

@@ -44,11 +44,11 @@ __global__ __launch_bounds__(256) void conv_cin2_kernel(const float* __restrict_
 // in LDS with the zero padding applied there; per ky a thread pulls its 8+k-1 patch columns into registers
 // (LDS broadcast reads) and reuses them across kx, so the inner loop is pure FMA.  Same FMA order as the
 // simple kernel (tap-major, x then y channel; padded taps add exactly 0), so results are bit-identical to it.
-template <int K>
+template <int K, typename TO = float>
 __global__ __launch_bounds__(256) void conv_cin2_tiled_kernel(const float* __restrict__ in, int in_ld,
                                                               const float* __restrict__ wgt,
                                                               const float* __restrict__ bias,
-                                                              float* __restrict__ out, int out_ld,
+                                                              TO* __restrict__ out, int out_ld,
                                                               int out_coff, int H, int W, int tiles_per_row,
                                                               int cout, int relu) {
   constexpr int TP = 16, R = K / 2, PW = TP + 2 * R, NP = 8;
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void conv_cin2_tiled_kernel(const float* __res
       if (xs + p < W) {
         float v = acc[p];
         if (relu) v = (v < 0.f) ? 0.f : v;
-        out[(rowbase + (long long)y * W + xs + p) * out_ld + out_coff + c] = v;
+        out[(rowbase + (long long)y * W + xs + p) * out_ld + out_coff + c] = (TO)v;      // bf16 output: round to nearest even
       }
     }
   }
@@ -135,11 +135,21 @@ __device__ __forceinline__ void rs_step(float* s, int lane) {
 // j in the lanes whose upper bits spell j — and THOSE lanes apply coords1 += delta and flow = coords1 - coords0 for their
 // (pixel, component) in parallel: one global round trip per wave instead of PIX dependent ones on lane 0 (which was most of this
 // kernel's time: it is a latency chain, not a bandwidth problem).
-template <int PIX>
+__device__ __forceinline__ f32x4 load4_widen(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 load4_widen(const __bf16* p) {      // four bf16 (8 bytes) -> fp32, exact
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  const u32x2 w = *reinterpret_cast<const u32x2*>(p);
+  f32x4 v;
+  v.x = __builtin_bit_cast(float, w[0] << 16); v.y = __builtin_bit_cast(float, w[0] & 0xffff0000u);
+  v.z = __builtin_bit_cast(float, w[1] << 16); v.w = __builtin_bit_cast(float, w[1] & 0xffff0000u);
+  return v;
+}
+
+template <int PIX, typename TI = float>
 __global__ __launch_bounds__(256) void flow_delta_kernel(
-    const float* __restrict__ in, int in_ld, int cin, const float* __restrict__ wgt,
+    const TI* __restrict__ in, int in_ld, int cin, const float* __restrict__ wgt,
     const float* __restrict__ bias, const float* __restrict__ coords0, float* coords1,
-    float* delta_out, float* flow_out, int flow_ld, long long rows, int H, int W, int tpr) {
+    float* delta_out, float* flow_out, int flow_ld, __bf16* flow_b16, int flow_b16_ld, long long rows, int H, int W, int tpr) {
   static_assert(PIX == 4 || PIX == 8, "two reduce-scatter depths are written out below");
   const int lane = threadIdx.x & 63;
   // wave-uniform on purpose (readfirstlane): the row / column tests below must be scalar branches, not per-lane ones whose phi
@@ -165,13 +175,13 @@ __global__ __launch_bounds__(256) void flow_delta_kernel(
         wa[kx] = *reinterpret_cast<const f32x4*>(wgt + (long long)((ky * 3 + kx) * 2) * cin + c);
         wb[kx] = *reinterpret_cast<const f32x4*>(wgt + (long long)((ky * 3 + kx) * 2 + 1) * cin + c);
       }
-      const float* rowp = in + ((rowid + (yvalid ? ky - 1 : 0)) * W) * in_ld + c;
+      const TI* rowp = in + ((rowid + (yvalid ? ky - 1 : 0)) * W) * in_ld + c;
 #pragma unroll
       for (int xi = 0; xi < PIX + 2; ++xi) {
         const int xx = x0 - 1 + xi;
         const bool valid = yvalid && (unsigned)xx < (unsigned)W;          // wave-uniform
         const int xc = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
-        f32x4 v = *reinterpret_cast<const f32x4*>(rowp + (long long)xc * in_ld);
+        f32x4 v = load4_widen(rowp + (long long)xc * in_ld);
         if (!valid) v = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kx = 2; kx >= 0; --kx) {            // pixel q = xi - kx sees this row as its tap kx (ascending kx per pixel as xi grows)
@@ -205,7 +215,9 @@ __global__ __launch_bounds__(256) void flow_delta_kernel(
     const float c1 = __fadd_rn(coords1[ic], d);
     coords1[ic] = c1;
     if (delta_out) delta_out[ic] = d;
-    if (flow_out) flow_out[p * flow_ld + o] = __fsub_rn(c1, coords0[ic]);
+    const float fl = __fsub_rn(c1, coords0[ic]);
+    if (flow_out) flow_out[p * flow_ld + o] = fl;
+    if (flow_b16) flow_b16[p * flow_b16_ld + o] = (__bf16)fl;       // the bf16 copy the K8b convolutions read (hx's 16-bit twin)
   }
 }
 
@@ -508,9 +520,12 @@ const char* pfk_status_string(int status) {
   }
 }
 
-int pfk_conv_cin2_f32(const float* in, int in_ld, const float* weight, const float* bias,
-                      float* out, int out_ld, int out_coff, int B, int H, int W, int k, int cout,
-                      int relu, pfk_stream_t stream) {
+}  // extern "C"
+
+template <typename TO>
+static int conv_cin2_launch(const float* in, int in_ld, const float* weight, const float* bias,
+                            TO* out, int out_ld, int out_coff, int B, int H, int W, int k, int cout,
+                            int relu, pfk_stream_t stream) {
   if (!in || !weight || !out || B <= 0 || H <= 0 || W <= 0 || cout <= 0) return PFK_ERR_BAD_ARG;
   if (k <= 0 || !(k & 1) || in_ld < 2 || out_ld < out_coff + cout) return PFK_ERR_BAD_ARG;
   const long long M = (long long)B * H * W;
@@ -520,24 +535,50 @@ int pfk_conv_cin2_f32(const float* in, int in_ld, const float* weight, const flo
     const long long tiles = (long long)B * H * tpr;
     if (tiles > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
     dim3 grid((unsigned)tiles), block(256);
-    if (k == 7) hipLaunchKernelGGL(conv_cin2_tiled_kernel<7>, grid, block, 0, st, in, in_ld, weight, bias, out, out_ld, out_coff, H, W, tpr, cout, relu);
-    else if (k == 5) hipLaunchKernelGGL(conv_cin2_tiled_kernel<5>, grid, block, 0, st, in, in_ld, weight, bias, out, out_ld, out_coff, H, W, tpr, cout, relu);
-    else hipLaunchKernelGGL(conv_cin2_tiled_kernel<3>, grid, block, 0, st, in, in_ld, weight, bias, out, out_ld, out_coff, H, W, tpr, cout, relu);
+    if (k == 7) hipLaunchKernelGGL((conv_cin2_tiled_kernel<7, TO>), grid, block, 0, st, in, in_ld, weight, bias, out, out_ld, out_coff, H, W, tpr, cout, relu);
+    else if (k == 5) hipLaunchKernelGGL((conv_cin2_tiled_kernel<5, TO>), grid, block, 0, st, in, in_ld, weight, bias, out, out_ld, out_coff, H, W, tpr, cout, relu);
+    else hipLaunchKernelGGL((conv_cin2_tiled_kernel<3, TO>), grid, block, 0, st, in, in_ld, weight, bias, out, out_ld, out_coff, H, W, tpr, cout, relu);
     return pfk_launch_status();
   }
-  const long long blocks = (M * cout + 255) / 256;
-  if (blocks > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(conv_cin2_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, in_ld, weight, bias, out, out_ld,
-                     out_coff, M, H, W, k, cout, relu);
-  return pfk_launch_status();
+  if constexpr (sizeof(TO) == 4) {
+    const long long blocks = (M * cout + 255) / 256;
+    if (blocks > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(conv_cin2_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, in_ld, weight, bias, out, out_ld,
+                       out_coff, M, H, W, k, cout, relu);
+    return pfk_launch_status();
+  } else {
+    return PFK_ERR_UNSUPPORTED;      // 16-bit output: the tiled kernel's sizes only (k = 3, 5, 7)
+  }
 }
 
-int pfk_flow_delta_f32(const float* in, int in_ld, int cin, const float* weight,
-                       const float* bias, const float* coords0, float* coords1, float* delta_out,
-                       float* flow_out, int flow_ld, int B, int H, int W, pfk_stream_t stream) {
+template <typename TI>
+static int flow_delta_launch(const TI* in, int in_ld, int cin, const float* weight,
+                             const float* bias, const float* coords0, float* coords1, float* delta_out,
+                             float* flow_out, int flow_ld, __bf16* flow_b16, int flow_b16_ld, int B, int H, int W, pfk_stream_t stream);
+
+extern "C" {
+
+int pfk_conv_cin2_f32(const float* in, int in_ld, const float* weight, const float* bias,
+                      float* out, int out_ld, int out_coff, int B, int H, int W, int k, int cout,
+                      int relu, pfk_stream_t stream) {
+  return conv_cin2_launch<float>(in, in_ld, weight, bias, out, out_ld, out_coff, B, H, W, k, cout, relu, stream);
+}
+
+int pfk_conv_cin2_b16(const float* in, int in_ld, const float* weight, const float* bias,
+                      void* out_bf16, int out_ld, int out_coff, int B, int H, int W, int k, int cout,
+                      int relu, pfk_stream_t stream) {
+  return conv_cin2_launch<__bf16>(in, in_ld, weight, bias, static_cast<__bf16*>(out_bf16), out_ld, out_coff, B, H, W, k, cout, relu, stream);
+}
+
+}  // extern "C"
+
+template <typename TI>
+static int flow_delta_launch(const TI* in, int in_ld, int cin, const float* weight,
+                             const float* bias, const float* coords0, float* coords1, float* delta_out,
+                             float* flow_out, int flow_ld, __bf16* flow_b16, int flow_b16_ld, int B, int H, int W, pfk_stream_t stream) {
   if (!in || !weight || !coords0 || !coords1 || B <= 0 || H <= 0 || W <= 0) return PFK_ERR_BAD_ARG;
-  if (cin <= 0 || in_ld < cin || (flow_out && flow_ld < 2)) return PFK_ERR_BAD_ARG;
-  if (!pfk_aligned16(in) || !pfk_aligned16(weight) || (in_ld & 3) || (cin & 3))
+  if (cin <= 0 || in_ld < cin || (flow_out && flow_ld < 2) || (flow_b16 && flow_b16_ld < 2)) return PFK_ERR_BAD_ARG;
+  if ((reinterpret_cast<uintptr_t>(in) & (sizeof(TI) * 4 - 1)) || !pfk_aligned16(weight) || (in_ld & 3) || (cin & 3))
     return PFK_ERR_ALIGNMENT;
   // 8 pixels per wave (fewest row loads) once that still gives every SIMD a few waves; 4 per wave below (batch 1: 7040 pixels)
   const long long rows = (long long)B * H;
@@ -547,12 +588,27 @@ int pfk_flow_delta_f32(const float* in, int in_ld, int cin, const float* weight,
   if (blocks > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (pixw == 8)
-    hipLaunchKernelGGL(flow_delta_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, st, in, in_ld, cin, weight, bias, coords0,
-                       coords1, delta_out, flow_out, flow_ld, rows, H, W, tpr);
+    hipLaunchKernelGGL((flow_delta_kernel<8, TI>), dim3((unsigned)blocks), dim3(256), 0, st, in, in_ld, cin, weight, bias, coords0,
+                       coords1, delta_out, flow_out, flow_ld, flow_b16, flow_b16_ld, rows, H, W, tpr);
   else
-    hipLaunchKernelGGL(flow_delta_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, in, in_ld, cin, weight, bias, coords0,
-                       coords1, delta_out, flow_out, flow_ld, rows, H, W, tpr);
+    hipLaunchKernelGGL((flow_delta_kernel<4, TI>), dim3((unsigned)blocks), dim3(256), 0, st, in, in_ld, cin, weight, bias, coords0,
+                       coords1, delta_out, flow_out, flow_ld, flow_b16, flow_b16_ld, rows, H, W, tpr);
   return pfk_launch_status();
+}
+
+extern "C" {
+
+int pfk_flow_delta_f32(const float* in, int in_ld, int cin, const float* weight,
+                       const float* bias, const float* coords0, float* coords1, float* delta_out,
+                       float* flow_out, int flow_ld, int B, int H, int W, pfk_stream_t stream) {
+  return flow_delta_launch<float>(in, in_ld, cin, weight, bias, coords0, coords1, delta_out, flow_out, flow_ld, nullptr, 0, B, H, W, stream);
+}
+
+int pfk_flow_delta_b16(const void* in_bf16, int in_ld, int cin, const float* weight,
+                       const float* bias, const float* coords0, float* coords1, float* delta_out,
+                       float* flow_out, int flow_ld, void* flow_out_b16, int flow_b16_ld, int B, int H, int W, pfk_stream_t stream) {
+  return flow_delta_launch<__bf16>(static_cast<const __bf16*>(in_bf16), in_ld, cin, weight, bias, coords0, coords1, delta_out, flow_out,
+                                   flow_ld, static_cast<__bf16*>(flow_out_b16), flow_b16_ld, B, H, W, stream);
 }
 
 int pfk_flow_from_coords_f32(const float* coords0, const float* coords1, float* flow_out,

@@ -60,6 +60,21 @@ void check_pm(const Tensor& t, const char* name) {
 
 float* fptr(const Tensor& t) { return t.data_ptr<float>(); }
 
+// [pixels, channels] view of fp32 or bf16 elements; returns true for bf16
+bool check_pm_any(const Tensor& t, const char* name) {
+  check_dev(t, name);
+  TORCH_CHECK(t.scalar_type() == at::kFloat || t.scalar_type() == at::kBFloat16, name, " must be float32 or bfloat16");
+  TORCH_CHECK(t.dim() == 2 && (t.size(1) == 1 || t.stride(1) == 1), name, " must be a [pixels, channels] view with contiguous channels");
+  return t.scalar_type() == at::kBFloat16;
+}
+
+void check_pm_b16(const Tensor& t, const char* name) {
+  check_dev(t, name);
+  TORCH_CHECK(t.scalar_type() == at::kBFloat16, name, " must be bfloat16");
+  TORCH_CHECK(t.dim() == 2 && (t.size(1) == 1 || t.stride(1) == 1), name, " must be a [pixels, channels] view with contiguous channels");
+}
+
+
 // out[b,i,j] = scale * <f1[b,i,:], f2[b,j,:]>
 void corr_volume(const Tensor& f1, const Tensor& f2, double scale, Tensor out) {
   OpScope scope(f1);
@@ -111,7 +126,8 @@ void fmap_pool2x2(const Tensor& in, Tensor out, int64_t B, int64_t H, int64_t W)
 
 void corr_lookup(at::TensorList levels, const Tensor& coords, int64_t radius, Tensor out) {
   OpScope scope(coords);
-  check_dev_f32(coords, "coords"); check_pm(out, "out");
+  check_dev_f32(coords, "coords");
+  const bool out_b16 = check_pm_any(out, "out");
   TORCH_CHECK(coords.dim() == 4 && coords.size(1) == 2 && coords.is_contiguous(), "corr_lookup: coords [B,2,h,w] contiguous");
   TORCH_CHECK(levels.size() >= 1 && levels.size() <= PFK_MAX_LEVELS, "corr_lookup: 1..8 levels");
   pfk_lookup_desc d{};
@@ -126,7 +142,7 @@ void corr_lookup(at::TensorList levels, const Tensor& coords, int64_t radius, Te
     d.levels[l] = v.data_ptr(); d.lvl_h[l] = v.size(1); d.lvl_w[l] = v.size(2);
   }
   d.num_levels = levels.size(); d.radius = radius;
-  d.coords = fptr(coords); d.out = fptr(out); d.out_ld = out.stride(0);
+  d.coords = fptr(coords); d.out = out.data_ptr(); d.out_ld = out.stride(0); d.out_bf16 = out_b16;
   TORCH_CHECK(out.size(0) == M, "corr_lookup: out rows");
   const int n = 2 * radius + 1;
   TORCH_CHECK(out.size(1) >= d.num_levels * n * n, "corr_lookup: out channels");
@@ -193,23 +209,85 @@ void conv2d(at::TensorList srcs, int64_t B, int64_t H, int64_t W, int64_t kh, in
   else check_ok(pfk_conv2d_f32(&d, cur_stream()), "conv2d");
 }
 
+// K8b: bf16 sources / weight (pfk_conv2d_b16); `out` may be bf16 or fp32, h / aux_z / residual fp32, aux_rh / h_b16 bf16
+void conv2d_b16(at::TensorList srcs, int64_t B, int64_t H, int64_t W, int64_t kh, int64_t kw, const Tensor& weight,
+                const c10::optional<Tensor>& bias, int64_t cout, int64_t epilogue, bool relu, double scale,
+                const c10::optional<Tensor>& out, const c10::optional<Tensor>& h, const c10::optional<Tensor>& h_b16,
+                const c10::optional<Tensor>& aux_z, const c10::optional<Tensor>& aux_rh, const c10::optional<Tensor>& residual,
+                int64_t stride, bool relu_after_residual) {
+  OpScope scope(weight);
+  TORCH_CHECK(srcs.size() >= 1 && srcs.size() <= 3, "conv2d_b16: 1..3 sources");
+  TORCH_CHECK(stride >= 1, "conv2d_b16: stride");
+  pfk_conv_b16_desc d{};
+  d.stride = (int)stride;
+  d.relu_after_residual = relu_after_residual;
+  const int64_t M = B * ((H - 1) / stride + 1) * ((W - 1) / stride + 1);
+  for (size_t i = 0; i < srcs.size(); ++i) {
+    check_pm_b16(srcs[i], "src");
+    TORCH_CHECK(srcs[i].size(0) == B * H * W, "conv2d_b16: src rows != B*H*W");
+    d.src[i].ptr = srcs[i].data_ptr(); d.src[i].ld = srcs[i].stride(0); d.src[i].channels = srcs[i].size(1);
+  }
+  d.num_src = srcs.size();
+  d.B = B; d.H = H; d.W = W; d.kh = kh; d.kw = kw; d.cout = cout;
+  d.epilogue = epilogue; d.relu = relu; d.scale = (float)scale;
+  check_dev(weight, "weight");
+  TORCH_CHECK(weight.scalar_type() == at::kBFloat16 && weight.is_contiguous() && weight.dim() == 2 && weight.size(0) == cout,
+              "conv2d_b16: bf16 packed weight [cout, ktot]");
+  TORCH_CHECK(weight.size(1) == pfk_conv_ktot_b16(&d), "conv2d_b16: packed weight has ktot ", weight.size(1), ", expected ",
+              pfk_conv_ktot_b16(&d));
+  d.weight = weight.data_ptr();
+  if (bias.has_value()) { check_dev_f32(*bias, "bias"); TORCH_CHECK(bias->numel() == cout && bias->is_contiguous()); d.bias = fptr(*bias); }
+  if (out.has_value()) {
+    check_dev(*out, "out");
+    TORCH_CHECK(out->dim() == 2 && (out->size(1) == 1 || out->stride(1) == 1) && out->size(0) == M && out->size(1) == cout,
+                "conv2d_b16: out must be a [M, cout] view");
+    TORCH_CHECK(out->scalar_type() == at::kBFloat16 || out->scalar_type() == at::kFloat, "conv2d_b16: out must be bfloat16 or float32");
+    d.out = out->data_ptr(); d.out_ld = out->stride(0); d.out_coff = 0; d.out_bf16 = out->scalar_type() == at::kBFloat16;
+  }
+  if (h.has_value()) { check_pm(*h, "h"); TORCH_CHECK(h->size(0) == M); d.h = fptr(*h); d.h_ld = h->stride(0); }
+  if (h_b16.has_value()) { check_pm_b16(*h_b16, "h_b16"); TORCH_CHECK(h_b16->size(0) == M); d.h_b16 = h_b16->data_ptr(); d.h_b16_ld = h_b16->stride(0); }
+  if (aux_z.has_value()) {
+    check_dev(*aux_z, "aux_z");
+    TORCH_CHECK(aux_z->scalar_type() == at::kBFloat16 && aux_z->is_contiguous(), "conv2d_b16: aux_z must be contiguous bfloat16");
+    d.aux_z = aux_z->data_ptr();
+  }
+  if (aux_rh.has_value()) {
+    check_dev(*aux_rh, "aux_rh");
+    TORCH_CHECK(aux_rh->scalar_type() == at::kBFloat16 && aux_rh->is_contiguous(), "conv2d_b16: aux_rh must be contiguous bfloat16");
+    d.aux_rh = aux_rh->data_ptr();
+  }
+  if (residual.has_value()) {
+    if (epilogue == PFK_EPI_LINEAR) check_pm(*residual, "residual"); else check_pm_b16(*residual, "residual");
+    TORCH_CHECK(residual->size(0) == M && residual->size(1) == cout, "conv2d_b16: residual must be a [M, cout] view");
+    d.residual = residual->data_ptr(); d.residual_ld = residual->stride(0);
+  }
+  check_ok(pfk_conv2d_b16(&d, cur_stream()), "conv2d_b16");
+}
+
+void debug_set_b16(int64_t cfg) { check_ok(pfk_debug_set_b16((int)cfg), "debug_set_b16"); }
+
 void conv_cin2(const Tensor& in, const Tensor& weight, const c10::optional<Tensor>& bias, Tensor out,
                int64_t B, int64_t H, int64_t W, int64_t k, bool relu) {
   OpScope scope(in);
-  check_pm(in, "in"); check_pm(out, "out"); check_dev_f32(weight, "weight");
+  check_pm(in, "in"); check_dev_f32(weight, "weight");
+  const bool out_b16 = check_pm_any(out, "out");
   const int cout = out.size(1);
   TORCH_CHECK(weight.is_contiguous() && weight.numel() == k * k * 2 * cout, "conv_cin2: weight [k*k,2,cout]");
   TORCH_CHECK(in.size(0) == B * H * W && out.size(0) == B * H * W && in.size(1) >= 2);
   const float* bp = nullptr;
   if (bias.has_value()) { check_dev_f32(*bias, "bias"); bp = fptr(*bias); }
-  check_ok(pfk_conv_cin2_f32(fptr(in), in.stride(0), fptr(weight), bp, fptr(out), out.stride(0), 0, B, H, W, k,
-                             cout, relu, cur_stream()), "conv_cin2");
+  if (out_b16) check_ok(pfk_conv_cin2_b16(fptr(in), in.stride(0), fptr(weight), bp, out.data_ptr(), out.stride(0), 0, B, H, W, k,
+                                          cout, relu, cur_stream()), "conv_cin2 (bf16 out)");
+  else check_ok(pfk_conv_cin2_f32(fptr(in), in.stride(0), fptr(weight), bp, fptr(out), out.stride(0), 0, B, H, W, k,
+                                  cout, relu, cur_stream()), "conv_cin2");
 }
 
 void flow_delta(const Tensor& in, const Tensor& weight, const c10::optional<Tensor>& bias, const Tensor& coords0,
-                Tensor coords1, const c10::optional<Tensor>& delta_out, const c10::optional<Tensor>& flow_out) {
+                Tensor coords1, const c10::optional<Tensor>& delta_out, const c10::optional<Tensor>& flow_out,
+                const c10::optional<Tensor>& flow_out_b16) {
   OpScope scope(in);
-  check_pm(in, "in"); check_dev_f32(weight, "weight"); check_dev_f32(coords0, "coords0"); check_dev_f32(coords1, "coords1");
+  const bool in_b16 = check_pm_any(in, "in");
+  check_dev_f32(weight, "weight"); check_dev_f32(coords0, "coords0"); check_dev_f32(coords1, "coords1");
   TORCH_CHECK(coords0.dim() == 4 && coords0.size(1) == 2 && coords0.is_contiguous() && coords1.is_contiguous() &&
               coords1.sizes() == coords0.sizes(), "flow_delta: coords [B,2,h,w] contiguous");
   const int B = coords0.size(0), H = coords0.size(2), W = coords0.size(3), cin = in.size(1);
@@ -218,6 +296,14 @@ void flow_delta(const Tensor& in, const Tensor& weight, const c10::optional<Tens
   if (bias.has_value()) { check_dev_f32(*bias, "bias"); bp = fptr(*bias); }
   if (delta_out.has_value()) { check_dev_f32(*delta_out, "delta"); TORCH_CHECK(delta_out->is_contiguous() && delta_out->sizes() == coords0.sizes()); dp = fptr(*delta_out); }
   if (flow_out.has_value()) { check_pm(*flow_out, "flow_out"); TORCH_CHECK(flow_out->size(1) >= 2); fp = fptr(*flow_out); fld = flow_out->stride(0); }
+  if (in_b16) {
+    void* fb = nullptr; int fbld = 0;
+    if (flow_out_b16.has_value()) { check_pm_b16(*flow_out_b16, "flow_out_b16"); TORCH_CHECK(flow_out_b16->size(1) >= 2); fb = flow_out_b16->data_ptr(); fbld = flow_out_b16->stride(0); }
+    check_ok(pfk_flow_delta_b16(in.data_ptr(), in.stride(0), cin, fptr(weight), bp, fptr(coords0), fptr(coords1), dp, fp, fld, fb, fbld,
+                                B, H, W, cur_stream()), "flow_delta (bf16 in)");
+    return;
+  }
+  TORCH_CHECK(!flow_out_b16.has_value(), "flow_delta: flow_out_b16 goes with a bfloat16 input");
   check_ok(pfk_flow_delta_f32(fptr(in), in.stride(0), cin, fptr(weight), bp, fptr(coords0), fptr(coords1), dp, fp,
                               fld, B, H, W, cur_stream()), "flow_delta");
 }
@@ -364,7 +450,8 @@ void corr_pool2x2_blocked(const Tensor& in, Tensor out, int64_t H, int64_t W) {
 
 void corr_lookup_blocked(at::TensorList levels, at::IntArrayRef lvl_h, at::IntArrayRef lvl_w, const Tensor& coords, int64_t radius, Tensor out) {
   OpScope scope(coords);
-  check_dev_f32(coords, "coords"); check_pm(out, "out");
+  check_dev_f32(coords, "coords");
+  const bool out_b16 = check_pm_any(out, "out");
   TORCH_CHECK(coords.dim() == 4 && coords.size(1) == 2 && coords.is_contiguous(), "corr_lookup_blocked: coords [B,2,h,w] contiguous");
   TORCH_CHECK(levels.size() >= 1 && levels.size() <= PFK_MAX_LEVELS && lvl_h.size() == levels.size() && lvl_w.size() == levels.size(),
               "corr_lookup_blocked: 1..8 levels with their map sizes");
@@ -382,7 +469,7 @@ void corr_lookup_blocked(at::TensorList levels, at::IntArrayRef lvl_h, at::IntAr
     d.levels[l] = v.data_ptr(); d.lvl_h[l] = (int)lvl_h[l]; d.lvl_w[l] = (int)lvl_w[l];
   }
   d.num_levels = levels.size(); d.radius = radius;
-  d.coords = fptr(coords); d.out = fptr(out); d.out_ld = out.stride(0);
+  d.coords = fptr(coords); d.out = out.data_ptr(); d.out_ld = out.stride(0); d.out_bf16 = out_b16;
   TORCH_CHECK(out.size(0) == M, "corr_lookup_blocked: out rows");
   const int n = 2 * radius + 1;
   TORCH_CHECK(out.size(1) >= d.num_levels * n * n, "corr_lookup_blocked: out channels");
@@ -724,11 +811,15 @@ TORCH_LIBRARY(pfk, m) {
   m.def("conv2d(Tensor[] srcs, int B, int H, int W, int kh, int kw, Tensor weight, Tensor? bias, int cout, "
         "int epilogue, bool relu, float scale, Tensor(a!)? out, Tensor(b!)? h, Tensor(c!)? aux_z, Tensor(d!)? aux_rh, "
         "Tensor(e!)? workspace=None, Tensor? residual=None, int stride=1, bool relu_after_residual=False, int cout_active=0, int cout_split=0) -> ()");
+  m.def("conv2d_b16(Tensor[] srcs, int B, int H, int W, int kh, int kw, Tensor weight, Tensor? bias, int cout, int epilogue, bool relu, "
+        "float scale, Tensor(a!)? out, Tensor(b!)? h=None, Tensor(c!)? h_b16=None, Tensor(d!)? aux_z=None, Tensor(e!)? aux_rh=None, "
+        "Tensor? residual=None, int stride=1, bool relu_after_residual=False) -> ()");
+  m.def("debug_set_b16(int cfg) -> ()", &debug_set_b16);
   m.def("conv_workspace_bytes() -> int", &conv_workspace_bytes);
   m.def("conv_workspace_fault_offset() -> int", &conv_workspace_fault_offset);
   m.def("conv_cin2(Tensor inp, Tensor weight, Tensor? bias, Tensor(a!) out, int B, int H, int W, int k, bool relu) -> ()");
   m.def("flow_delta(Tensor inp, Tensor weight, Tensor? bias, Tensor coords0, Tensor(a!) coords1, Tensor(b!)? delta_out, "
-        "Tensor(c!)? flow_out) -> ()");
+        "Tensor(c!)? flow_out, Tensor(d!)? flow_out_b16=None) -> ()");
   m.def("flow_from_coords(Tensor coords0, Tensor coords1, Tensor(a!) flow_out) -> ()");
   m.def("convex_upsample(Tensor flow, Tensor mask, Tensor(a!) out) -> ()");
   m.def("convex_upsample_pm(Tensor flow_pm, Tensor mask, Tensor(a!) out) -> ()");
@@ -754,6 +845,7 @@ TORCH_LIBRARY_IMPL(pfk, CUDA, m) {
   m.impl("corr_pool2x2_blocked", &corr_pool2x2_blocked);
   m.impl("corr_lookup_blocked", &corr_lookup_blocked);
   m.impl("conv2d", &conv2d);
+  m.impl("conv2d_b16", &conv2d_b16);
   m.impl("conv_cin2", &conv_cin2);
   m.impl("flow_delta", &flow_delta);
   m.impl("flow_from_coords", &flow_from_coords);

@@ -378,6 +378,7 @@ class RAFT(nn.Module):
         eng.load_state(net, inp)
         self._after_context(eng, inp)
         ops.flow_from_coords(coords0, coords1, eng.flow_view)
+        eng.flow_changed()
         if st is not None:
             st["graph"].replay()
         else:
@@ -439,7 +440,7 @@ class RAFT(nn.Module):
             if eng.profile is not None:     # bench.py's instrumented forward: HIP events around the lookup too (the HBM-bound kernel)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                corr_pm = corr_fn.lookup_pm(coords1)
+                corr_pm = corr_fn.lookup_pm(coords1, out=eng.lookup_out)
                 e1.record()
                 eng.profile.setdefault("lookup", []).append((e0, e1))
                 n = 2 * self.corr_radius + 1
@@ -447,7 +448,7 @@ class RAFT(nn.Module):
                 # N L [(2r+2)^2 + (2r+1)^2] 4 + 8 N bytes per pair and lookup
                 eng.bytes["lookup"] = float(pixels * (self.corr_levels * ((n + 1) ** 2 + n * n) * 4 + 8))
             else:
-                corr_pm = corr_fn.lookup_pm(coords1)
+                corr_pm = corr_fn.lookup_pm(coords1, out=eng.lookup_out)      # K8b engines take the lookup in bf16, written directly
             do_up = last or self.upsample_every_iter
             if side is None or not do_up:
                 if fuse and do_up:
@@ -496,7 +497,7 @@ class RAFT(nn.Module):
             with torch.cuda.stream(s_flow):
                 eng.motion_flow(branch=True)
                 flow_done = s_flow.record_event()
-            corr_pm = corr_fn.lookup_pm(coords1)
+            corr_pm = corr_fn.lookup_pm(coords1, out=eng.lookup_out)
             eng.motion_corr(corr_pm)
             main.wait_event(flow_done)                                # join: `conv` reads both halves of corflo
             eng.motion_join()

@@ -126,6 +126,12 @@ class UpdateEngine:
             raise ValueError(f"conv_precision must be one of {sorted(CONV_PRECISIONS)}, got {conv_precision!r}")
         self.conv_precision = conv_precision
         self.nsplit = CONV_PRECISIONS[conv_precision]
+        # "bf16" = BASELINE config 3's precision as the reference's reduced-precision switch gives it (model_benchmark.py:317-319 /
+        # torch.autocast: every convolution reads and writes 16-bit tensors): K8b, `pfk_conv2d_b16` — bf16 ACTIVATION STORAGE between
+        # this engine's own kernels (producer epilogues emit bf16 once), both GEMM operands by LDS-DMA; the recurrent state h, the
+        # coordinates / flow and every accumulator stay fp32.  Blocks with an aggregate branch (GMA: fp32 attention map as a GEMM
+        # operand; CCMR: the caller's torch module reads the motion features) keep the split kernel with one plane (fp32 storage).
+        self.b16 = conv_precision == "bf16" and not spec.aggregate
         self.ops = torch.ops.pfk
         self.spec = spec
         self.device = device
@@ -146,10 +152,12 @@ class UpdateEngine:
             return P[name].detach().to(device=dev, dtype=torch.float32)
 
         def seg1(c):
-            return [(0, c, round_up(c, 4))]
+            return [(0, c, round_up(c, 8 if self.b16 else 4))]
 
         def pk(weight, segments):
             # the weight tensor's dtype selects the kernel in torch.ops.pfk.conv2d: fp32 [cout, ktot] or bf16 planes
+            if self.b16:      # K8b: one bf16 matrix [cout, ktot], 64-channel K chunks
+                return pack_conv_weight(weight, segments, kpad=64).to(torch.bfloat16).contiguous()
             if self.nsplit == 0:
                 return pack_conv_weight(weight, segments)
             return split_bf16_planes(pack_conv_weight(weight, segments), self.nsplit)
@@ -177,7 +185,7 @@ class UpdateEngine:
         w["cv.w"] = pk(g("encoder.conv.weight"), seg1(cf))
         w["cv.b"] = g("encoder.conv.bias").contiguous()
         Ch = s.hidden
-        hxc = s.hx_channels
+        hxc = round_up(s.hidden + s.x_channels, 8) if self.b16 else s.hx_channels      # (the bf16 twin of hx has 16-byte rows)
         real = Ch + s.x_channels
         for kh, kw, sfx in s.gru_passes:
             wz, wr, wq = (g(f"gru.conv{k}{sfx}.weight") for k in "zrq")
@@ -233,17 +241,23 @@ class UpdateEngine:
         s, dev = self.spec, self.device
         M = B * H * W
         z = lambda c: torch.zeros(M, c, device=dev, dtype=torch.float32)  # noqa: E731
+        # activations between this engine's kernels: fp32, or bf16 on the K8b path
+        a = (lambda c: torch.zeros(M, c, device=dev, dtype=torch.bfloat16)) if self.b16 else z  # noqa: E731
         self.hx = z(s.hx_channels)
-        self.cor1 = z(s.c1) if s.c2 else None   # SmallMotionEncoder: convc1 writes corflo[:, :c1] directly
-        self.corflo = z((s.c2 if s.c2 else s.c1) + s.f2)
-        self.flo1 = z(s.f1)
-        self.zbuf = z(s.hidden)
-        self.rh = z(s.hidden)
+        # K8b: the 16-bit twin of hx the convolutions read — same channel layout; h is mirrored by the q epilogue, the motion
+        # features are written here only, the flow by the flow-head kernel (both widths)
+        self.hxb = a(round_up(s.hidden + s.x_channels, 8)) if self.b16 else None
+        self.corr16 = a(round_up(s.corr_channels, 8)) if self.b16 else None      # the lookup's output (pad columns stay zero)
+        self.cor1 = a(s.c1) if s.c2 else None   # SmallMotionEncoder: convc1 writes corflo[:, :c1] directly
+        self.corflo = a((s.c2 if s.c2 else s.c1) + s.f2)
+        self.flo1 = a(s.f1)
+        self.zbuf = a(s.hidden)
+        self.rh = a(s.hidden)
         # loop-invariant gate pre-activations (prepare_context): per GRU pass [M, 2 Ch] for z|r and [M, Ch] for q
-        self.ctx = {("zr" + sfx): z(2 * s.hidden) for _, _, sfx in s.gru_passes} if self.hoist_context else {}
+        self.ctx = {("zr" + sfx): a(2 * s.hidden) for _, _, sfx in s.gru_passes} if self.hoist_context else {}
         if self.hoist_context:
-            self.ctx.update({("q" + sfx): z(s.hidden) for _, _, sfx in s.gru_passes})
-        self.fm = z(s.fh_hidden * (2 if s.has_mask else 1))
+            self.ctx.update({("q" + sfx): a(s.hidden) for _, _, sfx in s.gru_passes})
+        self.fm = a(s.fh_hidden * (2 if s.has_mask else 1))
         self.mask = z(s.mask_channels) if s.has_mask else None
         self._scratch_c0 = torch.zeros(B, 2, H, W, device=dev, dtype=torch.float32)
         self._scratch_c1 = torch.zeros(B, 2, H, W, device=dev, dtype=torch.float32)
@@ -294,6 +308,29 @@ class UpdateEngine:
             self._fault_event.record()
 
     # views into hx
+    @property
+    def act(self):
+        """the buffer the convolutions read their [h | inp | motion | flow] operand from: hx, or its bf16 twin (K8b)"""
+        return self.hxb if self.b16 else self.hx
+
+    @property
+    def lookup_out(self):
+        """where the caller's lookup should write for this engine (None: the correlation block's own fp32 buffer)"""
+        return self.corr16 if self.b16 else None
+
+    def flow_changed(self) -> None:
+        """the flow slice of hx was written by something other than `flow_delta` (loop prologue, the drop-in seam): mirror it"""
+        if self.b16:
+            s = self.spec
+            o = s.hidden + s.context + s.enc_out
+            self.hxb[:, o: o + 2].copy_(self.hx[:, o: o + 2])
+
+    def state_changed(self) -> None:
+        """h / inp slices of hx were (re)loaded: mirror them into the bf16 twin"""
+        if self.b16:
+            n = self.spec.hidden + self.spec.context
+            self.hxb[:, :n].copy_(self.hx[:, :n])
+
     @property
     def h_view(self):
         return self.hx[:, : self.spec.hidden]
@@ -362,6 +399,7 @@ class UpdateEngine:
                 self.ops.nchw_to_pm(src, dst)
             else:                         # channels-last producer (the native encoders): rows are already pixel-major
                 dst.view(B, H, W, dst.shape[1]).copy_(src.permute(0, 2, 3, 1))
+        self.state_changed()
         self.prepare_context()
 
     def prepare_context(self) -> None:
@@ -369,10 +407,11 @@ class UpdateEngine:
         (class docstring) into `self.ctx` — what the per-iteration launches add to their pre-activations."""
         if not self.hoist_context:
             return
-        Ch = self.spec.hidden
+        Ch, Ci = self.spec.hidden, self.spec.context
+        inp = self.act[:, Ch: Ch + Ci]
         for kh, kw, sfx in self.spec.gru_passes:
-            self._conv([self.inp_view], kh, kw, "zrc" + sfx, 2 * Ch, relu=False, out=self.ctx["zr" + sfx])
-            self._conv([self.inp_view], kh, kw, "qc" + sfx, Ch, relu=False, out=self.ctx["q" + sfx])
+            self._conv([inp], kh, kw, "zrc" + sfx, 2 * Ch, relu=False, out=self.ctx["zr" + sfx])
+            self._conv([inp], kh, kw, "qc" + sfx, Ch, relu=False, out=self.ctx["q" + sfx])
 
     # ------------------------------------------------------------------ one iteration
     def _conv(self, srcs: List[torch.Tensor], kh, kw, key, cout, relu=True, scale=1.0, out=None,
@@ -385,8 +424,14 @@ class UpdateEngine:
         # a stream-K workspace belongs to ONE stream: `workspace` = True (the main chain's), a branch's own tensor, or False
         # (none: plain tile grid)
         ws = self.workspace if workspace is True else (workspace if isinstance(workspace, torch.Tensor) else None)
-        self.ops.conv2d(srcs, B, H, W, kh, kw, self.w[key + ".w"], self.w.get(key + ".b"), cout, epi, relu, scale,
-                        out, h, z, rh, ws, residual, 1, False, cout_active, cout_split)
+        if self.b16:
+            # K8b: z|r reads h from the bf16 twin (r * h is rounded to bf16 anyway), q updates the fp32 h and mirrors it
+            hb = self.hxb[:, : self.spec.hidden] if epi != EPI_LINEAR else None
+            self.ops.conv2d_b16(srcs, B, H, W, kh, kw, self.w[key + ".w"], self.w.get(key + ".b"), cout, epi, relu, scale,
+                                out, h if epi == EPI_GRU_Q else None, hb, z, rh, residual)
+        else:
+            self.ops.conv2d(srcs, B, H, W, kh, kw, self.w[key + ".w"], self.w.get(key + ".b"), cout, epi, relu, scale,
+                            out, h, z, rh, ws, residual, 1, False, cout_active, cout_split)
         if prof is not None:
             e1.record()
             if cout_active:
@@ -396,7 +441,7 @@ class UpdateEngine:
             # algorithmic work: 2 * pixels * cout * taps * real input channels (padding is not work)
             self.flops[key] = 2.0 * B * H * W * cout * kh * kw * self._real_cin[key]
             # algorithmic HBM bytes: every input channel read once, every output written once, the weight once (fp32)
-            self.bytes[key] = 4.0 * (B * H * W * (self._real_cin[key] + cout) + cout * kh * kw * self._real_cin[key])
+            self.bytes[key] = (2.0 if self.b16 else 4.0) * (B * H * W * (self._real_cin[key] + cout) + cout * kh * kw * self._real_cin[key])
 
     def motion(self, corr_pm: torch.Tensor) -> None:
         """BasicMotionEncoder / SmallMotionEncoder (update.py:104-112 / :85-91) into its hx slice; `flow` must already be in hx."""
@@ -427,7 +472,7 @@ class UpdateEngine:
         """conv over cat([cor, flo]) into the motion slice of hx (update.py:110-112 / :89-91)"""
         s = self.spec
         o = s.hidden + s.context
-        self._conv([self.corflo], 3, 3, "cv", s.enc_out, out=self.hx[:, o: o + s.enc_out])
+        self._conv([self.corflo], 3, 3, "cv", s.enc_out, out=self.act[:, o: o + s.enc_out])
 
     @property
     def motion_view(self):
@@ -447,17 +492,18 @@ class UpdateEngine:
         """SepConvGRU / ConvGRU passes (update.py:58-73 / :24-32) over hx = [h | x], h updated in place."""
         s = self.spec
         Ch = s.hidden
+        act = self.act
         if self.hoist_context:
-            rest = self.hx[:, Ch + s.context:]          # x without the context slice: motion features [| aggregated ones] | pad
+            rest = act[:, Ch + s.context:]          # x without the context slice: motion features [| aggregated ones] | pad
             for kh, kw, sfx in s.gru_passes:
-                self._conv([self.h_view, rest], kh, kw, "zr" + sfx, 2 * Ch, epi=EPI_GRU_ZR, h=self.h_view, z=self.zbuf, rh=self.rh,
+                self._conv([act[:, :Ch], rest], kh, kw, "zr" + sfx, 2 * Ch, epi=EPI_GRU_ZR, h=self.h_view, z=self.zbuf, rh=self.rh,
                            residual=self.ctx["zr" + sfx])
                 self._conv([self.rh, rest], kh, kw, "q" + sfx, Ch, epi=EPI_GRU_Q, h=self.h_view, z=self.zbuf,
                            residual=self.ctx["q" + sfx])
             return
         for kh, kw, sfx in s.gru_passes:
-            self._conv([self.hx], kh, kw, "zr" + sfx, 2 * Ch, epi=EPI_GRU_ZR, h=self.h_view, z=self.zbuf, rh=self.rh)
-            self._conv([self.rh, self.x_view], kh, kw, "q" + sfx, Ch, epi=EPI_GRU_Q, h=self.h_view, z=self.zbuf)
+            self._conv([act], kh, kw, "zr" + sfx, 2 * Ch, epi=EPI_GRU_ZR, h=self.h_view, z=self.zbuf, rh=self.rh)
+            self._conv([self.rh, act[:, Ch:]], kh, kw, "q" + sfx, Ch, epi=EPI_GRU_Q, h=self.h_view, z=self.zbuf)
 
     def motion_and_gru(self, corr_pm: torch.Tensor) -> None:
         """update.py:104-112 (encoder) + :58-73 / :24-32 (GRU); `flow` must already be in hx."""
@@ -491,16 +537,21 @@ class UpdateEngine:
             # launch, so that they share their split points (same bits) and the half launch still balances its blocks
             self._conv([self.h_view], 3, 3, "fm", 2 * s.fh_hidden, out=self.fm, cout_active=0 if want_mask else s.fh_hidden,
                        cout_split=s.fh_hidden)
-        elif s.has_mask and not want_mask and self._shape[0] * self._shape[1] * self._shape[2] >= 28160:
-            # split-bf16 kernels (no `cout_active`): the flow-head-only weights, where no launch is in the stream-K window
-            self._conv([self.h_view], 3, 3, "fh", s.fh_hidden, out=self.fm[:, : s.fh_hidden])
+        elif s.has_mask and not want_mask and (self.b16 or self._shape[0] * self._shape[1] * self._shape[2] >= 28160):
+            # split-bf16 / K8b kernels (no `cout_active`): the flow-head-only weights, where no launch is in the stream-K window
+            self._conv([self.act[:, : s.hidden]], 3, 3, "fh", s.fh_hidden, out=self.fm[:, : s.fh_hidden])
         else:
-            self._conv([self.h_view], 3, 3, "fm", s.fh_hidden * (2 if s.has_mask else 1), out=self.fm)
+            self._conv([self.act[:, : s.hidden]], 3, 3, "fm", s.fh_hidden * (2 if s.has_mask else 1), out=self.fm)
 
     def flow_delta(self, coords0: torch.Tensor, coords1: torch.Tensor, delta_out: Optional[torch.Tensor] = None,
                    write_flow: bool = True) -> None:
         """flow-head conv2 + `coords1 += delta`, `flow = coords1 - coords0` (update.py:14, raft.py:174,178) on the flow half of fm"""
         s = self.spec
+        if self.b16:      # bf16 hidden activation in; the flow goes to hx (fp32: 7x7 convolution, upsampling) and to its bf16 twin
+            o = s.hidden + s.context + s.enc_out
+            self.ops.flow_delta(self.fm[:, : s.fh_hidden], self.w["fh2.w"], self.w["fh2.b"], coords0, coords1, delta_out,
+                                self.flow_view if write_flow else None, self.hxb[:, o: o + 2] if write_flow else None)
+            return
         self.ops.flow_delta(self.fm[:, : s.fh_hidden], self.w["fh2.w"], self.w["fh2.b"], coords0, coords1, delta_out,
                             self.flow_view if write_flow else None)
 
@@ -633,6 +684,7 @@ class PfkUpdateBlock(torch.nn.Module):
         if new_forward:
             eng.watch_faults()
             ops.nchw_to_pm(net.float().contiguous(), eng.h_view)
+            eng.state_changed()
             if self._skip is not None:
                 self._skip.begin_forward()
         # §8 f2: on the non-final iterations of an eval forward nobody reads the mask (patch._DeadWorkSkip)
@@ -640,6 +692,7 @@ class PfkUpdateBlock(torch.nn.Module):
         if new_forward or inp is not self._inp_ref or inp._version != self._inp_version:
             ops.nchw_to_pm(inp.float().contiguous(), eng.inp_view)
             self._inp_ref, self._inp_version = inp, inp._version
+            eng.state_changed()
             eng.prepare_context()      # the loop-invariant part of the GRU pre-activations, once per (forward, scale)
         # corr: a channels-last view of a [M, C] buffer (what ptlflow_amd.CorrBlock returns) is used as is
         cpm = corr.permute(0, 2, 3, 1)
@@ -653,6 +706,10 @@ class PfkUpdateBlock(torch.nn.Module):
             corr_pm = torch.zeros(B * H * W, round_up(C, 4), device=net.device, dtype=torch.float32)
             ops.nchw_to_pm(corr.float().contiguous(), corr_pm[:, :C])
         ops.nchw_to_pm(flow.float().contiguous(), eng.flow_view)
+        eng.flow_changed()
+        if eng.b16:      # K8b reads a bf16 lookup result (a CorrBlock that writes it directly is the mirror's path, ptlflow_amd/raft.py)
+            eng.corr16[:, :C].copy_(corr_pm[:, :C])
+            corr_pm = eng.corr16
         if eng.spec.external_aggregate:
             # CCMR (ccmr/update.py:152-163): motion encoder on the kernels, the scale's XCiT block — the reference's own module,
             # torch — on the NCHW view of the motion features, its output into the aggregate slot of hx, then GRU + heads

@@ -34,7 +34,7 @@ def test_exports_every_declared_symbol(lib):
 
 
 def test_abi_version_and_status_strings(lib):
-    assert lib.pfk_abi_version() == 6
+    assert lib.pfk_abi_version() == 7
     lib.pfk_status_string.restype = ctypes.c_char_p
     assert lib.pfk_status_string(0) == b"ok"
     assert b"alignment" in lib.pfk_status_string(-2)
