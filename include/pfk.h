@@ -383,6 +383,11 @@ int pfk_mask_upsample_f32(const float* x, int x_ld, int cin, const float* weight
 int pfk_convex_upsample_pm_f32(const float* flow_pm, int flow_ld, const float* mask, int mask_ld,
                                float* out, int B, int H, int W, pfk_stream_t stream);
 
+/* same with a bf16 mask (ABI 7): mask_bf16 [M][mask_ld] bf16 logits (mask_ld in elements, rows 8-byte aligned) as the K8b mask head
+ * writes them — what `0.25 * self.mask(net)` is under the reference's reduced-precision switch; softmax and combination in fp32 */
+int pfk_convex_upsample_pm_b16(const float* flow_pm, int flow_ld, const void* mask_bf16, int mask_ld, float* out,
+                               int B, int H, int W, pfk_stream_t stream);
+
 /* ---- on-demand correlation behind the reference's alt_cuda_corr ABI --------------------------------
  * replaces corr_cuda_forward (ptlflow/utils/external/alt_cuda_corr/correlation_kernel.cu:258-285; pybind
  * `alt_cuda_corr.forward`, correlation.cpp:23-37, called from AlternateCorrBlock, raft/corr.py:76-101):

@@ -6,6 +6,17 @@
 
 namespace {
 
+__device__ __forceinline__ f32x4 load4_widen(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 load4_widen(const __bf16* p) {      // four bf16 (8 bytes) -> fp32, exact
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  const u32x2 w = *reinterpret_cast<const u32x2*>(p);
+  f32x4 v;
+  v.x = __builtin_bit_cast(float, w[0] << 16); v.y = __builtin_bit_cast(float, w[0] & 0xffff0000u);
+  v.z = __builtin_bit_cast(float, w[1] << 16); v.w = __builtin_bit_cast(float, w[1] & 0xffff0000u);
+  return v;
+}
+
+
 // out[p][co] = relu?( bias[co] + sum_{tap} in[p+off][0]*w[tap][0][co] + in[p+off][1]*w[tap][1][co] )
 // raft/update.py:100,107 (convf1).  Thread per (pixel, co); the flow taps are wave-broadcast
 // loads, the weights are read coalesced along co.
@@ -135,16 +146,6 @@ __device__ __forceinline__ void rs_step(float* s, int lane) {
 // j in the lanes whose upper bits spell j — and THOSE lanes apply coords1 += delta and flow = coords1 - coords0 for their
 // (pixel, component) in parallel: one global round trip per wave instead of PIX dependent ones on lane 0 (which was most of this
 // kernel's time: it is a latency chain, not a bandwidth problem).
-__device__ __forceinline__ f32x4 load4_widen(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-__device__ __forceinline__ f32x4 load4_widen(const __bf16* p) {      // four bf16 (8 bytes) -> fp32, exact
-  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-  const u32x2 w = *reinterpret_cast<const u32x2*>(p);
-  f32x4 v;
-  v.x = __builtin_bit_cast(float, w[0] << 16); v.y = __builtin_bit_cast(float, w[0] & 0xffff0000u);
-  v.z = __builtin_bit_cast(float, w[1] << 16); v.w = __builtin_bit_cast(float, w[1] & 0xffff0000u);
-  return v;
-}
-
 template <int PIX, typename TI = float>
 __global__ __launch_bounds__(256) void flow_delta_kernel(
     const TI* __restrict__ in, int in_ld, int cin, const float* __restrict__ wgt,
@@ -318,8 +319,10 @@ __global__ __launch_bounds__(256) void convex_upsample_kernel(const float* __res
 // (sy = idx >> 1, sx = 4 * (idx & 1) .. +3), so a tap is ONE 1 KiB load per wave (9 per 4 pixels instead of 36 of 256 bytes) and an
 // output row piece of the group is 128 contiguous bytes.  Every output element runs the scalar kernel's operation sequence
 // (max, exp, sum, one reciprocal, taps in order): the two kernels produce the same bits.  Needs 16-byte aligned mask rows.
+// TM = __bf16: the mask as the K8b mask head writes it (2-byte logits, widened exactly; half the bytes of this HBM-bound kernel).
+template <typename TM = float>
 __global__ __launch_bounds__(256) void convex_upsample4_kernel(const float* __restrict__ flow, int flow_ld,
-                                                               const float* __restrict__ mask,
+                                                               const TM* __restrict__ mask,
                                                                int mask_ld, float* __restrict__ out,
                                                                long long M, int H, int W) {
   const int lane = threadIdx.x & 63;
@@ -330,10 +333,10 @@ __global__ __launch_bounds__(256) void convex_upsample4_kernel(const float* __re
   const long long b = p / hw;
   const int pix = (int)(p - b * hw);
   const int y = pix / W, x = pix - y * W;
-  const f32x4* mrow = reinterpret_cast<const f32x4*>(mask + p * mask_ld) + idx;
+  const TM* mrow = mask + p * mask_ld + idx * 4;
   f32x4 m[9];
 #pragma unroll
-  for (int k = 0; k < 9; ++k) m[k] = mrow[k * 16];
+  for (int k = 0; k < 9; ++k) m[k] = load4_widen(mrow + k * 64);
   float vx[9], vy[9];
   const float* fx = flow + (b * 2 + 0) * hw;
   const float* fy = flow + (b * 2 + 1) * hw;
@@ -384,7 +387,7 @@ int launch_convex_upsample(const float* flow, int flow_ld, const float* mask, in
   if (pfk_aligned16(mask) && pfk_aligned16(out) && (mask_ld & 3) == 0) {
     const long long blocks = (M + 15) / 16;
     if (blocks > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(convex_upsample4_kernel, dim3((unsigned)blocks), dim3(256), 0, st, flow, flow_ld, mask, mask_ld, out, M, H, W);
+    hipLaunchKernelGGL(convex_upsample4_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, flow, flow_ld, mask, mask_ld, out, M, H, W);
   } else {
     const long long blocks = (M + 3) / 4;
     if (blocks > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
@@ -635,6 +638,18 @@ int pfk_upflow8_f32(const float* coords0, const float* coords1, float* out, int 
   if (blocks > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(upflow8_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), coords0, coords1, out,
                      B, H, W);
+  return pfk_launch_status();
+}
+
+int pfk_convex_upsample_pm_b16(const float* flow_pm, int flow_ld, const void* mask_bf16, int mask_ld, float* out,
+                               int B, int H, int W, pfk_stream_t stream) {
+  if (!flow_pm || !mask_bf16 || !out || B <= 0 || H <= 0 || W <= 0 || mask_ld < 576 || flow_ld < 2) return PFK_ERR_BAD_ARG;
+  if ((reinterpret_cast<uintptr_t>(mask_bf16) & 7u) || !pfk_aligned16(out) || (mask_ld & 3)) return PFK_ERR_ALIGNMENT;
+  const long long M = (long long)B * H * W;
+  const long long blocks = (M + 15) / 16;
+  if (blocks > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(convex_upsample4_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), flow_pm, flow_ld,
+                     static_cast<const __bf16*>(mask_bf16), mask_ld, out, M, H, W);
   return pfk_launch_status();
 }
 

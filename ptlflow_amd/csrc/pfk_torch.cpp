@@ -339,10 +339,16 @@ void upflow8(const Tensor& coords0, const Tensor& coords1, Tensor out) {
 
 void convex_upsample_pm(const Tensor& flow_pm, const Tensor& mask, Tensor out) {
   OpScope scope(flow_pm);
-  check_pm(flow_pm, "flow_pm"); check_pm(mask, "mask"); check_dev_f32(out, "out");
+  check_pm(flow_pm, "flow_pm"); check_dev_f32(out, "out");
+  const bool mask_b16 = check_pm_any(mask, "mask");
   TORCH_CHECK(out.dim() == 4 && out.size(1) == 2 && out.is_contiguous() && out.size(2) % 8 == 0 && out.size(3) % 8 == 0);
   const int B = out.size(0), H = out.size(2) / 8, W = out.size(3) / 8;
   TORCH_CHECK(mask.size(0) == (int64_t)B * H * W && mask.size(1) == 576 && flow_pm.size(0) == mask.size(0) && flow_pm.size(1) >= 2);
+  if (mask_b16) {
+    check_ok(pfk_convex_upsample_pm_b16(fptr(flow_pm), flow_pm.stride(0), mask.data_ptr(), mask.stride(0), fptr(out), B, H, W, cur_stream()),
+             "convex_upsample_pm (bf16 mask)");
+    return;
+  }
   check_ok(pfk_convex_upsample_pm_f32(fptr(flow_pm), flow_pm.stride(0), fptr(mask), mask.stride(0), fptr(out), B, H, W,
                                       cur_stream()), "convex_upsample_pm");
 }

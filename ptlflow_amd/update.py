@@ -258,7 +258,9 @@ class UpdateEngine:
         if self.hoist_context:
             self.ctx.update({("q" + sfx): a(s.hidden) for _, _, sfx in s.gru_passes})
         self.fm = a(s.fh_hidden * (2 if s.has_mask else 1))
-        self.mask = z(s.mask_channels) if s.has_mask else None
+        # the mask logits: fp32, or bf16 on the K8b path where the consumer is this package's own upsampling kernel (mask_channels
+        # 576; `mask_nchw()` hands the seam's torch consumer an fp32 copy)
+        self.mask = (a if s.mask_channels == 576 else z)(s.mask_channels) if s.has_mask else None
         self._scratch_c0 = torch.zeros(B, 2, H, W, device=dev, dtype=torch.float32)
         self._scratch_c1 = torch.zeros(B, 2, H, W, device=dev, dtype=torch.float32)
         self._delta = torch.zeros(B, 2, H, W, device=dev, dtype=torch.float32)
@@ -600,7 +602,7 @@ class UpdateEngine:
 
     def mask_nchw(self) -> torch.Tensor:
         B, H, W = self._shape
-        return self.mask.view(B, H, W, self.spec.mask_channels).permute(0, 3, 1, 2)
+        return self.mask.float().view(B, H, W, self.spec.mask_channels).permute(0, 3, 1, 2)
 
 
 class PfkUpdateBlock(torch.nn.Module):
