@@ -267,8 +267,19 @@ class _UpsampleSeam:
             self.ok = self._probe(flow.device)
         if not self.ok:
             return self.original(flow, mask)
-        if self.skip is not None and self.skip.upsample_is_dead():
-            return self.skip.scratch(flow)      # a non-final iteration's prediction: eval drops it (raft/raft.py:186-192)
+        if self.skip is not None:
+            if self.skip.upsample_is_dead():
+                return self.skip.scratch(flow)      # a non-final iteration's prediction: eval drops it (raft/raft.py:186-192)
+            eng = self.skip.take_deferred(mask)
+            if eng is not None:
+                # seam B3 left mask conv2 to this call: raft/update.py:152 + raft/raft.py:112-123 as ONE kernel on the mask head's
+                # hidden activation (K13, bit-identical to the pair); the flow goes pixel-major into the engine's flow slice, which
+                # the next block call rewrites from its own `flow` argument anyway
+                B, _, H, W = flow.shape
+                out = torch.empty(B, 2, 8 * H, 8 * W, device=flow.device, dtype=torch.float32)
+                torch.ops.pfk.nchw_to_pm(flow.contiguous(), eng.flow_view)
+                eng.mask_upsample(out)
+                return out
         return self._kernel(flow, mask)
 
 
@@ -358,30 +369,53 @@ class _DeadWorkSkip:
     never-handed-out scratch tensor before it.  Active per forward only when the model is in eval mode, no gradient graph is
     recorded and `model.iters` is a positive int; any call at or beyond `iters - 1` computes everything."""
 
-    def __init__(self, model: torch.nn.Module):
+    def __init__(self, model: torch.nn.Module, skip_dead: bool = True, fuse: bool = True):
         import weakref
         self._model = weakref.ref(model)
+        self.skip_dead = skip_dead   # False: every iteration keeps its mask head + upsampling (only the fused kernel is wanted)
+        self.fuse = fuse             # live iterations: mask conv2 + softmax + upsampling as ONE kernel inside `upsample_flow` (K13)
         self.active = False
         self.iters = 0
         self.call = 0           # index of the update-block call in flight (0-based) within the current forward
         self._dead_now = False  # the call in flight is a non-final one: its mask / upsampled flow are never read
         self._scratch = None
+        self._deferred = None   # (engine, data_ptr of the mask view handed out) of a live call whose mask conv2 was left to seam B5
 
-    def begin_forward(self) -> None:
+    def begin_forward(self, fp32: bool = True) -> None:
+        """`fp32` = the state tensors of this forward are float32.  A half / bf16 model (`model.half()`, validate.py:243-244) gets
+        its tensors back as fresh casts, so the block cannot tell the calls of one forward apart by storage: nothing is skipped
+        for it (the counter used to restart on every call and the final mask was never computed)."""
         m = self._model()
         it = getattr(m, "iters", None) if m is not None else None
-        self.active = bool(m is not None and not m.training and not torch.is_grad_enabled()
+        self.active = bool(fp32 and m is not None and not m.training and not torch.is_grad_enabled()
                            and isinstance(it, int) and not isinstance(it, bool) and it >= 1)
         self.iters = it if self.active else 0
         self.call = 0
         self._dead_now = False
+        self._deferred = None
 
     def next_call(self) -> bool:
         """Called by the block per call (after `begin_forward` on the first); True when this call's mask is dead."""
-        dead = self.active and not torch.is_grad_enabled() and self.call < self.iters - 1
+        dead = self.skip_dead and self.active and not torch.is_grad_enabled() and self.call < self.iters - 1
         self._dead_now = dead
         self.call += 1
+        self._deferred = None
         return dead
+
+    def may_defer(self) -> bool:
+        """A live call of an armed forward may leave mask conv2 to `upsample_flow` (the fused kernel): same conditions as skipping."""
+        m = self._model()
+        return bool(self.fuse and self.active and not self._dead_now and m is not None and not m.training and not torch.is_grad_enabled())
+
+    def defer(self, engine, mask_view: torch.Tensor) -> None:
+        self._deferred = (engine, mask_view.data_ptr())
+
+    def take_deferred(self, mask: torch.Tensor):
+        """The engine whose mask conv2 is pending, if `mask` is the (unfilled) view the block handed out for this very call."""
+        d, self._deferred = self._deferred, None
+        if d is not None and torch.is_tensor(mask) and mask.data_ptr() == d[1]:
+            return d[0]
+        return None
 
     def upsample_is_dead(self) -> bool:
         m = self._model()
@@ -395,8 +429,9 @@ class _DeadWorkSkip:
         return self._scratch
 
 
-def _dead_work_skip_for(model: torch.nn.Module):
-    """The shared skip state, or None (with a warning saying why) when skipping is not provably output-preserving for this model."""
+def _dead_work_skip_for(model: torch.nn.Module, warn: bool = True, skip_dead: bool = True, fuse: bool = True):
+    """The shared skip state, or None (with a warning saying why, when the caller asked for it explicitly) when skipping is not
+    provably output-preserving for this model."""
     import warnings
     why = None
     fwd, ups = _defining_class(model, "forward"), _defining_class(model, "upsample_flow")
@@ -414,23 +449,29 @@ def _dead_work_skip_for(model: torch.nn.Module):
               and isinstance(model.__dict__.get("upsample_flow"), _UpsampleSeam)):
         why = "seams B3 (a mask-head update block) and B5 are not both installed"
     if why is not None:
-        warnings.warn(f"ptlflow_amd: skip_dead_upsample refused, every iteration keeps its mask head + upsampling: {why}",
-                      RuntimeWarning, stacklevel=3)
+        if warn:
+            warnings.warn(f"ptlflow_amd: skip_dead_upsample refused, every iteration keeps its mask head + upsampling: {why}",
+                          RuntimeWarning, stacklevel=3)
         return None
-    return _DeadWorkSkip(model)
+    return _DeadWorkSkip(model, skip_dead=skip_dead, fuse=fuse)
 
 
 def accelerate(model: torch.nn.Module, corr: bool = True, update_block: bool = True,
                conv_precision: str = "fp32", encoders: bool = True, upsample: bool = True,
-               skip_dead_upsample: bool = False) -> torch.nn.Module:
+               skip_dead_upsample: Optional[bool] = None, fuse_mask_upsample: Optional[bool] = None) -> torch.nn.Module:
     """Patch seams B1/B3/B4 (+ B5, the model's `upsample_flow` method) of a ptlflow model instance in place and return it.
 
     ``conv_precision``: "fp32" (default, the parity path) or a split-bf16 mode of the convolutions
     ("bf16x6", "bf16x3", "bf16"), see ``UpdateEngine``.
-    ``skip_dead_upsample`` (opt-in, eval + no_grad forwards only): compute the mask head and the convex upsampling on the LAST
-    iteration only — the reference's loop computes them 32 times and returns the last (raft/raft.py:180-192).  `flows` stays
-    bit-identical.  Refused with a warning (everything keeps running every iteration) unless the model's `forward` is one of the
-    loops checked to drop the intermediate predictions, `model.iters` is an int and the model is in eval mode (`_DeadWorkSkip`)."""
+    ``skip_dead_upsample`` (eval + no_grad + float32 forwards only): compute the mask head and the convex upsampling on the LAST
+    iteration only — the reference's loop computes them 32 times and returns the last (raft/raft.py:180-192) — and run that
+    last one as the fused mask-conv2 + softmax + upsampling kernel inside `upsample_flow` (K13).  `flows` stays bit-identical.
+    ``None`` (default): ON wherever it is provably output-preserving — the model's `forward` and `upsample_flow` are those of
+    the loops checked to drop the intermediate predictions (`raft.RAFT`, `gma.GMA`), `model.iters` is a positive int and the
+    model is in eval mode when it is accelerated — silently off otherwise; ``True``: the same, with a warning saying why when it
+    is refused; ``False`` (opt-out): every iteration keeps its mask head and upsampling, as the reference (the fused kernel
+    still serves them where the same checks pass; ``fuse_mask_upsample=False`` keeps the two separate launches).  Re-armed per
+    forward: train mode, a gradient graph, a half / bf16 model or a changed `iters` are honoured (`_DeadWorkSkip`)."""
     load_native()
     mod_name = type(model).__module__
     # registered classes (`class raft(RAFT)`) live in the same module as the implementation
@@ -465,8 +506,11 @@ def accelerate(model: torch.nn.Module, corr: bool = True, update_block: bool = T
         # an instance attribute shadows the class's method; nn.Module.__setattr__ stores plain callables in __dict__
         model.__dict__[_UPSAMPLE] = model.upsample_flow
         model.__dict__["upsample_flow"] = _UpsampleSeam(model.upsample_flow)
-    if skip_dead_upsample and _SKIP not in model.__dict__:
-        skip = _dead_work_skip_for(model)
+    both = isinstance(getattr(model, "update_block", None), PfkUpdateBlock) and isinstance(model.__dict__.get("upsample_flow"), _UpsampleSeam)
+    if _SKIP not in model.__dict__ and (skip_dead_upsample is True or both) \
+            and not (skip_dead_upsample is False and fuse_mask_upsample is False):
+        skip = _dead_work_skip_for(model, warn=skip_dead_upsample is True, skip_dead=skip_dead_upsample is not False,
+                                   fuse=fuse_mask_upsample is not False)
         if skip is not None:
             model.__dict__[_SKIP] = skip
             model.update_block._skip = skip

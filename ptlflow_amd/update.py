@@ -520,12 +520,13 @@ class UpdateEngine:
         self.gru()
 
     def heads(self, coords0: torch.Tensor, coords1: torch.Tensor, delta_out: Optional[torch.Tensor],
-              want_mask: bool = True, write_flow: bool = True) -> None:
-        """update.py:13-14 + :152 and the coordinate bookkeeping of raft.py:174,178."""
+              want_mask: bool = True, write_flow: bool = True, mask_conv2: bool = True) -> None:
+        """update.py:13-14 + :152 and the coordinate bookkeeping of raft.py:174,178.  `mask_conv2=False`: the mask head's hidden
+        activation is computed, its second convolution is left to the caller (`mask_upsample`, the fused kernel)."""
         s = self.spec
         self.heads_conv1(want_mask)
         self.flow_delta(coords0, coords1, delta_out, write_flow)
-        if s.has_mask and want_mask:
+        if s.has_mask and want_mask and mask_conv2:
             self.mask_head()
 
     def heads_conv1(self, want_mask: bool = True) -> None:
@@ -627,7 +628,8 @@ class PfkUpdateBlock(torch.nn.Module):
         self._versions = None
         self._inp_ref, self._inp_version = None, -1      # strong references: the address cannot be recycled while cached
         self._attn_ref, self._attn_version = None, -1
-        self._skip = None      # patch._DeadWorkSkip when `accelerate(model, skip_dead_upsample=True)` was accepted
+        self._skip = None      # patch._DeadWorkSkip when `accelerate(model)` found the loop's dead work provably dead (patch.py)
+        self._last_out = None  # the `net` tensor handed back by the previous call: the same OBJECT coming in marks the next iteration
 
     def _param_versions(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
@@ -682,13 +684,14 @@ class PfkUpdateBlock(torch.nn.Module):
         # are (re)loaded unconditionally — the reference builds them as fresh tensors per forward (raft.py:158-160) and the
         # caching allocator hands the next forward the same addresses, so neither data_ptr nor _version can tell two
         # forwards apart.  Within a forward the loop passes the same `inp` object every iteration: identity + _version.
-        new_forward = net.data_ptr() != eng.hx.data_ptr()
+        # (a half / bf16 model gets `net` back as a fresh cast of the buffer: object identity tells its iterations apart)
+        new_forward = not (net is self._last_out or (net.dtype == torch.float32 and net.data_ptr() == eng.hx.data_ptr()))
         if new_forward:
             eng.watch_faults()
             ops.nchw_to_pm(net.float().contiguous(), eng.h_view)
             eng.state_changed()
             if self._skip is not None:
-                self._skip.begin_forward()
+                self._skip.begin_forward(fp32=net.dtype == torch.float32)
         # §8 f2: on the non-final iterations of an eval forward nobody reads the mask (patch._DeadWorkSkip)
         dead_mask = self._skip is not None and eng.spec.has_mask and self._skip.next_call()
         if new_forward or inp is not self._inp_ref or inp._version != self._inp_version:
@@ -730,11 +733,17 @@ class PfkUpdateBlock(torch.nn.Module):
             eng.motion_and_gru(corr_pm)
         if new_forward:
             eng._scratch_c1.zero_()     # the kernel's `coords1 += delta` lands here; `delta` itself does not depend on it — once per forward keeps it bounded
-        eng.heads(eng._scratch_c0, eng._scratch_c1, eng._delta, want_mask=not dead_mask, write_flow=False)
+        # a live call of an armed forward leaves mask conv2 to seam B5, which runs it fused with the softmax and the upsampling (K13)
+        defer = (self._skip is not None and eng.spec.has_mask and not dead_mask and eng.can_fuse_mask_upsample
+                 and net.dtype == torch.float32 and self._skip.may_defer())
+        eng.heads(eng._scratch_c0, eng._scratch_c1, eng._delta, want_mask=not dead_mask, write_flow=False, mask_conv2=not defer)
         mask = eng.mask_nchw() if eng.spec.has_mask else None
+        if defer:
+            self._skip.defer(eng, mask)
         out_net = eng.net_nchw()
         delta = eng._delta
         if net.dtype != torch.float32:
             out_net, delta = out_net.to(net.dtype), delta.to(net.dtype)
             mask = mask.to(net.dtype) if mask is not None else None
+        self._last_out = out_net
         return out_net, mask, delta

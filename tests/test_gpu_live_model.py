@@ -76,65 +76,112 @@ def test_accelerated_model(gpu, kind, H, W, iters):
     _run_case(model, gpu, H, W)
 
 
+def _count_mask_work(model, gpu, xs, iters):
+    """two forwards + one with `iters - 2`; returns (outputs, short flows, {mask conv2 launches, fused launches, upsampling launches})"""
+    eng_cls = type(model.update_block._get_engine(gpu))
+    calls = {"mk": 0, "fused": 0, "ups": 0}
+    eng_conv, eng_fused = eng_cls._conv, eng_cls.mask_upsample
+    seam = model.__dict__["upsample_flow"]
+    kernel = seam._kernel
+
+    def counting_conv(self, srcs, kh, kw, key, *a, **k):
+        calls["mk"] += key == "mk"
+        return eng_conv(self, srcs, kh, kw, key, *a, **k)
+
+    def counting_fused(self, out):
+        calls["fused"] += 1
+        return eng_fused(self, out)
+
+    def counting_kernel(flow, mask):
+        calls["ups"] += 1
+        return kernel(flow, mask)
+
+    eng_cls._conv, eng_cls.mask_upsample, seam._kernel = counting_conv, counting_fused, counting_kernel
+    try:
+        with torch.no_grad():
+            got = [model({"images": x}) for x in xs]
+            got = [{k: v.clone() for k, v in o.items()} for o in got]
+            n = dict(calls)
+            model.iters = iters - 2
+            short = model({"images": xs[0]})["flows"].clone()
+            model.iters = iters
+    finally:
+        eng_cls._conv, eng_cls.mask_upsample = eng_conv, eng_fused
+        del seam._kernel
+    return got, short, n
+
+
 @pytest.mark.parametrize("kind,H,W,iters", [("raft", 436, 1024, 32), ("raft", 184, 320, 5), ("gma", 184, 320, 6)], ids=lambda v: str(v))
 def test_skip_dead_upsample_on_the_reference_class(gpu, kind, H, W, iters):
-    """§8 f2 at the seams: `accelerate(model, skip_dead_upsample=True)` on the reference's own class returns bit-identical `flows`
-    and `flow_small` (raft/raft.py:189-192) while the mask head and the upsampling run on the last iteration only — also after
-    `model.iters` changes between forwards, and for a second pair (no state carried over)."""
+    """§8 f2 at the seams, on the reference's own class.  What a user gets from plain `accelerate(model)` — mask head + upsampling on
+    the last iteration only, and that one as the fused kernel behind `upsample_flow` — returns bit-identical `flows` / `flow_small`
+    (raft/raft.py:189-192) to the every-iteration path with the two separate launches; so do the two halves of the default on their
+    own (`fuse_mask_upsample=False`: skip only; `skip_dead_upsample=False`: fused kernel on every iteration) — also after `model.iters`
+    changes between forwards, and for a second pair (no state carried over)."""
     if not REAL:
         pytest.skip("no reference tree and no staged archive (oracle/_ref)")
     from ptlflow_amd import patch
     model = _build(kind, iters).to(gpu)
     xs = [O.smooth_pair(1, H, W, seed=11).to(gpu), O.smooth_pair(1, H, W, seed=12, shift=(-3, 6)).to(gpu)]
+    runs = {}
+    for name, kw in (("plain pair, every iteration", dict(skip_dead_upsample=False, fuse_mask_upsample=False)),
+                     ("default", {}),
+                     ("skip only", dict(skip_dead_upsample=True, fuse_mask_upsample=False)),
+                     ("fused only", dict(skip_dead_upsample=False))):
+        patch.accelerate(model, **kw)
+        try:
+            if name == "plain pair, every iteration":
+                assert model.update_block._skip is None
+            else:
+                assert model.update_block._skip is not None
+            runs[name] = _count_mask_work(model, gpu, xs, iters)
+        finally:
+            patch.restore(model)
+    want, want_short, n0 = runs["plain pair, every iteration"]
+    # (the B5 probe's own kernel call is counted when the seam is probed inside the window: allow one more)
+    assert n0["mk"] == 2 * iters and n0["fused"] == 0 and n0["ups"] in (2 * iters, 2 * iters + 1)
+    n = runs["default"][2]
+    assert n["mk"] == 0 and n["fused"] == 2 and n["ups"] in (0, 1), f"default path: {n} over two forwards of {iters} iterations"
+    n = runs["skip only"][2]
+    assert n["mk"] == 2 and n["fused"] == 0 and n["ups"] in (2, 3), f"skip only: {n}"
+    n = runs["fused only"][2]
+    assert n["mk"] == 0 and n["fused"] == 2 * iters and n["ups"] in (0, 1), f"fused only: {n}"
+    for name in ("default", "skip only", "fused only"):
+        got, got_short, _ = runs[name]
+        for g, w in zip(got, want):
+            assert torch.equal(g["flows"], w["flows"]) and torch.equal(g["flow_small"], w["flow_small"]), name
+        assert torch.equal(got_short, want_short), name
+    assert O.epe(want[0]["flows"][:, 0].cpu(), want[1]["flows"][:, 0].cpu())[0] > 0.05
+    assert O.epe(want_short[:, 0].cpu(), want[0]["flows"][:, 0].cpu())[0] > 0
+
+
+def test_half_model_keeps_every_iteration(gpu):
+    """`model.half()` (the reference's reduced-precision switch, validate.py:243-244 / model_benchmark.py:317-319) under the default
+    `accelerate(model)`: the block hands fp16 casts of its buffers back, so nothing can be skipped or deferred — the forward must be
+    the every-iteration one (the skip counter used to restart on every call and `flows` came back as zeros), finite, and
+    within fp16 distance of the fp32 forward."""
+    if not REAL:
+        pytest.skip("no reference tree and no staged archive (oracle/_ref)")
+    from ptlflow_amd import patch
+    iters, H, W = 6, 184, 320
+    model = _build("raft", iters).to(gpu)
+    x = O.smooth_pair(1, H, W, seed=11).to(gpu)
     patch.accelerate(model)
     try:
         with torch.no_grad():
-            want = [model({"images": x}) for x in xs]
-            want = [{k: v.clone() for k, v in o.items()} for o in want]
-            model.iters = iters - 2
-            want_short = model({"images": xs[0]})["flows"].clone()
-            model.iters = iters
+            ref32 = model({"images": x})["flows"].float().clone()
     finally:
         patch.restore(model)
-    patch.accelerate(model, skip_dead_upsample=True)
-    try:
-        skip = model.update_block._skip
-        assert skip is not None
-        calls = {"mask": 0, "ups": 0}
-        eng_conv = type(model.update_block._get_engine(gpu))._conv
-
-        def counting_conv(self, srcs, kh, kw, key, *a, **k):
-            if key == "mk":
-                calls["mask"] += 1
-            return eng_conv(self, srcs, kh, kw, key, *a, **k)
-
-        seam = model.__dict__["upsample_flow"]
-        kernel = seam._kernel
-
-        def counting_kernel(flow, mask):
-            calls["ups"] += 1
-            return kernel(flow, mask)
-
-        type(model.update_block._get_engine(gpu))._conv = counting_conv
-        seam._kernel = counting_kernel
+    model.half()
+    out = {}
+    for name, kw in (("default", {}), ("opted out", dict(skip_dead_upsample=False, fuse_mask_upsample=False))):
+        patch.accelerate(model, **kw)
         try:
             with torch.no_grad():
-                got = [model({"images": x}) for x in xs]
-                got = [{k: v.clone() for k, v in o.items()} for o in got]
-                n_mask, n_ups = calls["mask"], calls["ups"]
-                model.iters = iters - 2
-                got_short = model({"images": xs[0]})["flows"].clone()
-                model.iters = iters
+                out[name] = model({"images": x.half()})["flows"].float().clone()
         finally:
-            type(model.update_block._get_engine(gpu))._conv = eng_conv
-            del seam._kernel
-    finally:
-        patch.restore(model)
-    # (the B5 probe's own kernel call happens before counting starts only if the seam was probed earlier: allow it)
-    assert n_mask == 2, f"mask conv2 ran {n_mask} times over two forwards of {iters} iterations"
-    assert n_ups in (2, 3), f"convex upsampling ran {n_ups} times over two forwards"
-    for g, w in zip(got, want):
-        assert torch.equal(g["flows"], w["flows"]) and torch.equal(g["flow_small"], w["flow_small"])
-    assert torch.equal(got_short, want_short)
-    assert O.epe(want[0]["flows"][:, 0].cpu(), want[1]["flows"][:, 0].cpu())[0] > 0.05
-    assert O.epe(want_short[:, 0].cpu(), want[0]["flows"][:, 0].cpu())[0] > 0
+            patch.restore(model)
+    assert torch.isfinite(out["default"]).all() and out["default"].abs().max() > 0.5
+    assert torch.equal(out["default"], out["opted out"])
+    mean, mx = O.epe(out["default"][:, 0].cpu(), ref32[:, 0].cpu())
+    assert mean < 5e-2, f"fp16 forward vs fp32 forward: EPE mean {mean:.3e} max {mx:.3e}"

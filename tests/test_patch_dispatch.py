@@ -238,6 +238,51 @@ def test_skip_dead_upsample_is_refused_where_it_is_not_provably_dead():
     assert skip is None and len(warned) == 1
 
 
+def test_dead_work_skip_is_the_default_and_can_be_opted_out():
+    """Plain `accelerate(model)` arms the dead-work skip wherever the explicit request would be accepted, WITHOUT warnings where it
+    would be refused; `skip_dead_upsample=False` keeps every iteration's mask head + upsampling (the shared state then only serves
+    the fused mask-conv2 + upsampling kernel behind seam B5)."""
+    _native()
+    import warnings
+    from ptlflow_amd import patch
+
+    def attempt(model, **kw):
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            patch.accelerate(model, **kw)
+        try:
+            return getattr(model.update_block, "_skip", None), [str(x.message) for x in w if "skip_dead_upsample" in str(x.message)]
+        finally:
+            patch.restore(model)
+
+    model, mod = _build("raft", "RAFT", iters=4)
+    skip, warned = attempt(model)
+    assert skip is not None and skip.skip_dead and skip.fuse and not warned
+    skip, warned = attempt(model, skip_dead_upsample=False)
+    assert skip is not None and not skip.skip_dead and skip.fuse and not warned
+    with torch.no_grad():
+        skip.begin_forward()
+        assert [skip.next_call() for _ in range(5)] == [False] * 5          # opted out: no call is dead
+    gma, _ = _build("gma", "GMA", iters=4)
+    skip, warned = attempt(gma)
+    assert skip is not None and not warned
+
+    class Consumes(mod.RAFT):
+        def forward(self, inputs):
+            return super().forward(inputs)
+
+    torch.manual_seed(7)
+    skip, warned = attempt(Consumes(iters=4).eval())
+    assert skip is None and not warned                                      # default: refused silently
+    model.train()
+    skip, warned = attempt(model)
+    assert skip is None and not warned
+    model.eval()
+    small, _ = _build("raft", "RAFTSmall")
+    skip, warned = attempt(small)
+    assert skip is None and not warned
+
+
 def test_dead_work_skip_state_machine():
     """The shared state alone: dead on calls 0..iters-2 of an eval / no_grad forward, live on the last and on any call beyond,
     inactive in train mode or with gradients enabled, re-armed by `begin_forward` (which re-reads `model.iters`)."""
@@ -269,3 +314,17 @@ def test_dead_work_skip_state_machine():
         assert s.next_call() is True
         m.train()                                   # flipped mid-forward: the upsampling seam stops trusting the flag
         assert not s.upsample_is_dead()
+        m.eval()
+        # a half / bf16 forward is never armed (its tensors come back as fresh casts: the calls of one forward cannot be told apart)
+        s.begin_forward(fp32=False)
+        assert s.active is False and [s.next_call() for _ in range(4)] == [False] * 4 and not s.may_defer()
+        # deferral of mask conv2 to seam B5: live calls of an armed forward only, consumed once, by the very view handed out
+        s.begin_forward()
+        assert s.next_call() is True and not s.may_defer()
+        assert s.next_call() is True
+        assert s.next_call() is False and s.may_defer()
+        view, other = torch.zeros(3), torch.zeros(3)
+        s.defer("engine", view)
+        assert s.take_deferred(other) is None and s.take_deferred(view) is None      # a wrong tensor consumes the token too
+        s.defer("engine", view)
+        assert s.take_deferred(view) == "engine" and s.take_deferred(view) is None
