@@ -21,9 +21,9 @@ Besides the driver's contract fields the JSON line carries
                 (model_benchmark.py:421-466: torch.rand input, 1 warm-up + 10 synchronised forwards, median)
   split_bf16, skip_dead_upsample     the same forward with split-bf16 convolution products / without the reference's dead
                 per-iteration mask + upsample work (bit-identical output) — beside the headline, never as it
-  dropin        the path a ptlflow user gets: a torch-only RAFT whose forward is the reference's own caller loop
-                (ptlflow_amd/seam_model.py: module-global `get_corr_block`, `update_block(net, inp, corr, flow)` on NCHW tensors,
-                `upsample_flow` in torch ops) with `ptlflow_amd.patch.accelerate` applied; batch 1, the reference's protocol
+  dropin        the path a ptlflow user gets: the reference's own `ptlflow.models.raft.raft.RAFT` (oracle/ref_loader.py) with plain
+                `ptlflow_amd.patch.accelerate(model)` applied; batch 1 under the reference's protocol, driven by the reference's own
+                `model_benchmark.estimate_inference_time`; `every_iteration`: the same object with the dead-work skip opted out
   config3       BASELINE config 3: gma (fp32), raft / gma with bf16 operands (bf16 convolutions, bf16 correlation volume), and
                 SEA-RAFT's correlation path (per-level volumes against the halved fmap2 + 4 / 12 lookups, sea_raft/corr.py:71-117)
                 in fp32 and bf16 — every leg with its end-point / lookup error against the CPU oracle
@@ -171,72 +171,83 @@ def reference_raft(cpu_state, iters, small=False):
         return None, repr(e)[:200]
 
 
+def reference_function_protocol(model, H, W, n: int = 10):
+    """The reference's OWN `model_benchmark.estimate_inference_time` (model_benchmark.py:422-466, its `ptlflow.utils.timer.Timer`:
+    utils/timer.py:81-96) driving `model` — the function the published `model_benchmark-all.csv` numbers come from, imported
+    unmodified (oracle/ref_loader.ref_script).  Returns the leg, or None where the script is not importable."""
+    try:
+        from oracle import ref_loader
+        mb = ref_loader.ref_script("model_benchmark")
+        from jsonargparse import Namespace
+    except Exception as e:
+        return {"error": repr(e)[:200]}
+    times = sorted(mb.estimate_inference_time(Namespace(num_samples=n, batch_size=1), model, (H, W), "fp32"))
+    med = times[len(times) // 2]                       # `final_speed_mode: median`, model_benchmark.py:335-341
+    return {"value": 1.0 / med, "unit": "frame-pairs/s", "ms_median": 1e3 * med, "ms_min": 1e3 * times[0], "ms_max": 1e3 * times[-1],
+            "driver": "reference function",
+            "protocol": f"model_benchmark.estimate_inference_time (the reference's own function and Timer, {mb.__file__}): batch 1, "
+                        f"torch.rand input, 1 warm-up + {n} synchronised forwards, median"}
+
+
 def dropin_leg(cpu_state, dev, H, W, iters, pair_cpu, ref_flows, torch_baseline=False, batch8=None):
     """Throughput of the drop-in SEAM path — what `ptlflow.get_model("raft")` + `patch.accelerate(model)` runs: the REFERENCE'S
     OWN `RAFT` class (its `forward`, raft.py:125-194, its `preprocess_images` / `InputPadder` / `postprocess_predictions`) with
-    seams B1 / B3 / B4 / B5 on libpfk.  Batch 1 under model_benchmark.py's protocol, plus the batch-8 throughput setting.  Where
-    no reference is importable the torch-only stand-in (`ptlflow_amd.seam_model.SeamRAFT`, the same caller loop) takes its place
-    and `what` says so."""
+    seams B1 / B3 / B4 / B5 on libpfk.  The leg's own numbers are those of PLAIN `accelerate(model)` — the default a user gets: in
+    eval the loop's dead mask-head / upsampling work is skipped and the last iteration's runs as the fused kernel (`flows`
+    bit-identical); `every_iteration` = the same object with that opted out (`skip_dead_upsample=False, fuse_mask_upsample=False`:
+    the reference loop's work in full).  Batch 1 under model_benchmark.py's protocol — driven by the reference's own
+    `estimate_inference_time` where it is importable — plus the batch-8 throughput setting."""
     from ptlflow_amd import patch
     m, kind = reference_raft(cpu_state, iters)
-    leg = {}
-    if m is not None:
-        leg["what"] = (f"ptlflow.models.raft.raft.RAFT — the reference's own class ({kind}: "
-                       f"{'/root/reference' if kind == 'tree' else 'oracle/_ref archive staged by oracle/stage_ref.py'}) "
-                       "+ ptlflow_amd.patch.accelerate: seams B1/B3/B4/B5 on libpfk")
-        leg["model_class"] = f"{type(m).__module__}.{type(m).__name__}"
-    else:
-        from ptlflow_amd.seam_model import SeamRAFT
-        m = SeamRAFT(iters=iters).eval()
-        m.load_state_dict(cpu_state, strict=True)
-        leg["what"] = ("ptlflow_amd.seam_model.SeamRAFT (torch-only stand-in for the reference's caller loop; no reference importable"
-                       + (f": {kind}" if kind else "") + ") + ptlflow_amd.patch.accelerate: seams B1/B3/B4/B5 on libpfk")
-        leg["model_class"] = "ptlflow_amd.seam_model.SeamRAFT"
+    if m is None:
+        return {"skipped": "no reference importable (neither /root/reference nor the staged archive oracle/_ref)" + (f": {kind}" if kind else "")}
+    leg = {"what": (f"ptlflow.models.raft.raft.RAFT — the reference's own class ({kind}: "
+                    f"{'/root/reference' if kind == 'tree' else 'oracle/_ref archive staged by oracle/stage_ref.py'}) "
+                    "+ plain ptlflow_amd.patch.accelerate(model): seams B1/B3/B4/B5 on libpfk, dead work skipped (default)"),
+           "model_class": f"{type(m).__module__}.{type(m).__name__}"}
     m = m.to(dev)
     if torch_baseline:      # stock PyTorch-ROCm ops (MIOpen convolutions, matmul / avg_pool2d / grid_sample): today's ptlflow on this GPU
         with torch.no_grad():
             t = protocol_leg(m, dev, H, W, n=5)
         leg["torch_rocm_unpatched"] = {"value": t["value"], "unit": "frame-pairs/s", "ms_median": t["ms_median"],
                                        "what": "the same model object before patch.accelerate: stock PyTorch-ROCm ops"}
-    patch.accelerate(m)
-    try:
+
+    def measure(out_leg):
         with torch.no_grad():
             out = m({"images": pair_cpu.to(dev)})
             if ref_flows is not None:
                 mean, mx = _epe(out["flows"][:1, 0], ref_flows)
-                leg["epe_vs_cpu"] = {"mean": mean, "max": mx, "gate": 1e-3}
-            leg.update(protocol_leg(m, dev, H, W))
+                out_leg["epe_vs_cpu"] = {"mean": mean, "max": mx, "gate": 1e-3}
+            t = reference_function_protocol(m, H, W)
+            if t is None or "error" in t:                  # (the script could not be imported: this file's re-statement of the protocol)
+                t2 = protocol_leg(m, dev, H, W)
+                t2["driver"] = "bench.py re-statement" + (f" ({t['error']})" if t else "")
+                t = t2
+            out_leg.update(t)
             if batch8 is not None:
                 sec = timed(lambda: m(batch8), 2, 5)
-                leg["batch8"] = {"value": batch8["images"].shape[0] / sec, "unit": "frame-pairs/s", "ms_per_step": 1e3 * sec,
-                                 "note": "the same accelerated object on the headline's batch (8 smooth pairs per forward)"}
-            flows_every = out["flows"].clone()
+                out_leg["batch8"] = {"value": batch8["images"].shape[0] / sec, "unit": "frame-pairs/s", "ms_per_step": 1e3 * sec,
+                                     "note": "the same accelerated object on the headline's batch (8 smooth pairs per forward)"}
+        return out["flows"].clone()
+
+    patch.accelerate(m)
+    try:
+        leg["dead_work_skip"] = getattr(m.update_block, "_skip", None) is not None
+        flows_default = measure(leg)
     finally:
         patch.restore(m)
-    # the same object with the reference loop's dead work skipped at the seams (SURVEY §8 f2; opt-in, eval + no_grad only): mask head
-    # + convex upsampling on the final iteration only, `flows` bit-identical — reported beside the non-skipping form, never as it
     try:
-        import warnings
-        with warnings.catch_warnings(record=True) as w:
-            warnings.simplefilter("always")
-            patch.accelerate(m, skip_dead_upsample=True)
+        every = {}
+        patch.accelerate(m, skip_dead_upsample=False, fuse_mask_upsample=False)
         try:
-            sk = {"accepted": getattr(m.update_block, "_skip", None) is not None}
-            if not sk["accepted"]:
-                sk["refused"] = [str(x.message)[:200] for x in w][:1]
-            else:
-                with torch.no_grad():
-                    o2 = m({"images": pair_cpu.to(dev)})
-                    sk["identical_flows"] = bool(torch.equal(o2["flows"], flows_every))
-                    sk.update(protocol_leg(m, dev, H, W))
-                    if batch8 is not None:
-                        sec = timed(lambda: m(batch8), 2, 5)
-                        sk["batch8"] = {"value": batch8["images"].shape[0] / sec, "unit": "frame-pairs/s", "ms_per_step": 1e3 * sec}
-            leg["skip_dead"] = sk
+            flows_every = measure(every)
+            every["identical_flows"] = bool(torch.equal(flows_every, flows_default))
         finally:
             patch.restore(m)
+        leg["every_iteration"] = every
+        leg["identical_flows"] = every["identical_flows"]
     except Exception as e:
-        leg["skip_dead"] = {"error": repr(e)[:300]}
+        leg["every_iteration"] = {"error": repr(e)[:300]}
     return leg
 
 
@@ -735,7 +746,12 @@ def main():
                 from oracle import raft_oracle as O
             ref_raft = ref["flows"][:, 0] if ref is not None else None      # CPU forward of the cpu_baseline leg: same weights, pair 0
             # (a) like-for-like with the reference's published protocol (batch 1, rand, median of 10) on the mirror ...
-            result["model_benchmark_protocol"] = protocol_leg(model, dev, args.height, args.width)
+            mbp = reference_function_protocol(model, args.height, args.width)     # the reference's own function drives the mirror
+            if mbp is None or "error" in mbp:
+                mbp2 = protocol_leg(model, dev, args.height, args.width)
+                mbp2["driver"] = "bench.py re-statement" + (f" ({mbp['error']})" if mbp else "")
+                mbp = mbp2
+            result["model_benchmark_protocol"] = mbp
             del model
             torch.cuda.empty_cache()
             # ... and on the drop-in seam path (the reference's caller loop, seams B1 / B3 / B4 patched)

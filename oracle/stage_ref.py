@@ -36,7 +36,11 @@ PACKAGES_RECURSIVE = ["ptlflow/models/rapidflow", "ptlflow/models/rpknet", "ptlf
                       "ptlflow/models/lcv",      # lcv: RAFT's encoders / update block / loop around a learnable cost volume (B3-B5)
                       "ptlflow/models/llaflow"]  # llaflow: RAFT's / GMA's update block and encoders around its own cost volume (B3-B5)
 MODULES = ["ptlflow/utils/correlation.py", "ptlflow/utils/external/raft.py", "ptlflow/utils/flow_metrics.py",
-           "ptlflow/utils/registry.py", "ptlflow/utils/utils.py", "ptlflow/utils/timer.py", "LICENSE"]
+           "ptlflow/utils/registry.py", "ptlflow/utils/utils.py", "ptlflow/utils/timer.py", "LICENSE",
+           # the reference's own entry points (ref_loader.load_scripts): `ptlflow.get_model` (ptlflow/__init__.py:65-125) and
+           # `model_benchmark.estimate_inference_time` (model_benchmark.py:422-466) run on the accelerated model in
+           # tests/test_gpu_reference_scripts.py and bench.py's `model_benchmark_protocol` leg
+           "ptlflow/__init__.py", "ptlflow/utils/lightning/ptlflow_cli.py", "model_benchmark.py"]
 
 
 def _file_list(root: str):

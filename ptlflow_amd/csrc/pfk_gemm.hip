@@ -1171,6 +1171,7 @@ int launch_pp(const GemmArgs& a, int epi, int batches, hipStream_t st, int varia
   g.sk_groups = 1;
   if ((variant & 2) && tiles >= 64 && G >= 64) { g.sk_groups = 8; G -= G % 8; }
   if (abl) {   // timing ablations (results are garbage; scripts/conv_bench.py): linear epilogue, swizzled x3 or padded x2 only
+#ifdef PFK_BENCH_VARIANTS     // (not in the shipped library: ptlflow_amd/_build.py, PFK_BENCH_VARIANTS=1)
     if (epi != PFK_EPI_LINEAR || !((swz && bpc == 3) || (!swz && bpc == 2))) return PFK_ERR_BAD_ARG;
     switch (abl) {
       case 1: return swz ? launch_pp_one<PFK_EPI_LINEAR, LDS_LDX, 3, 1>(g, (unsigned)G, st) : launch_pp_one<PFK_EPI_LINEAR, LDS_LD, 2, 1>(g, (unsigned)G, st);
@@ -1178,6 +1179,9 @@ int launch_pp(const GemmArgs& a, int epi, int batches, hipStream_t st, int varia
       case 3: return swz ? launch_pp_one<PFK_EPI_LINEAR, LDS_LDX, 3, 3>(g, (unsigned)G, st) : launch_pp_one<PFK_EPI_LINEAR, LDS_LD, 2, 3>(g, (unsigned)G, st);
       default: return PFK_ERR_BAD_ARG;
     }
+#else
+    return PFK_ERR_BAD_ARG;
+#endif
   }
   if (bpc == 1) return swz ? launch_pp_epi<LDS_LDX, 1>(g, epi, (unsigned)G, st) : launch_pp_epi<LDS_LD, 1>(g, epi, (unsigned)G, st);
   if (bpc == 2) return swz ? launch_pp_epi<LDS_LDX, 2>(g, epi, (unsigned)G, st) : launch_pp_epi<LDS_LD, 2>(g, epi, (unsigned)G, st);
@@ -1223,9 +1227,14 @@ int launch_sk(const GemmArgs& a, int epi, hipStream_t st, int variant) {
   if (U * (G + 1) >= 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;   // the kernel's unit arithmetic is 32-bit
   g.sk_groups = 1;
   if ((variant & 2) && g.sk_tiles >= 64 && G >= 64) { g.sk_groups = 8; G -= G % 8; }
+  if (bpc == 2 && !swz) return launch_sk_epi<LDS_LD, 2>(g, epi, (unsigned)G, st);       // what the shipped library's heuristic selects
+#ifdef PFK_BENCH_VARIANTS     // the other LDS layouts / residencies of the round-2 schedule sweep (scripts/conv_bench.py cfg 30 + v)
   if (bpc == 1) return swz ? launch_sk_epi<LDS_LDX, 1>(g, epi, (unsigned)G, st) : launch_sk_epi<LDS_LD, 1>(g, epi, (unsigned)G, st);
-  if (bpc == 2) return swz ? launch_sk_epi<LDS_LDX, 2>(g, epi, (unsigned)G, st) : launch_sk_epi<LDS_LD, 2>(g, epi, (unsigned)G, st);
+  if (bpc == 2) return launch_sk_epi<LDS_LDX, 2>(g, epi, (unsigned)G, st);
   return launch_sk_epi<LDS_LDX, 3>(g, epi, (unsigned)G, st);
+#else
+  return PFK_ERR_BAD_ARG;
+#endif
 }
 
 // VARIANT: 0 = 4-wave double-buffered pipeline (v1), 1 = v3 one group, 2 = v3 two groups (in-block split-K);
@@ -1379,6 +1388,7 @@ int launch(const GemmArgs& a0, int epi, int batches, hipStream_t st) {
     // 32x128 wave tiles on either kernel — 0 .. 90 % slower than the heuristic's choice on every encoder and update-block shape.
     case 14: return launch_cfg_linear<128, 96, 32, 96, 101>(a, epi, batches, st);
     case 15: return launch_cfg_linear<128, 96, 32, 96, 0>(a, epi, batches, st);
+#ifdef PFK_BENCH_VARIANTS     // timing ablations (results are garbage; scripts/conv_bench.py only): not in the shipped library
     // MFMA-only skeletons of the bigger padded tiles (timing ablations)
     case 27: return epi == PFK_EPI_LINEAR ? launch_cfg<64, 128, 32, 64, 31>(a, epi, batches, st) : PFK_ERR_BAD_ARG;
     case 28: return epi == PFK_EPI_LINEAR ? launch_cfg<128, 128, 64, 64, 31>(a, epi, batches, st) : PFK_ERR_BAD_ARG;
@@ -1390,6 +1400,7 @@ int launch(const GemmArgs& a0, int epi, int batches, hipStream_t st) {
     case 24: return epi == PFK_EPI_LINEAR ? launch_cfg<64, 64, 32, 32, 41>(a, epi, batches, st) : PFK_ERR_BAD_ARG;
     case 25: return epi == PFK_EPI_LINEAR ? launch_cfg<64, 64, 32, 32, 51>(a, epi, batches, st) : PFK_ERR_BAD_ARG;
     case 26: return epi == PFK_EPI_LINEAR ? launch_cfg<64, 64, 32, 32, 61>(a, epi, batches, st) : PFK_ERR_BAD_ARG;
+#endif
     default: return PFK_ERR_BAD_ARG;
   }
 }

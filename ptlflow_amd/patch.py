@@ -349,8 +349,12 @@ _VOLUME_SEAM = "_pfk_learnable_volume_seam"
 _LAST_FLOW_ONLY_FORWARDS = {
     ("ptlflow.models.raft.raft", "RAFT"),
     ("ptlflow.models.gma.gma", "GMA"),
-    ("ptlflow_amd.seam_model", "SeamRAFT"),
 }
+
+
+def register_last_flow_only_forward(module: str, cls: str) -> None:
+    """Declare that `module.cls.forward` (and `upsample_flow`) is a loop of that kind — checked by whoever registers it."""
+    _LAST_FLOW_ONLY_FORWARDS.add((module, cls))
 _SKIP = "_pfk_dead_work_skip"
 
 

@@ -10,6 +10,7 @@ import argparse
 import math
 import os
 os.environ.setdefault("PFK_DEBUG_KNOBS", "1")   # tuning script: uses the pfk_debug_set_* knobs
+os.environ.setdefault("PFK_BENCH_VARIANTS", "1")   # the ablation / schedule-sweep configurations are compiled into a variants build only (ptlflow_amd/_build.py)
 import sys
 
 import torch

@@ -1,12 +1,13 @@
-"""A torch-only RAFT laid out like ptlflow's — the *caller side* of seams B1 / B3 / B4 for machines without ptlflow.
+"""TEST INFRASTRUCTURE (moved out of the product package in round 6: the staged reference superseded it everywhere else).
+A torch-only RAFT laid out like ptlflow's — the *caller side* of seams B1 / B3 / B4 for machines without ptlflow.
 
 `ptlflow_amd.RAFT` (raft.py) is the fast mirror: its own loop, pixel-major state, fused coordinate update.  What a ptlflow
 user gets after `patch.accelerate(model)` is something else: the reference's OWN loop (ptlflow/models/raft/raft.py:125-194)
 calling the wrapped seams — `get_corr_block(...)` looked up as a global of the model's module once per forward, then per
 iteration `corr_fn(coords1)`, `flow = coords1 - coords0`, `update_block(net, inp, corr, flow)`, `coords1 + delta_flow` and
 `upsample_flow` in torch ops (raft.py:112-123), NCHW tensors in between.  This module is that caller, written against torch
-only, so the seam path can be timed and checked on the GPU box where ptlflow itself is absent (bench.py `dropin` leg,
-tests/test_gpu_seam_model.py):
+only, so the seam path can be checked where neither the reference tree nor its staged archive exists
+(tests/test_seam_model.py, tests/test_gpu_seam_model.py):
 
 * un-patched it is a plain PyTorch RAFT (convolutions on MIOpen, `matmul` / `avg_pool2d` / `grid_sample` correlation block):
   what ptlflow runs on an MI355X today;
@@ -29,7 +30,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .raft import Encoder
+from ptlflow_amd.raft import Encoder
 
 
 # ----------------------------------------------------------------------------- seam B1: the torch correlation block
@@ -241,12 +242,13 @@ class SeamRAFT(nn.Module):
 
 def _register() -> None:
     """Declare this module's classes to `patch.accelerate` as the raft implementations they are (the shape check still applies)."""
-    from . import patch
-    from .update import basic_spec, small_spec
+    from ptlflow_amd import patch
+    from ptlflow_amd.update import basic_spec, small_spec
     patch.register_update_block(__name__, "BasicUpdateBlock", lambda cc: patch._with_corr_channels(basic_spec(), cc))
     patch.register_update_block(__name__, "SmallUpdateBlock", lambda cc: patch._with_corr_channels(small_spec(), cc))
     patch.register_encoder(__name__, "BasicEncoder")
     patch.register_encoder(__name__, "SmallEncoder")
+    patch.register_last_flow_only_forward(__name__, "SeamRAFT")      # its eval forward keeps the last prediction only, like raft.py:186-192
 
 
 _register()

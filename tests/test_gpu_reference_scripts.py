@@ -1,0 +1,79 @@
+"""The reference's own ENTRY POINTS on the accelerated path (BASELINE.json north_star: "ptlflow.get_model(), the LightningModule
+forward(), model_benchmark.py and validate.py stay drop-in"):
+
+* `ptlflow.get_model("raft")` — ptlflow/__init__.py:65-125 executed as it is (registry lookup, argument parser, instantiation),
+* `model_benchmark.estimate_inference_time(args, model, input_size, dtype_str)` — model_benchmark.py:422-466 executed as it is, with the
+  reference's own `ptlflow.utils.timer.Timer` (utils/timer.py:81-96: device synchronisation around every forward),
+* the half switch of validate.py:243-244 / model_benchmark.py:317-319 (`model.half()`, fp16 images),
+
+all on a model that went through `ptlflow_amd.patch.accelerate(model)` and nothing else.  The files are the reference's, unmodified
+(oracle/ref_loader.py: /root/reference here, the staged archive on the GPU box); stood in for are only the third-party packages this
+image lacks (jsonargparse, plotly, lightning's CLI classes — ref_loader._install_script_stubs)."""
+import pytest
+import torch
+
+from oracle import raft_oracle as O
+from oracle import ref_loader
+
+pytestmark = pytest.mark.gpu
+
+REAL = ref_loader.reference_available()
+
+
+def _entry_points():
+    if not REAL:
+        pytest.skip("no reference tree and no staged archive (oracle/_ref)")
+    ref_loader.load_scripts()
+    import ptlflow
+    return ptlflow, ref_loader.ref_script("model_benchmark")
+
+
+def test_get_model_then_accelerate_then_the_references_benchmark(gpu):
+    ptlflow, mb = _entry_points()
+    from jsonargparse import Namespace
+    from ptlflow_amd import patch
+    from ptlflow_amd.update import PfkUpdateBlock
+    torch.manual_seed(1234)
+    model = ptlflow.get_model("raft")                      # the registry's class, built by the reference's own get_model
+    assert type(model).__name__ == "raft" and type(model).__module__ == "ptlflow.models.raft.raft"
+    assert mb.__file__.startswith(ref_loader.REFERENCE_ROOT) and ptlflow.__file__.startswith(ref_loader.REFERENCE_ROOT)
+    model = model.eval()
+    x = O.smooth_pair(1, 436, 1024, seed=11)
+    with torch.no_grad():
+        ref = model({"images": x.clone()})["flows"]         # unpatched, CPU
+    model = model.cuda()                                    # model_benchmark.py:312-316
+    patch.accelerate(model)                                 # <- the only line that is not the reference's
+    try:
+        assert isinstance(model.update_block, PfkUpdateBlock) and model.update_block._skip is not None
+        args = Namespace(num_samples=10, batch_size=1)      # the two fields estimate_inference_time reads (its defaults: 20 / 1)
+        times = mb.estimate_inference_time(args, model, (436, 1024), "fp32")
+        assert len(times) == 10 and all(t > 0 for t in times)
+        times = sorted(times)
+        median_ms = 1e3 * times[len(times) // 2]            # `final_speed_mode: median`, model_benchmark.py:335-341
+        print(f"model_benchmark.estimate_inference_time on the accelerated ptlflow.get_model('raft'): median {median_ms:.2f} ms "
+              f"= {1e3 / median_ms:.1f} pairs/s at 436x1024, batch 1")
+        assert median_ms < 30.0, "the accelerated model runs at the unpatched model's speed: are the seams installed?"
+        with torch.no_grad():
+            got = model({"images": x.cuda()})["flows"].float().cpu()
+    finally:
+        patch.restore(model)
+    mean, mx = O.epe(got[:, 0], ref[:, 0])
+    assert mean <= 1e-3, f"EPE vs the unpatched CPU forward: mean {mean:.3e} max {mx:.3e}"
+
+
+def test_the_references_fp16_protocol(gpu):
+    """model_benchmark.py:317-319 / validate.py:243-244: `model.half()` + fp16 images through `estimate_inference_time(..., "fp16")`."""
+    ptlflow, mb = _entry_points()
+    from jsonargparse import Namespace
+    from ptlflow_amd import patch
+    torch.manual_seed(1234)
+    model = ptlflow.get_model("raft").eval().cuda().half()
+    patch.accelerate(model)
+    try:
+        times = mb.estimate_inference_time(Namespace(num_samples=3, batch_size=1), model, (184, 320), "fp16")
+        assert len(times) == 3
+        with torch.no_grad():
+            out = model({"images": O.smooth_pair(1, 184, 320, seed=11).cuda().half()})["flows"]
+        assert out.dtype == torch.float16 and torch.isfinite(out).all() and out.float().abs().max() > 0.5
+    finally:
+        patch.restore(model)

@@ -1,4 +1,4 @@
-"""The drop-in path a ptlflow user gets, on the MI355X: `ptlflow_amd.seam_model.SeamRAFT` — a torch-only RAFT whose forward IS
+"""The drop-in path a ptlflow user gets, on the MI355X: `tests/seam_model.py::SeamRAFT` — a torch-only RAFT whose forward IS
 the reference's caller loop (raft.py:125-194: module-global `get_corr_block`, `update_block(net, inp, corr, flow)` on NCHW
 tensors, `upsample_flow` in torch ops) — with `patch.accelerate` applied, against the CPU oracle (gate: EPE <= 1e-3).
 bench.py's `dropin` leg times exactly this object."""
@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 def _models(small, iters, seed):
     from ptlflow_amd.raft import RAFT
-    from ptlflow_amd.seam_model import SeamRAFT
+    from seam_model import SeamRAFT
     mirror = RAFT(small=small, iters=iters).load_synthetic(seed).eval()
     P = {k: v.clone() for k, v in mirror.state_dict().items()}
     seam = SeamRAFT(small=small, iters=iters).eval()
@@ -22,7 +22,8 @@ def _models(small, iters, seed):
 
 @pytest.mark.parametrize("small,H,W,iters", [(False, 436, 1024, 32), (True, 184, 320, 12), (False, 375, 1242, 4)])
 def test_accelerated_seam_model_vs_oracle(gpu, small, H, W, iters):
-    from ptlflow_amd import patch, seam_model
+    import seam_model
+    from ptlflow_amd import patch
     from ptlflow_amd.corr import CorrBlock
     from ptlflow_amd.encoder import PfkEncoder
     from ptlflow_amd.update import PfkUpdateBlock
@@ -56,7 +57,7 @@ def test_upsample_seam_dispatches_by_behaviour(gpu):
     """Seam B5 replaces `model.upsample_flow` only if the model's method agrees with the kernel on a probe: a method that computes
     something else (here: a x4 factor) keeps running its own code; gradient-carrying and CPU calls always do."""
     from ptlflow_amd import patch
-    from ptlflow_amd.seam_model import SeamRAFT, convex_upsample_torch
+    from seam_model import SeamRAFT, convex_upsample_torch
 
     class Odd(SeamRAFT):
         def upsample_flow(self, flow, mask):
@@ -95,7 +96,8 @@ def test_fp16_feature_maps_keep_an_fp32_volume(gpu):
     """`model.half()` is the reference's reduced-precision mode (validate.py:243-244): families whose encoder is not wrapped
     (sea_raft, ccmr, ms_raft_plus) hand fp16 maps to the B1 hook.  fp16 operands are exact in fp32, so the block must keep the
     fp32 volume (not round the maps to bf16) and return fp16 like the reference's `corr.to(coords.dtype)`-style cast."""
-    from ptlflow_amd import patch, seam_model
+    import seam_model
+    from ptlflow_amd import patch
     g = torch.Generator().manual_seed(5)
     f1 = (torch.randn(2, 128, 20, 28, generator=g) * 0.5).half()
     f2 = (torch.randn(2, 128, 20, 28, generator=g) * 0.5).half()

@@ -182,3 +182,25 @@ def test_oracle_pyramid_and_lookup_bit_exact_at_baseline_grids(h, w, D, L, r):
         assert ref.shape == out.shape == (1, L * (2 * r + 1) ** 2, h, w)
         assert not bool(torch.isnan(ref).any()), name
         assert torch.equal(ref, out), f"{name}: {(ref != out).sum().item()} of {ref.numel()} values differ"
+
+
+@pytest.mark.reference
+def test_reference_entry_points_load_unmodified():
+    """`ptlflow.get_model("raft")` through the reference's own ptlflow/__init__.py + registry, and `model_benchmark.py` importable as
+    a module (oracle/ref_loader.load_scripts): what tests/test_gpu_reference_scripts.py and bench.py run on the accelerated model."""
+    from oracle import ref_loader
+    if not ref_loader.reference_available():
+        pytest.skip("no reference")
+    ref_loader.load_scripts()
+    import inspect
+    import ptlflow
+    mb = ref_loader.ref_script("model_benchmark")
+    assert {"raft", "raft_small", "gma"} <= set(ptlflow.get_model_names())
+    torch.manual_seed(0)
+    model = ptlflow.get_model("raft_small")
+    assert type(model).__name__ == "raft_small" and model.iters == 32
+    src = inspect.getsource(mb.estimate_inference_time)
+    assert "timer.tic()" in src and "model(inputs)" in src and mb.Timer.__module__ == "ptlflow.utils.timer"
+    from jsonargparse import Namespace
+    times = mb.estimate_inference_time(Namespace(num_samples=1, batch_size=1), model.eval(), (64, 128), "fp32")
+    assert len(times) == 1 and times[0] > 0

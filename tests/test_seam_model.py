@@ -1,4 +1,4 @@
-"""`ptlflow_amd.seam_model.SeamRAFT` — the torch-only, reference-shaped caller of seams B1/B3/B4 used by bench.py's `dropin`
+"""`tests/seam_model.py::SeamRAFT` — the torch-only, reference-shaped caller of seams B1/B3/B4 used by bench.py's `dropin`
 leg — computes what the reference computes (CPU, against the oracle), carries the reference's state_dict layout, and is
 recognised by `patch.accelerate` exactly like a ptlflow model (dispatch by module + class + shapes; restore undoes it)."""
 import sys
@@ -11,7 +11,7 @@ from oracle import raft_oracle as O
 
 def _pair(small, iters, seed=5):
     from ptlflow_amd.raft import RAFT
-    from ptlflow_amd.seam_model import SeamRAFT
+    from seam_model import SeamRAFT
     mirror = RAFT(small=small, iters=iters).load_synthetic(seed).eval()
     seam = SeamRAFT(small=small, iters=iters).eval()
     missing = seam.load_state_dict(mirror.state_dict(), strict=True)       # same keys, same shapes as the mirror (= the reference's)
@@ -33,7 +33,7 @@ def test_unpatched_seam_model_matches_oracle_on_cpu(small, H, W, iters):
 
 
 def test_torch_corr_block_matches_oracle_lookup():
-    from ptlflow_amd.seam_model import TorchCorrBlock
+    from seam_model import TorchCorrBlock
     g = torch.Generator().manual_seed(1)
     f1, f2 = torch.randn(2, 64, 17, 21, generator=g), torch.randn(2, 64, 17, 21, generator=g)
     coords = O.coords_grid(2, 17, 21) + torch.rand(2, 2, 17, 21, generator=g) * 12 - 6
@@ -45,7 +45,8 @@ def test_torch_corr_block_matches_oracle_lookup():
 
 @pytest.mark.parametrize("small", [False, True])
 def test_accelerate_dispatches_on_seam_model(small):
-    from ptlflow_amd import patch, seam_model
+    import seam_model
+    from ptlflow_amd import patch
     from ptlflow_amd.encoder import PfkEncoder
     from ptlflow_amd.update import PfkUpdateBlock
     _, seam = _pair(small, 2)
