@@ -211,6 +211,8 @@ class PfkEncoder(torch.nn.Module):
             batch_dim = x[0].shape[0]
             x = torch.cat(list(x), dim=0)
         y = self._get_engine(x.device)(x)
+        if probe.dtype != torch.float32 and probe.is_floating_point():
+            y = y.to(probe.dtype)      # a half / bf16 model (`model.half()`, validate.py:243-244) gets its features in its own dtype
         if is_list:
             y = torch.split(y, [batch_dim, batch_dim], dim=0)
         return y

@@ -57,3 +57,15 @@ for (h, w) in ((55, 128), (47, 156)):
                 line += f" pix{pix}: row-major {t1:6.1f} us ({alg/t1/1e6:.2f} TB/s) blocked {t2:6.1f} us ({alg/t2/1e6:.2f} TB/s = {100*alg/t2/1e6/8:.1f}% of 8) same={same} |"
             ops.debug_set_lookup_pix(4)
             print(line, flush=True)
+            if B == 8:      # bf16 maps (config 3), fp32 and bf16 output rows
+                lb16 = [p.to(torch.bfloat16) for p in lb]
+                o16 = torch.zeros(B * N, 328, device=dev, dtype=torch.bfloat16)
+                line = f"  bf16 maps, blocked, {fname:8s}:"
+                for pix in (4, 8):
+                    ops.debug_set_lookup_pix(pix)
+                    ta = timeit(lambda: ops.corr_lookup_blocked(lb16, lh, lw, coords, r, o2))
+                    tb = timeit(lambda: ops.corr_lookup_blocked(lb16, lh, lw, coords, r, o16))
+                    tc = timeit(lambda: ops.corr_lookup_blocked(lb, lh, lw, coords, r, o16))
+                    line += f" pix{pix}: fp32 out {ta:6.1f} us | bf16 out {tb:6.1f} us | fp32 maps, bf16 out {tc:6.1f} us |"
+                ops.debug_set_lookup_pix(4)
+                print(line, flush=True)

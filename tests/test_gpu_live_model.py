@@ -76,6 +76,34 @@ def test_accelerated_model(gpu, kind, H, W, iters):
     _run_case(model, gpu, H, W)
 
 
+def test_gma_reference_class_at_the_config3_size(gpu):
+    """BASELINE config 3's gma at its quoted size — the reference's own `ptlflow.models.gma.gma.GMA`, 436x1024, 32 iterations — under
+    `patch.accelerate(model)`: fp32 against the same object's unpatched CPU forward (gate 1e-3), then `conv_precision="bf16"` against
+    the same CPU fp32 forward (gate: 2 x the autocast-CPU gap of this architecture at this size, 9.85e-2 px, measured by
+    tests/test_gpu_bf16_gate.py::test_gma_bf16_gate_headline on the oracle = 0.197 px)."""
+    if not REAL:
+        pytest.skip("no reference tree and no staged archive (oracle/_ref)")
+    from ptlflow_amd import patch
+    model = _build("gma", 32)
+    with torch.no_grad():
+        model.update_block.aggregator.gamma.fill_(0.4)      # the reference initialises gamma to 0 (aggregate branch silent)
+    x = O.smooth_pair(1, 436, 1024, seed=77)
+    with torch.no_grad():
+        ref = model({"images": x.clone()})["flows"][:, 0]
+    model.to(gpu)
+    for prec, gate in (("fp32", 1e-3), ("bf16", 0.197)):
+        patch.accelerate(model, conv_precision=prec)
+        try:
+            with torch.no_grad():
+                got = model({"images": x.to(gpu)})["flows"][:, 0].float().cpu()
+        finally:
+            patch.restore(model)
+        mean, mx = O.epe(got, ref)
+        print(f"gma (reference class) 436x1024 32 it, {prec}: EPE vs its own CPU fp32 forward mean {mean:.3e} max {mx:.3e}")
+        assert mean <= gate, f"{prec}: EPE mean {mean:.3e} max {mx:.3e} (gate {gate})"
+    model.cpu()
+
+
 def _count_mask_work(model, gpu, xs, iters):
     """two forwards + one with `iters - 2`; returns (outputs, short flows, {mask conv2 launches, fused launches, upsampling launches})"""
     eng_cls = type(model.update_block._get_engine(gpu))

@@ -74,6 +74,7 @@ def test_the_references_fp16_protocol(gpu):
         assert len(times) == 3
         with torch.no_grad():
             out = model({"images": O.smooth_pair(1, 184, 320, seed=11).cuda().half()})["flows"]
+        # (the model's dtype all the way through: every seam hands a half model half tensors back)
         assert out.dtype == torch.float16 and torch.isfinite(out).all() and out.float().abs().max() > 0.5
     finally:
         patch.restore(model)

@@ -20,7 +20,7 @@ def _models(small, iters, seed):
     return P, seam
 
 
-@pytest.mark.parametrize("small,H,W,iters", [(False, 436, 1024, 32), (True, 184, 320, 12), (False, 375, 1242, 4)])
+@pytest.mark.parametrize("small,H,W,iters", [(False, 436, 1024, 6), (True, 184, 320, 12), (False, 375, 1242, 4)])
 def test_accelerated_seam_model_vs_oracle(gpu, small, H, W, iters):
     import seam_model
     from ptlflow_amd import patch
