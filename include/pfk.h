@@ -319,6 +319,13 @@ typedef struct {
   int residual_ld;       /* in elements of that type */
   int stride;
   int relu_after_residual;
+  int residual_bf16;     /* LINEAR: 1 = `residual` holds bf16 rows (cout % 4 == 0), 0 = fp32 */
+  /* batched GEMM — `batches` > 1 independent problems of one shape in one grid (LINEAR, one source, 1 x 1, B == 1: M = H*W rows
+   * each): problem b reads src[0].ptr + b*src_batch_stride, weight + b*weight_batch_stride, residual + b*residual_batch_stride and
+   * writes out + b*out_batch_stride (strides in ELEMENTS of the respective type).  GMA's per-pair `attn @ v`
+   * (gma/gma_utils.py:100-113) on a bf16 attention map: A = attn[b] [N][N], B = v[b]^T [C][N]. */
+  int batches;
+  long long src_batch_stride, weight_batch_stride, out_batch_stride, residual_batch_stride;
 } pfk_conv_b16_desc;
 int pfk_conv_ktot_b16(const pfk_conv_b16_desc* d);
 int pfk_conv2d_b16(const pfk_conv_b16_desc* d, pfk_stream_t stream);

@@ -42,7 +42,11 @@ struct B16Args {
   int relu, relu2;
   float scale;
   void* out; int out_ld, out_coff, out_bf16;
-  const void* residual; int residual_ld;   // LINEAR: fp32 rows; GRU epilogues: bf16 rows
+  const void* residual; int residual_ld;   // LINEAR: fp32 rows (bf16 with residual_bf16); GRU epilogues: bf16 rows
+  int residual_bf16;
+  // batched GEMM (LINEAR, one source, 1x1): blockIdx.y selects the problem; byte strides of the source / weight / out / residual
+  int batches;
+  long long src_bs, w_bs, out_bs, res_bs;
   float* h; int h_ld;
   void* h_b16; int hb_ld;         // GRU_Q: bf16 copy of the new hidden state (the next convolutions' A operand), may be null
   void* aux_z; void* aux_rh;      // z, r*h: bf16 [M][Ch]
@@ -247,7 +251,9 @@ struct Epilogue16 {
       const bool ok = p < a.M && any;
       if constexpr (LIN) {
         res32[S][pass] = zero4;
-        if (ok) {
+        if (ok && a.residual_bf16) {       // bf16 rows (cout % 4 == 0 on these launches): widened at once
+          res32[S][pass] = widen(*reinterpret_cast<const u32x2*>(reinterpret_cast<const __bf16*>(a.residual) + p * a.residual_ld + n));
+        } else if (ok) {
           const float* rp = reinterpret_cast<const float*>(a.residual) + p * a.residual_ld + n;
           if (full) res32[S][pass] = *reinterpret_cast<const f32x4*>(rp);
           else {
@@ -420,7 +426,15 @@ struct KStep16 {
 // 4 = no fragment reads inside the K loop, 5 = no workgroup barrier
 template <int EPI, int BM, int BN, int WM, int WN, int NST, int ABL = 0>
 __global__ __launch_bounds__(64 * WM * WN, b16_blocks_per_cu(BM, BN, NST, WM * WN) * WM * WN / 4 > 0 ? b16_blocks_per_cu(BM, BN, NST, WM * WN) * WM * WN / 4 : 1)
-void conv_gemm_b16_kernel(const B16Args a) {
+void conv_gemm_b16_kernel(const B16Args a_in) {
+  B16Args a = a_in;
+  if (a.batches > 1) {        // batched GEMM: this block's problem
+    const long long by = blockIdx.y;
+    a.src[0] = static_cast<const char*>(a.src[0]) + by * a.src_bs;
+    a.weight = static_cast<const char*>(a.weight) + by * a.w_bs;
+    a.out = static_cast<char*>(a.out) + by * a.out_bs;
+    if (a.residual != nullptr) a.residual = static_cast<const char*>(a.residual) + by * a.res_bs;
+  }
   constexpr int TH = 64 * WM * WN;
   using St = Stager16<BM, BN, TH>;
   constexpr int MT = BM / (32 * WM), NT = BN / (32 * WN);
@@ -517,7 +531,7 @@ int launch_b16_one(const B16Args& a0, hipStream_t st) {
   attr_once.run([&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   });
-  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * WM * WN), smem, st, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)(a.batches > 1 ? a.batches : 1)), dim3(64 * WM * WN), smem, st, a);
   return pfk_launch_status();
 }
 
@@ -545,7 +559,7 @@ int launch_b16(const B16Args& a, int epi, hipStream_t st) {
     // dominates (mask conv2, 4 K-steps: 49.6 us on 128x128 vs 52.6); cout <= 128: 256x128; cout 64: 256x64 (15.6 vs 21 us);
     // grids under ~200 big tiles (batch 1): 128x64 with two blocks per CU (177 us per iteration against 208-296 for the others).
     const int pad64 = (a.b_rows + 63) / 64 * 64, pad128 = (a.b_rows + 127) / 128 * 128;
-    const long long tm = (a.M + 255) / 256;
+    const long long tm = ((a.M + 255) / 256) * (a.batches > 1 ? a.batches : 1);
     if (tm * (pad128 / 128) < 200) cfg = 4;
     else if (pad64 < pad128 && a.b_rows < 192) cfg = 3;
     else if (a.b_rows <= 128) cfg = 1;
@@ -628,10 +642,20 @@ int pfk_conv2d_b16(const pfk_conv_b16_desc* d, pfk_stream_t stream) {
   a.relu = d->relu; a.relu2 = d->relu_after_residual; a.scale = d->scale;
   fastdiv_make((unsigned)a.Wo, a.wo_mul, a.wo_sh);
   fastdiv_make((unsigned)a.Ho, a.ho_mul, a.ho_sh);
-  if (d->residual) {      // LINEAR: fp32 rows; GRU epilogues: bf16 rows
+  if (d->residual) {      // LINEAR: fp32 rows (bf16 with residual_bf16); GRU epilogues: bf16 rows
     if (d->residual_ld < d->cout) return PFK_ERR_BAD_ARG;
-    if ((reinterpret_cast<uintptr_t>(d->residual) & (d->epilogue == PFK_EPI_LINEAR ? 15u : 7u)) || (d->residual_ld & 3)) return PFK_ERR_ALIGNMENT;
-    a.residual = d->residual; a.residual_ld = d->residual_ld;
+    const bool r16 = d->epilogue != PFK_EPI_LINEAR || d->residual_bf16;
+    if ((reinterpret_cast<uintptr_t>(d->residual) & (r16 ? 7u : 15u)) || (d->residual_ld & 3) || (r16 && (d->cout & 3))) return PFK_ERR_ALIGNMENT;
+    a.residual = d->residual; a.residual_ld = d->residual_ld; a.residual_bf16 = d->epilogue == PFK_EPI_LINEAR && d->residual_bf16;
+  }
+  if (d->batches > 1) {
+    // batched GEMM: `batches` independent problems of the same shape in one grid (blockIdx.y) — GMA's attn @ v per frame pair
+    if (d->epilogue != PFK_EPI_LINEAR || d->num_src != 1 || d->kh != 1 || d->kw != 1 || d->B != 1) return PFK_ERR_BAD_ARG;
+    if ((d->src_batch_stride & 7) || (d->weight_batch_stride & 7) || (d->out_batch_stride & 3) || (d->residual_batch_stride & 3)) return PFK_ERR_ALIGNMENT;
+    a.batches = d->batches;
+    a.src_bs = d->src_batch_stride * 2; a.w_bs = d->weight_batch_stride * 2;
+    a.out_bs = d->out_batch_stride * (d->out_bf16 ? 2 : 4);
+    a.res_bs = d->residual_batch_stride * (d->residual_bf16 ? 2 : 4);
   }
   switch (d->epilogue) {
     case PFK_EPI_LINEAR:

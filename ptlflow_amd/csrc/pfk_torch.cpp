@@ -216,6 +216,35 @@ void conv2d_b16(at::TensorList srcs, int64_t B, int64_t H, int64_t W, int64_t kh
                 const c10::optional<Tensor>& aux_z, const c10::optional<Tensor>& aux_rh, const c10::optional<Tensor>& residual,
                 int64_t stride, bool relu_after_residual) {
   OpScope scope(weight);
+  if (weight.dim() == 3) {
+    // batched GEMM (pfk_conv_b16_desc.batches): src [Bt, M, K] bf16, weight [Bt, cout, K] bf16, out [Bt, M, cout], residual [Bt, M, cout]
+    TORCH_CHECK(srcs.size() == 1 && srcs[0].dim() == 3 && kh == 1 && kw == 1 && epilogue == PFK_EPI_LINEAR && out.has_value() && out->dim() == 3,
+                "conv2d_b16 (batched): one [Bt, M, K] source, [Bt, cout, K] weight, [Bt, M, cout] out, 1x1, linear epilogue");
+    const Tensor& a = srcs[0];
+    check_dev(a, "src"); check_dev(weight, "weight"); check_dev(*out, "out");
+    const int64_t Bt = a.size(0), M = a.size(1), K = a.size(2);
+    TORCH_CHECK(a.scalar_type() == at::kBFloat16 && weight.scalar_type() == at::kBFloat16 && a.stride(2) == 1 && weight.is_contiguous() &&
+                weight.size(0) == Bt && weight.size(1) == cout && weight.size(2) == (K + 63) / 64 * 64 && B == 1 && H * W == M &&
+                out->size(0) == Bt && out->size(1) == M && out->size(2) == cout && out->stride(2) == 1, "conv2d_b16 (batched): shapes");
+    pfk_conv_b16_desc d{};
+    d.src[0].ptr = a.data_ptr(); d.src[0].ld = a.stride(1); d.src[0].channels = K; d.num_src = 1;
+    d.B = 1; d.H = H; d.W = W; d.kh = 1; d.kw = 1; d.cout = cout; d.epilogue = PFK_EPI_LINEAR; d.relu = relu; d.scale = (float)scale;
+    d.weight = weight.data_ptr();
+    d.out = out->data_ptr(); d.out_ld = out->stride(1); d.out_bf16 = out->scalar_type() == at::kBFloat16;
+    TORCH_CHECK(d.out_bf16 || out->scalar_type() == at::kFloat, "conv2d_b16: out must be bfloat16 or float32");
+    d.batches = Bt; d.src_batch_stride = a.stride(0); d.weight_batch_stride = weight.stride(0); d.out_batch_stride = out->stride(0);
+    if (bias.has_value()) { check_dev_f32(*bias, "bias"); TORCH_CHECK(bias->numel() == cout && bias->is_contiguous()); d.bias = fptr(*bias); }
+    if (residual.has_value()) {
+      check_dev(*residual, "residual");
+      TORCH_CHECK(residual->dim() == 3 && residual->size(0) == Bt && residual->size(1) == M && residual->size(2) == cout && residual->stride(2) == 1,
+                  "conv2d_b16 (batched): residual [Bt, M, cout]");
+      d.residual_bf16 = residual->scalar_type() == at::kBFloat16;
+      TORCH_CHECK(d.residual_bf16 || residual->scalar_type() == at::kFloat, "conv2d_b16: residual must be bfloat16 or float32");
+      d.residual = residual->data_ptr(); d.residual_ld = residual->stride(1); d.residual_batch_stride = residual->stride(0);
+    }
+    check_ok(pfk_conv2d_b16(&d, cur_stream()), "conv2d_b16 (batched)");
+    return;
+  }
   TORCH_CHECK(srcs.size() >= 1 && srcs.size() <= 3, "conv2d_b16: 1..3 sources");
   TORCH_CHECK(stride >= 1, "conv2d_b16: stride");
   pfk_conv_b16_desc d{};
@@ -257,9 +286,10 @@ void conv2d_b16(at::TensorList srcs, int64_t B, int64_t H, int64_t W, int64_t kh
     d.aux_rh = aux_rh->data_ptr();
   }
   if (residual.has_value()) {
-    if (epilogue == PFK_EPI_LINEAR) check_pm(*residual, "residual"); else check_pm_b16(*residual, "residual");
+    const bool r16 = check_pm_any(*residual, "residual");
+    TORCH_CHECK(epilogue == PFK_EPI_LINEAR || r16, "conv2d_b16: the GRU epilogues take a bfloat16 residual (the context term)");
     TORCH_CHECK(residual->size(0) == M && residual->size(1) == cout, "conv2d_b16: residual must be a [M, cout] view");
-    d.residual = residual->data_ptr(); d.residual_ld = residual->stride(0);
+    d.residual = residual->data_ptr(); d.residual_ld = residual->stride(0); d.residual_bf16 = r16 && epilogue == PFK_EPI_LINEAR;
   }
   check_ok(pfk_conv2d_b16(&d, cur_stream()), "conv2d_b16");
 }

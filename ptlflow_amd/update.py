@@ -129,9 +129,10 @@ class UpdateEngine:
         # "bf16" = BASELINE config 3's precision as the reference's reduced-precision switch gives it (model_benchmark.py:317-319 /
         # torch.autocast: every convolution reads and writes 16-bit tensors): K8b, `pfk_conv2d_b16` — bf16 ACTIVATION STORAGE between
         # this engine's own kernels (producer epilogues emit bf16 once), both GEMM operands by LDS-DMA; the recurrent state h, the
-        # coordinates / flow and every accumulator stay fp32.  Blocks with an aggregate branch (GMA: fp32 attention map as a GEMM
-        # operand; CCMR: the caller's torch module reads the motion features) keep the split kernel with one plane (fp32 storage).
-        self.b16 = conv_precision == "bf16" and not spec.aggregate
+        # coordinates / flow and every accumulator stay fp32.  GMA's aggregate branch runs on a bf16 copy of the attention map (what
+        # `attn @ v` reads under autocast: half the bytes of the 198 MB-per-pair operand that every iteration streams).  CCMR (the
+        # caller's torch module reads the motion features) keeps the split kernel with one plane (fp32 storage).
+        self.b16 = conv_precision == "bf16" and not spec.external_aggregate
         self.ops = torch.ops.pfk
         self.spec = spec
         self.device = device
@@ -266,8 +267,11 @@ class UpdateEngine:
         self._delta = torch.zeros(B, 2, H, W, device=dev, dtype=torch.float32)
         if s.aggregate and not s.external_aggregate:
             N = H * W
-            self.vbuf = z(s.motion_channels)
-            self.vT = torch.zeros(B, s.motion_channels, round_up(N, 32), device=dev, dtype=torch.float32)
+            self.vbuf = a(s.motion_channels)
+            if self.b16:      # K-contiguous B operand of the batched attn @ v GEMM: [B][C][N padded to the kernel's 64-wide K-steps]
+                self.vT = torch.zeros(B, s.motion_channels, round_up(round_up(N, 8), 64), device=dev, dtype=torch.bfloat16)
+            else:
+                self.vT = torch.zeros(B, s.motion_channels, round_up(N, 32), device=dev, dtype=torch.float32)
             self.attn = None
         # scratch for the stream-K conv schedules (partials + flags), one per stream that may run convolutions concurrently: the
         # main chain, the flow branch of the motion encoder and the mask branch (RAFT._iterate's forked mode) — with its own
@@ -359,6 +363,12 @@ class UpdateEngine:
         N = H * W
         if attn.dim() != 4 or attn.shape[0] != B or attn.shape[1] != 1 or attn.shape[2] != N or attn.shape[3] != N:
             raise RuntimeError(f"attention must be [B,1,N,N] with one head, got {tuple(attn.shape)}")
+        if self.b16:      # the bf16 copy the per-iteration GEMM streams (rows padded to 16 bytes, pad columns zero), once per forward
+            a = torch.zeros(B, N, round_up(N, 8), device=attn.device, dtype=torch.bfloat16) if N % 8 else \
+                torch.empty(B, N, N, device=attn.device, dtype=torch.bfloat16)
+            a[:, :, :N].copy_(attn.reshape(B, N, N))
+            self.attn = a
+            return
         a = attn.float().reshape(B, N, N)
         if N % 4 or not a.is_contiguous():
             pad = torch.zeros(B, N, round_up(N, 4), device=a.device, dtype=torch.float32)
@@ -373,6 +383,23 @@ class UpdateEngine:
         N = H * W
         o = s.hidden + s.context
         mc = s.motion_channels
+        if self.b16:
+            # K8b: v = to_v(mf) in bf16, V^T by one small strided copy, then ONE batched GEMM over the pairs —
+            # out[b] = mf[b] + gamma * attn[b] @ v[b] with the bf16 attention map as the LDS-DMA'd A operand
+            hxb = self.hxb.view(B, N, self.hxb.shape[1])
+            self._conv([self.hxb[:, o: o + mc]], 1, 1, "tv", mc, relu=False, out=self.vbuf)
+            self.vT[:, :, :N].copy_(self.vbuf.view(B, N, mc).transpose(1, 2))
+            prof = self.profile
+            if prof is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            self.ops.conv2d_b16([self.attn], 1, H, W, 1, 1, self.vT, None, mc, EPI_LINEAR, False, self.gamma,
+                                hxb[:, :, o + mc: o + 2 * mc], None, None, None, None, hxb[:, :, o: o + mc])
+            if prof is not None:
+                e1.record()
+                prof.setdefault("ag", []).append((e0, e1))
+                self.flops["ag"] = 2.0 * B * N * N * mc
+            return
         mf = self.hx[:, o: o + mc]
         self._conv([mf], 1, 1, "tv", mc, relu=False, out=self.vbuf)
         self.ops.pm_to_cm(self.vbuf, self.vT)

@@ -240,3 +240,61 @@ def test_engine_b16_step_against_the_oracle_block(gpu, small):
     assert (delta.cpu() - rdelta).abs().max() < 8e-2 * (1 + rdelta.abs().max())
     if rmask is not None:
         assert (eng.mask_nchw().cpu() - rmask).abs().mean() < 2e-2 * (1 + rmask.abs().mean())
+
+
+@pytest.mark.parametrize("Bt,N,C", [(2, 920, 128), (3, 333, 64)])
+def test_conv_b16_batched_gemm_with_bf16_residual(gpu, Bt, N, C):
+    """GMA's `fmap + gamma * (attn @ v)` (gma/gma_utils.py:100-113) as ONE batched K8b launch: per pair A = attn[b] [N][N] bf16 (rows
+    padded to 16 bytes, pad columns zero), B = v[b]^T [C][K], bf16 residual rows and bf16 output inside a wider buffer."""
+    torch.manual_seed(14)
+    Np, K = (N + 7) // 8 * 8, ((N + 7) // 8 * 8 + 63) // 64 * 64
+    attn = torch.zeros(Bt, N, Np)
+    attn[:, :, :N] = torch.softmax(torch.randn(Bt, N, N) * 2, dim=-1)
+    attn = r16(attn)
+    v = r16(torch.randn(Bt, N, C))
+    mf = r16(torch.randn(Bt, N, C))
+    gamma = 0.37
+    ref = mf + gamma * torch.bmm(attn[:, :, :N], v)
+    vT = torch.zeros(Bt, C, K, device=gpu, dtype=BF)
+    vT[:, :, :N] = v.transpose(1, 2).to(gpu, BF)
+    buf = torch.full((Bt, N, 2 * C + 8), 3.0, device=gpu, dtype=BF)
+    buf[:, :, :C] = mf.to(gpu, BF)
+    hw = next((h, N // h) for h in range(int(math.sqrt(N)), 0, -1) if N % h == 0)
+    torch.ops.pfk.conv2d_b16([attn.to(gpu, BF)], 1, hw[0], hw[1], 1, 1, vT, None, C, EPI_LINEAR, False, gamma, buf[:, :, C: 2 * C],
+                             None, None, None, None, buf[:, :, :C])
+    close_b16(buf[:, :, C: 2 * C].float().cpu(), ref, True)
+    assert bool((buf[:, :, 2 * C:] == 3.0).all()) and torch.equal(buf[:, :, :C].float().cpu(), mf)
+
+
+def test_engine_b16_gma_step(gpu):
+    """One GMA update-block call on the K8b engine (aggregate branch on the bf16 attention map) against the oracle's block in fp32."""
+    from ptlflow_amd.raft import GMA
+    from ptlflow_amd.update import UpdateEngine
+    torch.manual_seed(15)
+    model = GMA().load_synthetic(5)
+    with torch.no_grad():
+        model.update_block.aggregator.gamma.fill_(0.4)
+    P = {k[len("update_block."):]: v for k, v in model.state_dict().items() if k.startswith("update_block.")}
+    s = model.spec
+    B, H, W = 2, 16, 24
+    N = H * W
+    net = torch.tanh(torch.randn(B, s.hidden, H, W))
+    inp = torch.relu(torch.randn(B, s.context, H, W))
+    corr = torch.randn(B, s.corr_channels, H, W)
+    flow = torch.randn(B, 2, H, W) * 2
+    attn = torch.softmax(torch.randn(B, 1, N, N), dim=-1)
+    rnet, rmask, rdelta = O.gma_update_block(P, net, inp, corr, flow, attn)
+    eng = UpdateEngine(P, s, gpu, "bf16")
+    assert eng.b16
+    eng.bind(B, H, W)
+    eng.load_state(net.to(gpu), inp.to(gpu))
+    eng.set_attention(attn.to(gpu))
+    torch.ops.pfk.nchw_to_pm(flow.to(gpu).contiguous(), eng.flow_view)
+    eng.flow_changed()
+    eng.corr16[:, : s.corr_channels] = pm(corr).to(gpu, BF)
+    c0 = O.coords_grid(B, H, W).to(gpu)
+    delta = torch.empty_like(c0)
+    eng.motion_and_gru(eng.corr16)
+    eng.heads(c0, c0 + flow.to(gpu), delta, want_mask=True)
+    assert (eng.net_nchw().cpu() - rnet).abs().max() < 6e-2 and (eng.net_nchw().cpu() - rnet).abs().mean() < 6e-3
+    assert (delta.cpu() - rdelta).abs().max() < 8e-2 * (1 + rdelta.abs().max())
