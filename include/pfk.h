@@ -494,6 +494,12 @@ int pfk_norm_apply_f32(const float* x, int x_ld, const float* mean, const float*
                        int residual_ld, float* out, int out_ld, int B, int HW, int C, int relu,
                        int relu_after_residual, pfk_stream_t stream);
 
+/* same with bf16 residual rows and a bf16 output (ABI 7; ld in elements, 8-byte aligned rows): x — the fp32 convolution output the
+ * statistics were taken from — is normalised in fp32; what the next convolution (pfk_conv2d_b16) reads is rounded once. */
+int pfk_norm_apply_b16(const float* x, int x_ld, const float* mean, const float* rstd, const void* residual_bf16,
+                       int residual_ld, void* out_bf16, int out_ld, int B, int HW, int C, int relu,
+                       int relu_after_residual, pfk_stream_t stream);
+
 /* In-place softmax over each row of x [rows][ld] (cols entries used) — GMA's attention map (gma/gma_utils.py:75-76:
  * `sim.softmax(dim=-1)`, once per forward; the similarity itself is pfk_corr_volume_f32 of the q / k maps). */
 int pfk_softmax_rows_f32(float* x, long long rows, int cols, long long ld, pfk_stream_t stream);

@@ -185,9 +185,30 @@ __global__ void instnorm_finish_kernel(const double* __restrict__ sum, const dou
 }
 
 // y = (x - mean) * rstd ; relu? ; [y = residual + y ; relu?]   (float4 per thread)
+// TR / TO = __bf16: the residual rows / the output as the K8b convolutions hold activations (ABI 7): the statistics and the
+// normalisation stay fp32 on the fp32 convolution output, only what the next convolution reads is 16 bits wide.
+__device__ __forceinline__ f32x4 na_load4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 na_load4(const __bf16* p) {
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  const u32x2 w = *reinterpret_cast<const u32x2*>(p);
+  f32x4 v;
+  v[0] = __builtin_bit_cast(float, w[0] << 16); v[1] = __builtin_bit_cast(float, w[0] & 0xffff0000u);
+  v[2] = __builtin_bit_cast(float, w[1] << 16); v[3] = __builtin_bit_cast(float, w[1] & 0xffff0000u);
+  return v;
+}
+__device__ __forceinline__ void na_store4(float* p, const f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void na_store4(__bf16* p, const f32x4 v) {
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  bf16x4 h;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) h[e] = (__bf16)v[e];
+  *reinterpret_cast<bf16x4*>(p) = h;
+}
+
+template <typename TR = float, typename TO = float>
 __global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict__ x, int x_ld, const float* __restrict__ mean,
-                                                         const float* __restrict__ rstd, const float* __restrict__ residual,
-                                                         int res_ld, float* __restrict__ out, int out_ld, long long M, int HW,
+                                                         const float* __restrict__ rstd, const TR* __restrict__ residual,
+                                                         int res_ld, TO* __restrict__ out, int out_ld, long long M, int HW,
                                                          int C, int relu, int relu_after) {
   const int tpr = C >> 2;
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -204,13 +225,13 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict
     for (int e = 0; e < 4; ++e) v[e] = (v[e] < 0.f) ? 0.f : v[e];
   }
   if (residual != nullptr) {
-    v = *reinterpret_cast<const f32x4*>(residual + p * res_ld + c4) + v;
+    v = na_load4(residual + p * res_ld + c4) + v;
     if (relu_after) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = (v[e] < 0.f) ? 0.f : v[e];
     }
   }
-  *reinterpret_cast<f32x4*>(out + p * out_ld + c4) = v;
+  na_store4(out + p * out_ld + c4, v);
 }
 
 
@@ -492,8 +513,26 @@ int pfk_norm_apply_f32(const float* x, int x_ld, const float* mean, const float*
   const long long threads = M * (C >> 2);
   const long long blocks = (threads + 255) / 256;
   if (blocks > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(norm_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, x_ld,
+  hipLaunchKernelGGL((norm_apply_kernel<float, float>), dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, x_ld,
                      mean, rstd, residual, residual_ld, out, out_ld, M, HW, C, relu, relu_after_residual);
+  return pfk_launch_status();
+}
+
+int pfk_norm_apply_b16(const float* x, int x_ld, const float* mean, const float* rstd, const void* residual_bf16,
+                       int residual_ld, void* out_bf16, int out_ld, int B, int HW, int C, int relu,
+                       int relu_after_residual, pfk_stream_t stream) {
+  if (!x || !mean || !rstd || !out_bf16 || B <= 0 || HW <= 0 || C <= 0 || x_ld < C || out_ld < C) return PFK_ERR_BAD_ARG;
+  if ((C & 3) || (x_ld & 3) || (out_ld & 3) || !pfk_aligned16(x) || (reinterpret_cast<uintptr_t>(out_bf16) & 7u) || !pfk_aligned16(mean) ||
+      !pfk_aligned16(rstd))
+    return PFK_ERR_ALIGNMENT;
+  if (residual_bf16 && (residual_ld < C || (residual_ld & 3) || (reinterpret_cast<uintptr_t>(residual_bf16) & 7u))) return PFK_ERR_ALIGNMENT;
+  const long long M = (long long)B * HW;
+  const long long threads = M * (C >> 2);
+  const long long blocks = (threads + 255) / 256;
+  if (blocks > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL((norm_apply_kernel<__bf16, __bf16>), dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, x_ld,
+                     mean, rstd, static_cast<const __bf16*>(residual_bf16), residual_ld, static_cast<__bf16*>(out_bf16), out_ld, M, HW, C,
+                     relu, relu_after_residual);
   return pfk_launch_status();
 }
 

@@ -678,10 +678,22 @@ void instnorm_stats(const Tensor& x, int64_t B, int64_t HW, double eps, Tensor m
 void norm_apply(const Tensor& x, const Tensor& mean, const Tensor& rstd, const c10::optional<Tensor>& residual, Tensor out,
                 int64_t B, int64_t HW, bool relu, bool relu_after_residual) {
   OpScope scope(x);
-  check_pm(x, "x"); check_pm(out, "out"); check_dev_f32(mean, "mean"); check_dev_f32(rstd, "rstd");
+  check_pm(x, "x"); check_dev_f32(mean, "mean"); check_dev_f32(rstd, "rstd");
+  const bool out_b16 = check_pm_any(out, "out");
   const int C = x.size(1);
   TORCH_CHECK(x.size(0) == B * HW && out.size(0) == B * HW && out.size(1) == C, "norm_apply: shapes");
   TORCH_CHECK(mean.numel() == B * C && rstd.numel() == B * C, "norm_apply: mean/rstd [B*C]");
+  if (out_b16) {      // the K8b encoders: bf16 residual rows (if any), bf16 output
+    const void* r16 = nullptr; int r16_ld = 0;
+    if (residual.has_value()) {
+      check_pm_b16(*residual, "residual");
+      TORCH_CHECK(residual->size(0) == B * HW && residual->size(1) == C, "norm_apply: residual shape");
+      r16 = residual->data_ptr(); r16_ld = residual->stride(0);
+    }
+    check_ok(pfk_norm_apply_b16(fptr(x), x.stride(0), fptr(mean), fptr(rstd), r16, r16_ld, out.data_ptr(), out.stride(0), (int)B, (int)HW, C,
+                                relu, relu_after_residual, cur_stream()), "norm_apply (bf16 out)");
+    return;
+  }
   const float* r = nullptr; int r_ld = 0;
   if (residual.has_value()) {
     check_pm(*residual, "residual");

@@ -51,6 +51,9 @@ class EncoderEngine:
         self.norm = norm
         self.device = device
         self.nsplit = CONV_PRECISIONS[conv_precision]
+        # "bf16": K8b (`pfk_conv2d_b16`, UpdateEngine's docstring) — bf16 activation storage between the layers; a convolution
+        # that feeds an instance norm writes fp32 (the statistics and the normalisation stay fp32), the norm-apply pass rounds once
+        self.b16 = conv_precision == "bf16"
         self._ws: Optional[torch.Tensor] = None
         self.max_matrix_bytes = 2 ** 31 - 1   # 32-bit byte offsets in the convolution kernels
         self.pack(params)
@@ -71,6 +74,8 @@ class EncoderEngine:
 
     def _pk(self, w: torch.Tensor) -> torch.Tensor:
         cin = w.shape[1]
+        if self.b16:
+            return pack_conv_weight(w, [(0, cin, cin)], kpad=64).to(torch.bfloat16).contiguous()
         packed = pack_conv_weight(w, [(0, cin, cin)])
         return packed if self.nsplit == 0 else split_bf16_planes(packed, self.nsplit)
 
@@ -95,15 +100,23 @@ class EncoderEngine:
         self.w = W
 
     # ------------------------------------------------------------------ kernels
-    def _conv(self, x, B, H, W, k, key, cout, stride=1, relu=False, residual=None, relu2=False):
+    def _conv(self, x, B, H, W, k, key, cout, stride=1, relu=False, residual=None, relu2=False, fp32_out=None):
         M = B * _out(H, stride) * _out(W, stride)
+        if self.b16:
+            # fp32 output where an instance norm follows (it reads the un-rounded convolution result), bf16 otherwise
+            f32 = (self.norm == "instance") if fp32_out is None else fp32_out
+            out = torch.empty(M, cout, device=self.device, dtype=torch.float32 if f32 else torch.bfloat16)
+            self.ops.conv2d_b16([x], B, H, W, k, k, self.w[key + ".w"], self.w[key + ".b"], cout, EPI_LINEAR, relu, 1.0, out,
+                                None, None, None, None, residual, stride, relu2)
+            return out
         out = torch.empty(M, cout, device=self.device, dtype=torch.float32)
         self.ops.conv2d([x], B, H, W, k, k, self.w[key + ".w"], self.w[key + ".b"], cout, EPI_LINEAR, relu, 1.0, out,
                         None, None, None, None, residual, stride, relu2)
         return out
 
     def _inorm(self, x, B, HW, relu, residual=None, relu2=False):
-        """InstanceNorm2d (+relu, + residual add + relu) in place on the pixel-major buffer x."""
+        """InstanceNorm2d (+relu, + residual add + relu) on the pixel-major buffer x: in place (fp32), or into a fresh bf16 buffer
+        on the K8b path (x is the fp32 convolution output, the result is what the next convolution reads)."""
         C = x.shape[1]
         need = self.ops.instnorm_workspace_bytes(B, C)
         if self._ws is None or self._ws.numel() < need:
@@ -111,8 +124,9 @@ class EncoderEngine:
         mean = torch.empty(B * C, device=self.device, dtype=torch.float32)
         rstd = torch.empty(B * C, device=self.device, dtype=torch.float32)
         self.ops.instnorm_stats(x, B, HW, EPS, mean, rstd, self._ws)
-        self.ops.norm_apply(x, mean, rstd, residual, x, B, HW, relu, relu2)
-        return x
+        out = torch.empty(x.shape[0], C, device=self.device, dtype=torch.bfloat16) if self.b16 else x
+        self.ops.norm_apply(x, mean, rstd, residual, out, B, HW, relu, relu2)
+        return out
 
     def _bottleneck(self, x, B, H, W, name, cout, stride):
         """BottleneckBlock.forward (extractor.py:110-119): relu(norm(1x1)) -> relu(norm(3x3, stride)) -> relu(norm(1x1)); relu(x + y)."""
@@ -164,11 +178,13 @@ class EncoderEngine:
         self.ops.conv_stem(img, self.w["stem.w"], self.w["stem.b"], x, self.norm != "instance")
         if self.norm == "instance":
             x = self._inorm(x, B, H1 * W1, relu=True)
+        elif self.b16:
+            x = x.to(torch.bfloat16)
         h, w = H1, W1
         for name, _cin, cout, stride in self.blocks:
             x = self._block(x, B, h, w, name, cout, stride)
             h, w = _out(h, stride), _out(w, stride)
-        y = self._conv(x, B, h, w, 1, "out", self.out_dim)
+        y = self._conv(x, B, h, w, 1, "out", self.out_dim, fp32_out=True)
         return y.view(B, h, w, self.out_dim).permute(0, 3, 1, 2)
 
 

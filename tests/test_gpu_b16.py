@@ -298,3 +298,46 @@ def test_engine_b16_gma_step(gpu):
     eng.heads(c0, c0 + flow.to(gpu), delta, want_mask=True)
     assert (eng.net_nchw().cpu() - rnet).abs().max() < 6e-2 and (eng.net_nchw().cpu() - rnet).abs().mean() < 6e-3
     assert (delta.cpu() - rdelta).abs().max() < 8e-2 * (1 + rdelta.abs().max())
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,H,W", [(64, 96, 3, 2, 21, 34), (64, 96, 1, 2, 20, 33), (96, 128, 3, 2, 11, 16)])
+def test_conv_b16_strided(gpu, cin, cout, k, stride, H, W):
+    """The encoders' stride-2 3x3 / 1x1 convolutions (raft/extractor.py:31-34, 50-58) on the K8b kernel, residual add + second relu
+    fused (the ResidualBlock's `relu(x + y)`), bf16 residual rows."""
+    torch.manual_seed(16)
+    B = 2
+    x = r16(torch.randn(B, cin, H, W))
+    wt = r16(torch.randn(cout, cin, k, k) / math.sqrt(cin * k * k))
+    bias = torch.randn(cout)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    res = r16(torch.randn(B, cout, Ho, Wo))
+    ref = F.relu(res + F.relu(F.conv2d(x, wt, bias, stride=stride, padding=k // 2)))
+    out = torch.zeros(B * Ho * Wo, cout, device=gpu, dtype=BF)
+    torch.ops.pfk.conv2d_b16([pm(x).to(gpu, BF)], B, H, W, k, k, pack16(wt, [(0, cin, cin)]), bias.cuda(), cout, EPI_LINEAR, True, 1.0, out,
+                             None, None, None, None, pm(res).to(gpu, BF), stride, True)
+    close_b16(unpm(out, B, Ho, Wo), ref, True)
+
+
+@pytest.mark.parametrize("norm,small", [("instance", False), ("batch", False), ("instance", True), ("none", True)])
+def test_encoder_b16_against_the_oracle_encoder(gpu, norm, small):
+    """BasicEncoder / SmallEncoder (raft/extractor.py:122-267) on the K8b path (bf16 activation storage between the layers, fp32
+    instance-norm statistics) against the oracle's fp32 encoder: the distance is the bf16 rounding of ~20 layers of activations."""
+    from ptlflow_amd.encoder import EncoderEngine
+    from ptlflow_amd.raft import Encoder
+    torch.manual_seed(17)
+    out_dim = 128 if small else 256
+    enc = Encoder(out_dim, norm, small).eval()
+    if norm == "batch":
+        for m in enc.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5); m.weight.data.uniform_(0.5, 1.5); m.bias.data.normal_(0, 0.1)
+    P = enc.state_dict()
+    x = torch.rand(2, 3, 96, 136) * 2 - 1
+    ref = O.encoder({k: v.clone() for k, v in P.items()}, x, norm, small)
+    got = EncoderEngine(P, norm, gpu, "bf16", small)(x.to(gpu)).float().cpu()
+    f32 = EncoderEngine(P, norm, gpu, "fp32", small)(x.to(gpu)).float().cpu()
+    assert got.shape == ref.shape
+    scale = ref.abs().mean()
+    assert (f32 - ref).abs().max() < 1e-3 * (1 + ref.abs().max())
+    assert (got - ref).abs().mean() < 2e-2 * scale, f"mean err {(got - ref).abs().mean():.3e} vs scale {scale:.3e}"
+    assert (got - ref).abs().max() < 0.25 * (1 + ref.abs().max())

@@ -132,6 +132,41 @@ def test_lookup_blocked_bit_exact(gpu, B, h, w, L, r):
             torch.ops.pfk.debug_set_lookup_pix(4)
 
 
+@pytest.mark.parametrize("B,h,w,L,r", [(1, 16, 24, 4, 4), (2, 23, 39, 4, 3), (1, 55, 128, 4, 4), (1, 13, 17, 2, 4), (1, 47, 156, 4, 4), (1, 46, 62, 4, 2)])
+def test_lookup_blocked_bf16_maps_bit_exact(gpu, B, h, w, L, r):
+    """K3 on bf16 maps in the blocked layout (pfk_corr_lookup_blocked_bf16; BASELINE config 3's volume): the window is fetched as
+    aligned pairs of bf16 elements — the result must be the oracle's lookup on the widened maps, bit for bit (grid_sample runs in fp32
+    under autocast), on every coordinate family, odd level widths included (the pair's odd partner outside the map is zero padding)."""
+    torch.manual_seed(3)
+    D = 32
+    f1, f2 = torch.randn(B, D, h, w), torch.randn(B, D, h, w)
+    pyr = [p.to(torch.bfloat16) for p in O.correlation_pyramid(f1, f2, L)]
+    wide = [p.float() for p in pyr]
+    lh, lw = [p.shape[-2] for p in pyr], [p.shape[-1] for p in pyr]
+    n = 2 * r + 1
+    for fill in (0.0, 9.0):       # whatever the pad elements of the edge tiles hold must not leak into a sample
+        lv = []
+        for p in pyr:
+            q = p.reshape(p.shape[0], p.shape[-2], p.shape[-1])
+            M_, hh, ww = q.shape
+            th, tw = (hh + 3) // 4, (ww + 7) // 8
+            t = torch.full((M_, th * 4, tw * 8), fill, dtype=torch.bfloat16)
+            t[:, :hh, :ww] = q
+            lv.append(t.view(M_, th, 4, tw, 8).permute(0, 1, 3, 2, 4).reshape(M_, th * tw * 32).contiguous().cuda())
+        for pix in (104, 8):
+            torch.ops.pfk.debug_set_lookup_pix(pix)
+            try:
+                for name, c in _coords_cases(B, h, w):
+                    ref = O.lookup(wide, c, r)
+                    out = torch.full((B * h * w, L * n * n), -7.0, device=gpu)
+                    torch.ops.pfk.corr_lookup_blocked(lv, lh, lw, c.cuda(), r, out)
+                    got = unpm(out, B, h, w)
+                    same = (got == ref) | (torch.isnan(got) & torch.isnan(ref))
+                    assert bool(same.all()), f"{name} (pix {pix}, pad {fill}): {(~same).sum().item()} of {same.numel()} differ"
+            finally:
+                torch.ops.pfk.debug_set_lookup_pix(4)
+
+
 @pytest.mark.parametrize("M,H,W", [(7, 55, 128), (64, 27, 64), (5, 13, 32), (3, 6, 16), (4, 3, 5), (2, 1, 2), (3, 47, 156), (2, 23, 78)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_pool_blocked_bit_exact(gpu, M, H, W, dtype):
