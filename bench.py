@@ -65,6 +65,7 @@ def host_cores() -> int:
 
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # same table, "Peak BF16/FP16 MFMA" (dense)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -112,6 +113,47 @@ def instrumented_forward(model, inputs):
     finally:
         eng.profile = None
     return stats
+
+
+def roofline_b16(model, inputs):
+    """`roofline_bf16`: the dominant launch of the bf16-storage forward (K8b, `pfk_conv2d_b16`) against the LARGER of its two floors —
+    algorithmic FLOPs / the dense bf16 matrix peak and algorithmic HBM bytes / 8 TB/s (these launches move 16-bit activations: some
+    are bound by their epilogue bytes, not by the matrix pipe) — plus the per-call-site table and the bf16 lookup."""
+    stats = instrumented_forward(model, inputs)
+    lookup = stats.pop("lookup", None)
+
+    def floors(v):
+        t_mfma = v["gflop_per_launch"] * 1e9 / (BF16_MFMA_PEAK_TFLOPS * 1e12)
+        t_hbm = (v["bytes_per_launch"] or 0.0) / (HBM_PEAK_GBS * 1e9)
+        return t_mfma, t_hbm
+
+    table = {}
+    for k, v in sorted(stats.items(), key=lambda kv: -kv[1]["total_ms"]):
+        t_mfma, t_hbm = floors(v)
+        t = v["avg_us"] * 1e-6
+        table[k] = {"avg_us": round(v["avg_us"], 2), "n": v["launches"], "tflops": round(v["gflop_per_launch"] / t / 1e3, 1),
+                    "gbs": round((v["bytes_per_launch"] or 0.0) / t / 1e9, 1), "bound": "mfma" if t_mfma >= t_hbm else "hbm",
+                    "frac_of_floor": round(max(t_mfma, t_hbm) / t, 3)}
+    dom = max(stats, key=lambda k: stats[k]["total_ms"])
+    v = stats[dom]
+    t_mfma, t_hbm = floors(v)
+    t = v["avg_us"] * 1e-6
+    if t_mfma >= t_hbm:
+        obj = {"bound": "mfma", "achieved": v["gflop_per_launch"] / t / 1e3, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s"}
+    else:
+        obj = {"bound": "hbm", "achieved": v["bytes_per_launch"] / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+    obj["frac"] = obj["achieved"] / obj["peak"]
+    obj.update({"kernel": f"conv_gemm_b16_kernel[{dom}]", "traffic": None, "avg_us": v["avg_us"], "launches_per_forward": v["launches"],
+                "gflop_per_launch": v["gflop_per_launch"], "algorithmic_bytes_per_launch": v["bytes_per_launch"],
+                "floor_us": {"mfma": 1e6 * t_mfma, "hbm": 1e6 * t_hbm},
+                "method": "HIP events around each launch, separate instrumented forward of the bf16-storage model (in situ, side stream live)",
+                "kernels": table})
+    if lookup and lookup.get("bytes_per_launch"):
+        gbs = lookup["bytes_per_launch"] / (lookup["avg_us"] * 1e-6) / 1e9
+        obj["lookup"] = {"kernel": "lookup_kernel (K3, bf16 maps in the blocked layout, paired fetch, bf16 rows out)", "bound": "hbm",
+                         "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "avg_us": lookup["avg_us"],
+                         "algorithmic_bytes_per_launch": lookup["bytes_per_launch"]}
+    return obj
 
 
 def timed(fn, warmup: int, steps: int) -> float:
@@ -780,6 +822,11 @@ def main():
                     if target is not None:
                         mean, mx = _epe(m(xin)["flows"][:1, 0], target)
                         legs[name].update({"epe_mean": mean, "epe_max": mx, "epe_against": "cpu fp32 forward of the same model"})
+                    if name == "raft_bf16" and not args.no_roofline:
+                        try:
+                            result["roofline_bf16"] = roofline_b16(m, xin)
+                        except Exception as e:
+                            result["roofline_bf16"] = {"error": repr(e)[:300]}
                     del m, xin
                     torch.cuda.empty_cache()
                 except Exception as e:

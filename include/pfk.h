@@ -480,6 +480,11 @@ int pfk_forward_interpolate_f32(const float* flow, float* out, int B, int H, int
 int pfk_conv_stem_f32(const float* img, const float* weight, const float* bias, float* out, int out_ld, int B,
                       int H, int W, int cout, int relu, pfk_stream_t stream);
 
+/* same with a bf16 output (ABI 7; cout = 32 or 64 only — the MFMA kernel): what the K8b convolutions (pfk_conv2d_b16) read next */
+int pfk_conv_stem_b16(const float* img, const float* weight, const float* bias, void* out_bf16, int out_ld, int B,
+                      int H, int W, int cout, int relu, pfk_stream_t stream);
+int pfk_debug_set_stem_valu(int on);       /* 1 = pfk_conv_stem_f32 always takes the VALU kernel (A/B timing) */
+
 /* InstanceNorm2d statistics (extractor.py:136-140; affine=False, biased variance, eps inside the sqrt) over
  * pixel-major x[B*HW][ld], channels [0, C): mean[b*C+c], rstd[b*C+c].  One pass over x, deterministic chunked reduction of sum(x) and
  * sum(x*x) in double (var = E[x^2] - mean^2 evaluated in double; results rounded to fp32); needs pfk_instnorm_workspace_bytes(B, C) bytes of 32-byte-aligned device scratch.

@@ -76,6 +76,164 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Stem on the matrix cores (round 6; cout = 32 or 64 — SmallEncoder / BasicEncoder).  The VALU kernel above runs the 33.6 GFLOP of a
+// 16-image 436x1024 stem at ~35 TFLOP/s (0.85 ms); as an implicit GEMM M = pixels, N = cout, K = 147 (+1 zero row) on
+// v_mfma_f32_32x32x2f32 the same launch is bound by the fp32 matrix pipe at ~0.21 ms.
+// One workgroup = 8 x 32 output pixels x all channels; four waves, wave w owns output rows 2w, 2w + 1 (two 32-pixel M tiles) x NT
+// 32-channel N tiles.  The 3 x 21 x 69 input patch (zero padding applied while staging) and the whole [148][cout] weight sit in LDS
+// (17 + 37 KB at cout 64: two workgroups per CU).  K-step s covers k = 2s, 2s + 1 with k = (ky * 7 + kx) * 3 + ci, the order of the
+// packed weight: lane (pixel l & 31, k-half l >> 5) reads ITS element of the im2col row straight from the patch —
+// patch[ci][2 py + ky][2 px + kx], the per-k offset a compile-time constant selected by the lane half — so no im2col matrix exists
+// anywhere.  The K loop is fully unrolled (74 steps x (2 + NT) ds_read_b32 + 2 NT MFMAs).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int SM_ROWS = 8, SM_COLS = 32;
+constexpr int SM_PR = 2 * SM_ROWS + STEM_K - 2, SM_PC = 2 * SM_COLS + STEM_K - 2;   // 21 x 69
+constexpr int SM_KTOT = 3 * STEM_K * STEM_K, SM_KSTEPS = (SM_KTOT + 1) / 2;       // 147 -> 74 steps of 2
+
+__host__ __device__ constexpr int sm_koff(int k) {           // patch offset of im2col column k
+  return (k % 3) * (SM_PR * SM_PC) + ((k / 3) / STEM_K) * SM_PC + (k / 3) % STEM_K;
+}
+
+bool g_stem_valu = false;      // pfk_debug_set_stem_valu(1): the VALU kernel for every width (A/B timing, tests)
+
+template <int NT, int S>
+struct StemSteps {
+  static __device__ __forceinline__ void run(f32x16 (&acc)[2][NT], const float* s_in, const float* s_w, const int (&abase)[2], int hl, int px) {
+    constexpr int k0 = 2 * S, k1 = (2 * S + 1 < SM_KTOT) ? 2 * S + 1 : SM_KTOT - 1;   // k = 147: the weight row is zero, any valid address
+    const int o = hl ? sm_koff(k1) : sm_koff(k0);
+    const float a0 = s_in[abase[0] + o], a1 = s_in[abase[1] + o];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const float b = s_w[((2 * S) + hl) * (NT * 32) + nt * 32 + px];
+      acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[0][nt], 0, 0, 0);
+      acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[1][nt], 0, 0, 0);
+    }
+    if constexpr (S + 1 < SM_KSTEPS) StemSteps<NT, S + 1>::run(acc, s_in, s_w, abase, hl, px);
+  }
+};
+
+// Persistent: the grid is two workgroups per CU, each stages the weight ONCE and walks the tile list with stride gridDim.x; the next
+// tile's patch is requested into registers before the current tile's MFMA loop and parked in the other LDS buffer behind it, so the
+// global-load latency of the staging hides under the matrix work (one __syncthreads per tile).
+constexpr int SM_PATCH = 3 * SM_PR * SM_PC, SM_PT = (SM_PATCH + 255) / 256;     // 4347 floats, 17 per thread
+
+template <int NT, typename TO>
+__global__ __launch_bounds__(256, 2) void conv_stem_mfma_kernel(const float* __restrict__ img, const float* __restrict__ wgt,
+                                                                 const float* __restrict__ bias, TO* __restrict__ out, int out_ld,
+                                                                 int H, int W, int Ho, int Wo, int tiles_x, int tiles_y, int ntiles,
+                                                                 int relu) {
+  constexpr int COUT = NT * 32;
+  __shared__ float s_in[2][SM_PATCH];
+  __shared__ float s_w[2 * SM_KSTEPS * COUT];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int px = lane & 31, hl = lane >> 5;
+  // this thread's patch elements: e = tid + 256 j -> (ci, yy, xx), the same for every tile
+  int poff[SM_PT];            // ci * H * W + yy * W + xx, relative to the patch origin (may be used with a negative origin)
+  short pyy[SM_PT], pxx[SM_PT];
+#pragma unroll
+  for (int j = 0; j < SM_PT; ++j) {
+    const int e = threadIdx.x + 256 * j;
+    const int ci = e / (SM_PR * SM_PC);
+    const int r = e - ci * (SM_PR * SM_PC);
+    const int yy = r / SM_PC, xx = r - yy * SM_PC;
+    pyy[j] = (short)yy; pxx[j] = (short)xx;
+    poff[j] = (ci * H + yy) * W + xx;
+  }
+  float pv[SM_PT];
+  auto fetch = [&](int tile) {
+    const int tx = tile % tiles_x, t1 = tile / tiles_x;
+    const int ty = t1 % tiles_y, b = t1 / tiles_y;
+    const int iy0 = 2 * ty * SM_ROWS - STEM_R, ix0 = 2 * tx * SM_COLS - STEM_R;
+    const float* src = img + (long long)b * 3 * H * W + (long long)iy0 * W + ix0;
+#pragma unroll
+    for (int j = 0; j < SM_PT; ++j) {
+      const int gy = iy0 + pyy[j], gx = ix0 + pxx[j];
+      pv[j] = 0.f;
+      if (threadIdx.x + 256 * j < SM_PATCH && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) pv[j] = src[poff[j]];
+    }
+  };
+  auto park = [&](float* dst) {
+#pragma unroll
+    for (int j = 0; j < SM_PT; ++j)
+      if (threadIdx.x + 256 * j < SM_PATCH) dst[threadIdx.x + 256 * j] = pv[j];
+  };
+
+  int tile = blockIdx.x;
+  if (tile < ntiles) fetch(tile);
+  for (int e = threadIdx.x; e < 2 * SM_KSTEPS * COUT / 4; e += 256) {        // [147][COUT] + one zero row, 16 bytes per thread
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (e * 4 < SM_KTOT * COUT) v = *reinterpret_cast<const f32x4*>(wgt + e * 4);
+    *reinterpret_cast<f32x4*>(s_w + e * 4) = v;
+  }
+  if (tile < ntiles) park(s_in[0]);
+  __syncthreads();
+  float b0[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) b0[nt] = bias ? bias[nt * 32 + px] : 0.f;
+  int abase[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) abase[mt] = (2 * (2 * wid + mt)) * SM_PC + 2 * px;
+
+  for (int buf = 0; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+    const int next = tile + gridDim.x;
+    if (next < ntiles) fetch(next);
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+    StemSteps<NT, 0>::run(acc, s_in[buf], s_w, abase, hl, px);
+    // accumulator layout: register r of lane l = pixel (r & 3) + 8 (r >> 2) + 4 (l >> 5) of the M tile, channel l & 31 of the N
+    // tile: a store instruction writes two 128-byte (fp32) row segments
+    const int tx = tile % tiles_x, t1 = tile / tiles_x;
+    const int ty = t1 % tiles_y, b = t1 / tiles_y;
+    const int yo0 = ty * SM_ROWS, xo0 = tx * SM_COLS;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int c = nt * 32 + px;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int yo = yo0 + 2 * wid + mt;
+        if (yo >= Ho) continue;
+        const long long row0 = ((long long)b * Ho + yo) * Wo;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int xo = xo0 + (r & 3) + 8 * (r >> 2) + 4 * hl;
+          if (xo >= Wo) continue;
+          float v = acc[mt][nt][r] + b0[nt];
+          if (relu) v = (v < 0.f) ? 0.f : v;
+          out[(row0 + xo) * out_ld + c] = (TO)v;
+        }
+      }
+    }
+    if (next < ntiles) park(s_in[buf ^ 1]);
+    __syncthreads();      // the next patch is complete; every wave is done reading this one before the tile after next overwrites it
+  }
+}
+
+template <typename TO>
+int stem_launch(const float* img, const float* weight, const float* bias, TO* out, int out_ld, int B, int H, int W, int cout, int relu,
+                hipStream_t st) {
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const int tiles_x = (Wo + SM_COLS - 1) / SM_COLS, tiles_y = (Ho + SM_ROWS - 1) / SM_ROWS;
+  const long long tiles = (long long)B * tiles_x * tiles_y;
+  if (tiles > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
+  if ((long long)3 * H * W >= 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;     // 32-bit offsets inside one image
+  const unsigned grid = (unsigned)(tiles < 512 ? tiles : 512);               // two workgroups per CU, persistent over the tile list
+  if (cout == 64)
+    hipLaunchKernelGGL((conv_stem_mfma_kernel<2, TO>), dim3(grid), dim3(256), 0, st, img, weight, bias, out, out_ld, H, W, Ho, Wo,
+                       tiles_x, tiles_y, (int)tiles, relu);
+  else if (cout == 32)
+    hipLaunchKernelGGL((conv_stem_mfma_kernel<1, TO>), dim3(grid), dim3(256), 0, st, img, weight, bias, out, out_ld, H, W, Ho, Wo,
+                       tiles_x, tiles_y, (int)tiles, relu);
+  else
+    return PFK_ERR_UNSUPPORTED;
+  return pfk_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Instance-norm statistics over pixel-major x[B*HW][ld], channels [0, C), C % 4 == 0.
 // ONE pass over x: per (image, chunk) partial sums of x and of x*x, both carried in double (an fp32 square is exact in double), reduced
 // over the chunks in a fixed order (chunk_reduce_kernel); finish: mean, var_biased = E[x^2] - mean^2 (in double: the cancellation
@@ -416,6 +574,9 @@ extern "C" {
 int pfk_conv_stem_f32(const float* img, const float* weight, const float* bias, float* out, int out_ld, int B,
                       int H, int W, int cout, int relu, pfk_stream_t stream) {
   if (!img || !weight || !out || B <= 0 || H <= 0 || W <= 0 || cout <= 0 || out_ld < cout) return PFK_ERR_BAD_ARG;
+  // cout 32 / 64 (the reference's two encoders) with a 16-byte aligned weight: the MFMA kernel; anything else: the VALU kernel
+  if ((cout == 32 || cout == 64) && pfk_aligned16(weight) && !g_stem_valu)
+    return stem_launch<float>(img, weight, bias, out, out_ld, B, H, W, cout, relu, static_cast<hipStream_t>(stream));
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
   const int tpr = (Wo + STEM_TP - 1) / STEM_TP;
   const long long tiles = (long long)B * Ho * tpr;
@@ -423,6 +584,19 @@ int pfk_conv_stem_f32(const float* img, const float* weight, const float* bias, 
   hipLaunchKernelGGL(conv_stem_kernel, dim3((unsigned)tiles), dim3(256), 0, static_cast<hipStream_t>(stream), img, weight,
                      bias, out, out_ld, H, W, Ho, Wo, tpr, cout, relu);
   return pfk_launch_status();
+}
+
+int pfk_conv_stem_b16(const float* img, const float* weight, const float* bias, void* out_bf16, int out_ld, int B, int H, int W,
+                      int cout, int relu, pfk_stream_t stream) {
+  if (!img || !weight || !out_bf16 || B <= 0 || H <= 0 || W <= 0 || cout <= 0 || out_ld < cout) return PFK_ERR_BAD_ARG;
+  if (!pfk_aligned16(weight) || (reinterpret_cast<uintptr_t>(out_bf16) & 1u)) return PFK_ERR_ALIGNMENT;
+  return stem_launch<__bf16>(img, weight, bias, static_cast<__bf16*>(out_bf16), out_ld, B, H, W, cout, relu, static_cast<hipStream_t>(stream));
+}
+
+int pfk_debug_set_stem_valu(int on) {
+  if (!pfk_debug_knobs_enabled()) return PFK_ERR_DISABLED;
+  g_stem_valu = on != 0;
+  return PFK_OK;
 }
 
 long long pfk_instnorm_workspace_bytes(int B, int C) { return (2LL * B * in_chunks(B) * C + 2LL * B * C) * (long long)sizeof(double); }

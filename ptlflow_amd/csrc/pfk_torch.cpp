@@ -295,6 +295,7 @@ void conv2d_b16(at::TensorList srcs, int64_t B, int64_t H, int64_t W, int64_t kh
 }
 
 void debug_set_b16(int64_t cfg) { check_ok(pfk_debug_set_b16((int)cfg), "debug_set_b16"); }
+void debug_set_stem_valu(int64_t on) { check_ok(pfk_debug_set_stem_valu((int)on), "debug_set_stem_valu"); }
 
 void conv_cin2(const Tensor& in, const Tensor& weight, const c10::optional<Tensor>& bias, Tensor out,
                int64_t B, int64_t H, int64_t W, int64_t k, bool relu) {
@@ -615,13 +616,18 @@ void pm_to_cm(const Tensor& in, Tensor out) {
 
 void conv_stem(const Tensor& img, const Tensor& weight, const c10::optional<Tensor>& bias, Tensor out, bool relu) {
   OpScope scope(img);
-  check_dev_f32(img, "img"); check_dev_f32(weight, "weight"); check_pm(out, "out");
+  check_dev_f32(img, "img"); check_dev_f32(weight, "weight");
+  const bool out_b16 = check_pm_any(out, "out");
   TORCH_CHECK(img.dim() == 4 && img.size(1) == 3 && img.is_contiguous(), "conv_stem: img [B,3,H,W] contiguous");
   const int B = img.size(0), H = img.size(2), W = img.size(3), cout = out.size(1);
   TORCH_CHECK(weight.is_contiguous() && weight.numel() == 49 * 3 * cout, "conv_stem: weight [49,3,cout]");
   TORCH_CHECK(out.size(0) == (int64_t)B * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1), "conv_stem: out rows");
   const float* b = nullptr;
   if (bias.has_value()) { check_dev_f32(*bias, "bias"); TORCH_CHECK(bias->numel() == cout && bias->is_contiguous()); b = fptr(*bias); }
+  if (out_b16) {
+    check_ok(pfk_conv_stem_b16(fptr(img), fptr(weight), b, out.data_ptr(), out.stride(0), B, H, W, cout, relu, cur_stream()), "conv_stem (bf16 out)");
+    return;
+  }
   check_ok(pfk_conv_stem_f32(fptr(img), fptr(weight), b, fptr(out), out.stride(0), B, H, W, cout, relu, cur_stream()), "conv_stem");
 }
 
@@ -863,6 +869,7 @@ TORCH_LIBRARY(pfk, m) {
         "float scale, Tensor(a!)? out, Tensor(b!)? h=None, Tensor(c!)? h_b16=None, Tensor(d!)? aux_z=None, Tensor(e!)? aux_rh=None, "
         "Tensor? residual=None, int stride=1, bool relu_after_residual=False) -> ()");
   m.def("debug_set_b16(int cfg) -> ()", &debug_set_b16);
+  m.def("debug_set_stem_valu(int on) -> ()", &debug_set_stem_valu);
   m.def("conv_workspace_bytes() -> int", &conv_workspace_bytes);
   m.def("conv_workspace_fault_offset() -> int", &conv_workspace_fault_offset);
   m.def("conv_cin2(Tensor inp, Tensor weight, Tensor? bias, Tensor(a!) out, int B, int H, int W, int k, bool relu) -> ()");

@@ -446,7 +446,9 @@ class RAFT(nn.Module):
                 n = 2 * self.corr_radius + 1
                 eng.flops["lookup"] = 0.0
                 # N L [(2r+2)^2 + (2r+1)^2] 4 + 8 N bytes per pair and lookup
-                eng.bytes["lookup"] = float(pixels * (self.corr_levels * ((n + 1) ** 2 + n * n) * 4 + 8))
+                # (element sizes as stored: bf16 maps / bf16 rows on the K8b path)
+                eng.bytes["lookup"] = float(pixels * (self.corr_levels * ((n + 1) ** 2 * corr_fn.volume_dtype.itemsize
+                                                                        + n * n * corr_pm.element_size()) + 8))
             else:
                 corr_pm = corr_fn.lookup_pm(coords1, out=eng.lookup_out)      # K8b engines take the lookup in bf16, written directly
             do_up = last or self.upsample_every_iter

@@ -30,8 +30,14 @@ def unpm(x, B, H, W):
     return x.view(B, H, W, -1).permute(0, 3, 1, 2).cpu()
 
 
-@pytest.mark.parametrize("B,H,W,cout,relu", [(1, 37, 70, 64, True), (2, 24, 64, 64, False), (1, 16, 130, 32, True)])
-def test_stem(gpu, B, H, W, cout, relu):
+@pytest.mark.parametrize("kernel", ["mfma", "valu", "mfma_bf16_out"])
+@pytest.mark.parametrize("B,H,W,cout,relu", [(1, 37, 70, 64, True), (2, 24, 64, 64, False), (1, 16, 130, 32, True), (3, 65, 131, 64, True),
+                                             (1, 7, 5, 32, False), (1, 40, 48, 48, True)])
+def test_stem(gpu, B, H, W, cout, relu, kernel):
+    """Conv2d(3, cout, 7, stride 2, padding 3) from the NCHW image (raft/extractor.py:146): the MFMA implicit-GEMM kernel (cout 32 / 64,
+    fp32 and bf16 output rows), the VALU kernel (every other width; forced here for 32 / 64 too) against float64 torch."""
+    if kernel == "mfma_bf16_out" and cout not in (32, 64):
+        pytest.skip("the bf16-output stem exists for the encoders' widths only")
     torch.manual_seed(1)
     img = torch.randn(B, 3, H, W)
     wt = torch.randn(cout, 3, 7, 7) / math.sqrt(147)
@@ -40,10 +46,18 @@ def test_stem(gpu, B, H, W, cout, relu):
     if relu:
         ref = F.relu(ref)
     Ho, Wo = ref.shape[-2:]
-    out = torch.full((B * Ho * Wo, cout + 4), 7.0, device=gpu)
+    b16 = kernel == "mfma_bf16_out"
+    out = torch.full((B * Ho * Wo, cout + 4), 7.0, device=gpu, dtype=torch.bfloat16 if b16 else torch.float32)
     w = wt.permute(2, 3, 1, 0).reshape(49, 3, cout).contiguous().cuda()
-    torch.ops.pfk.conv_stem(img.cuda(), w, bias.cuda(), out[:, :cout], relu)
-    close(unpm(out[:, :cout], B, Ho, Wo), ref)
+    torch.ops.pfk.debug_set_stem_valu(1 if kernel == "valu" else 0)
+    try:
+        torch.ops.pfk.conv_stem(img.cuda(), w, bias.cuda(), out[:, :cout], relu)
+    finally:
+        torch.ops.pfk.debug_set_stem_valu(0)
+    if b16:   # one rounding of the fp32 result
+        close(unpm(out[:, :cout], B, Ho, Wo), ref, rtol=2 ** -8, atol=2e-5)
+    else:
+        close(unpm(out[:, :cout], B, Ho, Wo), ref)
     assert bool((out[:, cout:] == 7.0).all())
 
 
