@@ -261,6 +261,15 @@ long long pfk_conv_workspace_fault_offset(void);
 int pfk_conv_ktot(const pfk_conv_desc* d);
 int pfk_conv2d_f32(const pfk_conv_desc* d, pfk_stream_t stream);
 
+/* Grouped launch (ABI 7): `n` (1..PFK_CONV_GROUP_MAX) INDEPENDENT convolutions — no output of one is a source, residual or weight of
+ * another — in ONE grid of 64 x 64 tiles; every descriptor has the LINEAR epilogue.  Results are those of `n` calls of
+ * pfk_conv2d_f32 without a workspace, bit for bit (a tile's K order does not depend on what runs beside it).  For the small-batch
+ * regime, where the update block's launches leave most CUs idle: convc1 | convf2 | the previous iteration's mask conv2
+ * (ptlflow/models/raft/update.py:105-108, :152 — `cor` and `flo` only meet in `conv`, the mask head reads `net` only).
+ * `workspace`, `cout_active`, `cout_split` of the descriptors: ignored / unsupported (PFK_ERR_UNSUPPORTED). */
+#define PFK_CONV_GROUP_MAX 4
+int pfk_conv2d_group_f32(const pfk_conv_desc* descs, int n, pfk_stream_t stream);
+
 /* Same convolution on the bf16 matrix cores with split operands (fp32 in HBM, fp32 accumulate, fp32 epilogue).
  * Every fp32 operand x is replaced by the sum of its first `nsplit` bf16 planes x0 = bf16(x), x1 = bf16(x - x0),
  * x2 = bf16(x - x0 - x1); a product keeps the terms a_i*b_j with i + j < nsplit:

@@ -645,8 +645,10 @@ __device__ __forceinline__ void v3_step(f32x16 (&acc)[MT][NT], Frags<MT, NT>& f0
   (v3_slot<BM, BN, MT, NT, ABL, LD, Qs>(acc, f0, f1, st, cA, cB, nA, nB, s_fill, live, ko), ...);
 }
 
+// (the kernel's body as a device function of (arguments, tile id, tiles in this problem's grid, batch element): conv_gemm_v3_kernel
+//  runs it on its own grid, conv_gemm_v3_group_kernel on one problem's share of a grouped grid)
 template <int BM, int BN, int WM, int WN, int EPI, int GROUPS, int ABL = 0, int LD = LDS_LD>
-__global__ __launch_bounds__(256 * GROUPS) void conv_gemm_v3_kernel(const GemmArgs a) {
+__device__ __forceinline__ void conv_gemm_v3_body(const GemmArgs& a, const int bid, const int nblk, const long long batch) {
   constexpr int WAVES_N = BN / WN;
   static_assert((BM / WM) * WAVES_N == 4, "4 waves per group");
   static_assert(BK == 32, "fragment schedule below is written for 4 sub-steps");
@@ -664,12 +666,10 @@ __global__ __launch_bounds__(256 * GROUPS) void conv_gemm_v3_kernel(const GemmAr
   const int wm0 = (wid / WAVES_N) * WM;
   const int wn0 = (wid % WAVES_N) * WN;
 
-  const int bid = pfk_xcd_remap(blockIdx.x, gridDim.x);
   int tile_m, tile_n;
-  tile_of(bid, (int)gridDim.x / a.tiles_n, a.tiles_n, a.supertile, tile_m, tile_n);
+  tile_of(bid, nblk / a.tiles_n, a.tiles_n, a.supertile, tile_m, tile_n);
   const long long m0 = (long long)tile_m * BM;
   const int n0 = tile_n * BN;
-  const long long batch = blockIdx.y;
 
   Stager<BM, BN, LD> st(a, m0, n0, gtid, batch);
   const int S = st.total_steps();
@@ -752,6 +752,38 @@ __global__ __launch_bounds__(256 * GROUPS) void conv_gemm_v3_kernel(const GemmAr
     if (grp) epilogue<MT, NT, EPI, 8, 16>(a, acc, m0 + wm0, n0 + wn0, lane, batch);
     else     epilogue<MT, NT, EPI, 0, 8>(a, acc, m0 + wm0, n0 + wn0, lane, batch);
   }
+}
+
+template <int BM, int BN, int WM, int WN, int EPI, int GROUPS, int ABL = 0, int LD = LDS_LD>
+__global__ __launch_bounds__(256 * GROUPS) void conv_gemm_v3_kernel(const GemmArgs a) {
+  conv_gemm_v3_body<BM, BN, WM, WN, EPI, GROUPS, ABL, LD>(a, pfk_xcd_remap(blockIdx.x, gridDim.x), (int)gridDim.x, blockIdx.y);
+}
+
+// -------------------------------------------------------------------------------------------------
+// Grouped launch (round 6): up to PFK_CONV_GROUP_MAX INDEPENDENT convolutions (LINEAR epilogue, 64x64 tiles) in ONE grid — block b
+// belongs to problem k with first[k] <= b < first[k + 1] and runs the tile kernel's body on that problem's arguments.  At batch 1
+// (7040 pixels) the update block's launches have 110..990 tiles for 256 CUs and run for 8..25 us each, mostly the serial latency
+// of ONE tile's K loop plus launch / drain: convc1 (440 tiles x 11 K-steps), convf2 (110 x 36) and the previous iteration's mask
+// conv2 (990 x 8) do not depend on each other (update.py:105-108: `cor` and `flo` only meet in `conv`; :152: the mask head reads
+// `net` only), so one grid of 1540 tiles replaces three launches and their three tails.  The runtime does not co-run kernels of one
+// stream and forked streams / graph branches were measured neutral (history, rounds 3-4): a single grid is the form that co-runs.
+// Every tile is computed exactly as its own launch would: same K order, same bits.
+// -------------------------------------------------------------------------------------------------
+struct GemmGroupArgs {
+  GemmArgs p[PFK_CONV_GROUP_MAX];
+  int first[PFK_CONV_GROUP_MAX + 1];
+  int n;
+};
+
+template <int LD>
+__global__ __launch_bounds__(256) void conv_gemm_v3_group_kernel(const GemmGroupArgs g) {
+  const int b = blockIdx.x;
+  int k = 0;
+#pragma unroll
+  for (int i = 1; i < PFK_CONV_GROUP_MAX; ++i)
+    if (i < g.n && b >= g.first[i]) k = i;
+  const int f0 = g.first[k], nblk = g.first[k + 1] - f0;
+  conv_gemm_v3_body<64, 64, 32, 32, PFK_EPI_LINEAR, 1, 0, LD>(g.p[k], pfk_xcd_remap(b - f0, nblk), nblk, 0);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1519,6 +1551,59 @@ int pfk_conv2d_f32(const pfk_conv_desc* d, pfk_stream_t stream) {
     a.sk_flags = reinterpret_cast<unsigned*>(static_cast<char*>(d->workspace) + (size_t)SK_MAX_BLOCKS * 64 * 64 * 4);
   }
   return launch(a, d->epilogue, 1, static_cast<hipStream_t>(stream));
+}
+
+int pfk_conv2d_group_f32(const pfk_conv_desc* descs, int n, pfk_stream_t stream) {
+  if (!descs || n < 1 || n > PFK_CONV_GROUP_MAX) return PFK_ERR_BAD_ARG;
+  GemmGroupArgs g{};
+  int order[PFK_CONV_GROUP_MAX];
+  long long total = 0;
+  for (int i = 0; i < n; ++i) {
+    const pfk_conv_desc* d = &descs[i];
+    if (!d->weight || d->epilogue != PFK_EPI_LINEAR) return PFK_ERR_BAD_ARG;
+    if ((d->cout_active > 0 && d->cout_active < d->cout) || d->cout_split > 0) return PFK_ERR_UNSUPPORTED;
+    if (!pfk_aligned16(d->weight)) return PFK_ERR_ALIGNMENT;
+    order[i] = i;
+  }
+  // problems with the longest K loop first: their tiles start in the first resident round and the short ones fill in behind them
+  for (int i = 1; i < n; ++i)
+    for (int j = i; j > 0 && conv_ktot(&descs[order[j]], 32) > conv_ktot(&descs[order[j - 1]], 32); --j) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+  for (int i = 0; i < n; ++i) {
+    const pfk_conv_desc* d = &descs[order[i]];
+    GemmArgs& a = g.p[i];
+    const int rc = desc_to_args(d, a, 32);
+    if (rc != PFK_OK) return rc;
+    a.weight = d->weight;
+    if ((long long)d->cout * a.ktot * 4 >= 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
+    a.vec_flags = gemm_vec_flags(a);
+    if (a.M >= 0x7fffffffLL || a.Wo <= 0 || a.Ho <= 0) return PFK_ERR_UNSUPPORTED;
+    fastdiv_make((unsigned)a.Wo, a.wo_mul, a.wo_sh);
+    fastdiv_make((unsigned)a.Ho, a.ho_mul, a.ho_sh);
+    a.tiles_n = (a.b_rows + 63) / 64;
+    a.supertile = 0;
+    const long long nblk = ((a.M + 63) / 64) * a.tiles_n;
+    g.first[i] = (int)total;
+    total += nblk;
+    if (nblk <= 0 || total > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
+  }
+  g.first[n] = (int)total;
+  g.n = n;
+  // the swizzled 48 KB layout (three blocks per CU) from three tiles per CU up, the padded 55 KB one below — the single launches' rule
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (total >= 3 * 256) {
+    constexpr size_t smem = (size_t)3 * (64 + 64) * LDS_LDX * sizeof(float);
+    auto kern = conv_gemm_v3_group_kernel<LDS_LDX>;
+    static pfk_device_once attr_once;
+    attr_once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); });
+    hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), smem, st, g);
+  } else {
+    constexpr size_t smem = (size_t)3 * (64 + 64) * LDS_LD * sizeof(float);
+    auto kern = conv_gemm_v3_group_kernel<LDS_LD>;
+    static pfk_device_once attr_once;
+    attr_once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); });
+    hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), smem, st, g);
+  }
+  return pfk_launch_status();
 }
 
 int pfk_mask_upsample_f32(const float* x, int x_ld, int cin, const float* weight_perm, const float* bias_perm, float scale,

@@ -209,6 +209,37 @@ void conv2d(at::TensorList srcs, int64_t B, int64_t H, int64_t W, int64_t kh, in
   else check_ok(pfk_conv2d_f32(&d, cur_stream()), "conv2d");
 }
 
+// Grouped launch (pfk_conv2d_group_f32): problem i = one fp32 source srcs[i] ([B*H*W, cin_i] view), k[i] x k[i] taps, stride 1, packed
+// weight weights[i] [cout_i, ktot_i], bias biases[i] (an empty tensor = none), relu[i], scale[i], out = outs[i] ([B*H*W, cout_i] view)
+void conv2d_group(at::TensorList srcs, int64_t B, int64_t H, int64_t W, at::IntArrayRef k, at::TensorList weights, at::TensorList biases,
+                  at::IntArrayRef relu, at::ArrayRef<double> scale, at::TensorList outs) {
+  const size_t n = srcs.size();
+  TORCH_CHECK(n >= 1 && n <= PFK_CONV_GROUP_MAX, "conv2d_group: 1..", PFK_CONV_GROUP_MAX, " problems");
+  TORCH_CHECK(k.size() == n && weights.size() == n && biases.size() == n && relu.size() == n && scale.size() == n && outs.size() == n,
+              "conv2d_group: one entry per problem in every list");
+  OpScope scope(srcs[0]);
+  pfk_conv_desc d[PFK_CONV_GROUP_MAX] = {};
+  for (size_t i = 0; i < n; ++i) {
+    check_pm(srcs[i], "src"); check_pm(outs[i], "out"); check_dev_f32(weights[i], "weight");
+    TORCH_CHECK(srcs[i].size(0) == B * H * W && outs[i].size(0) == B * H * W, "conv2d_group: rows != B*H*W");
+    const int cout = outs[i].size(1);
+    d[i].num_src = 1;
+    d[i].src[0].ptr = fptr(srcs[i]); d[i].src[0].ld = srcs[i].stride(0); d[i].src[0].channels = srcs[i].size(1);
+    d[i].B = B; d[i].H = H; d[i].W = W; d[i].kh = k[i]; d[i].kw = k[i]; d[i].cout = cout; d[i].stride = 1;
+    d[i].epilogue = PFK_EPI_LINEAR; d[i].relu = relu[i] != 0; d[i].scale = (float)scale[i];
+    TORCH_CHECK(weights[i].is_contiguous() && weights[i].dim() == 2 && weights[i].size(0) == cout && weights[i].size(1) == pfk_conv_ktot(&d[i]),
+                "conv2d_group: packed weight [cout, ktot] of problem ", i);
+    d[i].weight = fptr(weights[i]);
+    if (biases[i].numel() > 0) {
+      check_dev_f32(biases[i], "bias");
+      TORCH_CHECK(biases[i].numel() == cout && biases[i].is_contiguous(), "conv2d_group: bias [cout]");
+      d[i].bias = fptr(biases[i]);
+    }
+    d[i].out = fptr(outs[i]); d[i].out_ld = outs[i].stride(0); d[i].out_coff = 0;
+  }
+  check_ok(pfk_conv2d_group_f32(d, (int)n, cur_stream()), "conv2d_group");
+}
+
 // K8b: bf16 sources / weight (pfk_conv2d_b16); `out` may be bf16 or fp32, h / aux_z / residual fp32, aux_rh / h_b16 bf16
 void conv2d_b16(at::TensorList srcs, int64_t B, int64_t H, int64_t W, int64_t kh, int64_t kw, const Tensor& weight,
                 const c10::optional<Tensor>& bias, int64_t cout, int64_t epilogue, bool relu, double scale,
@@ -865,6 +896,7 @@ TORCH_LIBRARY(pfk, m) {
   m.def("conv2d(Tensor[] srcs, int B, int H, int W, int kh, int kw, Tensor weight, Tensor? bias, int cout, "
         "int epilogue, bool relu, float scale, Tensor(a!)? out, Tensor(b!)? h, Tensor(c!)? aux_z, Tensor(d!)? aux_rh, "
         "Tensor(e!)? workspace=None, Tensor? residual=None, int stride=1, bool relu_after_residual=False, int cout_active=0, int cout_split=0) -> ()");
+  m.def("conv2d_group(Tensor[] srcs, int B, int H, int W, int[] k, Tensor[] weights, Tensor[] biases, int[] relu, float[] scale, Tensor(a!)[] outs) -> ()");
   m.def("conv2d_b16(Tensor[] srcs, int B, int H, int W, int kh, int kw, Tensor weight, Tensor? bias, int cout, int epilogue, bool relu, "
         "float scale, Tensor(a!)? out, Tensor(b!)? h=None, Tensor(c!)? h_b16=None, Tensor(d!)? aux_z=None, Tensor(e!)? aux_rh=None, "
         "Tensor? residual=None, int stride=1, bool relu_after_residual=False) -> ()");
@@ -901,6 +933,7 @@ TORCH_LIBRARY_IMPL(pfk, CUDA, m) {
   m.impl("corr_lookup_blocked", &corr_lookup_blocked);
   m.impl("conv2d", &conv2d);
   m.impl("conv2d_b16", &conv2d_b16);
+  m.impl("conv2d_group", &conv2d_group);
   m.impl("conv_cin2", &conv_cin2);
   m.impl("flow_delta", &flow_delta);
   m.impl("flow_from_coords", &flow_from_coords);

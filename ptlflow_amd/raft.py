@@ -154,6 +154,7 @@ class RAFT(nn.Module):
         # inside a graph, and forked graph branches did not run concurrently (19.19 ms); eager forks on real streams gained
         # 0.3 ms only once every block was 48 KB (three per CU), which itself costs 0.5 ms.
         self.use_graph = use_graph
+        self.group_launches = None   # None: grouped launches of the motion encoder below 28 160 pixels (`_iterate`); True / False: forced
         self.max_graphs = 4          # recorded shapes kept (oldest dropped first): each holds its loop buffers and pyramid
         self._graphs: Dict[tuple, dict] = {}
         # True: never materialise the N x N volume, compute the lookup windows on demand (raft.py `alternate_corr`,
@@ -435,6 +436,12 @@ class RAFT(nn.Module):
         side_done = None
         fuse = has_mask and eng.can_fuse_mask_upsample and \
             (self.fuse_mask_upsample if self.fuse_mask_upsample is not None else pixels >= 28160)
+        # Small batches (below the side-stream threshold; fp32 tile kernel): convc1 | convf2 | the PREVIOUS iteration's mask conv2 as one
+        # grouped launch (`UpdateEngine.motion_grouped`), the previous iteration's upsampling right behind it — before this
+        # iteration's coordinate update overwrites the flow slice it reads.  Same launches' tiles, same bits.
+        grouped = side is None and not fuse and eng.can_group and not self.alternate_corr and \
+            (self.group_launches if self.group_launches is not None else pixels < 28160)
+        owed = False        # the previous iteration's mask conv2 + upsampling have not run yet
         for it in range(self.iters):
             last = it == self.iters - 1
             if eng.profile is not None:     # bench.py's instrumented forward: HIP events around the lookup too (the HBM-bound kernel)
@@ -452,6 +459,20 @@ class RAFT(nn.Module):
             else:
                 corr_pm = corr_fn.lookup_pm(coords1, out=eng.lookup_out)      # K8b engines take the lookup in bf16, written directly
             do_up = last or self.upsample_every_iter
+            if grouped:
+                eng.motion_and_gru(corr_pm, grouped=True, prev_mask=owed)
+                if owed:         # `eng.mask` = mask(it - 1) now; the flow slice still holds flow(it - 1)
+                    ops.convex_upsample_pm(eng.flow_view, eng.mask, flow_up)
+                    owed = False
+                eng.heads(coords0, coords1, None, want_mask=do_up, mask_conv2=last)
+                if do_up:
+                    if not has_mask:
+                        ops.upflow8(coords0, coords1, flow_up)
+                    elif last:
+                        ops.convex_upsample_pm(eng.flow_view, eng.mask, flow_up)
+                    else:
+                        owed = True
+                continue
             if side is None or not do_up:
                 if fuse and do_up:
                     eng.motion_and_gru(corr_pm)

@@ -497,6 +497,45 @@ class UpdateEngine:
         self._conv([self.flo1], 3, 3, "f2", s.f2, out=self.corflo[:, cor_c: cor_c + s.f2],
                    workspace=self.workspace_flow if branch else True)
 
+    @property
+    def can_group(self) -> bool:
+        """the grouped launch exists for the fp32 tile kernel (`pfk_conv2d_group_f32`)"""
+        return self.nsplit == 0 and not self.b16
+
+    def motion_grouped(self, corr_pm: torch.Tensor, prev_mask: bool = False) -> None:
+        """The motion encoder with convc1 | convf2 [| the PREVIOUS iteration's mask conv2] as ONE grouped launch
+        (`pfk_conv2d_group_f32`; update.py:105-108: `cor` and `flo` only meet in `conv`; :152: the mask head reads `net` only, i.e. the
+        mask half of `fm` that the previous `heads_conv1` left).  The small-batch schedule: at 7040 pixels these launches have 440 /
+        110 / 990 tiles for 256 CUs and each pays its own tail.  Same tiles, same K order, same bits as `motion()` + `mask_head()`."""
+        s = self.spec
+        B, H, W = self._shape
+        self.ops.conv_cin2(self.flow_view, self.w["f1.w"], self.w["f1.b"], self.flo1, B, H, W, 7, True)
+        cor_c = s.c2 if s.c2 else s.c1
+        srcs = [corr_pm, self.flo1]
+        ks = [1, 3]
+        keys = ["c1", "f2"]
+        relu, scale = [1, 1], [1.0, 1.0]
+        outs = [self.cor1 if s.c2 else self.corflo[:, : s.c1], self.corflo[:, cor_c: cor_c + s.f2]]
+        if prev_mask:
+            srcs.append(self.fm[:, s.fh_hidden:]); ks.append(1); keys.append("mk"); relu.append(0); scale.append(0.25); outs.append(self.mask)
+        prof = self.profile
+        if prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        self.ops.conv2d_group(srcs, B, H, W, ks, [self.w[k + ".w"] for k in keys],
+                              [self.w[k + ".b"] for k in keys], relu, scale, outs)
+        if prof is not None:
+            e1.record()
+            key = "+".join(keys)
+            prof.setdefault(key, []).append((e0, e1))
+            M = B * H * W
+            self.flops[key] = sum(2.0 * M * o.shape[1] * k * k * self._real_cin[kk] for o, k, kk in zip(outs, ks, keys))
+            self.bytes[key] = sum(4.0 * (M * (self._real_cin[kk] + o.shape[1]) + o.shape[1] * k * k * self._real_cin[kk])
+                                  for o, k, kk in zip(outs, ks, keys))
+        if s.c2:
+            self._conv([self.cor1], 3, 3, "c2", s.c2, out=self.corflo[:, : s.c2])
+        self.motion_join()
+
     def motion_join(self) -> None:
         """conv over cat([cor, flo]) into the motion slice of hx (update.py:110-112 / :89-91)"""
         s = self.spec
@@ -534,10 +573,14 @@ class UpdateEngine:
             self._conv([act], kh, kw, "zr" + sfx, 2 * Ch, epi=EPI_GRU_ZR, h=self.h_view, z=self.zbuf, rh=self.rh)
             self._conv([self.rh, act[:, Ch:]], kh, kw, "q" + sfx, Ch, epi=EPI_GRU_Q, h=self.h_view, z=self.zbuf)
 
-    def motion_and_gru(self, corr_pm: torch.Tensor) -> None:
-        """update.py:104-112 (encoder) + :58-73 / :24-32 (GRU); `flow` must already be in hx."""
+    def motion_and_gru(self, corr_pm: torch.Tensor, grouped: bool = False, prev_mask: bool = False) -> None:
+        """update.py:104-112 (encoder) + :58-73 / :24-32 (GRU); `flow` must already be in hx.  `grouped`: `motion_grouped`
+        (with `prev_mask` the previous iteration's mask conv2 rides in its grouped launch: `self.mask` is valid once this returns)."""
         s = self.spec
-        self.motion(corr_pm)
+        if grouped:
+            self.motion_grouped(corr_pm, prev_mask)
+        else:
+            self.motion(corr_pm)
         if s.aggregate:
             if s.external_aggregate:
                 raise RuntimeError("this block's aggregate slot is filled by the caller: use motion(), aggregate_view, gru()")
@@ -757,7 +800,8 @@ class PfkUpdateBlock(torch.nn.Module):
                 if new_forward or eng.attn is None or attention is not self._attn_ref or attention._version != self._attn_version:
                     eng.set_attention(attention)
                     self._attn_ref, self._attn_version = attention, attention._version
-            eng.motion_and_gru(corr_pm)
+            # small batches: convc1 | convf2 as one grouped launch (`motion_grouped`; same tiles, same bits)
+            eng.motion_and_gru(corr_pm, grouped=eng.can_group and B * H * W < 28160)
         if new_forward:
             eng._scratch_c1.zero_()     # the kernel's `coords1 += delta` lands here; `delta` itself does not depend on it — once per forward keeps it bounded
         # a live call of an armed forward leaves mask conv2 to seam B5, which runs it fused with the softmax and the upsampling (K13)

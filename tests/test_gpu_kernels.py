@@ -550,3 +550,33 @@ def test_conv_cout_active_has_the_full_launch_bits(gpu, B, H, W, with_ws):
         assert bool((ws[torch.ops.pfk.conv_workspace_bytes() - 768 * 64:][:768 * 4] == 0).all())
     ref = F.relu(F.conv2d(x.view(B, H, W, cin).permute(0, 3, 1, 2).cpu(), wt, bias.cpu(), padding=1))
     close(unpm(half[:, :act].contiguous(), B, H, W), ref[:, :act])
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 55, 128), (2, 13, 17), (1, 8, 9)])
+@pytest.mark.parametrize("n", [1, 2, 3, 4])
+def test_conv2d_group_equals_single_launches(gpu, B, H, W, n):
+    """pfk_conv2d_group_f32: n independent LINEAR convolutions in one grid of 64 x 64 tiles — convc1 (1x1, 324 -> 256), convf2 (3x3,
+    128 -> 64), the mask head's conv2 (1x1, 256 -> 576, x 0.25, no relu), a 3x3 192 -> 96 — against the same convolutions launched
+    one by one without a workspace (bit for bit) and against the oracle's fp32 convolution (2e-5)."""
+    from ptlflow_amd.packing import pack_conv_weight
+    torch.manual_seed(11)
+    M = B * H * W
+    shapes = [(324, 256, 1, 1, 1.0), (128, 64, 3, 1, 1.0), (256, 576, 1, 0, 0.25), (192, 96, 3, 1, 1.0)][:n]
+    srcs, ws, bs, outs, refs, ks, relus, scales = [], [], [], [], [], [], [], []
+    for cin, cout, k, relu, scale in shapes:
+        x = torch.randn(B, cin, H, W)
+        wt = torch.randn(cout, cin, k, k) / math.sqrt(cin * k * k)
+        bias = torch.randn(cout) * 0.1
+        ref = F.conv2d(x, wt, bias, padding=k // 2)
+        refs.append((F.relu(ref) if relu else ref) * scale)
+        buf = torch.zeros(M, cin + 4, device=gpu)            # a view with a wider row stride, as the engine's slices are
+        buf[:, :cin] = pm(x)
+        srcs.append(buf[:, :cin]); ws.append(pack_conv_weight(wt, [(0, cin, cin)]).cuda()); bs.append(bias.cuda())
+        outs.append(torch.full((M, cout + 8), -3.0, device=gpu)[:, :cout]); ks.append(k); relus.append(relu); scales.append(scale)
+    torch.ops.pfk.conv2d_group(srcs, B, H, W, ks, ws, bs, relus, scales, outs)
+    for i, (cin, cout, k, relu, scale) in enumerate(shapes):
+        one = torch.full((M, cout), -5.0, device=gpu)
+        torch.ops.pfk.conv2d([srcs[i]], B, H, W, k, k, ws[i], bs[i], cout, EPI_LINEAR, bool(relu), scale, one, None, None, None, None, None)
+        assert torch.equal(outs[i], one), f"problem {i} differs from its single launch"
+        close(unpm(outs[i], B, H, W), refs[i])
+        assert bool((outs[i]._base[:, cout:] == -3.0).all()), "wrote past the output view"

@@ -228,6 +228,34 @@ def test_forked_branches_are_bit_identical(gpu, small, B, H, W, every):
     assert len(auto._graphs) == 1
 
 
+@pytest.mark.parametrize("kind,B,H,W,every", [("raft", 1, 436, 1024, True), ("raft", 2, 184, 320, False), ("raft_small", 1, 184, 320, True),
+                                             ("gma", 1, 184, 320, True)])
+def test_grouped_launches_are_bit_identical(gpu, kind, B, H, W, every):
+    """`group_launches` (the small-batch default): convc1 | convf2 | the previous iteration's mask conv2 in ONE grid
+    (`pfk_conv2d_group_f32`), the previous iteration's upsampling behind it — the same tiles with the same K order on the same
+    operands as the one-launch-per-convolution schedule, so the outputs must not differ by a bit; repeated forwards on fresh inputs
+    (a wrong ordering against the flow slice / `fm` would show as a stale operand), eagerly and in the captured graph."""
+    from ptlflow_amd.raft import GMA, RAFT
+    if kind == "gma":
+        make = lambda **kw: GMA(iters=6, upsample_every_iter=every, **kw)                           # noqa: E731
+    else:
+        make = lambda **kw: RAFT(iters=6, small=kind == "raft_small", upsample_every_iter=every, **kw)  # noqa: E731
+    single, grouped = make().load_synthetic(5).eval().cuda(), make().load_synthetic(5).eval().cuda()
+    single.group_launches, grouped.group_launches = False, True
+    models = [single, grouped]
+    if kind != "gma":
+        graph = make(use_graph=True).load_synthetic(5).eval().cuda()
+        graph.group_launches = True
+        graph.fork_branches = False
+        models.append(graph)
+    for seed in (1, 2, 1, 3):
+        x = O.smooth_pair(B, H, W, seed=seed).cuda()
+        outs = [m({"images": x}) for m in models]
+        torch.cuda.synchronize()
+        for o in outs[1:]:
+            assert torch.equal(outs[0]["flows"], o["flows"]) and torch.equal(outs[0]["flow_small"], o["flow_small"]), f"seed {seed}"
+
+
 @pytest.mark.parametrize("kind", ["raft", "gma"])
 def test_side_stream_mask_head_is_bit_identical(gpu, kind):
     """overlap_mask_head=True runs mask conv2 + convex upsampling of iteration i on a second stream next to iteration i+1: same
