@@ -91,13 +91,12 @@ def _mark(target: Path, key: str) -> None:
     target.with_name(target.name + ".stamp").write_text(key)
 
 
-def embedded_hash(lib: Path):
+def embedded_hash(lib: Path, marker: bytes = b"PFK_SOURCE_HASH="):
     """The stamp compiled into a built libpfk.so, or None.  Read from the FILE (the `PFK_SOURCE_HASH=<stamp>` record of
     pfk_stamp.hip), never through dlopen: glibc caches handles by path, so a library relinked by this process would keep
     answering with the stamp of the mapping made before the relink."""
     if not lib.exists():
         return None
-    marker = b"PFK_SOURCE_HASH="
     data = lib.read_bytes()
     i = data.find(marker)
     while i >= 0:
@@ -162,9 +161,29 @@ def build_torch_ext(force: bool = False) -> Path:
     return LIBTORCH_EXT
 
 
+def up_to_date() -> bool:
+    """Both libraries carry the tree's stamp (read from the FILES): nothing to compile, whatever csrc/_obj holds."""
+    tree = source_hash()
+    if embedded_hash(LIBPFK) != tree or not LIBTORCH_EXT.exists():
+        return False
+    return embedded_hash(LIBTORCH_EXT, b"PFK_EXT_SOURCE_HASH=") == tree
+
+
 def build_all(force: bool = False) -> None:
-    build_libpfk(force)
-    build_torch_ext(force)
+    # a tree that ships correctly stamped libraries but no csrc/_obj (a wheel, a read-only checkout) needs no compiler and no write
+    if not force and up_to_date():
+        return
+    # several ranks (torchrun, bench.py --gpus N) that find a stale tree must not relink the same .so side by side: one exclusive
+    # lock file next to the libraries; whoever gets it second finds the libraries up to date
+    import fcntl
+    with open(PKG / ".build.lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if force or not up_to_date():
+                build_libpfk(force)
+                build_torch_ext(force)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
 
 
 if __name__ == "__main__":

@@ -176,6 +176,7 @@ class CorrBlock:
 
     def _build(self, fmap1: torch.Tensor, fmap2: torch.Tensor) -> "CorrBlock":
         ops = _ops()
+        self._rowmajor_cache = None
         self.out_dtype = fmap1.dtype
         B, D, h, w = fmap1.shape
         self.B, self.h, self.w = B, h, w
@@ -245,14 +246,17 @@ class CorrBlock:
     @property
     def corr_pyramid(self) -> List[torch.Tensor]:
         """The pyramid as the reference holds it (raft/corr.py:21-27): ``[B*N, h_l, w_l]`` maps.  Row-major storage is returned as
-        is; blocked storage is un-tiled into fresh tensors (tests / inspection — the lookups read the blocked storage)."""
+        is; blocked storage is un-tiled ONCE per build into copies that later accesses share (tests / inspection — the lookups read
+        the blocked storage, so writes into the returned tensors do not reach them: treat the result as read-only)."""
         if self.layout != "blocked":
             return self._levels
-        out = []
-        for lv, (hl, wl) in zip(self._levels, self._lvl_hw):
-            th, tw = (hl + 3) // 4, (wl + 7) // 8
-            out.append(lv.view(-1, th, tw, 4, 8).permute(0, 1, 3, 2, 4).reshape(-1, th * 4, tw * 8)[:, :hl, :wl].contiguous())
-        return out
+        if self._rowmajor_cache is None:       # one un-tiling per build (dropped by `_build`); the result is a READ-ONLY copy
+            out = []
+            for lv, (hl, wl) in zip(self._levels, self._lvl_hw):
+                th, tw = (hl + 3) // 4, (wl + 7) // 8
+                out.append(lv.view(-1, th, tw, 4, 8).permute(0, 1, 3, 2, 4).reshape(-1, th * 4, tw * 8)[:, :hl, :wl].contiguous())
+            self._rowmajor_cache = out
+        return self._rowmajor_cache
 
     # ------------------------------------------------------------------ training (autograd) side
     def _zero_grad_levels(self) -> None:

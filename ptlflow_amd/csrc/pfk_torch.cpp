@@ -858,7 +858,9 @@ void debug_set_altcorr(int64_t v) { check_ok(pfk_debug_set_altcorr((int)v), "deb
 #ifndef PFK_SOURCE_HASH
 #define PFK_SOURCE_HASH "unstamped"
 #endif
-std::string source_hash() { return std::string(PFK_SOURCE_HASH) + ":" + pfk_source_hash(); }   // "<this extension's stamp>:<libpfk.so's stamp>"
+// the same stamp as a record that ptlflow_amd/_build.py finds in the FILE (embedded_hash): staleness is decided without loading it
+__attribute__((used)) static const char pfk_ext_stamp_record[] = "PFK_EXT_SOURCE_HASH=" PFK_SOURCE_HASH;
+std::string source_hash() { return std::string(pfk_ext_stamp_record + 20) + ":" + pfk_source_hash(); }   // "<this extension's stamp>:<libpfk.so's stamp>"
 
 }  // namespace
 

@@ -28,6 +28,7 @@ Nothing in ptlflow is edited or copied; `restore(model)` undoes the patch.
 """
 from __future__ import annotations
 
+import contextvars
 import importlib
 import sys
 from typing import Callable, Dict, Optional, Tuple
@@ -180,6 +181,30 @@ def _supported_envelope(fmap1: torch.Tensor, fmap2: torch.Tensor, num_levels: in
     return max(h * w, h2 * w2) * D * 4 < 2 ** 31 - 1 and B * h * w * num_levels * (2 * radius + 1) ** 2 * 4 < 2 ** 31 - 1
 
 
+# the accelerated model instance whose forward is running publishes its lookup layout here (None: no such forward on this context)
+_LAYOUT: "contextvars.ContextVar[Optional[bool]]" = contextvars.ContextVar("pfk_lookup_channels_last", default=None)
+_LAYOUT_HOOKS = "_pfk_layout_hooks"
+
+
+def _bracket_forward_with_layout(model: torch.nn.Module, channels_last: bool) -> None:
+    """forward pre-hook / hook pair on the INSTANCE: sets `_LAYOUT` for the duration of its forward (re-entrant: a token stack)."""
+    state = model.__dict__.get(_LAYOUT_HOOKS)
+    if state is not None:
+        state["channels_last"] = channels_last
+        return
+    state = {"channels_last": channels_last, "tokens": []}
+
+    def pre(_m, _args, _kwargs=None):
+        state["tokens"].append(_LAYOUT.set(state["channels_last"]))
+
+    def post(_m, _args, _out):
+        if state["tokens"]:
+            _LAYOUT.reset(state["tokens"].pop())
+
+    state["handles"] = (model.register_forward_pre_hook(pre), model.register_forward_hook(post, always_call=True))
+    model.__dict__[_LAYOUT_HOOKS] = state
+
+
 def _make_corr_hook(module_name: str, original):
     pyramid = _PYRAMID.get(module_name, "avgpool")
 
@@ -189,11 +214,11 @@ def _make_corr_hook(module_name: str, original):
         # shapes stay on the reference's own implementation.
         if fmap1.is_cuda and not alternate_corr and not kw and _supported_envelope(fmap1, fmap2, num_levels, radius):
             # layout per model INSTANCE (several instances of one family module may be accelerated with different `update_block=`
-            # settings): the caller is the model's `forward` (raft.py:146-152 and its siblings call `get_corr_block` directly), so its
-            # frame's `self` is the instance; anything else gets the hook's default, set by the last `accelerate` on this module
-            caller = sys._getframe(1).f_locals.get("self")
-            cl = isinstance(getattr(caller, "update_block", None), PfkUpdateBlock) if isinstance(caller, torch.nn.Module) \
-                else get_corr_block.channels_last
+            # settings): `accelerate` brackets the instance's forward with hooks that publish its setting in a context variable
+            # (`_LAYOUT`); a caller outside such a forward gets the hook's default, set by the last `accelerate` on this module
+            cl = _LAYOUT.get()
+            if cl is None:
+                cl = get_corr_block.channels_last
             return _pfk_get_corr_block(fmap1, fmap2, num_levels=num_levels, radius=radius, pyramid=pyramid, channels_last=cl)
         return original(fmap1=fmap1, fmap2=fmap2, num_levels=num_levels, radius=radius, alternate_corr=alternate_corr, **kw)
 
@@ -490,6 +515,7 @@ def accelerate(model: torch.nn.Module, corr: bool = True, update_block: bool = T
     hook = getattr(mod, "get_corr_block", None)
     if corr and hasattr(mod, _ORIG) and hasattr(hook, "channels_last"):      # (default for callers that are not a model's forward)
         hook.channels_last = isinstance(getattr(model, "update_block", None), PfkUpdateBlock)
+        _bracket_forward_with_layout(model, hook.channels_last)
     cb = getattr(model, "corr_block", None)
     if corr and isinstance(cb, torch.nn.Module) and (type(cb).__module__, type(cb).__name__) in _BILINEAR_VOLUMES \
             and _VOLUME_SEAM not in cb.__dict__:
@@ -523,6 +549,10 @@ def accelerate(model: torch.nn.Module, corr: bool = True, update_block: bool = T
 
 
 def restore(model: torch.nn.Module) -> torch.nn.Module:
+    state = model.__dict__.pop(_LAYOUT_HOOKS, None)
+    if state is not None:
+        for h in state["handles"]:
+            h.remove()
     if _SKIP in model.__dict__:
         del model.__dict__[_SKIP]
         if isinstance(getattr(model, "update_block", None), PfkUpdateBlock):

@@ -213,12 +213,16 @@ class UpdateEngine:
         if s.has_mask:
             w["fm.w"] = pk(torch.cat([g("flow_head.conv1.weight"), g("mask.0.weight")], 0), seg1(Ch))
             w["fm.b"] = torch.cat([g("flow_head.conv1.bias"), g("mask.0.bias")]).contiguous()
-            w["mk.w"] = pk(g("mask.2.weight"), seg1(256))
+            # the mask head's hidden width = what `fm` holds behind the flow head's half (raft/update.py:131-135: both 256)
+            mask_hidden = g("mask.2.weight").shape[1]
+            assert mask_hidden == g("mask.0.weight").shape[0], "mask.2 reads mask.0's output"
+            w["mk.w"] = pk(g("mask.2.weight"), seg1(mask_hidden))
             w["mk.b"] = g("mask.2.bias").contiguous()
-            if self.nsplit == 0 and s.mask_channels == 576 and s.fh_hidden % 32 == 0:
+            if self.nsplit == 0 and s.mask_channels == 576 and mask_hidden % 32 == 0 and mask_hidden == s.fh_hidden:
                 # fused mask conv2 + softmax + convex upsampling (`pfk_mask_upsample_f32`): the 1x1 weight / bias with their rows in
-                # the kernel's [quarter][tile][32] order (packing.permute_mask_head, include/pfk.h)
-                w["mku.w"], w["mku.b"] = permute_mask_head(pack_conv_weight(g("mask.2.weight"), seg1(s.fh_hidden)), w["mk.b"])
+                # the kernel's [quarter][tile][32] order (packing.permute_mask_head, include/pfk.h); `fm` is split at fh_hidden, so
+                # the fused kernel is only armed where the two hidden widths agree
+                w["mku.w"], w["mku.b"] = permute_mask_head(pack_conv_weight(g("mask.2.weight"), seg1(mask_hidden)), w["mk.b"])
             # flow-head conv1 alone: the iterations whose mask is never looked at (`upsample_every_iter=False`) skip the mask half
             w["fh.w"] = pk(g("flow_head.conv1.weight"), seg1(Ch))
             w["fh.b"] = g("flow_head.conv1.bias").contiguous()

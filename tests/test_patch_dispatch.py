@@ -328,3 +328,53 @@ def test_dead_work_skip_state_machine():
         assert s.take_deferred(other) is None and s.take_deferred(view) is None      # a wrong tensor consumes the token too
         s.defer("engine", view)
         assert s.take_deferred(view) == "engine" and s.take_deferred(view) is None
+
+
+def test_lookup_layout_travels_with_the_instance_forward():
+    """The per-instance lookup layout (no frame inspection): `accelerate` brackets the instance's forward with hooks that
+    publish the setting in a context variable; outside such a forward the variable is unset (module default applies); nested and
+    failing forwards restore it."""
+    from ptlflow_amd import patch
+
+    class Probe(torch.nn.Module):
+        def __init__(self, inner=None, fail=False):
+            super().__init__()
+            self.inner, self.fail = inner, fail
+
+        def forward(self, x):
+            seen = [patch._LAYOUT.get()]
+            if self.inner is not None:
+                seen += self.inner(x)
+                seen.append(patch._LAYOUT.get())
+            if self.fail:
+                raise ValueError("boom")
+            return seen
+
+    a, b = Probe(), Probe()
+    patch._bracket_forward_with_layout(a, True)
+    patch._bracket_forward_with_layout(b, False)
+    assert patch._LAYOUT.get() is None
+    assert a(0) == [True] and b(0) == [False] and patch._LAYOUT.get() is None
+    outer = Probe(inner=b)
+    patch._bracket_forward_with_layout(outer, True)
+    assert outer(0) == [True, False, True] and patch._LAYOUT.get() is None
+    bad = Probe(fail=True)
+    patch._bracket_forward_with_layout(bad, True)
+    with pytest.raises(ValueError):
+        bad(0)
+    assert patch._LAYOUT.get() is None, "a failing forward must not leave its layout behind"
+    patch._bracket_forward_with_layout(a, False)          # re-accelerating updates the setting, no second pair of hooks
+    assert a(0) == [False] and len(a._forward_pre_hooks) == 1
+    patch.restore(a)
+    assert a(0) == [None] and not a._forward_pre_hooks and not a._forward_hooks
+
+
+def test_build_is_a_no_op_on_stamped_libraries(tmp_path, monkeypatch):
+    """with both libraries carrying the tree's stamp `build_all` returns before touching csrc/_obj (no compiler, no write)."""
+    from ptlflow_amd import _build
+    if not _build.up_to_date():
+        pytest.skip("libraries not built for this tree")
+    monkeypatch.setattr(_build, "OBJ", tmp_path / "must_not_be_created")
+    monkeypatch.setattr(_build, "_run", lambda cmd: (_ for _ in ()).throw(AssertionError("compiler invoked")))
+    _build.build_all()
+    assert not (tmp_path / "must_not_be_created").exists()
