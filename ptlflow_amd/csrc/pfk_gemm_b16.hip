@@ -149,9 +149,14 @@ struct Stager16 {
 
   // One K-step's pieces into `stage`.  Past the end of K every A lane is out of range (zeros) and B is parked on K-step 0 (valid
   // memory, multiplied by zeros): the K loop stays branch-free and the counted vmcnt uniform.
+  int abl = 0;      // PFK_BENCH_VARIANTS ablations 6 / 7: the A pieces of every tap but the first fetch nothing (6: zero-fill, 7: not issued)
   template <int I>
   __device__ __forceinline__ void piece(char* stage, bool live, bool cok, int coff, int koff) const {
     if constexpr (I < A_PT) {
+#ifdef PFK_BENCH_VARIANTS
+      if (abl == 7 && tap != 0) return;
+      if (abl == 6 && tap != 0) { dma16(rs, stage + I * RPP * ROW16 + wave_off, OOB, coff); return; }
+#endif
       dma16(rs, stage + I * RPP * ROW16 + wave_off, (live && cok) ? aoff[I] : OOB, coff);
     } else {
       dma16(rsw, stage + A_BYTES + (I - A_PT) * RPP * ROW16 + wave_off, wvoff[I - A_PT], koff);
@@ -455,6 +460,7 @@ void conv_gemm_b16_kernel(const B16Args a_in) {
   const int n0 = tile_n * BN;
 
   St st(a, m0, n0, tid);
+  st.abl = ABL;
   const int nsteps = st.total;
 
   f32x16 acc[MT][NT];
@@ -579,6 +585,13 @@ int launch_b16(const B16Args& a, int epi, hipStream_t st) {
       case 12: return launch_b16_one<PFK_EPI_LINEAR, 128, 128, 2, 2, 2, 1>(a, st);
       case 22: return launch_b16_one<PFK_EPI_LINEAR, 128, 128, 2, 2, 2, 2>(a, st);
       case 32: return launch_b16_one<PFK_EPI_LINEAR, 128, 128, 2, 2, 2, 3>(a, st);
+      // the 256x256 tile (cfg 6): no MFMAs / no DMA / no epilogue / A fetched for the first tap only (zero-filled, not issued)
+      case 16: return launch_b16_one<PFK_EPI_LINEAR, 256, 256, 2, 4, 2, 1>(a, st);
+      case 26: return launch_b16_one<PFK_EPI_LINEAR, 256, 256, 2, 4, 2, 2>(a, st);
+      case 36: return launch_b16_one<PFK_EPI_LINEAR, 256, 256, 2, 4, 2, 3>(a, st);
+      case 66: return launch_b16_one<PFK_EPI_LINEAR, 256, 256, 2, 4, 2, 6>(a, st);
+      case 76: return launch_b16_one<PFK_EPI_LINEAR, 256, 256, 2, 4, 2, 7>(a, st);
+      case 61: return launch_b16_one<PFK_EPI_LINEAR, 256, 128, 4, 2, 3, 6>(a, st);
       default: return PFK_ERR_BAD_ARG;
     }
   }
