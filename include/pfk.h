@@ -395,6 +395,12 @@ int pfk_upflow8_f32(const float* coords0, const float* coords1, float* out, int 
 int pfk_mask_upsample_f32(const float* x, int x_ld, int cin, const float* weight_perm, const float* bias_perm, float scale,
                           const float* flow_pm, int flow_ld, float* out, int B, int H, int W, pfk_stream_t stream);
 
+/* K13b — the same on the K8b path (ABI 7): x bf16 [M][x_ld] (cin % 64 == 0, x_ld % 8 == 0), weight_perm bf16 [640][cin] in the same
+ * row order, bias / flow / out fp32.  Every logit is rounded to bf16 where pfk_conv2d_b16 (bf16 out) would store it: bit-identical
+ * to that launch + pfk_convex_upsample_pm_b16. */
+int pfk_mask_upsample_b16(const void* x_bf16, int x_ld, int cin, const void* weight_perm_bf16, const float* bias_perm, float scale,
+                          const float* flow_pm, int flow_ld, float* out, int B, int H, int W, pfk_stream_t stream);
+
 /* same, with the flow read pixel-major (flow_pm[p*flow_ld + 0..1], e.g. the update engine's hx slice) */
 int pfk_convex_upsample_pm_f32(const float* flow_pm, int flow_ld, const float* mask, int mask_ld,
                                float* out, int B, int H, int W, pfk_stream_t stream);

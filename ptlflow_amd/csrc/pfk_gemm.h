@@ -349,4 +349,42 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[MT][NT]) {
 extern int g_bf_cfg;
 int launch_bf(const GemmArgs& a, int epi, int nsplit, hipStream_t st);
 
+// One (pixel, sub-pixel) of the fused epilogue: the nine logits -> softmax -> convex combination of the neighbours' flows, with the
+// arithmetic of the unfused pair operation for operation — conv epilogue (pfk_gemm.h, LINEAR): + bias, x scale; convex_upsample_kernel
+// (pfk_misc.hip, compiled with -ffp-contract=off): max, exp, sum in tap order, one reciprocal, multiply then add.  In the unfused
+// pair the mask goes through memory between the two kernels and pfk_misc.hip never contracts, so NOTHING here may be contracted
+// into an FMA either: this translation unit is compiled with contraction on and HIP's __fmul_rn / __fadd_rn are plain operators
+// (they do not stop it), hence the pragma.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void mask_upsample_combine(const float (&m_in)[9], const f32x2* nfp, float& ox, float& oy) {
+#pragma clang fp contract(off)
+  float m[9];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { m[k] = m_in[k]; mx = fmaxf(mx, m[k]); }
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { m[k] = expf(m[k] - mx); sum = sum + m[k]; }
+  const float inv = 1.0f / sum;
+  float ax = 0.f, ay = 0.f;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const f32x2 f = nfp[k];
+    const float wk = m[k] * inv;
+    const float tx = wk * f[0], ty = wk * f[1];
+    ax = ax + tx;
+    ay = ay + ty;
+  }
+  ox = ax;
+  oy = ay;
+}
+// the conv epilogue's + bias, x scale on one logit, un-contracted
+__device__ __forceinline__ float mask_logit(float acc, float bias, float sc) {
+#pragma clang fp contract(off)
+  float v = acc + bias;
+  v = v * sc;
+  return v;
+}
+
+
 }  // namespace pfkg

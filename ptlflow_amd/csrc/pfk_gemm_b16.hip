@@ -610,6 +610,159 @@ int launch_b16(const B16Args& a, int epi, hipStream_t st) {
   }
 }
 
+// -------------------------------------------------------------------------------------------------
+// K13b — mask head conv2 + softmax + convex upsampling on the K8b path (raft/update.py:152 + raft/raft.py:112-123), the bf16 form of
+// pfk_gemm.hip::mask_upsample_kernel: same geometry (a block = 128 pixels x 16 sub-pixels x all nine taps: four waves stacked in M, wave
+// tile 32 x 160 = five 32x32 accumulators, weight / bias rows pre-permuted to [quarter][tile][32] by the host), operands bf16 through
+// LDS-DMA (64-channel K-steps, two stages of (128 + 160) x 128 B = 72 KB: two blocks per CU), products on v_mfma_f32_32x32x16_bf16.
+// On this path the unfused pair writes 65 MB of bf16 logits per iteration at batch 8 and reads them back on a side stream next to the
+// main stream's HBM-bound launches; here the logits never leave the registers.  Each logit is rounded to bf16 exactly where the unfused
+// launch stores it ((acc + bias) * scale, round to nearest even) and the epilogue is the shared mask_upsample_combine: the 8x flow is
+// bit-identical to pfk_conv2d_b16 (bf16 out) + pfk_convex_upsample_pm_b16.
+// -------------------------------------------------------------------------------------------------
+struct MuB16Args {
+  const void* x; int x_ld, cin;          // bf16 [M][x_ld]
+  const void* w;                         // bf16 [640][cin], rows permuted
+  const float* bias;                     // [640] permuted, may be null
+  float scale;
+  const float* flow; int flow_ld;        // fp32 pixel-major flow
+  float* out;                            // [B][2][8H][8W]
+  int H, W;
+  long long M;
+  unsigned wo_mul, ho_mul; int wo_sh, ho_sh;
+};
+
+constexpr int MUB_BM = 128, MUB_BN = 160, MUB_ROWS = 640;
+
+__global__ __launch_bounds__(256, 2) void mask_upsample_b16_kernel(const MuB16Args a) {
+  constexpr int BM = MUB_BM, BN = MUB_BN, NT = 5;
+  constexpr int A_BYTES = BM * ROW16, STAGE = (BM + BN) * ROW16;
+  constexpr int A_PT = BM / 32, B_PT = BN / 32, PIECES = A_PT + B_PT;     // 32 rows per pass of the 256 threads
+  extern __shared__ __attribute__((aligned(16))) char smem_mu[];           // [2][STAGE]; the epilogue's flow neighbourhoods afterwards
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int bid = pfk_xcd_remap(blockIdx.x, gridDim.x);   // the four quarters of a pixel tile are neighbours: one A panel through one L2
+  const int quarter = bid & 3;
+  const long long m0 = (long long)(bid >> 2) * BM;
+  const int n0 = quarter * BN;
+
+  const __amdgpu_buffer_rsrc_t rsx = make_rsrc(a.x), rsw = make_rsrc(a.w);
+  const int r0 = tid >> 3;
+  const int lc8 = ((tid & 7) ^ ((r0 >> 1) & 7)) * 8;      // logical chunk of this lane's physical slot (rows of one thread share the key)
+  const unsigned wave_off = (unsigned)wid * 1024u;
+  unsigned avo[A_PT], bvo[B_PT];
+#pragma unroll
+  for (int i = 0; i < A_PT; ++i) {
+    const long long p = m0 + r0 + 32 * i;
+    avo[i] = p < a.M ? (unsigned)(p * a.x_ld + lc8) * 2u : OOB;
+  }
+#pragma unroll
+  for (int i = 0; i < B_PT; ++i) bvo[i] = (unsigned)((n0 + r0 + 32 * i) * a.cin + lc8) * 2u;
+  const int nsteps = a.cin / BK16;
+
+  auto issue = [&](int step, char* stage) {
+    const int off = step * (BK16 * 2);
+#pragma unroll
+    for (int i = 0; i < A_PT; ++i) dma16(rsx, stage + i * 32 * ROW16 + wave_off, avo[i], off);
+#pragma unroll
+    for (int i = 0; i < B_PT; ++i) dma16(rsw, stage + A_BYTES + i * 32 * ROW16 + wave_off, bvo[i], off);
+  };
+
+  f32x16 acc[1][NT];
+  zero_acc<1, NT>(acc);
+  const int frow = lane & 31, hl = lane >> 5, key = (lane >> 1) & 7;
+  int ko[4];
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) ko[kb] = ((2 * kb + hl) ^ key) << 4;
+  const int a_row = (wid * 32 + frow) * ROW16;
+  const int b_row = A_BYTES + frow * ROW16;
+
+  issue(0, smem_mu);
+  for (int step = 0; step < nsteps; ++step) {
+    char* cur = smem_mu + (step & 1) * STAGE;
+    if (step + 1 < nsteps) {
+      issue(step + 1, smem_mu + ((step + 1) & 1) * STAGE);
+      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PIECES) : "memory");      // this step's pieces have landed, the next step's stay in flight
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const bf16x8 fa = *reinterpret_cast<const bf16x8*>(cur + a_row + ko[kb]);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const bf16x8 fb = *reinterpret_cast<const bf16x8*>(cur + b_row + nt * 32 * ROW16 + ko[kb]);
+        acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[0][nt], 0, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();      // every wave is done with `cur` before the step after next lands in it
+  }
+
+  // ---- epilogue (pfk_gemm.hip::mask_upsample_kernel's, with the logits rounded to bf16 as the unfused launch stores them)
+  f32x2* nf = reinterpret_cast<f32x2*>(smem_mu);     // [BM][9]: 8 x flow of every pixel's 3x3 neighbourhood, zero outside the image
+  const unsigned H = (unsigned)a.H, W = (unsigned)a.W;
+  for (int e = tid; e < BM * 9; e += 256) {
+    const int pl = e / 9, k = e - pl * 9;
+    const unsigned p = (unsigned)m0 + (unsigned)pl;
+    f32x2 v = {0.f, 0.f};
+    if ((long long)p < a.M) {
+      const unsigned prow = fastdiv_u32(p, a.wo_mul, a.wo_sh);          // b*H + y
+      const unsigned bimg = fastdiv_u32(prow, a.ho_mul, a.ho_sh);
+      const int x = (int)(p - prow * W), y = (int)(prow - bimg * H);
+      const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
+      if ((unsigned)yy < H && (unsigned)xx < W) {
+        const float* f = a.flow + ((size_t)(bimg * H + (unsigned)yy) * W + (unsigned)xx) * (size_t)a.flow_ld;
+        v[0] = 8.0f * f[0];
+        v[1] = 8.0f * f[1];
+      }
+    }
+    nf[e] = v;
+  }
+  __syncthreads();
+
+  const int col = lane & 31;
+  const int odd = col >> 4;                          // this lane's own taps are 2j + odd
+  const int s = quarter * 16 + (col & 15), sy = s >> 3, sx = s & 7;
+  const int wm0 = wid * 32;
+  float bias[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) bias[j] = a.bias != nullptr ? a.bias[n0 + j * 32 + col] : 0.f;
+  const float sc = a.scale;
+  const size_t HW8 = (size_t)H * W * 64;
+#pragma unroll
+  for (int r = 0; r < 16; r += 2) {
+    const int rr = r + odd;                          // the row this lane finishes
+    const int row = wm0 + (rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5);
+    const unsigned p = (unsigned)m0 + (unsigned)row;
+    float own[NT], oth[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const float l0 = (float)(__bf16)mask_logit(acc[0][j][r], bias[j], sc), l1 = (float)(__bf16)mask_logit(acc[0][j][r + 1], bias[j], sc);
+      own[j] = odd ? l1 : l0;                        // tap 2j + odd of my row
+      oth[j] = __shfl_xor(odd ? l0 : l1, 16, 64);    // send the partner's row, receive tap 2j + (1 - odd) of mine
+    }
+    float m[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int j = k >> 1;
+      m[k] = ((k & 1) == odd) ? own[j] : oth[j];
+    }
+    float ox, oy;
+    mask_upsample_combine(m, nf + row * 9, ox, oy);
+    if ((long long)p < a.M) {
+      const unsigned prow = fastdiv_u32(p, a.wo_mul, a.wo_sh);
+      const unsigned bimg = fastdiv_u32(prow, a.ho_mul, a.ho_sh);
+      const unsigned x = p - prow * W, y = prow - bimg * H;
+      const size_t o = (size_t)(8 * y + (unsigned)sy) * (8 * W) + 8 * x + (unsigned)sx;
+      a.out[((size_t)bimg * 2 + 0) * HW8 + o] = ox;
+      a.out[((size_t)bimg * 2 + 1) * HW8 + o] = oy;
+    }
+  }
+}
+
 int b16_ktot(const pfk_conv_b16_desc* d) {
   if (!d || d->num_src < 1 || d->num_src > 3) return PFK_ERR_BAD_ARG;
   int k = 0;
@@ -628,6 +781,29 @@ int pfk_debug_set_b16(int cfg) {
 }
 
 int pfk_conv_ktot_b16(const pfk_conv_b16_desc* d) { return b16_ktot(d); }
+
+int pfk_mask_upsample_b16(const void* x_bf16, int x_ld, int cin, const void* weight_perm_bf16, const float* bias_perm, float scale,
+                          const float* flow_pm, int flow_ld, float* out, int B, int H, int W, pfk_stream_t stream) {
+  if (!x_bf16 || !weight_perm_bf16 || !flow_pm || !out || B <= 0 || H <= 0 || W <= 0 || cin <= 0 || x_ld < cin || flow_ld < 2) return PFK_ERR_BAD_ARG;
+  if ((cin & 63) || (x_ld & 7) || !pfk_aligned16(x_bf16) || !pfk_aligned16(weight_perm_bf16)) return PFK_ERR_ALIGNMENT;
+  const long long M = (long long)B * H * W;
+  if (M >= 0x7fffffffLL || M * x_ld * 2 >= 0x7fffffffLL || (long long)MUB_ROWS * cin * 2 >= 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
+  MuB16Args a{};
+  a.x = x_bf16; a.x_ld = x_ld; a.cin = cin; a.w = weight_perm_bf16; a.bias = bias_perm; a.scale = scale;
+  a.flow = flow_pm; a.flow_ld = flow_ld; a.out = out; a.H = H; a.W = W; a.M = M;
+  fastdiv_make((unsigned)W, a.wo_mul, a.wo_sh);
+  fastdiv_make((unsigned)H, a.ho_mul, a.ho_sh);
+  const long long nblk = ((M + MUB_BM - 1) / MUB_BM) * 4;
+  if (nblk > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
+  constexpr size_t smem = 2 * (MUB_BM + MUB_BN) * ROW16;
+  static_assert(MUB_BM * 9 * 8 <= (int)smem, "the epilogue's flow neighbourhoods reuse the staging LDS");
+  static pfk_device_once attr_once;
+  attr_once.run([&] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mask_upsample_b16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  });
+  hipLaunchKernelGGL(mask_upsample_b16_kernel, dim3((unsigned)nblk), dim3(256), smem, static_cast<hipStream_t>(stream), a);
+  return pfk_launch_status();
+}
 
 int pfk_conv2d_b16(const pfk_conv_b16_desc* d, pfk_stream_t stream) {
   if (!d || !d->weight || d->num_src < 1 || d->num_src > 3) return PFK_ERR_BAD_ARG;

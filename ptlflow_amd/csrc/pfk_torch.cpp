@@ -419,7 +419,10 @@ void convex_upsample_pm(const Tensor& flow_pm, const Tensor& mask, Tensor out) {
 void mask_upsample(const Tensor& x, const Tensor& weight_perm, const c10::optional<Tensor>& bias_perm, double scale,
                    const Tensor& flow_pm, Tensor out) {
   OpScope scope(x);
-  check_pm(x, "x"); check_pm(flow_pm, "flow_pm"); check_dev_f32(weight_perm, "weight"); check_dev_f32(out, "out");
+  const bool b16 = check_pm_any(x, "x");
+  check_pm(flow_pm, "flow_pm"); check_dev_f32(out, "out");
+  if (b16) check_dev(weight_perm, "weight"); else check_dev_f32(weight_perm, "weight");
+  TORCH_CHECK(!b16 || weight_perm.scalar_type() == at::kBFloat16, "mask_upsample: a bf16 activation needs the bf16 permuted weight");
   TORCH_CHECK(out.dim() == 4 && out.size(1) == 2 && out.is_contiguous() && out.size(2) % 8 == 0 && out.size(3) % 8 == 0, "mask_upsample: out [B,2,8H,8W]");
   const int B = out.size(0), H = out.size(2) / 8, W = out.size(3) / 8;
   const int cin = x.size(1);
@@ -427,6 +430,11 @@ void mask_upsample(const Tensor& x, const Tensor& weight_perm, const c10::option
   TORCH_CHECK(weight_perm.is_contiguous() && weight_perm.dim() == 2 && weight_perm.size(0) == 640 && weight_perm.size(1) == cin, "mask_upsample: weight [640, cin] (packing.permute_mask_head)");
   const float* bp = nullptr;
   if (bias_perm.has_value()) { check_dev_f32(*bias_perm, "bias"); TORCH_CHECK(bias_perm->numel() == 640 && bias_perm->is_contiguous()); bp = fptr(*bias_perm); }
+  if (b16) {
+    check_ok(pfk_mask_upsample_b16(x.data_ptr(), x.stride(0), cin, weight_perm.data_ptr(), bp, (float)scale, fptr(flow_pm), flow_pm.stride(0),
+                                   fptr(out), B, H, W, cur_stream()), "mask_upsample (bf16)");
+    return;
+  }
   check_ok(pfk_mask_upsample_f32(fptr(x), x.stride(0), cin, fptr(weight_perm), bp, (float)scale, fptr(flow_pm), flow_pm.stride(0),
                                  fptr(out), B, H, W, cur_stream()), "mask_upsample");
 }

@@ -430,12 +430,14 @@ class RAFT(nn.Module):
         side = None
         # (measured, one MI355X: +0.9 % at batch 8 of 436x1024; -1.4 % at batch 1, where the loop's launches are short and the extra
         #  events cost more than the filled tails give back: only for >= 4 x 7040 pixels)
-        if has_mask and self.overlap_mask_head and pixels >= 28160 and not capturing:
+        fuse = has_mask and eng.can_fuse_mask_upsample and \
+            (self.fuse_mask_upsample if self.fuse_mask_upsample is not None else pixels >= 28160)
+        # (K8b with the fused K13b: 55 us of mostly matrix / VALU work per iteration — on the main stream it measured 26.44 ms per
+        #  batch-8 forward against 26.76 on the side stream, where it competes with the HBM-bound bf16 launches beside it)
+        if has_mask and self.overlap_mask_head and pixels >= 28160 and not capturing and not (fuse and eng.b16):
             side = self._stream(dev, "mask")
         main = torch.cuda.current_stream(dev)
         side_done = None
-        fuse = has_mask and eng.can_fuse_mask_upsample and \
-            (self.fuse_mask_upsample if self.fuse_mask_upsample is not None else pixels >= 28160)
         # Small batches (below the side-stream threshold; fp32 tile kernel): convc1 | convf2 | the PREVIOUS iteration's mask conv2 as one
         # grouped launch (`UpdateEngine.motion_grouped`), the previous iteration's upsampling right behind it — before this
         # iteration's coordinate update overwrites the flow slice it reads.  Same launches' tiles, same bits.

@@ -223,6 +223,10 @@ class UpdateEngine:
                 # the kernel's [quarter][tile][32] order (packing.permute_mask_head, include/pfk.h); `fm` is split at fh_hidden, so
                 # the fused kernel is only armed where the two hidden widths agree
                 w["mku.w"], w["mku.b"] = permute_mask_head(pack_conv_weight(g("mask.2.weight"), seg1(mask_hidden)), w["mk.b"])
+            elif self.b16 and s.mask_channels == 576 and mask_hidden % 64 == 0 and mask_hidden == s.fh_hidden:
+                # K13b (`pfk_mask_upsample_b16`): the same row order, bf16 (whole 64-channel K-steps: the packed K is the plain channel order)
+                wp, bp = permute_mask_head(pack_conv_weight(g("mask.2.weight"), seg1(mask_hidden)), w["mk.b"])
+                w["mku.w"], w["mku.b"] = wp.to(torch.bfloat16).contiguous(), bp
             # flow-head conv1 alone: the iterations whose mask is never looked at (`upsample_every_iter=False`) skip the mask half
             w["fh.w"] = pk(g("flow_head.conv1.weight"), seg1(Ch))
             w["fh.b"] = g("flow_head.conv1.bias").contiguous()
@@ -659,7 +663,8 @@ class UpdateEngine:
             self.profile.setdefault(key, []).append((a, b))
             M = x.shape[0]
             self.flops[key] = 2.0 * M * 576 * s.fh_hidden
-            self.bytes[key] = 4.0 * (M * s.fh_hidden + 576 * s.fh_hidden + 2 * M + 2 * 64 * M)
+            eb = 2.0 if self.b16 else 4.0       # activation / weight element size; flow in and 8x flow out are fp32 on both paths
+            self.bytes[key] = eb * (M * s.fh_hidden + 576 * s.fh_hidden) + 4.0 * (2 * M + 2 * 64 * M)
 
     def step(self, corr_pm: torch.Tensor, coords0: torch.Tensor, coords1: torch.Tensor, want_mask: bool = True) -> None:
         """One full RAFT iteration body after the lookup; updates hx (net, flow) and coords1 in place."""

@@ -31,6 +31,9 @@ def main():
     ap.add_argument("--skip-dead", action="store_true")
     ap.add_argument("--precisions", default="fp32,bf16")
     ap.add_argument("--cfg", type=int, default=0, help="force a K8b tile configuration (needs PFK_DEBUG_KNOBS=1)")
+    ap.add_argument("--graph", action="store_true", help="use_graph=True: the iteration loop replayed from a captured hipGraph")
+    ap.add_argument("--no-overlap", action="store_true", help="mask head + upsampling on the main stream")
+    ap.add_argument("--no-fuse", action="store_true", help="mask conv2 and the upsampling as two launches")
     args = ap.parse_args()
     dev = torch.device("cuda")
     if args.cfg:
@@ -44,8 +47,12 @@ def main():
     x = {"images": O.smooth_pair(args.batch, 436, 1024, 1234).to(dev)}
     ref = None
     for prec in args.precisions.split(","):
-        m = cls(conv_precision=prec, **kw).eval()
+        m = cls(conv_precision=prec, **kw, **({"use_graph": True} if args.graph else {})).eval()
         m.load_state_dict(P)
+        if args.no_overlap:
+            m.overlap_mask_head = False
+        if args.no_fuse:
+            m.fuse_mask_upsample = False
         m = m.to(dev)
         out = m(x)["flows"][:, 0].float()
         torch.cuda.synchronize()

@@ -341,3 +341,47 @@ def test_encoder_b16_against_the_oracle_encoder(gpu, norm, small):
     assert (f32 - ref).abs().max() < 1e-3 * (1 + ref.abs().max())
     assert (got - ref).abs().mean() < 2e-2 * scale, f"mean err {(got - ref).abs().mean():.3e} vs scale {scale:.3e}"
     assert (got - ref).abs().max() < 0.25 * (1 + ref.abs().max())
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 55, 128), (2, 13, 17), (1, 8, 9), (3, 47, 156)])
+def test_mask_upsample_fused_b16(gpu, B, H, W):
+    """K13b `pfk_mask_upsample_b16` (mask conv2 + softmax + convex upsampling on bf16 operands, no mask in memory) against the two K8b
+    launches it replaces (`conv2d_b16` with scale 0.25 -> bf16 [M, 576] logits -> `convex_upsample_pm`): bit-identical (every logit is
+    rounded to bf16 where the unfused launch stores it); and against the oracle's `convex_upsample` on the fp32 convolution of the
+    bf16-rounded operands, to the distance one bf16 rounding of the logits makes."""
+    from ptlflow_amd.packing import pack_conv_weight, permute_mask_head
+    torch.manual_seed(19)
+    M, cin = B * H * W, 256
+    fm = r16(torch.randn(M, 512))                  # fh | mask hidden: the kernel reads the second half as a strided view
+    wt = r16(torch.randn(576, cin, 1, 1) / math.sqrt(cin))
+    bias = torch.randn(576) * 0.1
+    hx = torch.randn(M, 8)
+    wp, bp = permute_mask_head(pack_conv_weight(wt, [(0, cin, cin)]), bias)
+    fm_g, hx_g = fm.to(gpu, BF), hx.cuda()
+    x_g, flow_g = fm_g[:, 256:], hx_g[:, 4:6]
+    mask = torch.empty(M, 576, device=gpu, dtype=BF)
+    torch.ops.pfk.conv2d_b16([x_g], B, H, W, 1, 1, pack16(wt, [(0, cin, cin)]), bias.cuda(), 576, EPI_LINEAR, False, 0.25, mask)
+    want = torch.empty(B, 2, 8 * H, 8 * W, device=gpu)
+    torch.ops.pfk.convex_upsample_pm(flow_g, mask, want)
+    got = torch.full((B, 2, 8 * H, 8 * W), 7.0, device=gpu)
+    torch.ops.pfk.mask_upsample(x_g, wp.to(gpu, BF), bp.cuda(), 0.25, flow_g, got)
+    assert torch.equal(got, want), f"max diff {(got - want).abs().max().item():.3e}"
+    x_nchw = fm[:, 256:].reshape(B, H, W, cin).permute(0, 3, 1, 2)
+    mask_ref = r16(0.25 * F.conv2d(x_nchw, wt, bias))
+    flow_ref = hx[:, 4:6].reshape(B, H, W, 2).permute(0, 3, 1, 2)
+    ref = O.convex_upsample(flow_ref, mask_ref)
+    assert (got.cpu() - ref).abs().max() < 2e-2 * (1 + ref.abs().max())
+
+
+@pytest.mark.parametrize("kind,B,H,W", [("raft", 8, 480, 640), ("raft", 1, 184, 320), ("gma", 2, 200, 328)])
+def test_fused_mask_upsample_b16_is_bit_identical_in_the_forward(gpu, kind, B, H, W):
+    """`fuse_mask_upsample` on the K8b path: whole forwards with K13b and with the pair (both on the side stream where it opens) give
+    the same bits, over repeated forwards on fresh inputs."""
+    from ptlflow_amd.raft import GMA, RAFT
+    make = (lambda: GMA(iters=5, conv_precision="bf16")) if kind == "gma" else (lambda: RAFT(iters=5, conv_precision="bf16"))
+    a, b = make().load_synthetic(5).eval().cuda(), make().load_synthetic(5).eval().cuda()
+    a.fuse_mask_upsample, b.fuse_mask_upsample = False, True
+    for seed in (1, 2, 1):
+        x = O.smooth_pair(B, H, W, seed=seed).cuda()
+        fa, fb = a({"images": x}), b({"images": x})
+        assert torch.equal(fa["flows"], fb["flows"]) and torch.equal(fa["flow_small"], fb["flow_small"]), seed
