@@ -119,6 +119,95 @@ __global__ __launch_bounds__(256) void conv_cin2_tiled_kernel(const float* __res
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same 7x7 convolution on the matrix cores (round 6; cout = 64 or 128 — SmallMotionEncoder / BasicMotionEncoder's convf1,
+// raft/update.py:80,98).  The tiled VALU kernel runs the 1.4 GFLOP of a batch-8 launch in 31.5 us (33 us with bf16 rows out) — per
+// iteration, on every path (fp32: 1.0 ms of a 101 ms forward; K8b: 1.05 ms of 27).  As an implicit GEMM M = pixels, N = cout, K = 98 on
+// v_mfma_f32_32x32x2f32 a K-step is ONE tap: k = 2 tap + c, so the two halves of a wave read the x / y flow component of the same
+// patch cell.  A workgroup = 4 rows x 32 columns of output pixels (wave w: row w, one 32-pixel M tile x NT 32-channel N tiles); the
+// 2 x 10 x 38 flow patch (zero padding applied while staging) and the whole [98][cout] weight sit in LDS (3 + 50 KB at cout 128:
+// two workgroups per CU); persistent over the tile list (the weight is staged once per workgroup).  The accumulators START at the
+// bias and the MFMA adds k = 0, 1, 2, ... in order — an fmaf chain in the tiled kernel's order (tap-major, x then y): same bits.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int C2M_ROWS = 4, C2M_COLS = 32, C2M_K = 7, C2M_R = 3;
+constexpr int C2M_PR = C2M_ROWS + C2M_K - 1, C2M_PC = C2M_COLS + C2M_K - 1;     // 10 x 38 patch cells
+constexpr int C2M_PATCH = C2M_PR * C2M_PC;                                        // per flow component
+constexpr int C2M_STEPS = C2M_K * C2M_K;                                          // 49 K-steps of 2
+
+template <int NT, int S>
+struct Cin2Steps {
+  static __device__ __forceinline__ void run(f32x16 (&acc)[NT], const float* s_in, const float* s_w, int abase, int hl, int px) {
+    constexpr int ky = S / C2M_K, kx = S % C2M_K;
+    const float a = s_in[abase + ky * C2M_PC + kx];              // abase already holds this lane half's component plane
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+      acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s_w[(2 * S + hl) * (NT * 32) + nt * 32 + px], acc[nt], 0, 0, 0);
+    if constexpr (S + 1 < C2M_STEPS) Cin2Steps<NT, S + 1>::run(acc, s_in, s_w, abase, hl, px);
+  }
+};
+
+template <int NT, typename TO>
+__global__ __launch_bounds__(256, 2) void conv_cin2_mfma_kernel(const float* __restrict__ in, int in_ld, const float* __restrict__ wgt,
+                                                                 const float* __restrict__ bias, TO* __restrict__ out, int out_ld,
+                                                                 int out_coff, int H, int W, int tiles_x, int tiles_y, int ntiles,
+                                                                 int relu) {
+  constexpr int COUT = NT * 32;
+  __shared__ float s_in[2 * C2M_PATCH];
+  __shared__ float s_w[2 * C2M_STEPS * COUT];
+  for (int e = threadIdx.x; e < 2 * C2M_STEPS * COUT / 4; e += 256)
+    *reinterpret_cast<f32x4*>(s_w + e * 4) = *reinterpret_cast<const f32x4*>(wgt + e * 4);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int px = lane & 31, hl = lane >> 5;
+  const int abase = hl * C2M_PATCH + wid * C2M_PC + px;
+  float b0[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) b0[nt] = bias ? bias[nt * 32 + px] : 0.f;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int tx = tile % tiles_x, t1 = tile / tiles_x;
+    const int ty = t1 % tiles_y, b = t1 / tiles_y;
+    const int y0 = ty * C2M_ROWS, x0 = tx * C2M_COLS;
+    const long long img = (long long)b * H * W;
+    __syncthreads();                     // the previous tile's reads of s_in are done (first pass: orders nothing, harmless)
+    for (int e = threadIdx.x; e < C2M_PATCH; e += 256) {
+      const int yy = e / C2M_PC, xx = e - yy * C2M_PC;
+      const int gy = y0 + yy - C2M_R, gx = x0 + xx - C2M_R;
+      float fx = 0.f, fy = 0.f;
+      if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
+        const float* src = in + (img + (long long)gy * W + gx) * in_ld;
+        fx = src[0];
+        fy = src[1];
+      }
+      s_in[e] = fx;
+      s_in[C2M_PATCH + e] = fy;
+    }
+    __syncthreads();
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nt][r] = b0[nt];
+    Cin2Steps<NT, 0>::run(acc, s_in, s_w, abase, hl, px);
+    const int y = y0 + wid;
+    if (y < H) {
+      const long long row0 = img + (long long)y * W;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int c = nt * 32 + px;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * hl;
+          if (x >= W) continue;
+          float v = acc[nt][r];
+          if (relu) v = (v < 0.f) ? 0.f : v;
+          out[(row0 + x) * out_ld + out_coff + c] = (TO)v;
+        }
+      }
+    }
+  }
+}
+
+bool g_cin2_valu = false;      // pfk_debug_set_cin2_valu(1): the tiled VALU kernel for every width (A/B timing, tests)
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -533,6 +622,19 @@ static int conv_cin2_launch(const float* in, int in_ld, const float* weight, con
   if (k <= 0 || !(k & 1) || in_ld < 2 || out_ld < out_coff + cout) return PFK_ERR_BAD_ARG;
   const long long M = (long long)B * H * W;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (k == 7 && (cout == 64 || cout == 128) && pfk_aligned16(weight) && !g_cin2_valu) {
+    const int tiles_x = (W + C2M_COLS - 1) / C2M_COLS, tiles_y = (H + C2M_ROWS - 1) / C2M_ROWS;
+    const long long tiles = (long long)B * tiles_x * tiles_y;
+    if (tiles > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
+    const unsigned grid = (unsigned)(tiles < 512 ? tiles : 512);       // two workgroups per CU, persistent over the tile list
+    if (cout == 128)
+      hipLaunchKernelGGL((conv_cin2_mfma_kernel<4, TO>), dim3(grid), dim3(256), 0, st, in, in_ld, weight, bias, out, out_ld, out_coff, H, W,
+                         tiles_x, tiles_y, (int)tiles, relu);
+    else
+      hipLaunchKernelGGL((conv_cin2_mfma_kernel<2, TO>), dim3(grid), dim3(256), 0, st, in, in_ld, weight, bias, out, out_ld, out_coff, H, W,
+                         tiles_x, tiles_y, (int)tiles, relu);
+    return pfk_launch_status();
+  }
   if (k == 3 || k == 5 || k == 7) {
     const int tpr = (W + 15) / 16;
     const long long tiles = (long long)B * H * tpr;
@@ -565,6 +667,12 @@ int pfk_conv_cin2_f32(const float* in, int in_ld, const float* weight, const flo
                       float* out, int out_ld, int out_coff, int B, int H, int W, int k, int cout,
                       int relu, pfk_stream_t stream) {
   return conv_cin2_launch<float>(in, in_ld, weight, bias, out, out_ld, out_coff, B, H, W, k, cout, relu, stream);
+}
+
+int pfk_debug_set_cin2_valu(int on) {
+  if (!pfk_debug_knobs_enabled()) return PFK_ERR_DISABLED;
+  g_cin2_valu = on != 0;
+  return PFK_OK;
 }
 
 int pfk_conv_cin2_b16(const float* in, int in_ld, const float* weight, const float* bias,

@@ -327,6 +327,7 @@ void conv2d_b16(at::TensorList srcs, int64_t B, int64_t H, int64_t W, int64_t kh
 
 void debug_set_b16(int64_t cfg) { check_ok(pfk_debug_set_b16((int)cfg), "debug_set_b16"); }
 void debug_set_stem_valu(int64_t on) { check_ok(pfk_debug_set_stem_valu((int)on), "debug_set_stem_valu"); }
+void debug_set_cin2_valu(int64_t on) { check_ok(pfk_debug_set_cin2_valu((int)on), "debug_set_cin2_valu"); }
 
 void conv_cin2(const Tensor& in, const Tensor& weight, const c10::optional<Tensor>& bias, Tensor out,
                int64_t B, int64_t H, int64_t W, int64_t k, bool relu) {
@@ -912,6 +913,7 @@ TORCH_LIBRARY(pfk, m) {
         "Tensor? residual=None, int stride=1, bool relu_after_residual=False) -> ()");
   m.def("debug_set_b16(int cfg) -> ()", &debug_set_b16);
   m.def("debug_set_stem_valu(int on) -> ()", &debug_set_stem_valu);
+  m.def("debug_set_cin2_valu(int on) -> ()", &debug_set_cin2_valu);
   m.def("conv_workspace_bytes() -> int", &conv_workspace_bytes);
   m.def("conv_workspace_fault_offset() -> int", &conv_workspace_fault_offset);
   m.def("conv_cin2(Tensor inp, Tensor weight, Tensor? bias, Tensor(a!) out, int B, int H, int W, int k, bool relu) -> ()");

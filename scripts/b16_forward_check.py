@@ -35,7 +35,7 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="mask head + upsampling on the main stream")
     ap.add_argument("--no-fuse", action="store_true", help="mask conv2 and the upsampling as two launches")
     args = ap.parse_args()
-    dev = torch.device("cuda")
+    dev = torch.device("cuda", 0)
     if args.cfg:
         import ptlflow_amd
         ptlflow_amd.load_native()

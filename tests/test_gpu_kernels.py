@@ -389,6 +389,36 @@ def test_conv_cin2(gpu, k, cout, W):
     close(unpm(out, B, H, W), ref)
 
 
+@pytest.mark.parametrize("B,H,W,cout", [(2, 13, 17, 128), (1, 55, 128, 128), (1, 47, 156, 128), (2, 9, 70, 64), (1, 3, 5, 128)])
+def test_conv_cin2_mfma_has_the_valu_kernels_bits(gpu, B, H, W, cout):
+    """convf1 (7x7, 2 -> 64 / 128, raft/update.py:80,98) on the matrix cores: the accumulators start at the bias and the MFMA adds the
+    98 products in the tiled VALU kernel's order (tap-major, x then y) — an fmaf chain: the two kernels must agree bit for bit, with
+    fp32 and with bf16 rows out, into a channel slice of a wider buffer; and both match the oracle's convolution."""
+    from ptlflow_amd.packing import pack_cin2_weight
+    torch.manual_seed(8)
+    flow = torch.randn(B, 2, H, W) * 3
+    wt = torch.randn(cout, 2, 7, 7) / 10
+    bias = torch.randn(cout)
+    ref = F.relu(F.conv2d(flow, wt, bias, padding=3))
+    buf = torch.zeros(B * H * W, 8, device=gpu)
+    buf[:, 4:6] = pm(flow)
+    w = pack_cin2_weight(wt).cuda()
+    for dt in (torch.float32, torch.bfloat16):
+        outs = []
+        for valu in (1, 0):
+            torch.ops.pfk.debug_set_cin2_valu(valu)
+            try:
+                wide = torch.full((B * H * W, cout + 8), -2.0, device=gpu, dtype=dt)
+                torch.ops.pfk.conv_cin2(buf[:, 4:6], w, bias.cuda(), wide[:, 4: 4 + cout], B, H, W, 7, True)
+            finally:
+                torch.ops.pfk.debug_set_cin2_valu(0)
+            assert bool((wide[:, :4] == -2.0).all()) and bool((wide[:, 4 + cout:] == -2.0).all()), "wrote outside the channel slice"
+            outs.append(wide[:, 4: 4 + cout].float())
+        assert torch.equal(outs[0], outs[1]), f"{dt}: max diff {(outs[0] - outs[1]).abs().max().item():.3e}"
+        if dt == torch.float32:
+            close(unpm(outs[1].contiguous(), B, H, W), ref)
+
+
 @pytest.mark.parametrize("B,H,W,cin", [
     (2, 11, 15, 256),       # 4 pixels per wave, ragged row ends (15 = 3 waves + 3 pixels)
     (2, 48, 350, 256),      # >= 4096 waves of 8 pixels: the 8-pixel kernel, last wave of a row holds 6 pixels
