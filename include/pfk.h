@@ -347,7 +347,7 @@ int pfk_conv_cin2_f32(const float* in, int in_ld, const float* weight, const flo
                       float* out, int out_ld, int out_coff, int B, int H, int W, int k, int cout,
                       int relu, pfk_stream_t stream);
 
-int pfk_debug_set_cin2_valu(int on);      /* 1 = the tiled VALU kernel also where the MFMA kernel (k = 7, cout 64 / 128) would run */
+int pfk_debug_set_cin2_valu(int on);      /* 0 = by size; 1 = the tiled VALU kernel everywhere; 2 = the MFMA kernel (k = 7, cout 64 / 128) at every size */
 
 /* same with a bf16 output (ABI 7; k = 3, 5 or 7): `out_bf16` holds bf16 elements, out_ld / out_coff in elements — the A operand of
  * convf2 on the K8b path (pfk_conv2d_b16) */

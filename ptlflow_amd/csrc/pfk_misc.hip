@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void conv_cin2_mfma_kernel(const float* __r
   }
 }
 
-bool g_cin2_valu = false;      // pfk_debug_set_cin2_valu(1): the tiled VALU kernel for every width (A/B timing, tests)
+int g_cin2_valu = 0;           // pfk_debug_set_cin2_valu: 0 = by size, 1 = always the tiled VALU kernel, 2 = the MFMA kernel at every size
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -622,8 +622,13 @@ static int conv_cin2_launch(const float* in, int in_ld, const float* weight, con
   if (k <= 0 || !(k & 1) || in_ld < 2 || out_ld < out_coff + cout) return PFK_ERR_BAD_ARG;
   const long long M = (long long)B * H * W;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (k == 7 && (cout == 64 || cout == 128) && pfk_aligned16(weight) && !g_cin2_valu) {
-    const int tiles_x = (W + C2M_COLS - 1) / C2M_COLS, tiles_y = (H + C2M_ROWS - 1) / C2M_ROWS;
+  // the MFMA kernel from one tile per CU up (batch 8 of 55x128: 33.1 -> 26.6 us, bf16 rows 31.0 -> 24.2); below that its per-workgroup
+  // weight staging (50 KB) is not amortised (batch 1, 56 tiles: 12.3 us against 7.4 for the VALU kernel) — gpurun_out/r6r_cin2.log.
+  // g_cin2_valu: 1 = always the VALU kernel, 2 = the MFMA kernel at every size (tests).  Same bits either way.
+  const int c2_tx = (W + C2M_COLS - 1) / C2M_COLS, c2_ty = (H + C2M_ROWS - 1) / C2M_ROWS;
+  if (k == 7 && (cout == 64 || cout == 128) && pfk_aligned16(weight) && g_cin2_valu != 1 &&
+      ((long long)B * c2_tx * c2_ty >= 256 || g_cin2_valu == 2)) {
+    const int tiles_x = c2_tx, tiles_y = c2_ty;
     const long long tiles = (long long)B * tiles_x * tiles_y;
     if (tiles > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
     const unsigned grid = (unsigned)(tiles < 512 ? tiles : 512);       // two workgroups per CU, persistent over the tile list
@@ -671,7 +676,7 @@ int pfk_conv_cin2_f32(const float* in, int in_ld, const float* weight, const flo
 
 int pfk_debug_set_cin2_valu(int on) {
   if (!pfk_debug_knobs_enabled()) return PFK_ERR_DISABLED;
-  g_cin2_valu = on != 0;
+  g_cin2_valu = (on == 1 || on == 2) ? on : 0;
   return PFK_OK;
 }
 

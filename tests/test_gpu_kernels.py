@@ -405,7 +405,7 @@ def test_conv_cin2_mfma_has_the_valu_kernels_bits(gpu, B, H, W, cout):
     w = pack_cin2_weight(wt).cuda()
     for dt in (torch.float32, torch.bfloat16):
         outs = []
-        for valu in (1, 0):
+        for valu in (1, 2):        # 1 = the tiled VALU kernel, 2 = the MFMA kernel whatever the size
             torch.ops.pfk.debug_set_cin2_valu(valu)
             try:
                 wide = torch.full((B * H * W, cout + 8), -2.0, device=gpu, dtype=dt)
