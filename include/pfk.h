@@ -516,11 +516,16 @@ int pfk_norm_apply_f32(const float* x, int x_ld, const float* mean, const float*
                        int residual_ld, float* out, int out_ld, int B, int HW, int C, int relu,
                        int relu_after_residual, pfk_stream_t stream);
 
-/* same with bf16 residual rows and a bf16 output (ABI 7; ld in elements, 8-byte aligned rows): x — the fp32 convolution output the
- * statistics were taken from — is normalised in fp32; what the next convolution (pfk_conv2d_b16) reads is rounded once. */
-int pfk_norm_apply_b16(const float* x, int x_ld, const float* mean, const float* rstd, const void* residual_bf16,
+/* same with bf16 residual rows and a bf16 output (ABI 7; ld in elements, 8-byte aligned rows).  x = the convolution output the
+ * statistics were taken from: fp32 rows (x_bf16 = 0), or bf16 rows (x_bf16 = 1; `out_bf16` may be `x` itself: in place) — what
+ * F.instance_norm reads under the reference's autocast switch, where the convolution in front of it returns a 16-bit tensor
+ * (the arithmetic is fp32 either way: instance_norm is on autocast's fp32 list). */
+int pfk_norm_apply_b16(const void* x, int x_bf16, int x_ld, const float* mean, const float* rstd, const void* residual_bf16,
                        int residual_ld, void* out_bf16, int out_ld, int B, int HW, int C, int relu,
                        int relu_after_residual, pfk_stream_t stream);
+/* the statistics of bf16 rows (pfk_instnorm_stats_f32 otherwise: one pass, double partial sums, deterministic) */
+int pfk_instnorm_stats_b16(const void* x_bf16, int ld, int B, int HW, int C, float eps, float* mean, float* rstd,
+                           void* workspace, long long workspace_bytes, pfk_stream_t stream);
 
 /* In-place softmax over each row of x [rows][ld] (cols entries used) — GMA's attention map (gma/gma_utils.py:75-76:
  * `sim.softmax(dim=-1)`, once per forward; the similarity itself is pfk_corr_volume_f32 of the q / k maps). */

@@ -251,8 +251,21 @@ static inline int in_chunks(int B) { int c = 1024 / (B > 0 ? B : 1); return c < 
 // that error (measured on BasicEncoder gradients: 9e-3 with fp32 sums, 1e-6 with double; MIOpen's fp32 kernels 9e-4).
 typedef double f64x4s __attribute__((ext_vector_type(4)));
 
+// four consecutive channels of a pixel-major row as fp32: fp32 rows as they are, bf16 rows widened exactly
+__device__ __forceinline__ f32x4 ld4f(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 ld4f(const __bf16* p) {
+  typedef unsigned int u32x2e __attribute__((ext_vector_type(2)));
+  const u32x2e w = *reinterpret_cast<const u32x2e*>(p);
+  f32x4 v;
+  v[0] = __builtin_bit_cast(float, w[0] << 16); v[1] = __builtin_bit_cast(float, w[0] & 0xffff0000u);
+  v[2] = __builtin_bit_cast(float, w[1] << 16); v[3] = __builtin_bit_cast(float, w[1] & 0xffff0000u);
+  return v;
+}
+
 // part: two arrays [B][nch][C] one after the other (sum, then sum of squares; `astride` doubles apart)
-__global__ __launch_bounds__(256) void instnorm_partial_kernel(const float* __restrict__ x, int ld, int C, int HW,
+// TX = __bf16: the statistics of a bf16 convolution output (what F.instance_norm sees under the reference's autocast switch)
+template <typename TX>
+__global__ __launch_bounds__(256) void instnorm_partial_kernel(const TX* __restrict__ x, int ld, int C, int HW,
                                                                double* __restrict__ part, long long astride) {
   __shared__ f64x4s red[2][256];
   const int b = blockIdx.y, chunk = blockIdx.x;
@@ -266,14 +279,14 @@ __global__ __launch_bounds__(256) void instnorm_partial_kernel(const float* __re
   const int r0 = chunk * rows, r1 = min(HW, r0 + rows);
   f64x4s s0 = {0., 0., 0., 0.}, q0 = {0., 0., 0., 0.};
   if (active) {
-    const float* base = x + (long long)b * HW * ld + c4;
+    const TX* base = x + (long long)b * HW * ld + c4;
     // two independent accumulator sets: the fp64 add / fma chain of one set would otherwise serialise the loop (a chunk has
     // only a few hundred rows per thread and, at batch 1, the grid is far from filling the chip)
     f64x4s s1 = {0., 0., 0., 0.}, q1 = {0., 0., 0., 0.};
     int r = r0 + rr;
     for (; r + rpi < r1; r += 2 * rpi) {
-      const f32x4 v0 = *reinterpret_cast<const f32x4*>(base + (long long)r * ld);
-      const f32x4 v1 = *reinterpret_cast<const f32x4*>(base + (long long)(r + rpi) * ld);
+      const f32x4 v0 = ld4f(base + (long long)r * ld);
+      const f32x4 v1 = ld4f(base + (long long)(r + rpi) * ld);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const double d0 = (double)v0[e], d1 = (double)v1[e];
@@ -282,7 +295,7 @@ __global__ __launch_bounds__(256) void instnorm_partial_kernel(const float* __re
       }
     }
     if (r < r1) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(base + (long long)r * ld);
+      const f32x4 v = ld4f(base + (long long)r * ld);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const double d = (double)v[e];
@@ -363,8 +376,8 @@ __device__ __forceinline__ void na_store4(__bf16* p, const f32x4 v) {
   *reinterpret_cast<bf16x4*>(p) = h;
 }
 
-template <typename TR = float, typename TO = float>
-__global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict__ x, int x_ld, const float* __restrict__ mean,
+template <typename TR = float, typename TO = float, typename TX = float>
+__global__ __launch_bounds__(256) void norm_apply_kernel(const TX* __restrict__ x, int x_ld, const float* __restrict__ mean,
                                                          const float* __restrict__ rstd, const TR* __restrict__ residual,
                                                          int res_ld, TO* __restrict__ out, int out_ld, long long M, int HW,
                                                          int C, int relu, int relu_after) {
@@ -376,7 +389,7 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict
   const long long sidx = (p / HW) * C + c4;
   const f32x4 m = *reinterpret_cast<const f32x4*>(mean + sidx);
   const f32x4 r = *reinterpret_cast<const f32x4*>(rstd + sidx);
-  f32x4 v = *reinterpret_cast<const f32x4*>(x + p * x_ld + c4);
+  f32x4 v = ld4f(x + p * x_ld + c4);
   v = (v - m) * r;
   if (relu) {
 #pragma unroll
@@ -601,10 +614,13 @@ int pfk_debug_set_stem_valu(int on) {
 
 long long pfk_instnorm_workspace_bytes(int B, int C) { return (2LL * B * in_chunks(B) * C + 2LL * B * C) * (long long)sizeof(double); }
 
-int pfk_instnorm_stats_f32(const float* x, int ld, int B, int HW, int C, float eps, float* mean, float* rstd,
-                           void* workspace, long long workspace_bytes, pfk_stream_t stream) {
+}  // extern "C"
+
+template <typename TX>
+static int instnorm_stats_launch(const TX* x, int ld, int B, int HW, int C, float eps, float* mean, float* rstd,
+                                 void* workspace, long long workspace_bytes, pfk_stream_t stream) {
   if (!x || !mean || !rstd || !workspace || B <= 0 || HW <= 0 || C <= 0 || ld < C) return PFK_ERR_BAD_ARG;
-  if ((C & 3) || (ld & 3) || C > 1024 || !pfk_aligned16(x) || !pfk_aligned16(mean) || !pfk_aligned16(rstd) ||
+  if ((C & 3) || (ld & 3) || C > 1024 || (reinterpret_cast<uintptr_t>(x) & (sizeof(TX) * 4 - 1)) || !pfk_aligned16(mean) || !pfk_aligned16(rstd) ||
       (reinterpret_cast<uintptr_t>(workspace) & 31u))
     return PFK_ERR_ALIGNMENT;
   if (workspace_bytes < pfk_instnorm_workspace_bytes(B, C)) return PFK_ERR_BAD_ARG;
@@ -615,11 +631,23 @@ int pfk_instnorm_stats_f32(const float* x, int ld, int B, int HW, int C, float e
   double* sq = sum + (size_t)B * C;                          // [B][C]
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 grid((unsigned)nch, (unsigned)B), rgrid((unsigned)((C + 63) / 64), (unsigned)B);
-  hipLaunchKernelGGL(instnorm_partial_kernel, grid, dim3(256), 0, st, x, ld, C, HW, part, astride);
+  hipLaunchKernelGGL(instnorm_partial_kernel<TX>, grid, dim3(256), 0, st, x, ld, C, HW, part, astride);
   hipLaunchKernelGGL(chunk_reduce_kernel, rgrid, dim3(1024), 0, st, part, astride, 2, nch, C, sum, (long long)B * C);
   const int total = B * C;
   hipLaunchKernelGGL(instnorm_finish_kernel, dim3((total + 255) / 256), dim3(256), 0, st, sum, sq, HW, eps, mean, rstd, total);
   return pfk_launch_status();
+}
+
+extern "C" {
+
+int pfk_instnorm_stats_f32(const float* x, int ld, int B, int HW, int C, float eps, float* mean, float* rstd,
+                           void* workspace, long long workspace_bytes, pfk_stream_t stream) {
+  return instnorm_stats_launch<float>(x, ld, B, HW, C, eps, mean, rstd, workspace, workspace_bytes, stream);
+}
+
+int pfk_instnorm_stats_b16(const void* x_bf16, int ld, int B, int HW, int C, float eps, float* mean, float* rstd,
+                           void* workspace, long long workspace_bytes, pfk_stream_t stream) {
+  return instnorm_stats_launch<__bf16>(static_cast<const __bf16*>(x_bf16), ld, B, HW, C, eps, mean, rstd, workspace, workspace_bytes, stream);
 }
 
 long long pfk_norm_bwd_workspace_bytes(int B, int C) { return ((long long)B * in_chunks(B) * C * 2 + (long long)B * C * 2) * (long long)sizeof(double); }
@@ -692,21 +720,27 @@ int pfk_norm_apply_f32(const float* x, int x_ld, const float* mean, const float*
   return pfk_launch_status();
 }
 
-int pfk_norm_apply_b16(const float* x, int x_ld, const float* mean, const float* rstd, const void* residual_bf16,
+int pfk_norm_apply_b16(const void* x, int x_bf16, int x_ld, const float* mean, const float* rstd, const void* residual_bf16,
                        int residual_ld, void* out_bf16, int out_ld, int B, int HW, int C, int relu,
                        int relu_after_residual, pfk_stream_t stream) {
   if (!x || !mean || !rstd || !out_bf16 || B <= 0 || HW <= 0 || C <= 0 || x_ld < C || out_ld < C) return PFK_ERR_BAD_ARG;
-  if ((C & 3) || (x_ld & 3) || (out_ld & 3) || !pfk_aligned16(x) || (reinterpret_cast<uintptr_t>(out_bf16) & 7u) || !pfk_aligned16(mean) ||
-      !pfk_aligned16(rstd))
+  if ((C & 3) || (x_ld & 3) || (out_ld & 3) || (reinterpret_cast<uintptr_t>(x) & (x_bf16 ? 7u : 15u)) ||
+      (reinterpret_cast<uintptr_t>(out_bf16) & 7u) || !pfk_aligned16(mean) || !pfk_aligned16(rstd))
     return PFK_ERR_ALIGNMENT;
   if (residual_bf16 && (residual_ld < C || (residual_ld & 3) || (reinterpret_cast<uintptr_t>(residual_bf16) & 7u))) return PFK_ERR_ALIGNMENT;
   const long long M = (long long)B * HW;
   const long long threads = M * (C >> 2);
   const long long blocks = (threads + 255) / 256;
   if (blocks > 0x7fffffffLL) return PFK_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL((norm_apply_kernel<__bf16, __bf16>), dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, x_ld,
-                     mean, rstd, static_cast<const __bf16*>(residual_bf16), residual_ld, static_cast<__bf16*>(out_bf16), out_ld, M, HW, C,
-                     relu, relu_after_residual);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const __bf16* r16 = static_cast<const __bf16*>(residual_bf16);
+  __bf16* o16 = static_cast<__bf16*>(out_bf16);
+  if (x_bf16)
+    hipLaunchKernelGGL((norm_apply_kernel<__bf16, __bf16, __bf16>), dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const __bf16*>(x), x_ld,
+                       mean, rstd, r16, residual_ld, o16, out_ld, M, HW, C, relu, relu_after_residual);
+  else
+    hipLaunchKernelGGL((norm_apply_kernel<__bf16, __bf16, float>), dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const float*>(x), x_ld,
+                       mean, rstd, r16, residual_ld, o16, out_ld, M, HW, C, relu, relu_after_residual);
   return pfk_launch_status();
 }
 

@@ -711,12 +711,18 @@ int64_t instnorm_workspace_bytes(int64_t B, int64_t C) { return pfk_instnorm_wor
 
 void instnorm_stats(const Tensor& x, int64_t B, int64_t HW, double eps, Tensor mean, Tensor rstd, Tensor workspace) {
   OpScope scope(x);
-  check_pm(x, "x"); check_dev_f32(mean, "mean"); check_dev_f32(rstd, "rstd");
+  const bool x_b16 = check_pm_any(x, "x");
+  check_dev_f32(mean, "mean"); check_dev_f32(rstd, "rstd");
   const int C = x.size(1);
   TORCH_CHECK(x.size(0) == B * HW, "instnorm_stats: rows");
   TORCH_CHECK(mean.is_contiguous() && rstd.is_contiguous() && mean.numel() == B * C && rstd.numel() == B * C, "instnorm_stats: mean/rstd [B*C]");
   check_dev(workspace, "workspace");
   TORCH_CHECK(workspace.is_contiguous(), "instnorm_stats: workspace");
+  if (x_b16) {
+    check_ok(pfk_instnorm_stats_b16(x.data_ptr(), x.stride(0), (int)B, (int)HW, C, (float)eps, fptr(mean), fptr(rstd),
+                                    workspace.data_ptr(), (long long)workspace.nbytes(), cur_stream()), "instnorm_stats (bf16 rows)");
+    return;
+  }
   check_ok(pfk_instnorm_stats_f32(fptr(x), x.stride(0), (int)B, (int)HW, C, (float)eps, fptr(mean), fptr(rstd),
                                   workspace.data_ptr(), (long long)workspace.nbytes(), cur_stream()), "instnorm_stats");
 }
@@ -724,8 +730,10 @@ void instnorm_stats(const Tensor& x, int64_t B, int64_t HW, double eps, Tensor m
 void norm_apply(const Tensor& x, const Tensor& mean, const Tensor& rstd, const c10::optional<Tensor>& residual, Tensor out,
                 int64_t B, int64_t HW, bool relu, bool relu_after_residual) {
   OpScope scope(x);
-  check_pm(x, "x"); check_dev_f32(mean, "mean"); check_dev_f32(rstd, "rstd");
+  const bool x_b16 = check_pm_any(x, "x");
+  check_dev_f32(mean, "mean"); check_dev_f32(rstd, "rstd");
   const bool out_b16 = check_pm_any(out, "out");
+  TORCH_CHECK(out_b16 || !x_b16, "norm_apply: bf16 rows in need a bf16 output");
   const int C = x.size(1);
   TORCH_CHECK(x.size(0) == B * HW && out.size(0) == B * HW && out.size(1) == C, "norm_apply: shapes");
   TORCH_CHECK(mean.numel() == B * C && rstd.numel() == B * C, "norm_apply: mean/rstd [B*C]");
@@ -736,7 +744,7 @@ void norm_apply(const Tensor& x, const Tensor& mean, const Tensor& rstd, const c
       TORCH_CHECK(residual->size(0) == B * HW && residual->size(1) == C, "norm_apply: residual shape");
       r16 = residual->data_ptr(); r16_ld = residual->stride(0);
     }
-    check_ok(pfk_norm_apply_b16(fptr(x), x.stride(0), fptr(mean), fptr(rstd), r16, r16_ld, out.data_ptr(), out.stride(0), (int)B, (int)HW, C,
+    check_ok(pfk_norm_apply_b16(x.data_ptr(), x_b16 ? 1 : 0, x.stride(0), fptr(mean), fptr(rstd), r16, r16_ld, out.data_ptr(), out.stride(0), (int)B, (int)HW, C,
                                 relu, relu_after_residual, cur_stream()), "norm_apply (bf16 out)");
     return;
   }

@@ -51,8 +51,8 @@ class EncoderEngine:
         self.norm = norm
         self.device = device
         self.nsplit = CONV_PRECISIONS[conv_precision]
-        # "bf16": K8b (`pfk_conv2d_b16`, UpdateEngine's docstring) — bf16 activation storage between the layers; a convolution
-        # that feeds an instance norm writes fp32 (the statistics and the normalisation stay fp32), the norm-apply pass rounds once
+        # "bf16": K8b (`pfk_conv2d_b16`, UpdateEngine's docstring) — bf16 activation storage between the layers, instance norms
+        # included (statistics and normalisation in fp32 arithmetic on the bf16 rows, as F.instance_norm under autocast)
         self.b16 = conv_precision == "bf16"
         self._ws: Optional[torch.Tensor] = None
         self.max_matrix_bytes = 2 ** 31 - 1   # 32-bit byte offsets in the convolution kernels
@@ -103,9 +103,10 @@ class EncoderEngine:
     def _conv(self, x, B, H, W, k, key, cout, stride=1, relu=False, residual=None, relu2=False, fp32_out=None):
         M = B * _out(H, stride) * _out(W, stride)
         if self.b16:
-            # fp32 output where an instance norm follows (it reads the un-rounded convolution result), bf16 otherwise
-            f32 = (self.norm == "instance") if fp32_out is None else fp32_out
-            out = torch.empty(M, cout, device=self.device, dtype=torch.float32 if f32 else torch.bfloat16)
+            # bf16 rows out, also in front of an instance norm: under the reference's autocast switch a convolution returns a
+            # 16-bit tensor and F.instance_norm (fp32 arithmetic) reads that — statistics and normalisation of the rounded values
+            # (half the bytes of the three passes over the largest activations of the forward); fp32 only for the network's output
+            out = torch.empty(M, cout, device=self.device, dtype=torch.float32 if fp32_out else torch.bfloat16)
             self.ops.conv2d_b16([x], B, H, W, k, k, self.w[key + ".w"], self.w[key + ".b"], cout, EPI_LINEAR, relu, 1.0, out,
                                 None, None, None, None, residual, stride, relu2)
             return out
@@ -115,8 +116,8 @@ class EncoderEngine:
         return out
 
     def _inorm(self, x, B, HW, relu, residual=None, relu2=False):
-        """InstanceNorm2d (+relu, + residual add + relu) on the pixel-major buffer x: in place (fp32), or into a fresh bf16 buffer
-        on the K8b path (x is the fp32 convolution output, the result is what the next convolution reads)."""
+        """InstanceNorm2d (+relu, + residual add + relu) in place on the pixel-major buffer x — fp32 rows, or the bf16 rows of the K8b
+        path (only the stem, a VALU / fp32-MFMA kernel, hands over fp32 rows there: those are normalised into a fresh bf16 buffer)."""
         C = x.shape[1]
         need = self.ops.instnorm_workspace_bytes(B, C)
         if self._ws is None or self._ws.numel() < need:
@@ -124,8 +125,8 @@ class EncoderEngine:
         mean = torch.empty(B * C, device=self.device, dtype=torch.float32)
         rstd = torch.empty(B * C, device=self.device, dtype=torch.float32)
         self.ops.instnorm_stats(x, B, HW, EPS, mean, rstd, self._ws)
-        out = torch.empty(x.shape[0], C, device=self.device, dtype=torch.bfloat16) if self.b16 else x
-        self.ops.norm_apply(x, mean, rstd, residual, out, B, HW, relu, relu2)
+        out = torch.empty(x.shape[0], C, device=self.device, dtype=torch.bfloat16) if (self.b16 and x.dtype != torch.bfloat16) else x
+        self.ops.norm_apply(x, mean, rstd, residual, out, B, HW, relu, relu2)      # (bf16 rows: in place, like the fp32 path)
         return out
 
     def _bottleneck(self, x, B, H, W, name, cout, stride):

@@ -339,7 +339,13 @@ def test_encoder_b16_against_the_oracle_encoder(gpu, norm, small):
     assert got.shape == ref.shape
     scale = ref.abs().mean()
     assert (f32 - ref).abs().max() < 1e-3 * (1 + ref.abs().max())
-    assert (got - ref).abs().mean() < 2e-2 * scale, f"mean err {(got - ref).abs().mean():.3e} vs scale {scale:.3e}"
+    # the yardstick: the same encoder under the reference's reduced-precision switch on the CPU (torch.autocast(bfloat16): 16-bit
+    # convolution outputs, fp32 instance norms on them) — this path may not be further from fp32 than 1.5x that, or 2 % of the scale
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        auto = O.encoder({k: v.clone() for k, v in P.items()}, x, norm, small).float()
+    gap = (auto - ref).abs().mean()
+    err = (got - ref).abs().mean()
+    assert err < max(2e-2 * scale, 1.5 * gap), f"mean err {err:.3e}, autocast gap {gap:.3e}, scale {scale:.3e}"
     assert (got - ref).abs().max() < 0.25 * (1 + ref.abs().max())
 
 
