@@ -175,8 +175,8 @@ class EncoderEngine:
         max_b = max(1, self.max_matrix_bytes // per_image)
         if B > max_b:
             return torch.cat([self(img[i:i + max_b]) for i in range(0, B, max_b)], 0)
-        # K8b without an instance norm behind the stem: the MFMA stem kernel rounds to bf16 itself (widths 32 / 64)
-        stem_b16 = self.b16 and self.norm != "instance" and self.stem_dim in (32, 64)
+        # K8b: the MFMA stem kernel rounds to bf16 itself (widths 32 / 64), also in front of an instance norm (`_conv`'s note)
+        stem_b16 = self.b16 and self.stem_dim in (32, 64)
         x = torch.empty(B * H1 * W1, self.stem_dim, device=self.device, dtype=torch.bfloat16 if stem_b16 else torch.float32)
         self.ops.conv_stem(img, self.w["stem.w"], self.w["stem.b"], x, self.norm != "instance")
         if self.norm == "instance":
