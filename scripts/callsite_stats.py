@@ -21,7 +21,9 @@ from collections import defaultdict
 
 SEQ = ["c1", "c2", "f2", "cv", "zr1", "q1", "zr2", "q2", "fm", "mk"]
 NAMED = {"lookup_kernel": "lookup", "conv_cin2": "convf1 (7x7)", "flow_delta": "flow_delta", "convex_upsample": "upsample",
-         "mask_upsample_kernel": "mask_upsample (fused)"}
+         "mask_upsample": "mask_upsample (fused)",        # K13 (fp32) and K13b (`mask_upsample_b16_kernel`)
+         "conv_gemm_v3_group_kernel": "c1+f2[+mk] (grouped)"}   # round 6, small batches: convc1 | convf2 | previous mask conv2 in one grid
+GROUPED_SEQ = ["c2", "cv", "zr1", "q1", "zr2", "q2", "fm", "mk"]   # what follows a grouped launch (mk: the last iteration's only)
 
 
 def find(path, pat):
@@ -38,8 +40,9 @@ def classify(rows, fused=None):
     out = []
     # with the fused kernel K13 an iteration has no separate mask conv2: nine implicit-GEMM launches per lookup, not ten
     if fused is None:
-        fused = any("mask_upsample_kernel" in r["Kernel_Name"] for r in rows)
+        fused = any("mask_upsample" in r["Kernel_Name"] for r in rows)
     SEQ = [k for k in globals()["SEQ"] if k != "mk"] if fused else globals()["SEQ"]
+    BASE_SEQ = SEQ
     for r in rows:
         name = r["Kernel_Name"]
         site = None
@@ -48,7 +51,9 @@ def classify(rows, fused=None):
                 site = v
                 break
         if site == "lookup":
-            idx = 0
+            idx, SEQ = 0, BASE_SEQ
+        elif site == NAMED["conv_gemm_v3_group_kernel"]:
+            idx, SEQ = 0, GROUPED_SEQ
         elif site is None and "conv_gemm" in name and idx is not None:
             # mk runs on the side stream when the mask branch overlaps: it is the only conv_gemm launch of that queue
             if idx < len(SEQ):
@@ -73,7 +78,7 @@ def main():
     for r in rows:
         queues[r.get("Queue_Id", "0")].append(r)
     main_q = max(queues, key=lambda q: sum("lookup_kernel" in r["Kernel_Name"] for r in queues[q]))
-    fused = any("mask_upsample_kernel" in r["Kernel_Name"] for r in rows)
+    fused = any("mask_upsample" in r["Kernel_Name"] for r in rows)
     # the mask branch on a side queue (batch 8): mask conv2 is that queue's launch, the main queue has nine GEMM launches per lookup
     side_mk = any(q != main_q and any("convex_upsample" in r["Kernel_Name"] for r in rs) for q, rs in queues.items())
     acc = defaultdict(lambda: [0, 0])
@@ -119,7 +124,7 @@ def main():
     hdr = "| call site | launches | avg us |" + ("".join(f" {c} (avg) |" for c in counters))
     lines.append(hdr)
     lines.append("|---|---:|---:|" + "---:|" * len(counters))
-    order = ["lookup"] + SEQ + ["convf1 (7x7)", "flow_delta", "upsample", "mask_upsample (fused)"]
+    order = ["lookup", NAMED["conv_gemm_v3_group_kernel"]] + SEQ + ["convf1 (7x7)", "flow_delta", "upsample", "mask_upsample (fused)"]
     for site in order:
         if site not in acc:
             continue
