@@ -26,10 +26,10 @@ def _gate(kind, H, W, iters, gpu, seed):
     base = make().load_synthetic(seed).eval()
     P = {k: v.clone() for k, v in base.state_dict().items()}
     x = O.smooth_pair(1, H, W, seed)
-    fwd = O.gma_forward if kind == "gma" else O.raft_forward
-    ref32 = fwd(P, x, iters=iters)["flows"][:, 0]
-    with torch.autocast("cpu", dtype=torch.bfloat16):
-        ref_ac = fwd(P, x, iters=iters)["flows"][:, 0].float()
+    from _cpu_cache import cpu_forward      # the fp32 CPU forward of the headline configuration is shared with test_gpu_model.py
+    key = ("synthetic", seed, "smooth", seed)
+    ref32 = cpu_forward(kind, P, x, iters, key=key)["flows"][:, 0]
+    ref_ac = cpu_forward(kind, P, x, iters, autocast=True, key=key)["flows"][:, 0].float()
     gap, gap_max = O.epe(ref_ac, ref32)
     m = make(conv_precision="bf16").eval()
     m.load_state_dict(P)
@@ -48,7 +48,7 @@ def test_raft_bf16_gate_headline(gpu):
 
 def test_gma_bf16_gate_headline(gpu):
     """gma, 436x1024, 32 iterations."""
-    _gate("gma", 436, 1024, 32, gpu, 77)
+    _gate("gma", 436, 1024, 32, gpu, 1234)
 
 
 def test_bf16_pyramid_and_lookup(gpu):

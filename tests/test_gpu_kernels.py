@@ -144,6 +144,7 @@ def test_lookup_blocked_bf16_maps_bit_exact(gpu, B, h, w, L, r):
     wide = [p.float() for p in pyr]
     lh, lw = [p.shape[-2] for p in pyr], [p.shape[-1] for p in pyr]
     n = 2 * r + 1
+    cases = [(name, c, O.lookup(wide, c, r)) for name, c in _coords_cases(B, h, w)]      # the oracle's answer, once per field
     for fill in (0.0, 9.0):       # whatever the pad elements of the edge tiles hold must not leak into a sample
         lv = []
         for p in pyr:
@@ -156,8 +157,7 @@ def test_lookup_blocked_bf16_maps_bit_exact(gpu, B, h, w, L, r):
         for pix in (104, 8):
             torch.ops.pfk.debug_set_lookup_pix(pix)
             try:
-                for name, c in _coords_cases(B, h, w):
-                    ref = O.lookup(wide, c, r)
+                for name, c, ref in cases:
                     out = torch.full((B * h * w, L * n * n), -7.0, device=gpu)
                     torch.ops.pfk.corr_lookup_blocked(lv, lh, lw, c.cuda(), r, out)
                     got = unpm(out, B, h, w)

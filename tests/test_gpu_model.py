@@ -17,7 +17,8 @@ def _run_pair(small, H, W, iters, B=1, seed=1234, upsample_every_iter=True, smoo
     model = RAFT(small=small, iters=iters, upsample_every_iter=upsample_every_iter).load_synthetic(seed).eval()
     P = {k: v.clone() for k, v in model.state_dict().items()}
     x = O.smooth_pair(B, H, W, seed) if smooth else rand_pair(B, H, W, seed)
-    ref = O.raft_forward(P, x, iters=iters, small=small)
+    from _cpu_cache import cpu_forward
+    ref = cpu_forward("raft", P, x, iters, small=small, key=("synthetic", seed, "smooth" if smooth else "rand", seed))
     model = model.cuda()
     out = model({"images": x.cuda()})
     torch.cuda.synchronize()
@@ -92,7 +93,8 @@ def test_gma_headline_config(gpu):
     model = GMA(iters=32).load_synthetic(1234).eval()
     P = {k: v.clone() for k, v in model.state_dict().items()}
     x = O.smooth_pair(1, 436, 1024, seed=1234)
-    ref = O.gma_forward(P, x, iters=32)
+    from _cpu_cache import cpu_forward
+    ref = cpu_forward("gma", P, x, 32, key=("synthetic", 1234, "smooth", 1234))
     out = model.cuda()({"images": x.cuda()})
     assert tuple(out["flows"].shape) == (1, 1, 2, 436, 1024)
     mean, mx = O.epe(out["flows"][:, 0].cpu(), ref["flows"][:, 0])

@@ -191,7 +191,8 @@ def _epe(precisions, H, W, iters, small=False, seed=1234):
     base = RAFT(small=small, iters=iters).load_synthetic(seed).eval()
     P = {k: v.clone() for k, v in base.state_dict().items()}
     x = O.smooth_pair(1, H, W, seed)
-    ref = O.raft_forward(P, x, iters=iters, small=small)
+    from _cpu_cache import cpu_forward
+    ref = cpu_forward("raft", P, x, iters, small=small, key=("synthetic", seed, "smooth", seed))
     res = {}
     for prec in precisions:
         model = RAFT(small=small, iters=iters, conv_precision=prec).eval()
