@@ -320,10 +320,15 @@ __global__ __launch_bounds__(256) void instnorm_partial_kernel(const TX* __restr
 // accumulators each; slices are combined through LDS in a fixed order, so the result does not depend on the launch.  (A single
 // thread per (b, c) walking all chunks is a chain of nch dependent adds — 66 us at 256 chunks, more than the pass that produced
 // them; four slices: 17 us.)
+// FINISH (the statistics pass): NA == 2 (sums, sums of squares) and the thread that holds both totals of a (b, c) writes mean / rstd
+// itself — instnorm_finish_kernel's arithmetic, one launch less per norm (15 per feature-encoder forward; ~5 us each at batch 1).
+template <bool FINISH = false>
 __global__ __launch_bounds__(1024) void chunk_reduce_kernel(const double* __restrict__ part, long long astride, int NA, int nch, int C,
-                                                            double* __restrict__ tot, long long tstride) {
+                                                            double* __restrict__ tot, long long tstride, int HW = 0, float eps = 0.f,
+                                                            float* __restrict__ mean = nullptr, float* __restrict__ rstd = nullptr) {
   __shared__ double red[16][64];
   const int cl = threadIdx.x & 63, b = blockIdx.y, c = blockIdx.x * 64 + cl, sl = threadIdx.x >> 6;
+  double fin[2] = {0., 0.};
   for (int a = 0; a < NA; ++a) {
     double s0 = 0., s1 = 0.;
     if (c < C) {
@@ -338,9 +343,19 @@ __global__ __launch_bounds__(1024) void chunk_reduce_kernel(const double* __rest
       double s = 0.;
 #pragma unroll
       for (int k = 0; k < 16; k += 4) s += (red[k][cl] + red[k + 1][cl]) + (red[k + 2][cl] + red[k + 3][cl]);
-      tot[a * tstride + (long long)b * C + c] = s;
+      if constexpr (FINISH) fin[a & 1] = s;
+      else tot[a * tstride + (long long)b * C + c] = s;
     }
     __syncthreads();
+  }
+  if constexpr (FINISH) {
+    if (sl == 0 && c < C) {
+      const double m = fin[0] / (double)HW;
+      double var = fin[1] / (double)HW - m * m;
+      var = var > 0. ? var : 0.;
+      mean[(long long)b * C + c] = (float)m;
+      rstd[(long long)b * C + c] = (float)(1.0 / sqrt(var + (double)eps));
+    }
   }
 }
 
@@ -632,9 +647,8 @@ static int instnorm_stats_launch(const TX* x, int ld, int B, int HW, int C, floa
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 grid((unsigned)nch, (unsigned)B), rgrid((unsigned)((C + 63) / 64), (unsigned)B);
   hipLaunchKernelGGL(instnorm_partial_kernel<TX>, grid, dim3(256), 0, st, x, ld, C, HW, part, astride);
-  hipLaunchKernelGGL(chunk_reduce_kernel, rgrid, dim3(1024), 0, st, part, astride, 2, nch, C, sum, (long long)B * C);
-  const int total = B * C;
-  hipLaunchKernelGGL(instnorm_finish_kernel, dim3((total + 255) / 256), dim3(256), 0, st, sum, sq, HW, eps, mean, rstd, total);
+  (void)sq;
+  hipLaunchKernelGGL(chunk_reduce_kernel<true>, rgrid, dim3(1024), 0, st, part, astride, 2, nch, C, sum, (long long)B * C, HW, eps, mean, rstd);
   return pfk_launch_status();
 }
 
@@ -671,7 +685,7 @@ int pfk_norm_bwd_f32(const float* x, int x_ld, const float* dy, int dy_ld, const
                      relu, p1, p2);
   const int total = B * C;
   // p1 and p2 are adjacent [B][nch][C] arrays, d1 and d2 adjacent [B][C] arrays: one reduction launch for both
-  hipLaunchKernelGGL(chunk_reduce_kernel, dim3((unsigned)((C + 63) / 64), (unsigned)B), dim3(1024), 0, st, p1, (long long)B * nch * C, 2, nch, C,
+  hipLaunchKernelGGL(chunk_reduce_kernel<false>, dim3((unsigned)((C + 63) / 64), (unsigned)B), dim3(1024), 0, st, p1, (long long)B * nch * C, 2, nch, C,
                      d1, (long long)B * C);
   if (sum_g || sum_gxhat)
     hipLaunchKernelGGL(norm_bwd_copy_kernel, dim3((total + 255) / 256), dim3(256), 0, st, d1, d2, sum_g, sum_gxhat, total);
