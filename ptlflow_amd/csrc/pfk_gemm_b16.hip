@@ -602,6 +602,10 @@ int launch_b16(const B16Args& a, int epi, hipStream_t st) {
     case 3: return launch_b16_epi<256, 64, 4, 2, 3>(a, epi, st);
     case 4: return launch_b16_epi<128, 64, 2, 2, 3>(a, epi, st);
     case 5: return launch_b16_epi<128, 128, 2, 2, 3>(a, epi, st);
+    // 128x128 / EIGHT waves / 2 stages (64 KB): two blocks = 16 waves per CU.  Twice cfg 2's waves on the same tile buy 0-4 % (fm 79.8 vs
+    // 83.4 us, 80.2 on the 256x256 tile; convc2 69.5 vs 69.8; z|r 55.2 vs 57.0; q slower; mask conv2 44.0 vs 50.2 — gpurun_out/r6u_cfg8.log):
+    // residency is not what holds these launches back.  Not selected by the heuristic (mask conv2 runs fused, K13b).
+    case 8: return launch_b16_epi<128, 128, 4, 2, 2>(a, epi, st);
     case 6:       // (no q epilogue on this tile: its 128-row wave tile has four bands of fp32 h / z / context operands — spills; q has cout = Ch <= 128 anyway)
       if (epi == PFK_EPI_LINEAR) return launch_b16_one<PFK_EPI_LINEAR, 256, 256, 2, 4, 2>(a, st);
       if (epi == PFK_EPI_GRU_ZR) return launch_b16_one<PFK_EPI_GRU_ZR, 256, 256, 2, 4, 2>(a, st);
