@@ -143,7 +143,19 @@ def roofline_b16(model, inputs):
     else:
         obj = {"bound": "hbm", "achieved": v["bytes_per_launch"] / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
     obj["frac"] = obj["achieved"] / obj["peak"]
-    obj.update({"kernel": f"conv_gemm_b16_kernel[{dom}]", "traffic": None, "avg_us": v["avg_us"], "launches_per_forward": v["launches"],
+    traffic = None
+    try:   # the committed rocprofv3 PMC passes of the K8b forward (profiles/pmc_traffic.json, entries `<site>_bf16@b<batch>`), if they cover this launch
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        B = inputs["images"].shape[0]
+        rec = pmc["entries"].get(f"{dom.rstrip('12')}_bf16@b{B}")
+        if rec and tuple(inputs["images"].shape[-2:]) == (436, 1024):
+            from ptlflow_amd import _build
+            traffic = {"bytes": (2 * rec["fetch_kb"] + rec["write_kb"]) * 1024, "algorithmic_bytes": int(v["bytes_per_launch"]),
+                       "stale": _build.source_hash() != pmc.get("kernel_source_sha16"),
+                       "source": "profiles/pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes of the bf16-storage forward)"}
+    except Exception:
+        pass
+    obj.update({"kernel": f"conv_gemm_b16_kernel[{dom}]", "traffic": traffic, "avg_us": v["avg_us"], "launches_per_forward": v["launches"],
                 "gflop_per_launch": v["gflop_per_launch"], "algorithmic_bytes_per_launch": v["bytes_per_launch"],
                 "floor_us": {"mfma": 1e6 * t_mfma, "hbm": 1e6 * t_hbm},
                 "method": "HIP events around each launch, separate instrumented forward of the bf16-storage model (in situ, side stream live)",

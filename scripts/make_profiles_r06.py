@@ -168,6 +168,11 @@ update-block convolutions (fp32), batch 8, 3 rounds round-robin, the library's c
         subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "pmc_extract.py"), "--fetch", os.path.join(O, "z6_pmc_fetch"),
                         "--write", os.path.join(O, "z6_pmc_write"), "--sq", os.path.join(O, "z6_pmc_sq"), "--batch", "8", "--out", tj],
                        check=True, stdout=subprocess.DEVNULL)
+    if all(os.path.isdir(os.path.join(O, n)) for n in ("z6_pmc_fetch_bf16", "z6_pmc_write_bf16", "z6_pmc_sq_bf16")):
+        # the same passes of the K8b forward: entries `<site>_bf16@b8` (bench.py's roofline_bf16.traffic)
+        subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "pmc_extract.py"), "--fetch", os.path.join(O, "z6_pmc_fetch_bf16"),
+                        "--write", os.path.join(O, "z6_pmc_write_bf16"), "--sq", os.path.join(O, "z6_pmc_sq_bf16"), "--batch", "8", "--tag", "_bf16",
+                        "--out", tj], check=True, stdout=subprocess.DEVNULL)
     doc = json.load(open(tj))
     sys.path.insert(0, ROOT)
     from ptlflow_amd import _build

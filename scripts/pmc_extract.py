@@ -23,7 +23,7 @@ def load(d):
     acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
     idx, last = None, None
     # round 5: with the fused mask conv2 + softmax + upsampling kernel (K13) an iteration has nine implicit-GEMM launches, not ten
-    fused = any("mask_upsample_kernel" in r["Kernel_Name"] for r in rows)
+    fused = any("mask_upsample" in r["Kernel_Name"] for r in rows)      # K13 (fp32) or K13b (`mask_upsample_b16_kernel`)
     seq = [k for k in SEQ if k != "mk"] if fused else SEQ
     for r in rows:
         name, did = r["Kernel_Name"], r["Dispatch_Id"]
@@ -32,7 +32,7 @@ def load(d):
             if "lookup_kernel" in name:
                 idx = 0
                 cur = "lookup"
-            elif "mask_upsample_kernel" in name:
+            elif "mask_upsample" in name:
                 cur = "mku"
             elif "conv_gemm" in name and idx is not None and idx < len(seq):
                 cur = seq[idx]
