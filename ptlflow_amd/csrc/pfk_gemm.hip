@@ -740,7 +740,7 @@ struct GemmGroupArgs {
   int n;
 };
 
-template <int LD>
+template <int LD, int BN = 64, int WN = 32>
 __global__ __launch_bounds__(256) void conv_gemm_v3_group_kernel(const GemmGroupArgs g) {
   const int b = blockIdx.x;
   int k = 0;
@@ -748,7 +748,7 @@ __global__ __launch_bounds__(256) void conv_gemm_v3_group_kernel(const GemmGroup
   for (int i = 1; i < PFK_CONV_GROUP_MAX; ++i)
     if (i < g.n && b >= g.first[i]) k = i;
   const int f0 = g.first[k], nblk = g.first[k + 1] - f0;
-  conv_gemm_v3_body<64, 64, 32, 32, PFK_EPI_LINEAR, 1, 0, LD>(g.p[k], pfk_xcd_remap(b - f0, nblk), nblk, 0);
+  conv_gemm_v3_body<64, BN, 32, WN, PFK_EPI_LINEAR, 1, 0, LD>(g.p[k], pfk_xcd_remap(b - f0, nblk), nblk, 0);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1533,6 +1533,12 @@ int pfk_conv2d_group_f32(const pfk_conv_desc* descs, int n, pfk_stream_t stream)
   // problems with the longest K loop first: their tiles start in the first resident round and the short ones fill in behind them
   for (int i = 1; i < n; ++i)
     for (int j = i; j > 0 && conv_ktot(&descs[order[j]], 32) > conv_ktot(&descs[order[j - 1]], 32); --j) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+  // 64 x 128 tiles (72 KB swizzled: two blocks per CU) where every problem's width is a multiple of 128 and its K loop is long — GMA's
+  // per-pair `attn @ v` (cout 128, 220 K-steps): four pairs are 440 tiles = ONE resident round, against 880 tiles of 64 x 64 on 768
+  // slots (a second round of 112 tiles); the same K order per output element either way: same bits
+  bool wide = true;
+  for (int i = 0; i < n; ++i) wide = wide && (descs[i].cout % 128 == 0) && conv_ktot(&descs[i], 32) >= 64 * 32;
+  const int BN = wide ? 128 : 64;
   for (int i = 0; i < n; ++i) {
     const pfk_conv_desc* d = &descs[order[i]];
     GemmArgs& a = g.p[i];
@@ -1544,7 +1550,7 @@ int pfk_conv2d_group_f32(const pfk_conv_desc* descs, int n, pfk_stream_t stream)
     if (a.M >= 0x7fffffffLL || a.Wo <= 0 || a.Ho <= 0) return PFK_ERR_UNSUPPORTED;
     fastdiv_make((unsigned)a.Wo, a.wo_mul, a.wo_sh);
     fastdiv_make((unsigned)a.Ho, a.ho_mul, a.ho_sh);
-    a.tiles_n = (a.b_rows + 63) / 64;
+    a.tiles_n = (a.b_rows + BN - 1) / BN;
     a.supertile = 0;
     const long long nblk = ((a.M + 63) / 64) * a.tiles_n;
     g.first[i] = (int)total;
@@ -1555,7 +1561,13 @@ int pfk_conv2d_group_f32(const pfk_conv_desc* descs, int n, pfk_stream_t stream)
   g.n = n;
   // the swizzled 48 KB layout (three blocks per CU) from three tiles per CU up, the padded 55 KB one below — the single launches' rule
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (total >= 3 * 256) {
+  if (wide) {
+    constexpr size_t smem = (size_t)3 * (64 + 128) * LDS_LDX * sizeof(float);
+    auto kern = conv_gemm_v3_group_kernel<LDS_LDX, 128, 64>;
+    static pfk_device_once attr_once;
+    attr_once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); });
+    hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), smem, st, g);
+  } else if (total >= 3 * 256) {
     constexpr size_t smem = (size_t)3 * (64 + 64) * LDS_LDX * sizeof(float);
     auto kern = conv_gemm_v3_group_kernel<LDS_LDX>;
     static pfk_device_once attr_once;

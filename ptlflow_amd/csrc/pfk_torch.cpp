@@ -210,13 +210,14 @@ void conv2d(at::TensorList srcs, int64_t B, int64_t H, int64_t W, int64_t kh, in
 }
 
 // Grouped launch (pfk_conv2d_group_f32): problem i = one fp32 source srcs[i] ([B*H*W, cin_i] view), k[i] x k[i] taps, stride 1, packed
-// weight weights[i] [cout_i, ktot_i], bias biases[i] (an empty tensor = none), relu[i], scale[i], out = outs[i] ([B*H*W, cout_i] view)
+// weight weights[i] [cout_i, ktot_i], bias biases[i] (an empty tensor = none), relu[i], scale[i], out = outs[i] ([B*H*W, cout_i] view),
+// residuals[i] (optional; an empty tensor = none): added after relu / scale
 void conv2d_group(at::TensorList srcs, int64_t B, int64_t H, int64_t W, at::IntArrayRef k, at::TensorList weights, at::TensorList biases,
-                  at::IntArrayRef relu, at::ArrayRef<double> scale, at::TensorList outs) {
+                  at::IntArrayRef relu, at::ArrayRef<double> scale, at::TensorList outs, at::TensorList residuals) {
   const size_t n = srcs.size();
   TORCH_CHECK(n >= 1 && n <= PFK_CONV_GROUP_MAX, "conv2d_group: 1..", PFK_CONV_GROUP_MAX, " problems");
-  TORCH_CHECK(k.size() == n && weights.size() == n && biases.size() == n && relu.size() == n && scale.size() == n && outs.size() == n,
-              "conv2d_group: one entry per problem in every list");
+  TORCH_CHECK(k.size() == n && weights.size() == n && biases.size() == n && relu.size() == n && scale.size() == n && outs.size() == n &&
+              (residuals.size() == n || residuals.size() == 0), "conv2d_group: one entry per problem in every list (residuals: n or none)");
   OpScope scope(srcs[0]);
   pfk_conv_desc d[PFK_CONV_GROUP_MAX] = {};
   for (size_t i = 0; i < n; ++i) {
@@ -236,6 +237,11 @@ void conv2d_group(at::TensorList srcs, int64_t B, int64_t H, int64_t W, at::IntA
       d[i].bias = fptr(biases[i]);
     }
     d[i].out = fptr(outs[i]); d[i].out_ld = outs[i].stride(0); d[i].out_coff = 0;
+    if (residuals.size() == n && residuals[i].numel() > 0) {      // out = residual + scale * relu?(conv + bias)  (an empty tensor = none)
+      check_pm(residuals[i], "residual");
+      TORCH_CHECK(residuals[i].size(0) == B * H * W && residuals[i].size(1) == cout, "conv2d_group: residual must be a [M, cout] view");
+      d[i].residual = fptr(residuals[i]); d[i].residual_ld = residuals[i].stride(0);
+    }
   }
   check_ok(pfk_conv2d_group_f32(d, (int)n, cur_stream()), "conv2d_group");
 }
@@ -915,7 +921,7 @@ TORCH_LIBRARY(pfk, m) {
   m.def("conv2d(Tensor[] srcs, int B, int H, int W, int kh, int kw, Tensor weight, Tensor? bias, int cout, "
         "int epilogue, bool relu, float scale, Tensor(a!)? out, Tensor(b!)? h, Tensor(c!)? aux_z, Tensor(d!)? aux_rh, "
         "Tensor(e!)? workspace=None, Tensor? residual=None, int stride=1, bool relu_after_residual=False, int cout_active=0, int cout_split=0) -> ()");
-  m.def("conv2d_group(Tensor[] srcs, int B, int H, int W, int[] k, Tensor[] weights, Tensor[] biases, int[] relu, float[] scale, Tensor(a!)[] outs) -> ()");
+  m.def("conv2d_group(Tensor[] srcs, int B, int H, int W, int[] k, Tensor[] weights, Tensor[] biases, int[] relu, float[] scale, Tensor(a!)[] outs, Tensor[] residuals) -> ()");
   m.def("conv2d_b16(Tensor[] srcs, int B, int H, int W, int kh, int kw, Tensor weight, Tensor? bias, int cout, int epilogue, bool relu, "
         "float scale, Tensor(a!)? out, Tensor(b!)? h=None, Tensor(c!)? h_b16=None, Tensor(d!)? aux_z=None, Tensor(e!)? aux_rh=None, "
         "Tensor? residual=None, int stride=1, bool relu_after_residual=False) -> ()");

@@ -284,6 +284,7 @@ class UpdateEngine:
         # scratch for the stream-K conv schedules (partials + flags), one per stream that may run convolutions concurrently: the
         # main chain, the flow branch of the motion encoder and the mask branch (RAFT._iterate's forked mode) — with its own
         # workspace a branch's launches pick the same schedule as in the serial order (bit-identical results)
+        self._empty = torch.empty(0, device=dev, dtype=torch.float32)      # "no bias" / "no residual" entry of a grouped launch
         nws = self.ops.conv_workspace_bytes()
         self.workspace = torch.zeros(nws, device=dev, dtype=torch.uint8)
         self.workspace_flow = torch.zeros(nws, device=dev, dtype=torch.uint8)
@@ -411,6 +412,25 @@ class UpdateEngine:
         mf = self.hx[:, o: o + mc]
         self._conv([mf], 1, 1, "tv", mc, relu=False, out=self.vbuf)
         self.ops.pm_to_cm(self.vbuf, self.vT)
+        if self.nsplit == 0 and B > 1:
+            # fp32: the pairs' `attn[b] @ v[b]` are INDEPENDENT GEMMs of 110 x 2 = 220 tiles each (one block per CU on 220 CUs, one
+            # wave per SIMD: 0.45 of the matrix peak) — as ONE grouped grid (`pfk_conv2d_group_f32`, up to four problems per launch)
+            # the 880 tiles of four pairs are resident together, three blocks per CU.  Same tiles, same K order: same bits.
+            for b0 in range(0, B, 4):
+                bs = list(range(b0, min(B, b0 + 4)))
+                rows = [slice(b * N, (b + 1) * N) for b in bs]
+                prof = self.profile
+                if prof is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                self.ops.conv2d_group([self.attn[b] for b in bs], 1, H, W, [1] * len(bs), [self.vT[b] for b in bs],
+                                      [self._empty] * len(bs), [0] * len(bs), [self.gamma] * len(bs),
+                                      [self.hx[r, o + mc: o + 2 * mc] for r in rows], [self.hx[r, o: o + mc] for r in rows])
+                if prof is not None:
+                    e1.record()
+                    prof.setdefault("ag", []).append((e0, e1))
+                    self.flops["ag"] = 2.0 * len(bs) * N * N * mc
+            return
         for b in range(B):
             rows = slice(b * N, (b + 1) * N)
             src = self.attn[b]
@@ -531,7 +551,7 @@ class UpdateEngine:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         self.ops.conv2d_group(srcs, B, H, W, ks, [self.w[k + ".w"] for k in keys],
-                              [self.w[k + ".b"] for k in keys], relu, scale, outs)
+                              [self.w[k + ".b"] for k in keys], relu, scale, outs, [])
         if prof is not None:
             e1.record()
             key = "+".join(keys)

@@ -603,10 +603,39 @@ def test_conv2d_group_equals_single_launches(gpu, B, H, W, n):
         buf[:, :cin] = pm(x)
         srcs.append(buf[:, :cin]); ws.append(pack_conv_weight(wt, [(0, cin, cin)]).cuda()); bs.append(bias.cuda())
         outs.append(torch.full((M, cout + 8), -3.0, device=gpu)[:, :cout]); ks.append(k); relus.append(relu); scales.append(scale)
-    torch.ops.pfk.conv2d_group(srcs, B, H, W, ks, ws, bs, relus, scales, outs)
+    torch.ops.pfk.conv2d_group(srcs, B, H, W, ks, ws, bs, relus, scales, outs, [])
     for i, (cin, cout, k, relu, scale) in enumerate(shapes):
         one = torch.full((M, cout), -5.0, device=gpu)
         torch.ops.pfk.conv2d([srcs[i]], B, H, W, k, k, ws[i], bs[i], cout, EPI_LINEAR, bool(relu), scale, one, None, None, None, None, None)
         assert torch.equal(outs[i], one), f"problem {i} differs from its single launch"
         close(unpm(outs[i], B, H, W), refs[i])
         assert bool((outs[i]._base[:, cout:] == -3.0).all()), "wrote past the output view"
+
+
+def test_conv2d_group_with_residuals(gpu):
+    """The grouped launch's `residuals` (out = residual + scale * (conv + bias)): GMA's per-pair `mf + gamma * attn @ v`
+    (gma/gma_utils.py:100-113) — four independent [N x N] x [N x 128] products in one grid, each with its own A, weight, residual and
+    output rows — against the same products launched one by one (bit for bit) and the oracle's matmul."""
+    torch.manual_seed(12)
+    H, W, C, n = 12, 20, 128, 4
+    N = H * W
+    attn = torch.softmax(torch.randn(n, N, N), -1)
+    v = torch.randn(n, N, C)
+    mf = torch.randn(n * N, 2 * C + 8)
+    gamma = 0.37
+    Np = (N + 31) // 32 * 32
+    vT = torch.zeros(n, C, Np)
+    vT[:, :, :N] = v.transpose(1, 2)
+    hx = mf.cuda()
+    hx1 = hx.clone()
+    a_g, vT_g = attn.cuda(), vT.cuda()
+    empty = torch.empty(0, device=gpu)
+    rows = [slice(b * N, (b + 1) * N) for b in range(n)]
+    torch.ops.pfk.conv2d_group([a_g[b] for b in range(n)], 1, H, W, [1] * n, [vT_g[b] for b in range(n)], [empty] * n, [0] * n, [gamma] * n,
+                               [hx[r, C: 2 * C] for r in rows], [hx[r, :C] for r in rows])
+    for b, r in enumerate(rows):
+        torch.ops.pfk.conv2d([a_g[b]], 1, H, W, 1, 1, vT_g[b], None, C, EPI_LINEAR, False, gamma, hx1[r, C: 2 * C], None, None, None, None, hx1[r, :C])
+    assert torch.equal(hx, hx1)
+    ref = mf[:, :C].view(n, N, C) + gamma * torch.bmm(attn, v)
+    close(hx[:, C: 2 * C].cpu().view(n, N, C), ref)
+    assert torch.equal(hx[:, 2 * C:].cpu(), mf[:, 2 * C:]) and torch.equal(hx[:, :C].cpu(), mf[:, :C])
