@@ -554,7 +554,8 @@ int launch_b16_epi(const B16Args& a, int epi, hipStream_t st) {
 int g_b16_cfg = 0;       // pfk_debug_set_b16(cfg): 0 = heuristic
 
 // tile configurations: 1 = 256x128 / 8 waves / 3 stages (144 KB, one block per CU), 2 = 128x128 / 4 waves / 2 stages (64 KB, two),
-// 3 = 256x64 / 8 waves / 3 stages (120 KB), 4 = 128x64 / 4 waves / 3 stages (72 KB, two), 5 = 128x128 / 4 waves / 3 stages (96 KB, one)
+// 3 = 256x64 / 8 waves / 3 stages (120 KB), 4 = 128x64 / 4 waves / 3 stages (72 KB, two), 5 = 128x128 / 4 waves / 3 stages (96 KB, one),
+// 6 = 256x256 / 8 waves / 2 stages (128 KB, one), 8 = 128x128 / 8 waves / 2 stages (64 KB, two), 9 = 256x64 / 8 waves / 2 stages (80 KB, two)
 int launch_b16(const B16Args& a, int epi, hipStream_t st) {
   int cfg = g_b16_cfg;
   if (cfg == 0) {
@@ -566,9 +567,18 @@ int launch_b16(const B16Args& a, int epi, hipStream_t st) {
     // grids under ~200 big tiles (batch 1): 128x64 with two blocks per CU (177 us per iteration against 208-296 for the others).
     const int pad64 = (a.b_rows + 63) / 64 * 64, pad128 = (a.b_rows + 127) / 128 * 128;
     const long long tm = ((a.M + 255) / 256) * (a.batches > 1 ? a.batches : 1);
+    // Round 6, the encoders' grids (many rounds of tiles, K = 9 or 2 steps): with ONE block per CU nothing runs under a tile's
+    // prologue and epilogue — ablations on 64 -> 64 3x3 at 16 x 218 x 512: no epilogue 275 -> 195 us, no MFMAs 279 (!), A for the first
+    // tap only 265 — so the configurations with TWO resident blocks win there: 256x64 x 2 stages (cfg 9: 294 -> 225 us; 164 -> 116 at 8
+    // images), 128x128 / eight waves / 2 stages (cfg 8) for cout <= 128 (96 -> 96 at 16 x 109 x 256: 161.6 -> 146.0; 128 -> 128 at
+    // 16 x 55 x 128: 50.6 -> 48.6) and for every short-K LINEAR launch (1x1 128 -> 256: 34.4 -> 28.8; mask conv2 50.2 -> 44.0) —
+    // gpurun_out/r6y_l1.log, r6z_l1.log, r6z2.log.  The update block's batch-8 grids (220 row tiles) keep their tiles (convf2 16.9 vs
+    // 17.8, conv 39.1 vs 40.0, q 38 vs 49 us).
+    const bool lin = epi == PFK_EPI_LINEAR;
     if (tm * (pad128 / 128) < 200) cfg = 4;
-    else if (pad64 < pad128 && a.b_rows < 192) cfg = 3;
-    else if (a.b_rows <= 128) cfg = 1;
+    else if (pad64 < pad128 && a.b_rows < 192) cfg = (lin && tm >= 512) ? 9 : 3;
+    else if (lin && a.steps <= 4) cfg = 8;
+    else if (a.b_rows <= 128) cfg = (lin && tm >= 400) ? 8 : 1;
     else if (epi == PFK_EPI_GRU_Q) cfg = 1;
     else cfg = (a.steps >= 6 || a.b_rows % 256 == 0) ? 6 : 2;
   }
@@ -592,6 +602,11 @@ int launch_b16(const B16Args& a, int epi, hipStream_t st) {
       case 66: return launch_b16_one<PFK_EPI_LINEAR, 256, 256, 2, 4, 2, 6>(a, st);
       case 76: return launch_b16_one<PFK_EPI_LINEAR, 256, 256, 2, 4, 2, 7>(a, st);
       case 61: return launch_b16_one<PFK_EPI_LINEAR, 256, 128, 4, 2, 3, 6>(a, st);
+      // the 256x64 tile (cfg 3: cout 64 — the encoders' first layer, convf2): A for the first tap only / no DMA / no MFMAs / no epilogue
+      case 63: return launch_b16_one<PFK_EPI_LINEAR, 256, 64, 4, 2, 3, 6>(a, st);
+      case 23: return launch_b16_one<PFK_EPI_LINEAR, 256, 64, 4, 2, 3, 2>(a, st);
+      case 13: return launch_b16_one<PFK_EPI_LINEAR, 256, 64, 4, 2, 3, 1>(a, st);
+      case 33: return launch_b16_one<PFK_EPI_LINEAR, 256, 64, 4, 2, 3, 3>(a, st);
       default: return PFK_ERR_BAD_ARG;
     }
   }
@@ -606,6 +621,7 @@ int launch_b16(const B16Args& a, int epi, hipStream_t st) {
     // 83.4 us, 80.2 on the 256x256 tile; convc2 69.5 vs 69.8; z|r 55.2 vs 57.0; q slower; mask conv2 44.0 vs 50.2 — gpurun_out/r6u_cfg8.log):
     // residency is not what holds these launches back.  Not selected by the heuristic (mask conv2 runs fused, K13b).
     case 8: return launch_b16_epi<128, 128, 4, 2, 2>(a, epi, st);
+    case 9: return launch_b16_epi<256, 64, 4, 2, 2>(a, epi, st);       // 256x64 / eight waves / TWO stages (80 KB): two blocks per CU
     case 6:       // (no q epilogue on this tile: its 128-row wave tile has four bands of fp32 h / z / context operands — spills; q has cout = Ch <= 128 anyway)
       if (epi == PFK_EPI_LINEAR) return launch_b16_one<PFK_EPI_LINEAR, 256, 256, 2, 4, 2>(a, st);
       if (epi == PFK_EPI_GRU_ZR) return launch_b16_one<PFK_EPI_GRU_ZR, 256, 256, 2, 4, 2>(a, st);

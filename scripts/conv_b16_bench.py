@@ -29,6 +29,10 @@ SHAPES = [
     ("fm", [128], 512, 3, 3, 0), ("mk", [256], 576, 1, 1, 0),
     ("zr1hL", [128, 128], 256, 1, 5, 0), ("q1hL", [128, 128], 128, 1, 5, 0),     # the GRU launches' GEMMs with the plain epilogue
     ("zr1g", [128, 256], 256, 1, 5, 1), ("q1g", [128, 256], 128, 1, 5, 2),       # GMA width (h | motion | aggregated motion)
+    ("l1", [64], 64, 3, 3, 0),       # BasicEncoder layer 1 (run with --H 218 --W 512 --batch 16: fnet at the headline's batch 8)
+    ("l2", [96], 96, 3, 3, 0),       # layer 2 (--H 109 --W 256 --batch 16)
+    ("l3", [128], 128, 3, 3, 0),     # layer 3 (--H 55 --W 128 --batch 16)
+    ("lo", [128], 256, 1, 1, 0),     # the output 1x1 convolution (--H 55 --W 128 --batch 16)
 ]
 
 

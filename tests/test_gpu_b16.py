@@ -48,7 +48,7 @@ def close_b16(got, ref, out_bf16):
     assert not bool(bad.any()), f"{int(bad.sum())} of {bad.numel()} outside the gate, max err {(got - ref).abs().max().item():.3e}"
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 8, 9])
 @pytest.mark.parametrize("B,H,W,segs,cout,kh,kw,relu,out_b16", [
     (1, 12, 20, [64], 96, 3, 3, True, True),
     (2, 9, 7, [328], 256, 1, 1, True, True),            # convc1: 324 correlation channels in a 328-wide bf16 row
