@@ -834,6 +834,16 @@ def main():
                     if target is not None:
                         mean, mx = _epe(m(xin)["flows"][:1, 0], target)
                         legs[name].update({"epe_mean": mean, "epe_max": mx, "epe_against": "cpu fp32 forward of the same model"})
+                    if name.endswith("_bf16"):      # the same model at the reference's protocol size (one pair per forward, median of 10)
+                        x1 = {"images": xin["images"][:1].contiguous()}
+                        for _ in range(2):
+                            m(x1)
+                        torch.cuda.synchronize()
+                        ts = []
+                        for _ in range(10):
+                            t0 = time.perf_counter(); m(x1); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+                        ts.sort()
+                        legs[name]["batch1"] = {"value": 1.0 / ts[len(ts) // 2], "unit": "frame-pairs/s", "ms_median": 1e3 * ts[len(ts) // 2]}
                     if name == "raft_bf16" and not args.no_roofline:
                         try:
                             result["roofline_bf16"] = roofline_b16(m, xin)
