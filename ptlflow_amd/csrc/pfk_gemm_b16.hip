@@ -42,6 +42,7 @@ struct B16Args {
   int relu, relu2;
   float scale;
   void* out; int out_ld, out_coff, out_bf16;
+  int out_vec16;                  // LINEAR, bf16 rows, no residual, every row piece 16-byte aligned: the 8-columns-per-lane epilogue (16-byte stores)
   const void* residual; int residual_ld;   // LINEAR: fp32 rows (bf16 with residual_bf16); GRU epilogues: bf16 rows
   int residual_bf16;
   // batched GEMM (LINEAR, one source, 1x1): blockIdx.y selects the problem; byte strides of the source / weight / out / residual
@@ -290,6 +291,49 @@ struct Epilogue16 {
 #pragma unroll
       for (int r = 0; r < 16; ++r) reg[((r & 3) + 8 * (r >> 2) + row_l) * CW + nt * 32 + col_l] = acc[MTI][nt][r] + bias[nt];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private region: in-order LDS, no workgroup barrier needed
+    if constexpr (LIN) {
+      // bf16 rows without a residual (the update block's and most encoder launches): EIGHT columns per lane — one 16-byte store per
+      // lane and pass instead of two 8-byte ones (the store tail of these epilogues is issue-bound: MI355X_MICROARCH.md, "8x dwordx4
+      // halves it"); a wave instruction then writes 8 rows x 64..128 contiguous bytes
+      if (a.out_vec16) {
+        constexpr int LPR8 = CW / 8, RPS8 = 64 / LPR8, PASSES8 = 32 / RPS8;
+        const int rrow8 = lane / LPR8, c8 = (lane % LPR8) * 8;
+        const int n8 = n - c4 + c8;                     // (n = n_base + c4)
+        const float sc = a.scale;
+#pragma unroll
+        for (int pass = 0; pass < PASSES8; ++pass) {
+          const int row = pass * RPS8 + rrow8;
+          f32x4 v0 = *reinterpret_cast<const f32x4*>(reg + row * CW + c8), v1 = *reinterpret_cast<const f32x4*>(reg + row * CW + c8 + 4);
+          const long long p = m_base + MTI * 32 + row;
+          if (p >= a.M || n8 >= a.b_rows) continue;
+          if (a.relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v0[e] = (v0[e] < 0.f) ? 0.f : v0[e]; v1[e] = (v1[e] < 0.f) ? 0.f : v1[e]; }
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v0[e] *= sc; v1[e] *= sc; }
+          if (a.relu2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v0[e] = (v0[e] < 0.f) ? 0.f : v0[e]; v1[e] = (v1[e] < 0.f) ? 0.f : v1[e]; }
+          }
+          __bf16* ob = reinterpret_cast<__bf16*>(a.out) + p * a.out_ld + a.out_coff + n8;
+          if (n8 + 7 < a.b_rows) {
+            const u32x2 lo = pack_bf16x4(v0), hi = pack_bf16x4(v1);
+            typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+            const u32x4v w = {lo[0], lo[1], hi[0], hi[1]};
+            *(__attribute__((address_space(1))) u32x4v*)ob = w;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              if (n8 + e < a.b_rows) ((gbf16*)ob)[e] = (__bf16)v0[e];
+              if (n8 + 4 + e < a.b_rows) ((gbf16*)ob)[4 + e] = (__bf16)v1[e];
+            }
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        return;
+      }
+    }
 #pragma unroll
     for (int pass = 0; pass < PASSES; ++pass) {
       const int row = pass * RPS + rrow;
@@ -556,8 +600,10 @@ int g_b16_cfg = 0;       // pfk_debug_set_b16(cfg): 0 = heuristic
 // tile configurations: 1 = 256x128 / 8 waves / 3 stages (144 KB, one block per CU), 2 = 128x128 / 4 waves / 2 stages (64 KB, two),
 // 3 = 256x64 / 8 waves / 3 stages (120 KB), 4 = 128x64 / 4 waves / 3 stages (72 KB, two), 5 = 128x128 / 4 waves / 3 stages (96 KB, one),
 // 6 = 256x256 / 8 waves / 2 stages (128 KB, one), 8 = 128x128 / 8 waves / 2 stages (64 KB, two), 9 = 256x64 / 8 waves / 2 stages (80 KB, two)
-int launch_b16(const B16Args& a, int epi, hipStream_t st) {
+int launch_b16(const B16Args& a0, int epi, hipStream_t st) {
+  B16Args a = a0;
   int cfg = g_b16_cfg;
+  if (cfg >= 50 && cfg < 60) { cfg -= 50; a.out_vec16 = 0; }      // tuning knob: 50 + cfg = the same configuration with 8-byte epilogue stores
   if (cfg == 0) {
     // Measured on MI355X (scripts/conv_b16_bench.py, RAFT update-block shapes at 55x128, gpurun_out/r6g_pref.log batch 8, r6a_b16_b1.log
     // batch 1).  These launches are as much HBM / L2-stream bound as matrix bound, so the tile that moves the fewest operand bytes per
@@ -871,6 +917,8 @@ int pfk_conv2d_b16(const pfk_conv_b16_desc* d, pfk_stream_t stream) {
       if (!d->out || d->out_ld < d->out_coff + d->cout) return PFK_ERR_BAD_ARG;
       if ((d->out_ld & 3) || (d->out_coff & 3) || (reinterpret_cast<uintptr_t>(d->out) & (d->out_bf16 ? 7u : 15u))) return PFK_ERR_ALIGNMENT;
       a.out = d->out; a.out_ld = d->out_ld; a.out_coff = d->out_coff; a.out_bf16 = d->out_bf16;
+      a.out_vec16 = d->out_bf16 && !d->residual && (d->batches <= 1 || (d->out_batch_stride & 7) == 0) &&
+                    !((reinterpret_cast<uintptr_t>(d->out) & 15u) || (d->out_ld & 7) || (d->out_coff & 7));
       break;
     case PFK_EPI_GRU_ZR:
       if (!d->h_b16 || !d->aux_z || !d->aux_rh || (d->cout & 63)) return PFK_ERR_BAD_ARG;
