@@ -297,7 +297,11 @@ int pfk_conv2d_bf16s(const pfk_conv_desc* d, const void* weight_planes, int nspl
  * `residual`: LINEAR — fp32 rows added after relu / scale (pfk_conv_desc); GRU epilogues — BF16 rows [M][cout] added to the gate
  * pre-activation (the loop-invariant context term: at batch 8 these launches are bound by the HBM bytes of their epilogues, and the
  * term is a convolution output that autocast would hold in 16 bits anyway).
- * kh * kw <= 32.  No workspace, no stream-K: tile grids only. */
+ * kh * kw <= 32.  No workspace, no stream-K: tile grids only.
+ * Alignment: sources / weight 16 bytes.  The GRU epilogues move their bf16 operands and results as 16-byte row pieces: Ch % 8 == 0,
+ * h_b16 / aux_z / aux_rh / the bf16 `residual` 16-byte aligned with row strides that are multiples of 8 elements (h: 16 bytes, h_ld % 4).
+ * LINEAR: `out` 8 bytes (bf16) / 16 bytes (fp32), out_ld / out_coff multiples of 4; bf16 rows without a residual whose pieces are 16-byte
+ * aligned (out 16 bytes, out_ld and out_coff multiples of 8) are stored with 16-byte accesses. */
 typedef struct {
   const void* ptr;   /* bf16 rows */
   int ld;            /* row stride in elements (multiple of 8) */

@@ -212,8 +212,14 @@ __device__ __forceinline__ u32x2 pack_bf16x4(const f32x4 v) {
 // in the same in-order vmcnt queue as loads: a load issued behind a store waits for that store's completion).
 template <int MT, int NT, int EPI>
 struct Epilogue16 {
-  static constexpr int CW = NT * 32, LPR = CW / 4, RPS = 64 / LPR, PASSES = 32 / RPS;
   static constexpr bool LIN = EPI == PFK_EPI_LINEAR, ZR = EPI == PFK_EPI_GRU_ZR, Q = EPI == PFK_EPI_GRU_Q;
+  // columns per lane of the row-wise pass: 4 (LINEAR: fp32 rows / residuals; its bf16 rows without a residual take the 8-column branch of
+  // band()), 8 for the GRU epilogues — every bf16 side operand (context term, h twin, z) and every bf16 result (z, r * h, the h twin) is ONE
+  // 16-byte access per lane and pass, the fp32 h two; half the passes and half the store instructions of the 4-column form
+  static constexpr int COLS = LIN ? 4 : 8;
+  static constexpr int CW = NT * 32, LPR = CW / COLS, RPS = 64 / LPR, PASSES = 32 / RPS;
+  typedef unsigned int u32x4e __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(1))) u32x4e gu32x4e;
   typedef __attribute__((address_space(1))) float gfloat;
   typedef __attribute__((address_space(1))) f32x4 gf32x4;
   typedef __attribute__((address_space(1))) u32x2 gu32x2;
@@ -226,13 +232,13 @@ struct Epilogue16 {
   // epilogue (8 registers per pass) has one: its later bands are requested behind the previous band's stores and wait for them.
   static constexpr int NSETS = Q ? 1 : 2;
   f32x4 res32[LIN ? 2 : 1][LIN ? PASSES : 1];
-  u32x2 res16[LIN ? 1 : NSETS][LIN ? 1 : PASSES], aux16[LIN ? 1 : NSETS][LIN ? 1 : PASSES];
-  f32x4 h32[1][Q ? PASSES : 1];
+  u32x4e res16[LIN ? 1 : NSETS][LIN ? 1 : PASSES], aux16[LIN ? 1 : NSETS][LIN ? 1 : PASSES];      // eight bf16 each
+  f32x4 h32[1][Q ? PASSES : 1][2];
 
   __device__ __forceinline__ Epilogue16(const B16Args& a, long long m_base_, int n_base, int lane) : m_base(m_base_) {
-    rrow = lane / LPR; c4 = (lane % LPR) * 4;
+    rrow = lane / LPR; c4 = (lane % LPR) * COLS;
     n = n_base + c4;
-    full = n + 3 < a.b_rows; any = n < a.b_rows;
+    full = n + COLS - 1 < a.b_rows; any = n < a.b_rows;
     has_res = a.residual != nullptr;
   }
 
@@ -243,13 +249,20 @@ struct Epilogue16 {
     return v;
   }
 
+  static __device__ __forceinline__ f32x4 widen_lo(const u32x4e w) { const u32x2 h = {w[0], w[1]}; return widen(h); }
+  static __device__ __forceinline__ f32x4 widen_hi(const u32x4e w) { const u32x2 h = {w[2], w[3]}; return widen(h); }
+  static __device__ __forceinline__ u32x4e pack_bf16x8(const f32x4 a, const f32x4 b) {
+    const u32x2 lo = pack_bf16x4(a), hi = pack_bf16x4(b);
+    const u32x4e w = {lo[0], lo[1], hi[0], hi[1]};
+    return w;
+  }
+
   // request band MTI's global operands into register set MTI & 1
   template <int MTI>
   __device__ __forceinline__ void prefetch(const B16Args& a) {
     constexpr int S = MTI & (NSETS - 1);
     if (LIN && !has_res) return;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    const u32x2 zero2 = {0u, 0u};
     const int ch = a.ch_hidden;
 #pragma unroll
     for (int pass = 0; pass < PASSES; ++pass) {
@@ -269,12 +282,14 @@ struct Epilogue16 {
           }
         }
       } else {
-        res16[S][pass] = (ok && has_res) ? *reinterpret_cast<const u32x2*>(reinterpret_cast<const __bf16*>(a.residual) + p * a.residual_ld + n) : zero2;
+        const u32x4e zero8 = {0u, 0u, 0u, 0u};
+        res16[S][pass] = (ok && has_res) ? *reinterpret_cast<const u32x4e*>(reinterpret_cast<const __bf16*>(a.residual) + p * a.residual_ld + n) : zero8;
         if constexpr (ZR) {
-          aux16[S][pass] = (ok && n >= ch) ? *reinterpret_cast<const u32x2*>(reinterpret_cast<const __bf16*>(a.h_b16) + p * a.hb_ld + (n - ch)) : zero2;
+          aux16[S][pass] = (ok && n >= ch) ? *reinterpret_cast<const u32x4e*>(reinterpret_cast<const __bf16*>(a.h_b16) + p * a.hb_ld + (n - ch)) : zero8;
         } else {
-          aux16[S][pass] = ok ? *reinterpret_cast<const u32x2*>(reinterpret_cast<const __bf16*>(a.aux_z) + p * ch + n) : zero2;
-          h32[S][pass] = ok ? *reinterpret_cast<const f32x4*>(a.h + p * a.h_ld + n) : zero4;
+          aux16[S][pass] = ok ? *reinterpret_cast<const u32x4e*>(reinterpret_cast<const __bf16*>(a.aux_z) + p * ch + n) : zero8;
+          h32[S][pass][0] = ok ? *reinterpret_cast<const f32x4*>(a.h + p * a.h_ld + n) : zero4;
+          h32[S][pass][1] = ok ? *reinterpret_cast<const f32x4*>(a.h + p * a.h_ld + n + 4) : zero4;
         }
       }
     }
@@ -370,24 +385,31 @@ struct Epilogue16 {
             if (n + 2 < a.b_rows) ((gfloat*)op)[2] = v[2];
           }
         }
-      } else if constexpr (ZR) {     // cout = 2 * ch, ch % 4 == 0: four columns never straddle z | r
-        v += widen(res16[S][pass]);
-        f32x4 g;
+      } else if constexpr (ZR) {     // cout = 2 * ch, ch % 8 == 0: eight columns never straddle z | r
+        f32x4 w = *reinterpret_cast<const f32x4*>(reg + row * CW + c4 + 4);      // columns 4..7 of this lane (v holds 0..3)
+        v += widen_lo(res16[S][pass]);
+        w += widen_hi(res16[S][pass]);
+        f32x4 g0, g1;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) g[e] = fast_sigmoid(v[e]);
-        if (n < ch) *(gu32x2*)(reinterpret_cast<__bf16*>(a.aux_z) + p * ch + n) = pack_bf16x4(g);
-        else *(gu32x2*)(reinterpret_cast<__bf16*>(a.aux_rh) + p * ch + (n - ch)) = pack_bf16x4(g * widen(aux16[S][pass]));
+        for (int e = 0; e < 4; ++e) { g0[e] = fast_sigmoid(v[e]); g1[e] = fast_sigmoid(w[e]); }
+        if (n < ch) *(gu32x4e*)(reinterpret_cast<__bf16*>(a.aux_z) + p * ch + n) = pack_bf16x8(g0, g1);
+        else *(gu32x4e*)(reinterpret_cast<__bf16*>(a.aux_rh) + p * ch + (n - ch)) =
+            pack_bf16x8(g0 * widen_lo(aux16[S][pass]), g1 * widen_hi(aux16[S][pass]));
       } else {  // PFK_EPI_GRU_Q
-        v += widen(res16[S][pass]);
-        const f32x4 z = widen(aux16[S][pass]), hv = h32[S][pass];
-        f32x4 o;
+        f32x4 w = *reinterpret_cast<const f32x4*>(reg + row * CW + c4 + 4);
+        v += widen_lo(res16[S][pass]);
+        w += widen_hi(res16[S][pass]);
+        const f32x4 z0 = widen_lo(aux16[S][pass]), z1 = widen_hi(aux16[S][pass]), h0 = h32[S][pass][0], h1 = h32[S][pass][1];
+        f32x4 o0, o1;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float q = fast_tanh(v[e]);
-          o[e] = __fadd_rn(__fmul_rn(__fsub_rn(1.0f, z[e]), hv[e]), __fmul_rn(z[e], q));   // update.py:64,71
+          const float q0 = fast_tanh(v[e]), q1 = fast_tanh(w[e]);
+          o0[e] = __fadd_rn(__fmul_rn(__fsub_rn(1.0f, z0[e]), h0[e]), __fmul_rn(z0[e], q0));   // update.py:64,71
+          o1[e] = __fadd_rn(__fmul_rn(__fsub_rn(1.0f, z1[e]), h1[e]), __fmul_rn(z1[e], q1));
         }
-        *(gf32x4*)(a.h + p * a.h_ld + n) = o;
-        if (a.h_b16 != nullptr) *(gu32x2*)(reinterpret_cast<__bf16*>(a.h_b16) + p * a.hb_ld + n) = pack_bf16x4(o);
+        *(gf32x4*)(a.h + p * a.h_ld + n) = o0;
+        *(gf32x4*)(a.h + p * a.h_ld + n + 4) = o1;
+        if (a.h_b16 != nullptr) *(gu32x4e*)(reinterpret_cast<__bf16*>(a.h_b16) + p * a.hb_ld + n) = pack_bf16x8(o0, o1);
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads are done before the next band overwrites the region
@@ -900,7 +922,9 @@ int pfk_conv2d_b16(const pfk_conv_b16_desc* d, pfk_stream_t stream) {
   if (d->residual) {      // LINEAR: fp32 rows (bf16 with residual_bf16); GRU epilogues: bf16 rows
     if (d->residual_ld < d->cout) return PFK_ERR_BAD_ARG;
     const bool r16 = d->epilogue != PFK_EPI_LINEAR || d->residual_bf16;
-    if ((reinterpret_cast<uintptr_t>(d->residual) & (r16 ? 7u : 15u)) || (d->residual_ld & 3) || (r16 && (d->cout & 3))) return PFK_ERR_ALIGNMENT;
+    const bool gru = d->epilogue != PFK_EPI_LINEAR;      // the GRU epilogues read the term as 16-byte pieces
+    if ((reinterpret_cast<uintptr_t>(d->residual) & ((r16 && !gru) ? 7u : 15u)) || (d->residual_ld & (gru ? 7 : 3)) || (r16 && (d->cout & 3)))
+      return PFK_ERR_ALIGNMENT;
     a.residual = d->residual; a.residual_ld = d->residual_ld; a.residual_bf16 = d->epilogue == PFK_EPI_LINEAR && d->residual_bf16;
   }
   if (d->batches > 1) {
@@ -920,16 +944,16 @@ int pfk_conv2d_b16(const pfk_conv_b16_desc* d, pfk_stream_t stream) {
       a.out_vec16 = d->out_bf16 && !d->residual && (d->batches <= 1 || (d->out_batch_stride & 7) == 0) &&
                     !((reinterpret_cast<uintptr_t>(d->out) & 15u) || (d->out_ld & 7) || (d->out_coff & 7));
       break;
-    case PFK_EPI_GRU_ZR:
+    case PFK_EPI_GRU_ZR:      // (16-byte row pieces: Ch % 8 == 0, 16-byte aligned bf16 buffers, row strides multiples of 8 elements)
       if (!d->h_b16 || !d->aux_z || !d->aux_rh || (d->cout & 63)) return PFK_ERR_BAD_ARG;
-      if ((reinterpret_cast<uintptr_t>(d->h_b16) & 7u) || (d->h_b16_ld & 3) || (reinterpret_cast<uintptr_t>(d->aux_z) & 7u) ||
-          (reinterpret_cast<uintptr_t>(d->aux_rh) & 7u)) return PFK_ERR_ALIGNMENT;
+      if ((reinterpret_cast<uintptr_t>(d->h_b16) & 15u) || (d->h_b16_ld & 7) || (reinterpret_cast<uintptr_t>(d->aux_z) & 15u) ||
+          (reinterpret_cast<uintptr_t>(d->aux_rh) & 15u)) return PFK_ERR_ALIGNMENT;
       a.h_b16 = const_cast<void*>(d->h_b16); a.hb_ld = d->h_b16_ld; a.aux_z = d->aux_z; a.aux_rh = d->aux_rh; a.ch_hidden = d->cout / 2;
       break;
     case PFK_EPI_GRU_Q:
       if (!d->h || !d->aux_z || (d->cout & 31)) return PFK_ERR_BAD_ARG;
-      if (!pfk_aligned16(d->h) || (d->h_ld & 3) || (reinterpret_cast<uintptr_t>(d->aux_z) & 7u)) return PFK_ERR_ALIGNMENT;
-      if (d->h_b16 && ((reinterpret_cast<uintptr_t>(d->h_b16) & 7u) || (d->h_b16_ld & 3) || d->h_b16_ld < d->cout)) return PFK_ERR_ALIGNMENT;
+      if (!pfk_aligned16(d->h) || (d->h_ld & 3) || (reinterpret_cast<uintptr_t>(d->aux_z) & 15u)) return PFK_ERR_ALIGNMENT;
+      if (d->h_b16 && ((reinterpret_cast<uintptr_t>(d->h_b16) & 15u) || (d->h_b16_ld & 7) || d->h_b16_ld < d->cout)) return PFK_ERR_ALIGNMENT;
       a.h = d->h; a.h_ld = d->h_ld; a.aux_z = d->aux_z; a.ch_hidden = d->cout;
       a.h_b16 = d->h_b16; a.hb_ld = d->h_b16_ld;
       break;
